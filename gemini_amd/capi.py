@@ -1,0 +1,87 @@
+"""ctypes loader for libgemini_hip.so (the C ABI of include/gemini_hip.h).
+
+Fails loudly: there is no CPU or PyTorch fallback for any entry point.  If the shared library is
+missing (run `python -c "import __graft_entry__ as g; g.build()"`) or no GPU is visible, callers
+get an exception, never a silently different code path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgemini_hip.so")
+
+GM_OK = 0
+ERRORS = {-1: "GM_EINVAL", -2: "GM_ENOTINIT", -3: "GM_EHANDLE", -4: "GM_EHIP", -5: "GM_ENOMEM", -6: "GM_ESTATE"}
+
+# every symbol include/gemini_hip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "gm_init", "gm_shutdown", "gm_last_error", "gm_abi_version",
+    "gm_g1_msm", "gm_g1_bases_register", "gm_g1_bases_free", "gm_g1_bases_len", "gm_g1_bases_download",
+    "gm_g1_msm_h", "gm_g1_msm_v", "gm_g1_msm_d", "gm_g1_msm_d_partial", "gm_g1_sum",
+    "gm_g1_fixed_base_register", "gm_g1_srs_register", "gm_set_msm_window",
+    "gm_fr_vec_alloc", "gm_fr_vec_free", "gm_fr_vec_len", "gm_fr_vec_upload", "gm_fr_vec_download",
+    "gm_fr_vec_fill", "gm_fr_vec_ptr", "gm_fr_vec_set_len",
+    "gm_fr_fold", "gm_fr_powers", "gm_fr_tensor", "gm_fr_hadamard", "gm_fr_ip", "gm_fr_eval_le",
+    "gm_fr_lincomb", "gm_fr_div_vanishing",
+    "gm_sc_new", "gm_sc_new_v", "gm_sc_round", "gm_sc_fold", "gm_sc_rounds", "gm_sc_final", "gm_sc_free",
+    "gm_sc_set_shard",
+]
+
+
+class GeminiHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library (no GPU needed for this step)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path."
+            )
+        lib = C.CDLL(LIB_PATH)
+        lib.gm_last_error.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != GM_OK:
+        raise GeminiHipError(rc, load().gm_last_error().decode())
+
+
+_initialised = False
+
+
+def init(device: int | None = None):
+    """gm_init on LOCAL_RANK (one process per GPU)."""
+    global _initialised
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    check(load().gm_init(C.c_int(device)))
+    _initialised = True
+
+
+def ensure_init():
+    if not _initialised:
+        init()
+
+
+def ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)

@@ -1,0 +1,492 @@
+// extern "C" surface of libgemini_hip.so (declared in include/gemini_hip.h) + process context.
+#include <cstring>
+#include <vector>
+
+#include "ctx.hpp"
+#include "host_field.hpp"
+
+namespace gm {
+
+// ---- error strings -----------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return e == hipErrorOutOfMemory ? GM_ENOMEM : GM_EHIP;
+}
+
+int DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return GM_OK;
+  if (p) {
+    (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  GM_HIP(hipMalloc(&p, want));
+  cap = want;
+  return GM_OK;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+static Context* g_ctx = nullptr;
+static std::mutex g_ctx_mu;
+Context* context() { return g_ctx; }
+
+Bases* find_bases(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  auto it = g_ctx->bases.find(h);
+  return it == g_ctx->bases.end() ? nullptr : it->second.get();
+}
+FrVec* find_vec(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  auto it = g_ctx->vecs.find(h);
+  return it == g_ctx->vecs.end() ? nullptr : it->second.get();
+}
+Sumcheck* find_prover(uint64_t h) {
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  auto it = g_ctx->provers.find(h);
+  return it == g_ctx->provers.end() ? nullptr : it->second.get();
+}
+uint64_t put_bases(std::unique_ptr<Bases> b) {
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  uint64_t h = g_ctx->next_handle++;
+  g_ctx->bases[h] = std::move(b);
+  return h;
+}
+uint64_t put_vec(std::unique_ptr<FrVec> v) {
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  uint64_t h = g_ctx->next_handle++;
+  g_ctx->vecs[h] = std::move(v);
+  return h;
+}
+uint64_t put_prover(std::unique_ptr<Sumcheck> p) {
+  std::lock_guard<std::mutex> lk(g_ctx->mu);
+  uint64_t h = g_ctx->next_handle++;
+  g_ctx->provers[h] = std::move(p);
+  return h;
+}
+
+// implemented in msm.hip / fr.hip
+int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std::unique_ptr<Bases>& out);
+int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* d_scalars, int mont, size_t n,
+                        std::unique_ptr<Bases>& out);
+int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_t ng, bool src_is_device,
+              const uint64_t twist[4], uint64_t* handle);
+void sc_destroy(Sumcheck* S);
+int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
+int sc_fold(Context* C, Sumcheck* S, const uint64_t challenge[4]);
+int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has);
+int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out);
+int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out);
+int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out);
+int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out);
+int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]);
+int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results);
+int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out);
+int fr_fill(Context* C, FrVec* v, const uint64_t val[4]);
+int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k, FrVec* q, uint64_t* rem_out);
+
+}  // namespace gm
+
+using namespace gm;
+
+extern "C" {
+
+int gm_abi_version(void) { return 1; }
+
+const char* gm_last_error(void) { return g_err; }
+
+int gm_init(int device) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  if (g_ctx) {
+    GM_CHECK(g_ctx->device == device, GM_EINVAL, "gm_init: already bound to device %d (one process per GPU)", g_ctx->device);
+    return GM_OK;
+  }
+  int count = 0;
+  GM_HIP(hipGetDeviceCount(&count));
+  GM_CHECK(count > 0, GM_EHIP, "gm_init: no HIP device visible");
+  GM_CHECK(device >= 0 && device < count, GM_EINVAL, "gm_init: device %d out of range (%d visible)", device, count);
+  GM_HIP(hipSetDevice(device));
+  auto* C = new Context();
+  C->device = device;
+  hipDeviceProp_t prop;
+  GM_HIP(hipGetDeviceProperties(&prop, device));
+  C->cu_count = prop.multiProcessorCount;
+  GM_HIP(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
+  GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
+  g_ctx = C;
+  return GM_OK;
+}
+
+void gm_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  if (!g_ctx) return;
+  Context* C = g_ctx;
+  (void)hipStreamSynchronize(C->stream);
+  for (auto& kv : C->bases)
+    if (kv.second->d) (void)hipFree(kv.second->d);
+  for (auto& kv : C->vecs)
+    if (kv.second->d) (void)hipFree(kv.second->d);
+  for (auto& kv : C->provers) sc_destroy(kv.second.get());
+  MsmWorkspace& w = C->msm;
+  for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
+                    &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc})
+    b->release();
+  if (w.host_planes) (void)hipHostFree(w.host_planes);
+  C->fr_scratch.release();
+  if (C->host_small) (void)hipHostFree(C->host_small);
+  (void)hipStreamDestroy(C->stream);
+  delete C;
+  g_ctx = nullptr;
+}
+
+int gm_set_msm_window(int c) {
+  GM_CTX();
+  GM_CHECK(c == 0 || (c >= 2 && c <= 22), GM_EINVAL, "gm_set_msm_window: c = %d not in {0} u [2, 22]", c);
+  C->msm_c_override = c;
+  return GM_OK;
+}
+
+// ---- bases ---------------------------------------------------------------------------------
+int gm_g1_bases_register(const void* bases, size_t base_stride, size_t n, uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(handle != nullptr && (bases != nullptr || n == 0), GM_EINVAL, "bases_register: null pointer");
+  std::unique_ptr<Bases> b;
+  int rc = bases_from_host(C, bases, base_stride, n, b);
+  if (rc) return rc;
+  *handle = put_bases(std::move(b));
+  return GM_OK;
+}
+
+int gm_g1_bases_free(uint64_t handle) {
+  GM_CTX();
+  std::unique_ptr<Bases> b;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->bases.find(handle);
+    GM_CHECK(it != C->bases.end(), GM_EHANDLE, "bases_free: unknown handle %llu", (unsigned long long)handle);
+    b = std::move(it->second);
+    C->bases.erase(it);
+  }
+  if (b->d) GM_HIP(hipFree(b->d));
+  return GM_OK;
+}
+
+int gm_g1_bases_len(uint64_t handle, size_t* n) {
+  GM_CTX();
+  Bases* b = find_bases(handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "bases_len: unknown handle %llu", (unsigned long long)handle);
+  *n = b->n;
+  return GM_OK;
+}
+
+int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96) {
+  GM_CTX();
+  Bases* b = find_bases(handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "bases_download: unknown handle %llu", (unsigned long long)handle);
+  GM_CHECK(offset + n <= b->n, GM_EINVAL, "bases_download: range [%zu, %zu) outside %zu bases", offset, offset + n, b->n);
+  if (n) {
+    GM_HIP(hipMemcpyAsync(out96, b->d + offset * 96, n * 96, hipMemcpyDeviceToHost, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+  }
+  return GM_OK;
+}
+
+static int msm_host_scalars(Context* C, Bases* b, size_t offset, int reversed, const uint64_t* scalars, size_t n,
+                            uint64_t out_jac[18]) {
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(C->msm_mu);
+    if ((rc = C->msm.scalars.ensure(n * 32 + 32))) return rc;
+    if (n) GM_HIP(hipMemcpyAsync(C->msm.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
+  }
+  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, C->msm.scalars.p, 0, n, true, out_jac);
+}
+
+int gm_g1_msm(const void* bases, size_t base_stride, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+  GM_CTX();
+  GM_CHECK(out_jac != nullptr && ((bases != nullptr && scalars != nullptr) || n == 0), GM_EINVAL, "msm: null pointer");
+  std::unique_ptr<Bases> b;
+  int rc = bases_from_host(C, bases, base_stride, n, b);
+  if (rc) return rc;
+  rc = msm_host_scalars(C, b.get(), 0, 0, scalars, n, out_jac);
+  if (b->d) (void)hipFree(b->d);
+  return rc;
+}
+
+int gm_g1_msm_h(uint64_t handle, size_t offset, int reversed, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
+  GM_CTX();
+  Bases* b = find_bases(handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "msm_h: unknown bases handle %llu", (unsigned long long)handle);
+  GM_CHECK(out_jac != nullptr && (scalars != nullptr || n == 0), GM_EINVAL, "msm_h: null pointer");
+  return msm_host_scalars(C, b, offset, reversed, scalars, n, out_jac);
+}
+
+int gm_g1_msm_v(uint64_t bases_handle, size_t offset, int reversed, uint64_t vec_handle, size_t voffset, size_t n,
+                uint64_t out_jac[18]) {
+  GM_CTX();
+  Bases* b = find_bases(bases_handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "msm_v: unknown bases handle %llu", (unsigned long long)bases_handle);
+  FrVec* v = find_vec(vec_handle);
+  GM_CHECK(v != nullptr, GM_EHANDLE, "msm_v: unknown vector handle %llu", (unsigned long long)vec_handle);
+  GM_CHECK(voffset + n <= v->len, GM_EINVAL, "msm_v: range [%zu, %zu) outside vector of length %zu", voffset, voffset + n, v->len);
+  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, v->d + voffset * 32, 1, n, true, out_jac);
+}
+
+int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
+                uint64_t out_jac[18]) {
+  GM_CTX();
+  Bases* b = find_bases(bases_handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "msm_d: unknown bases handle %llu", (unsigned long long)bases_handle);
+  GM_CHECK(out_jac != nullptr && (d_scalars != nullptr || n == 0), GM_EINVAL, "msm_d: null pointer");
+  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, d_scalars, mont, n, true, out_jac);
+}
+
+int gm_g1_msm_d_partial(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
+                        uint64_t out_jac[18]) {
+  GM_CTX();
+  Bases* b = find_bases(bases_handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "msm_d_partial: unknown bases handle %llu", (unsigned long long)bases_handle);
+  GM_CHECK(out_jac != nullptr && (d_scalars != nullptr || n == 0), GM_EINVAL, "msm_d_partial: null pointer");
+  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, d_scalars, mont, n, false, out_jac);
+}
+
+int gm_g1_sum(const uint64_t* points_jac, size_t k, uint64_t out_jac[18]) {
+  GM_CHECK(out_jac != nullptr && (points_jac != nullptr || k == 0), GM_EINVAL, "g1_sum: null pointer");
+  gmh::G1 acc = gmh::G1::identity();
+  for (size_t i = 0; i < k; i++) acc = acc.add(gmh::G1::from_limbs(points_jac + 18 * i));
+  acc.normalized().to_limbs(out_jac);
+  return GM_OK;
+}
+
+int gm_g1_fixed_base_register(const uint64_t base_affine[12], const uint64_t* scalars, size_t n, uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(base_affine && handle && (scalars || n == 0), GM_EINVAL, "fixed_base_register: null pointer");
+  uint8_t* d_sc = nullptr;
+  if (n) {
+    GM_HIP(hipMalloc((void**)&d_sc, n * 32));
+    GM_HIP(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
+  }
+  std::unique_ptr<Bases> b;
+  int rc = fixed_base_generate(C, base_affine, d_sc, 0, n, b);
+  if (d_sc) (void)hipFree(d_sc);
+  if (rc) return rc;
+  *handle = put_bases(std::move(b));
+  return GM_OK;
+}
+
+int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], size_t n, uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(base_affine && tau && handle, GM_EINVAL, "srs_register: null pointer");
+  // powers of tau on device (Montgomery), then fixed-base multiplication
+  auto v = std::make_unique<FrVec>();
+  v->cap = n;
+  if (n) GM_HIP(hipMalloc((void**)&v->d, n * 32));
+  gmh::Fr t = gmh::Fr::from_canonical(tau);
+  uint64_t tm[4];
+  t.to_limbs(tm);
+  int rc = fr_powers(C, tm, n, v.get());
+  std::unique_ptr<Bases> b;
+  if (!rc) rc = fixed_base_generate(C, base_affine, v->d, 1, n, b);
+  if (v->d) (void)hipFree(v->d);
+  if (rc) return rc;
+  *handle = put_bases(std::move(b));
+  return GM_OK;
+}
+
+// ---- Fr vectors ------------------------------------------------------------------------------
+int gm_fr_vec_alloc(size_t n, uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(handle != nullptr, GM_EINVAL, "vec_alloc: null handle pointer");
+  auto v = std::make_unique<FrVec>();
+  v->cap = n;
+  v->len = n;
+  if (n) GM_HIP(hipMalloc((void**)&v->d, n * 32));
+  *handle = put_vec(std::move(v));
+  return GM_OK;
+}
+int gm_fr_vec_free(uint64_t handle) {
+  GM_CTX();
+  std::unique_ptr<FrVec> v;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->vecs.find(handle);
+    GM_CHECK(it != C->vecs.end(), GM_EHANDLE, "vec_free: unknown handle %llu", (unsigned long long)handle);
+    v = std::move(it->second);
+    C->vecs.erase(it);
+  }
+  if (v->d) GM_HIP(hipFree(v->d));
+  return GM_OK;
+}
+#define GM_VEC(var, h, who)                  \
+  FrVec* var = find_vec(h);                  \
+  GM_CHECK(var != nullptr, GM_EHANDLE, who ": unknown vector handle %llu", (unsigned long long)(h))
+
+int gm_fr_vec_len(uint64_t handle, size_t* n) {
+  GM_CTX();
+  GM_VEC(v, handle, "vec_len");
+  *n = v->len;
+  return GM_OK;
+}
+int gm_fr_vec_set_len(uint64_t handle, size_t n) {
+  GM_CTX();
+  GM_VEC(v, handle, "vec_set_len");
+  GM_CHECK(n <= v->cap, GM_EINVAL, "vec_set_len: %zu exceeds capacity %zu", n, v->cap);
+  v->len = n;
+  return GM_OK;
+}
+int gm_fr_vec_ptr(uint64_t handle, void** dptr) {
+  GM_CTX();
+  GM_VEC(v, handle, "vec_ptr");
+  *dptr = v->d;
+  return GM_OK;
+}
+int gm_fr_vec_upload(uint64_t handle, size_t offset, const uint64_t* mont, size_t n) {
+  GM_CTX();
+  GM_VEC(v, handle, "vec_upload");
+  GM_CHECK(offset + n <= v->cap, GM_EINVAL, "vec_upload: range [%zu, %zu) outside capacity %zu", offset, offset + n, v->cap);
+  if (n) {
+    GM_HIP(hipMemcpyAsync(v->d + offset * 32, mont, n * 32, hipMemcpyHostToDevice, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+  }
+  return GM_OK;
+}
+int gm_fr_vec_download(uint64_t handle, size_t offset, uint64_t* mont, size_t n) {
+  GM_CTX();
+  GM_VEC(v, handle, "vec_download");
+  GM_CHECK(offset + n <= v->cap, GM_EINVAL, "vec_download: range [%zu, %zu) outside capacity %zu", offset, offset + n, v->cap);
+  if (n) {
+    GM_HIP(hipMemcpyAsync(mont, v->d + offset * 32, n * 32, hipMemcpyDeviceToHost, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+  }
+  return GM_OK;
+}
+int gm_fr_vec_fill(uint64_t handle, const uint64_t value_mont[4]) {
+  GM_CTX();
+  GM_VEC(v, handle, "vec_fill");
+  return fr_fill(C, v, value_mont);
+}
+
+int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out) {
+  GM_CTX();
+  GM_VEC(vf, f, "fr_fold");
+  GM_VEC(vo, out, "fr_fold");
+  return fr_fold(C, vf, r_mont, vo);
+}
+int gm_fr_powers(const uint64_t x_mont[4], size_t n, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_powers");
+  return fr_powers(C, x_mont, n, vo);
+}
+int gm_fr_tensor(const uint64_t* rhos_mont, size_t k, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_tensor");
+  return fr_tensor(C, rhos_mont, k, vo);
+}
+int gm_fr_hadamard(uint64_t a, uint64_t b, uint64_t out) {
+  GM_CTX();
+  GM_VEC(va, a, "fr_hadamard");
+  GM_VEC(vb, b, "fr_hadamard");
+  GM_VEC(vo, out, "fr_hadamard");
+  return fr_hadamard(C, va, vb, vo);
+}
+int gm_fr_ip(uint64_t a, uint64_t b, uint64_t result_mont[4]) {
+  GM_CTX();
+  GM_VEC(va, a, "fr_ip");
+  GM_VEC(vb, b, "fr_ip");
+  return fr_ip(C, va, vb, result_mont);
+}
+int gm_fr_eval_le(uint64_t poly, const uint64_t* xs_mont, size_t npoints, uint64_t* results_mont) {
+  GM_CTX();
+  GM_VEC(vp, poly, "fr_eval_le");
+  return fr_eval_le(C, vp, xs_mont, npoints, results_mont);
+}
+int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_lincomb");
+  std::vector<FrVec*> ps(k);
+  for (size_t j = 0; j < k; j++) {
+    ps[j] = find_vec(polys[j]);
+    GM_CHECK(ps[j] != nullptr, GM_EHANDLE, "fr_lincomb: unknown vector handle %llu", (unsigned long long)polys[j]);
+  }
+  return fr_lincomb(C, ps.data(), coeffs_mont, k, vo);
+}
+int gm_fr_div_vanishing(uint64_t f, const uint64_t* points_mont, size_t k, uint64_t quotient, uint64_t* rem_mont) {
+  GM_CTX();
+  GM_VEC(vf, f, "fr_div_vanishing");
+  GM_VEC(vq, quotient, "fr_div_vanishing");
+  return fr_div_linear_factors(C, vf, points_mont, k, vq, rem_mont);
+}
+
+// ---- sumcheck ---------------------------------------------------------------------------------
+#define GM_SC(var, h, who)                     \
+  Sumcheck* var = find_prover(h);              \
+  GM_CHECK(var != nullptr, GM_EHANDLE, who ": unknown prover handle %llu", (unsigned long long)(h))
+
+int gm_sc_new(const uint64_t* f_mont, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist_mont[4],
+              uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(f_mont && g_mont && twist_mont && handle, GM_EINVAL, "sc_new: null pointer");
+  return sc_create(C, f_mont, nf, g_mont, ng, false, twist_mont, handle);
+}
+int gm_sc_new_v(uint64_t f_vec, uint64_t g_vec, const uint64_t twist_mont[4], uint64_t* handle) {
+  GM_CTX();
+  GM_VEC(vf, f_vec, "sc_new_v");
+  GM_VEC(vg, g_vec, "sc_new_v");
+  GM_CHECK(twist_mont && handle, GM_EINVAL, "sc_new_v: null pointer");
+  return sc_create(C, vf->d, vf->len, vg->d, vg->len, true, twist_mont, handle);
+}
+int gm_sc_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_round");
+  GM_CHECK(a_mont && b_mont && has_msg, GM_EINVAL, "sc_round: null pointer");
+  return sc_round(C, S, challenge_or_null, a_mont, b_mont, has_msg);
+}
+int gm_sc_fold(uint64_t handle, const uint64_t challenge_mont[4]) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_fold");
+  return sc_fold(C, S, challenge_mont);
+}
+int gm_sc_rounds(uint64_t handle, size_t* tot_rounds, size_t* round) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_rounds");
+  if (tot_rounds) *tot_rounds = S->tot_rounds;
+  if (round) *round = S->round;
+  return GM_OK;
+}
+int gm_sc_final(uint64_t handle, uint64_t f0_mont[4], uint64_t g0_mont[4], int* has) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_final");
+  return sc_final(C, S, f0_mont, g0_mont, has);
+}
+int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_set_shard");
+  S->pair_offset = pair_offset;
+  return GM_OK;
+}
+int gm_sc_free(uint64_t handle) {
+  GM_CTX();
+  std::unique_ptr<Sumcheck> p;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->provers.find(handle);
+    GM_CHECK(it != C->provers.end(), GM_EHANDLE, "sc_free: unknown handle %llu", (unsigned long long)handle);
+    p = std::move(it->second);
+    C->provers.erase(it);
+  }
+  sc_destroy(p.get());
+  return GM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// Process-wide state of libgemini_hip.so: one GPU per process, opaque u64 handles for
+// device-resident bases / Fr vectors / sumcheck provers, grow-only workspaces, error strings.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/gemini_hip.h"
+
+namespace gm {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define GM_HIP(expr)                                                     \
+  do {                                                                   \
+    hipError_t _e = (expr);                                              \
+    if (_e != hipSuccess) return ::gm::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define GM_CHECK(cond, code, ...)  \
+  do {                             \
+    if (!(cond)) {                 \
+      ::gm::set_error(__VA_ARGS__); \
+      return (code);               \
+    }                              \
+  } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes);
+  void release();
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct Bases {
+  uint8_t* d = nullptr;  // n x 96 bytes: x, y Montgomery; identity = all zero
+  size_t n = 0;
+};
+
+struct FrVec {
+  uint8_t* d = nullptr;  // cap x 32 bytes, Montgomery
+  size_t cap = 0;
+  size_t len = 0;
+};
+
+struct Sumcheck {
+  // ping-pong state of TimeProver (src/subprotocols/sumcheck/time_prover.rs:42-52)
+  uint8_t* f[2] = {nullptr, nullptr};
+  uint8_t* g[2] = {nullptr, nullptr};
+  int cur = 0;
+  size_t nf = 0, ng = 0;
+  uint64_t twist[4];  // Montgomery
+  size_t round = 0, tot_rounds = 0;
+  uint64_t pair_offset = 0;  // shard origin (gm_sc_set_shard)
+  uint8_t* partials = nullptr;   // per-block (a, b) partial sums
+  uint64_t* host_partials = nullptr;  // pinned
+  std::mutex mu;
+};
+
+struct MsmWorkspace {
+  DevBuf scalars, counts, offsets, cursor, entries, buckets, pk[2], pp[2], rows, cols, planes, misc;
+  uint64_t* host_planes = nullptr;  // pinned staging for the D2H of window bit-planes
+  size_t host_planes_cap = 0;
+};
+
+struct Context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::mutex mu;       // guards handle tables
+  std::mutex msm_mu;   // MSM workspace is single-flight (the reference's MSM calls are sequential)
+  uint64_t next_handle = 1;
+  std::unordered_map<uint64_t, std::unique_ptr<Bases>> bases;
+  std::unordered_map<uint64_t, std::unique_ptr<FrVec>> vecs;
+  std::unordered_map<uint64_t, std::unique_ptr<Sumcheck>> provers;
+  MsmWorkspace msm;
+  DevBuf fr_scratch;
+  uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
+  int msm_c_override = 0;
+  int cu_count = 256;
+};
+
+Context* context();  // nullptr before gm_init
+
+Bases* find_bases(uint64_t h);
+FrVec* find_vec(uint64_t h);
+Sumcheck* find_prover(uint64_t h);
+uint64_t put_bases(std::unique_ptr<Bases> b);
+uint64_t put_vec(std::unique_ptr<FrVec> v);
+uint64_t put_prover(std::unique_ptr<Sumcheck> p);
+
+#define GM_CTX()                                            \
+  ::gm::Context* C = ::gm::context();                       \
+  GM_CHECK(C != nullptr, GM_ENOTINIT, "gm_init has not been called")
+
+// MSM engine (msm.hip)
+int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, int64_t step, const void* d_scalars,
+            int mont, size_t n, bool normalize, uint64_t out_jac[18]);
+
+}  // namespace gm

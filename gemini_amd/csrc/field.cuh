@@ -173,7 +173,7 @@ GM_DEV Fp<P> fp_dbl(const Fp<P>& a) {
 // v_mad_u64_u32 (32x32+64) plus a carry fold.  t never exceeds N+1 limbs because
 // both moduli satisfy 2p < 2^(32N) ("no-carry" property of the top limb).
 template <class P>
-GM_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+GM_DEV Fp<P> fp_mul_cios(const Fp<P>& a, const Fp<P>& b) {
   constexpr int N = P::N;
   uint32_t t[N + 1];
 #pragma unroll
@@ -211,6 +211,13 @@ GM_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
   fp_cond_sub<P>(r, t[N]);
   return r;
 }
+
+// The production multiplier: product-scanning Montgomery, one v_mad_u64_u32 + v_addc_co_u32 per
+// partial product into a 96-bit column accumulator (generated, see gen_field_mul.py).
+// fp_mul_cios above is the plain-C form kept as an in-kernel cross-check.
+template <class P>
+GM_DEV Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b);
+#include "field_mul_gen.inc"
 
 template <class P>
 GM_DEV Fp<P> fp_sqr(const Fp<P>& a) {

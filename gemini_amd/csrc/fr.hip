@@ -1,0 +1,758 @@
+// Scalar-field (Fr) kernels: the sumcheck time prover and the dense vector passes of src/misc.rs.
+//
+// All vectors are arrays of 32-byte Montgomery elements (the ark-ff memory image), read and
+// written with 16-byte vector accesses; lane i touches element i of a wave-contiguous tile so
+// a wave moves 2 KiB per load instruction.  These kernels are HBM-streaming work with ~10
+// modular multiplications per 384 bytes moved (sumcheck round); the arithmetic is the
+// 8-limb product-scanning multiplier of field.cuh.
+#include <vector>
+
+#include "ctx.hpp"
+#include "field.cuh"
+#include "host_field.hpp"
+
+namespace gm {
+
+constexpr int FR_BYTES = 32;
+
+__device__ __noinline__ Fr fr_mul_fn(const Fr a, const Fr b) { return fp_mul<FrParams>(a, b); }
+GM_DEV Fr fr_mul(const Fr& a, const Fr& b) { return fp_mul<FrParams>(a, b); }
+GM_DEV Fr fr_add(const Fr& a, const Fr& b) { return fp_add<FrParams>(a, b); }
+GM_DEV Fr fr_sub(const Fr& a, const Fr& b) { return fp_sub<FrParams>(a, b); }
+
+GM_DEV Fr fr_load_or_zero(const uint8_t* base, size_t i, size_t n) {
+  if (i < n) return fp_load<FrParams>(base + i * FR_BYTES);
+  return Fr::zero();
+}
+
+// table of x^(2^b), b < 40, passed by value to kernels that need x^k for per-thread k
+struct PowTable {
+  uint32_t p[40][8];
+};
+GM_DEV Fr pow_from_table(const PowTable& t, uint64_t e) {
+  Fr acc = Fr::one();
+  for (int b = 0; b < 40; b++) {
+    if ((e >> b) & 1ull) {
+      Fr m;
+#pragma unroll
+      for (int i = 0; i < 8; i++) m.l[i] = t.p[b][i];
+      acc = fr_mul(acc, m);
+    }
+  }
+  return acc;
+}
+
+GM_DEV Fr fr_shfl_down(const Fr& v, int d) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], d);
+  return r;
+}
+GM_DEV Fr wave_sum(Fr v) {
+#pragma unroll 1
+  for (int d = 32; d >= 1; d >>= 1) v = fr_add(v, fr_shfl_down(v, d));
+  return v;
+}
+// block-wide sum of K values per thread; result valid in thread 0.  blockDim = 256.
+template <int K>
+GM_DEV void block_sum(Fr (&v)[K], uint8_t* lds /* 4 * K * 32 bytes */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    v[k] = wave_sum(v[k]);
+    if (lane == 0) fp_store<FrParams>(lds + (wave * K + k) * FR_BYTES, v[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      Fr s = fp_load<FrParams>(lds + k * FR_BYTES);
+      for (int w = 1; w < 4; w++) s = fr_add(s, fp_load<FrParams>(lds + (w * K + k) * FR_BYTES));
+      v[k] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// sumcheck round: optional fold (time_prover.rs:75-80) fused with the next message (:83-123)
+// ------------------------------------------------------------------------------------------
+struct ScArgs {
+  const uint8_t* f_in;
+  const uint8_t* g_in;
+  uint8_t* f_out;
+  uint8_t* g_out;
+  size_t nf_in, ng_in;  // lengths of the input vectors
+  uint32_t rho_tau[8];  // rho * twist   (fold multiplier of f)
+  uint32_t rho[8];      // rho           (fold multiplier of g)
+  uint32_t tau[8];      // twist the MESSAGE is computed with (already squared when folding)
+  uint32_t origin[8];   // tau^(2 * first pair index of this shard)
+  PowTable tau2;        // (tau^2)^(2^b)
+  uint32_t log_threads; // total threads = 2^log_threads
+  size_t npairs;        // loop bound: pairs of the message vectors (covers both vectors entirely)
+};
+
+template <bool FOLD, bool MSG>
+__global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
+  const size_t T = (size_t)1 << A.log_threads;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fr rho_tau, rho, tau, tw, step;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    rho_tau.l[i] = A.rho_tau[i];
+    rho.l[i] = A.rho[i];
+    tau.l[i] = A.tau[i];
+    tw.l[i] = A.origin[i];
+    step.l[i] = A.tau2.p[A.log_threads][i];
+  }
+  Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};  // a, b1 = sum fe*go*tw, b2 = sum ge*fo*tw
+  if (MSG && t < A.npairs) tw = fr_mul(tw, pow_from_table(A.tau2, t));
+  // message vectors: FOLD ? folded (length ceil(n_in/2)) : the inputs
+  const size_t nf = FOLD ? (A.nf_in + 1) / 2 : A.nf_in;
+  const size_t ng = FOLD ? (A.ng_in + 1) / 2 : A.ng_in;
+  for (size_t j = t; j < A.npairs; j += T) {
+    Fr fe, fo, ge, go;
+    if (FOLD) {
+      Fr f0 = fr_load_or_zero(A.f_in, 4 * j, A.nf_in), f1 = fr_load_or_zero(A.f_in, 4 * j + 1, A.nf_in);
+      Fr f2 = fr_load_or_zero(A.f_in, 4 * j + 2, A.nf_in), f3 = fr_load_or_zero(A.f_in, 4 * j + 3, A.nf_in);
+      Fr g0 = fr_load_or_zero(A.g_in, 4 * j, A.ng_in), g1 = fr_load_or_zero(A.g_in, 4 * j + 1, A.ng_in);
+      Fr g2 = fr_load_or_zero(A.g_in, 4 * j + 2, A.ng_in), g3 = fr_load_or_zero(A.g_in, 4 * j + 3, A.ng_in);
+      fe = fr_add(f0, fr_mul(rho_tau, f1));
+      fo = fr_add(f2, fr_mul(rho_tau, f3));
+      ge = fr_add(g0, fr_mul(rho, g1));
+      go = fr_add(g2, fr_mul(rho, g3));
+      if (2 * j < nf) fp_store<FrParams>(A.f_out + (2 * j) * FR_BYTES, fe);
+      if (2 * j + 1 < nf) fp_store<FrParams>(A.f_out + (2 * j + 1) * FR_BYTES, fo);
+      if (2 * j < ng) fp_store<FrParams>(A.g_out + (2 * j) * FR_BYTES, ge);
+      if (2 * j + 1 < ng) fp_store<FrParams>(A.g_out + (2 * j + 1) * FR_BYTES, go);
+    } else {
+      fe = fr_load_or_zero(A.f_in, 2 * j, nf);
+      fo = fr_load_or_zero(A.f_in, 2 * j + 1, nf);
+      ge = fr_load_or_zero(A.g_in, 2 * j, ng);
+      go = fr_load_or_zero(A.g_in, 2 * j + 1, ng);
+    }
+    if (MSG) {
+      Fr u = fr_mul(fe, tw), w = fr_mul(fo, tw);
+      acc[0] = fr_add(acc[0], fr_mul(u, ge));
+      acc[1] = fr_add(acc[1], fr_mul(u, go));
+      acc[2] = fr_add(acc[2], fr_mul(w, ge));
+      tw = fr_mul(tw, step);
+    }
+  }
+  if (MSG) {
+    block_sum<3>(acc, lds);
+    if (threadIdx.x == 0) {
+      // b = b1 + tau * b2
+      Fr b = fr_add(acc[1], fr_mul(tau, acc[2]));
+      fp_store<FrParams>(partials + ((size_t)blockIdx.x * 2) * FR_BYTES, acc[0]);
+      fp_store<FrParams>(partials + ((size_t)blockIdx.x * 2 + 1) * FR_BYTES, b);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// vector helpers
+// ------------------------------------------------------------------------------------------
+// out[i] = f[2i] + r * f[2i+1]                                                   misc.rs:52-56
+__global__ __launch_bounds__(256) void k_fold(const uint8_t* __restrict__ f, size_t n, const uint32_t* __restrict__ r8,
+                                              uint8_t* __restrict__ out) {
+  const size_t m = (n + 1) / 2;
+  Fr r = fp_load<FrParams>(r8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+    Fr e = fp_load<FrParams>(f + (2 * i) * FR_BYTES);
+    Fr o = fr_load_or_zero(f, 2 * i + 1, n);
+    fp_store<FrParams>(out + i * FR_BYTES, fr_add(e, fr_mul(r, o)));
+  }
+}
+
+// out[i] = x^i: wave tiles of 64 * K elements, lane-strided inside the tile      misc.rs:59-65
+__global__ __launch_bounds__(256) void k_powers(PowTable xt, size_t n, uint8_t* __restrict__ out) {
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Fr cur = pow_from_table(xt, t);
+  Fr step = pow_from_table(xt, T);
+  for (size_t i = t; i < n; i += T) {
+    fp_store<FrParams>(out + i * FR_BYTES, cur);
+    cur = fr_mul(cur, step);
+  }
+}
+
+// half tables for tensor: tab[idx] = prod_{j<k} rho_j^{bit_j(idx)}
+__global__ __launch_bounds__(256) void k_tensor_table(const uint32_t* __restrict__ rhos, uint32_t k, uint8_t* __restrict__ tab) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (1u << k)) return;
+  Fr acc = Fr::one();
+  for (uint32_t j = 0; j < k; j++)
+    if ((idx >> j) & 1u) acc = fr_mul(acc, fp_load<FrParams>(rhos + 8 * j));
+  fp_store<FrParams>(tab + (size_t)idx * FR_BYTES, acc);
+}
+// out[idx] = lo[idx & mask] * hi[idx >> klo]                                   misc.rs:133-149
+__global__ __launch_bounds__(256) void k_tensor(const uint8_t* __restrict__ lo, const uint8_t* __restrict__ hi,
+                                                uint32_t klo, size_t n, uint8_t* __restrict__ out) {
+  const size_t mask = ((size_t)1 << klo) - 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr a = fp_load<FrParams>(lo + (i & mask) * FR_BYTES);
+    Fr b = fp_load<FrParams>(hi + (i >> klo) * FR_BYTES);
+    fp_store<FrParams>(out + i * FR_BYTES, fr_mul(a, b));
+  }
+}
+
+// out = a . b                                                                   misc.rs:205-208
+__global__ __launch_bounds__(256) void k_hadamard(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
+                                                  uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + i * FR_BYTES, fr_mul(fp_load<FrParams>(a + i * FR_BYTES), fp_load<FrParams>(b + i * FR_BYTES)));
+}
+
+// partial inner products, one per block                                         misc.rs:215-218
+__global__ __launch_bounds__(256) void k_ip(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
+                                            uint8_t* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * FR_BYTES];
+  Fr acc[1] = {Fr::zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc[0] = fr_add(acc[0], fr_mul(fp_load<FrParams>(a + i * FR_BYTES), fp_load<FrParams>(b + i * FR_BYTES)));
+  block_sum<1>(acc, lds);
+  if (threadIdx.x == 0) fp_store<FrParams>(partials + (size_t)blockIdx.x * FR_BYTES, acc[0]);
+}
+
+// evaluate_le at up to 3 points in one pass over the coefficients               misc.rs:194-199
+// thread-strided: thread t owns coefficients t, t+T, ...; sum_i p_i x^i = sum_t x^t * Horner_{x^T}(p_t, p_{t+T}, ...)
+struct EvalArgs {
+  PowTable xt[3];
+  uint32_t npoints;
+  uint32_t log_threads;
+};
+__global__ __launch_bounds__(256) void k_eval_le(const uint8_t* __restrict__ p, size_t n, EvalArgs A,
+                                                 uint8_t* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
+  const size_t T = (size_t)1 << A.log_threads;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+  if (t < n) {
+    Fr step[3];
+    for (uint32_t k = 0; k < 3; k++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) step[k].l[i] = A.xt[k < A.npoints ? k : 0].p[A.log_threads][i];
+    // highest index owned by this thread
+    size_t cnt = (n - t + T - 1) / T;
+    for (size_t c = cnt; c-- > 0;) {
+      Fr coef = fp_load<FrParams>(p + (t + c * T) * FR_BYTES);
+      for (uint32_t k = 0; k < A.npoints; k++) acc[k] = fr_add(fr_mul(acc[k], step[k]), coef);
+    }
+    for (uint32_t k = 0; k < A.npoints; k++) acc[k] = fr_mul(acc[k], pow_from_table(A.xt[k], t));
+  }
+  block_sum<3>(acc, lds);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; k++) fp_store<FrParams>(partials + ((size_t)blockIdx.x * 3 + k) * FR_BYTES, acc[k]);
+}
+
+// out[i] = sum_j c_j p_j[i], polynomials of different lengths (missing = 0)      misc.rs:37-48
+struct LincombArgs {
+  const uint8_t* p[24];
+  size_t len[24];
+  uint32_t c[24][8];
+  uint32_t k;
+};
+__global__ __launch_bounds__(256) void k_lincomb(LincombArgs A, size_t n, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = Fr::zero();
+    for (uint32_t j = 0; j < A.k; j++) {
+      if (i < A.len[j]) {
+        Fr c;
+#pragma unroll
+        for (int q = 0; q < 8; q++) c.l[q] = A.c[j][q];
+        acc = fr_add(acc, fr_mul(c, fp_load<FrParams>(A.p[j] + i * FR_BYTES)));
+      }
+    }
+    fp_store<FrParams>(out + i * FR_BYTES, acc);
+  }
+}
+// accumulate variant for more than 24 polynomials: out[i] += ...
+__global__ __launch_bounds__(256) void k_lincomb_acc(LincombArgs A, size_t n, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = fp_load<FrParams>(out + i * FR_BYTES);
+    for (uint32_t j = 0; j < A.k; j++) {
+      if (i < A.len[j]) {
+        Fr c;
+#pragma unroll
+        for (int q = 0; q < 8; q++) c.l[q] = A.c[j][q];
+        acc = fr_add(acc, fr_mul(c, fp_load<FrParams>(A.p[j] + i * FR_BYTES)));
+      }
+    }
+    fp_store<FrParams>(out + i * FR_BYTES, acc);
+  }
+}
+
+// number of trailing (high-index) zero elements: each block reports the highest non-zero index + 1
+__global__ __launch_bounds__(256) void k_high_nonzero(const uint8_t* __restrict__ v, size_t n, unsigned long long* __restrict__ result) {
+  unsigned long long best = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr x = fp_load<FrParams>(v + i * FR_BYTES);
+    if (!x.is_zero()) best = i + 1;
+  }
+  if (best) atomicMax(result, best);
+}
+
+__global__ void k_fill(uint8_t* __restrict__ v, size_t n, const uint32_t* __restrict__ val) {
+  Fr x = fp_load<FrParams>(val);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(v + i * FR_BYTES, x);
+}
+
+// Division by a linear factor (x - alpha), high to low: q_i = f_{i+1} + alpha * q_{i+1}.
+// Blocked three-phase evaluation of the first-order recurrence (an affine-map scan):
+//   phase 1: per chunk c of K coefficients, t_c = sum_{j in chunk} f_j alpha^(j - lo_c)
+//   phase 2: suffix combine S_c = t_c + alpha^K S_{c+1}   (sequential over the few chunk sums per
+//            block, then across blocks on one wave -- the chunk count is n / K)
+//   phase 3: rerun the recurrence inside each chunk seeded with S_{c+1}
+// The same quotient as DensePolynomial::div by (x - alpha)                   src/kzg/time.rs:134-145
+constexpr int DIV_K = 64;
+__global__ __launch_bounds__(256) void k_div_phase1(const uint8_t* __restrict__ f, size_t n, const uint32_t* __restrict__ alpha8,
+                                                    uint8_t* __restrict__ chunk_sums) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nch = (n + DIV_K - 1) / DIV_K;
+  if (c >= nch) return;
+  Fr alpha = fp_load<FrParams>(alpha8);
+  const size_t lo = c * DIV_K, hi = min(lo + (size_t)DIV_K, n);
+  Fr acc = Fr::zero();
+  for (size_t j = hi; j-- > lo;) acc = fr_add(fr_mul(acc, alpha), fp_load<FrParams>(f + j * FR_BYTES));
+  fp_store<FrParams>(chunk_sums + c * FR_BYTES, acc);
+}
+// in-place suffix combine over chunk sums with multiplier m = alpha^K, done by ONE thread per
+// segment of `seg` chunks plus a sequential pass over segments (nch / seg is small)
+__global__ __launch_bounds__(256) void k_div_phase2a(uint8_t* __restrict__ sums, size_t nch, size_t seg, const uint32_t* __restrict__ m8,
+                                                     uint8_t* __restrict__ seg_sums) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nseg = (nch + seg - 1) / seg;
+  if (s >= nseg) return;
+  Fr m = fp_load<FrParams>(m8);
+  const size_t lo = s * seg, hi = min(lo + seg, nch);
+  Fr acc = Fr::zero();
+  for (size_t c = hi; c-- > lo;) {
+    acc = fr_add(fr_mul(acc, m), fp_load<FrParams>(sums + c * FR_BYTES));
+    fp_store<FrParams>(sums + c * FR_BYTES, acc);  // local suffix (within the segment)
+  }
+  fp_store<FrParams>(seg_sums + s * FR_BYTES, acc);
+}
+// sequential over segments (one thread): carry[s] = value flowing INTO segment s from above
+__global__ void k_div_phase2b(const uint8_t* __restrict__ seg_sums, size_t nseg, size_t seg, size_t nch, PowTable mt,
+                              uint8_t* __restrict__ carry) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Fr acc = Fr::zero();
+  Fr mseg = pow_from_table(mt, seg);
+  for (size_t s = nseg; s-- > 0;) {
+    fp_store<FrParams>(carry + s * FR_BYTES, acc);
+    const size_t len = min(seg, nch - s * seg);
+    Fr mm = len == seg ? mseg : pow_from_table(mt, len);
+    acc = fr_add(fr_mul(acc, mm), fp_load<FrParams>(seg_sums + s * FR_BYTES));
+  }
+}
+// phase 3: q_i for i in chunk c.  S_{c+1} = local suffix of chunk c+1 within its segment
+// + m^(chunks remaining in that segment) * carry[segment]
+__global__ __launch_bounds__(256) void k_div_phase3(const uint8_t* __restrict__ f, size_t n, const uint32_t* __restrict__ alpha8,
+                                                    const uint8_t* __restrict__ sums, const uint8_t* __restrict__ carry,
+                                                    size_t seg, PowTable mt, uint8_t* __restrict__ q, uint8_t* __restrict__ rem) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nch = (n + DIV_K - 1) / DIV_K;
+  if (c >= nch) return;
+  Fr alpha = fp_load<FrParams>(alpha8);
+  // value of the recurrence state entering chunk c from above: state = sum_{j >= hi_c} f_j alpha^(j - hi_c)
+  Fr state = Fr::zero();
+  if (c + 1 < nch) {
+    const size_t c1 = c + 1, s1 = c1 / seg;
+    const size_t seg_hi = min((s1 + 1) * seg, nch);
+    state = fr_add(fp_load<FrParams>(sums + c1 * FR_BYTES),
+                   fr_mul(pow_from_table(mt, seg_hi - c1), fp_load<FrParams>(carry + s1 * FR_BYTES)));
+  }
+  const size_t lo = c * DIV_K, hi = min(lo + (size_t)DIV_K, n);
+  // q_{j-1} = f_j + alpha * q_j  with q_{n-1} := 0 ; state before processing f_j equals q_j
+  for (size_t j = hi; j-- > lo;) {
+    state = fr_add(fr_mul(state, alpha), fp_load<FrParams>(f + j * FR_BYTES));
+    if (j >= 1) fp_store<FrParams>(q + (j - 1) * FR_BYTES, state);
+    else fp_store<FrParams>(rem, state);  // f(alpha)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------
+static void make_pow_table(const gmh::Fr& x, PowTable& t) {
+  gmh::Fr cur = x;
+  for (int b = 0; b < 40; b++) {
+    memcpy(t.p[b], cur.l, 32);
+    cur = cur.sqr();
+  }
+}
+static unsigned grid_for(size_t n, unsigned max_blocks = 2048) {
+  size_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (unsigned)b;
+}
+
+static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho, uint64_t a_out[4], uint64_t b_out[4]) {
+  ScArgs A;
+  memset(&A, 0, sizeof A);
+  gmh::Fr tau = gmh::Fr::from_limbs(S->twist);
+  gmh::Fr tau_msg = fold ? tau.sqr() : tau;
+  gmh::Fr rho_tau = rho * tau;
+  A.f_in = S->f[S->cur];
+  A.g_in = S->g[S->cur];
+  A.f_out = S->f[S->cur ^ 1];
+  A.g_out = S->g[S->cur ^ 1];
+  A.nf_in = S->nf;
+  A.ng_in = S->ng;
+  memcpy(A.rho_tau, rho_tau.l, 32);
+  memcpy(A.rho, rho.l, 32);
+  memcpy(A.tau, tau_msg.l, 32);
+  gmh::Fr tau2 = tau_msg.sqr();
+  make_pow_table(tau2, A.tau2);
+  const size_t nf = fold ? (S->nf + 1) / 2 : S->nf, ng = fold ? (S->ng + 1) / 2 : S->ng;
+  const size_t pf = (nf + 1) / 2, pg = (ng + 1) / 2;
+  A.npairs = pf > pg ? pf : pg;
+  // shard origin: tau_msg^(2 * first pair) where first pair = (element offset after fold) / 2
+  uint64_t elem_off = fold ? S->pair_offset : 2 * S->pair_offset;  // pair_offset counts pairs of the CURRENT vectors
+  {
+    uint64_t first_pair = elem_off / 2;
+    gmh::Fr o = gmh::Fr::one();
+    gmh::Fr base = tau2;
+    uint64_t e = first_pair;
+    while (e) {
+      if (e & 1) o = o * base;
+      base = base.sqr();
+      e >>= 1;
+    }
+    memcpy(A.origin, o.l, 32);
+  }
+  // threads: power of two, up to 2^17 (512 blocks of 256)
+  uint32_t lt = 8;
+  while (lt < 17 && ((size_t)1 << lt) < A.npairs) lt++;
+  A.log_threads = lt;
+  const unsigned blocks = (unsigned)(((size_t)1 << lt) / 256);
+  hipStream_t st = C->stream;
+  if (fold && msg)
+    hipLaunchKernelGGL((k_sc_round<true, true>), dim3(blocks), dim3(256), 0, st, A, S->partials);
+  else if (fold)
+    hipLaunchKernelGGL((k_sc_round<true, false>), dim3(blocks), dim3(256), 0, st, A, S->partials);
+  else
+    hipLaunchKernelGGL((k_sc_round<false, true>), dim3(blocks), dim3(256), 0, st, A, S->partials);
+  GM_HIP(hipGetLastError());
+  if (msg) {
+    GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, st));
+    GM_HIP(hipStreamSynchronize(st));
+    gmh::Fr a = gmh::Fr::zero(), b = gmh::Fr::zero();
+    for (unsigned i = 0; i < blocks; i++) {
+      a = a + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8);
+      b = b + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8 + 4);
+    }
+    a.to_limbs(a_out);
+    b.to_limbs(b_out);
+  }
+  if (fold) {
+    S->cur ^= 1;
+    S->nf = (S->nf + 1) / 2;
+    S->ng = (S->ng + 1) / 2;
+    gmh::Fr t2 = tau.sqr();
+    t2.to_limbs(S->twist);
+    S->pair_offset = S->pair_offset / 2;
+  }
+  return GM_OK;
+}
+
+static size_t ceil_log2_sz(size_t n) {
+  size_t b = 0, v = n > 1 ? n - 1 : 0;
+  while (v) {
+    b++;
+    v >>= 1;
+  }
+  return b;
+}
+
+int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_t ng, bool src_is_device,
+              const uint64_t twist[4], uint64_t* handle) {
+  GM_CHECK(nf >= 1 && ng >= 1, GM_EINVAL, "sumcheck: empty vectors");
+  auto S = std::make_unique<Sumcheck>();
+  S->nf = nf;
+  S->ng = ng;
+  memcpy(S->twist, twist, 32);
+  S->tot_rounds = ceil_log2_sz(nf > ng ? nf : ng);  // time_prover.rs:35-38
+  GM_HIP(hipMalloc((void**)&S->f[0], nf * FR_BYTES));
+  GM_HIP(hipMalloc((void**)&S->f[1], ((nf + 1) / 2) * FR_BYTES));
+  GM_HIP(hipMalloc((void**)&S->g[0], ng * FR_BYTES));
+  GM_HIP(hipMalloc((void**)&S->g[1], ((ng + 1) / 2) * FR_BYTES));
+  GM_HIP(hipMalloc((void**)&S->partials, 512 * 2 * FR_BYTES));
+  GM_HIP(hipHostMalloc((void**)&S->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
+  hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  GM_HIP(hipMemcpyAsync(S->f[0], f_src, nf * FR_BYTES, kind, C->stream));
+  GM_HIP(hipMemcpyAsync(S->g[0], g_src, ng * FR_BYTES, kind, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  *handle = put_prover(std::move(S));
+  return GM_OK;
+}
+
+void sc_destroy(Sumcheck* S) {
+  for (int i = 0; i < 2; i++) {
+    if (S->f[i]) (void)hipFree(S->f[i]);
+    if (S->g[i]) (void)hipFree(S->g[i]);
+  }
+  if (S->partials) (void)hipFree(S->partials);
+  if (S->host_partials) (void)hipHostFree(S->host_partials);
+}
+
+// Prover::next_message                                                      time_prover.rs:83-123
+int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_CHECK(S->round <= S->tot_rounds, GM_ESTATE, "More rounds than needed.");
+  const bool fold = challenge != nullptr;
+  const bool msg = S->round != S->tot_rounds;
+  gmh::Fr rho = fold ? gmh::Fr::from_limbs(challenge) : gmh::Fr::zero();
+  if (fold || msg) {
+    int rc = sc_launch(C, S, fold, msg, rho, a, b);
+    if (rc) return rc;
+  }
+  if (!msg) {
+    *has_msg = 0;
+    return GM_OK;
+  }
+  S->round += 1;
+  *has_msg = 1;
+  return GM_OK;
+}
+
+int sc_fold(Context* C, Sumcheck* S, const uint64_t challenge[4]) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  uint64_t a[4], b[4];
+  return sc_launch(C, S, true, false, gmh::Fr::from_limbs(challenge), a, b);
+}
+
+int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (S->round != S->tot_rounds) {
+    *has = 0;
+    return GM_OK;
+  }
+  GM_HIP(hipMemcpyAsync(f0, S->f[S->cur], FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipMemcpyAsync(g0, S->g[S->cur], FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  *has = 1;
+  return GM_OK;
+}
+
+// ---- vector helper entry points (called from capi.hip) ---------------------------------------
+static int upload_small(Context* C, const void* src, size_t bytes, uint8_t** dptr) {
+  int rc = C->fr_scratch.ensure(1 << 20);
+  if (rc) return rc;
+  GM_HIP(hipMemcpyAsync(C->fr_scratch.p, src, bytes, hipMemcpyHostToDevice, C->stream));
+  *dptr = C->fr_scratch.as<uint8_t>();
+  return GM_OK;
+}
+
+int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out) {
+  const size_t m = (f->len + 1) / 2;
+  GM_CHECK(out->cap >= m, GM_EINVAL, "fold: output capacity %zu < %zu", out->cap, m);
+  GM_CHECK(out != f, GM_EINVAL, "fold: output must not alias the input");
+  uint8_t* dr;
+  int rc = upload_small(C, r, 32, &dr);
+  if (rc) return rc;
+  if (m) hipLaunchKernelGGL(k_fold, dim3(grid_for(m)), dim3(256), 0, C->stream, f->d, f->len, (const uint32_t*)dr, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = m;
+  return GM_OK;
+}
+
+int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out) {
+  GM_CHECK(out->cap >= n, GM_EINVAL, "powers: output capacity %zu < %zu", out->cap, n);
+  PowTable t;
+  make_pow_table(gmh::Fr::from_limbs(x), t);
+  if (n) hipLaunchKernelGGL(k_powers, dim3(grid_for(n, 512)), dim3(256), 0, C->stream, t, n, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = n;
+  return GM_OK;
+}
+
+int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out) {
+  GM_CHECK(k >= 1 && k <= 32, GM_EINVAL, "tensor: need 1 <= k <= 32 elements (got %zu)", k);
+  const size_t n = (size_t)1 << k;
+  GM_CHECK(out->cap >= n, GM_EINVAL, "tensor: output capacity %zu < %zu", out->cap, n);
+  const uint32_t klo = (uint32_t)(k / 2 > 0 ? (k + 1) / 2 : k), khi = (uint32_t)k - klo;
+  int rc = C->fr_scratch.ensure((1 << 20) + (((size_t)1 << klo) + ((size_t)1 << khi)) * FR_BYTES);
+  if (rc) return rc;
+  uint8_t* base = C->fr_scratch.as<uint8_t>();
+  GM_HIP(hipMemcpyAsync(base, rhos, k * 32, hipMemcpyHostToDevice, C->stream));
+  uint8_t* lo = base + (1 << 20);
+  uint8_t* hi = lo + ((size_t)1 << klo) * FR_BYTES;
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << klo)), dim3(256), 0, C->stream, (const uint32_t*)base, klo, lo);
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << khi)), dim3(256), 0, C->stream,
+                     (const uint32_t*)(base + (size_t)klo * 32), khi, hi);
+  hipLaunchKernelGGL(k_tensor, dim3(grid_for(n)), dim3(256), 0, C->stream, lo, hi, klo, n, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = n;
+  return GM_OK;
+}
+
+int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out) {
+  GM_CHECK(a->len == b->len, GM_EINVAL, "hadamard: lengths differ (%zu vs %zu)", a->len, b->len);
+  GM_CHECK(out->cap >= a->len, GM_EINVAL, "hadamard: output capacity %zu < %zu", out->cap, a->len);
+  if (a->len) hipLaunchKernelGGL(k_hadamard, dim3(grid_for(a->len)), dim3(256), 0, C->stream, a->d, b->d, a->len, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = a->len;
+  return GM_OK;
+}
+
+int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]) {
+  GM_CHECK(a->len == b->len, GM_EINVAL, "ip: lengths differ (%zu vs %zu)", a->len, b->len);
+  const unsigned blocks = grid_for(a->len, 512);
+  int rc = C->fr_scratch.ensure(1 << 20);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_ip, dim3(blocks), dim3(256), 0, C->stream, a->d, b->d, a->len, C->fr_scratch.as<uint8_t>());
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, (size_t)blocks * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  gmh::Fr s = gmh::Fr::zero();
+  for (unsigned i = 0; i < blocks; i++) s = s + gmh::Fr::from_limbs(C->host_small + (size_t)i * 4);
+  s.to_limbs(result);
+  return GM_OK;
+}
+
+int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results) {
+  GM_CHECK(npoints >= 1 && npoints <= 3, GM_EINVAL, "eval_le: 1..3 points per pass (got %zu)", npoints);
+  EvalArgs A;
+  memset(&A, 0, sizeof A);
+  for (size_t k = 0; k < npoints; k++) make_pow_table(gmh::Fr::from_limbs(xs + 4 * k), A.xt[k]);
+  A.npoints = (uint32_t)npoints;
+  uint32_t lt = 8;
+  while (lt < 17 && ((size_t)1 << lt) < p->len) lt++;
+  A.log_threads = lt;
+  const unsigned blocks = (unsigned)(((size_t)1 << lt) / 256);
+  int rc = C->fr_scratch.ensure(1 << 20);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_eval_le, dim3(blocks), dim3(256), 0, C->stream, p->d, p->len, A, C->fr_scratch.as<uint8_t>());
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, (size_t)blocks * 3 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  for (size_t k = 0; k < npoints; k++) {
+    gmh::Fr s = gmh::Fr::zero();
+    for (unsigned i = 0; i < blocks; i++) s = s + gmh::Fr::from_limbs(C->host_small + ((size_t)i * 3 + k) * 4);
+    s.to_limbs(results + 4 * k);
+  }
+  return GM_OK;
+}
+
+int fr_trim(Context* C, FrVec* v) {
+  // DensePolynomial::from_coefficients_vec strips high zero coefficients
+  if (v->len == 0) return GM_OK;
+  int rc = C->fr_scratch.ensure(1 << 20);
+  if (rc) return rc;
+  GM_HIP(hipMemsetAsync(C->fr_scratch.p, 0, 8, C->stream));
+  hipLaunchKernelGGL(k_high_nonzero, dim3(grid_for(v->len)), dim3(256), 0, C->stream, v->d, v->len,
+                     C->fr_scratch.as<unsigned long long>());
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, 8, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  v->len = (size_t)C->host_small[0];
+  return GM_OK;
+}
+
+int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out) {
+  size_t n = 0;
+  for (size_t j = 0; j < k; j++) n = polys[j]->len > n ? polys[j]->len : n;
+  GM_CHECK(out->cap >= n, GM_EINVAL, "lincomb: output capacity %zu < %zu", out->cap, n);
+  for (size_t j = 0; j < k; j++) GM_CHECK(polys[j] != out, GM_EINVAL, "lincomb: output must not alias an input");
+  if (n == 0) {
+    out->len = 0;
+    return GM_OK;
+  }
+  for (size_t j0 = 0; j0 < k || j0 == 0; j0 += 24) {
+    LincombArgs A;
+    memset(&A, 0, sizeof A);
+    size_t cnt = k - j0 < 24 ? k - j0 : 24;
+    A.k = (uint32_t)cnt;
+    for (size_t j = 0; j < cnt; j++) {
+      A.p[j] = polys[j0 + j]->d;
+      A.len[j] = polys[j0 + j]->len;
+      memcpy(A.c[j], coeffs + 4 * (j0 + j), 32);
+    }
+    if (j0 == 0)
+      hipLaunchKernelGGL(k_lincomb, dim3(grid_for(n)), dim3(256), 0, C->stream, A, n, out->d);
+    else
+      hipLaunchKernelGGL(k_lincomb_acc, dim3(grid_for(n)), dim3(256), 0, C->stream, A, n, out->d);
+    if (k == 0) break;
+  }
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = n;
+  return fr_trim(C, out);
+}
+
+int fr_fill(Context* C, FrVec* v, const uint64_t val[4]) {
+  uint8_t* dv;
+  int rc = upload_small(C, val, 32, &dv);
+  if (rc) return rc;
+  if (v->len) hipLaunchKernelGGL(k_fill, dim3(grid_for(v->len)), dim3(256), 0, C->stream, v->d, v->len, (const uint32_t*)dv);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
+
+// quotient of f by prod_j (x - points[j]): k successive divisions by linear factors.
+// rem_out[j] = value of the j-th intermediate polynomial at points[j] (= f(points[0]) for j = 0).
+int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k, FrVec* q, uint64_t* rem_out) {
+  GM_CHECK(k >= 1 && k <= 8, GM_EINVAL, "div_vanishing: 1..8 points (got %zu)", k);
+  GM_CHECK(q != f, GM_EINVAL, "div_vanishing: quotient must not alias the dividend");
+  if (f->len <= k) {
+    q->len = 0;
+    return GM_OK;
+  }
+  GM_CHECK(q->cap >= f->len - 1, GM_EINVAL, "div_vanishing: quotient capacity %zu < %zu", q->cap, f->len - 1);
+  const size_t n0 = f->len;
+  const size_t nch0 = (n0 + DIV_K - 1) / DIV_K;
+  const size_t seg = 64;
+  const size_t nseg0 = (nch0 + seg - 1) / seg;
+  // scratch: [1 MiB small][chunk sums][seg sums][carry][tmp poly for odd passes]
+  size_t need = (1 << 20) + (nch0 + 2 * nseg0 + 8) * FR_BYTES + n0 * FR_BYTES;
+  int rc = C->fr_scratch.ensure(need);
+  if (rc) return rc;
+  uint8_t* base = C->fr_scratch.as<uint8_t>();
+  uint8_t* sums = base + (1 << 20);
+  uint8_t* seg_sums = sums + nch0 * FR_BYTES;
+  uint8_t* carry = seg_sums + nseg0 * FR_BYTES;
+  uint8_t* tmp = carry + (nseg0 + 8) * FR_BYTES;
+  const uint8_t* src = f->d;
+  size_t n = n0;
+  for (size_t j = 0; j < k; j++) {
+    // ping-pong so the final quotient lands in q: passes write q, tmp, q, ... ending in q
+    uint8_t* dst = ((k - 1 - j) % 2 == 0) ? q->d : tmp;
+    gmh::Fr alpha = gmh::Fr::from_limbs(points + 4 * j);
+    gmh::Fr m = alpha;
+    for (int s = 0; s < 6; s++) m = m.sqr();  // alpha^64 = alpha^DIV_K
+    PowTable mt;
+    make_pow_table(m, mt);
+    uint64_t small[8];
+    memcpy(small, alpha.l, 32);
+    memcpy(small + 4, m.l, 32);
+    GM_HIP(hipMemcpyAsync(base, small, 64, hipMemcpyHostToDevice, C->stream));
+    const size_t nch = (n + DIV_K - 1) / DIV_K, nseg = (nch + seg - 1) / seg;
+    hipLaunchKernelGGL(k_div_phase1, dim3(grid_for(nch)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums);
+    hipLaunchKernelGGL(k_div_phase2a, dim3(grid_for(nseg)), dim3(256), 0, C->stream, sums, nch, seg, (const uint32_t*)(base + 32), seg_sums);
+    hipLaunchKernelGGL(k_div_phase2b, dim3(1), dim3(64), 0, C->stream, seg_sums, nseg, seg, nch, mt, carry);
+    hipLaunchKernelGGL(k_div_phase3, dim3(grid_for(nch)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums, carry, seg, mt, dst,
+                       base + 128 + j * 32);
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipStreamSynchronize(C->stream));  // `small` staging reused next pass
+    src = dst;
+    n -= 1;
+  }
+  if (rem_out) {
+    GM_HIP(hipMemcpyAsync(rem_out, base + 128, k * 32, hipMemcpyDeviceToHost, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+  }
+  q->len = n;
+  return GM_OK;
+}
+
+}  // namespace gm

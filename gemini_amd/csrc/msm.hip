@@ -1,0 +1,636 @@
+// G1 multi-scalar multiplication for gfx950: signed-digit bucket method (Pippenger).
+//
+// Replaces ark-ec 0.4.2 `VariableBaseMSM::msm_bigint` -- in-tree statement of the algorithm:
+// src/kzg/msm/variable_base.rs:21-61 (signed digits), :99-176 (buckets, running sum, Horner).
+// The result is the group element sum_i s_i P_i, which does not depend on the window width,
+// bucket order or summation order, so it is bit-exact against the reference after
+// normalisation.  The decomposition below is GPU-first, not a translation of the CPU loop:
+//
+//   1. k_msm_hist     scalars -> signed c-bit digits; histogram of (window, |digit|) keys
+//   2. k_scan         exclusive scan -> bucket offsets
+//   3. k_msm_scatter  counting sort: entries[] = (key, sign, pair index) grouped by key
+//   4. k_acc0         the hot kernel.  Thread t sums the affine bases of entries
+//                     [t*L, (t+1)*L) into an XYZZ accumulator, run by run.  Work per lane is
+//                     exactly L mixed additions whatever the digit distribution is -- the
+//                     reference's own benchmark inputs put EVERY point of a window in one bucket
+//                     (src/circuit.rs:349-365), which serialises a thread-per-bucket kernel.
+//                     Runs interior to a chunk are complete buckets; the first and last run
+//                     of a chunk are emitted as keyed partials.
+//   5. k_merge        wave-cooperative segmented reduction of keyed partials (128 slots ->
+//                     <= 2 per wave per level, values staged in LDS, keys in registers, 64-wide
+//                     shuffles), repeated until one wave remains.
+//   6. k_group_sum    bucket reduction by plain sums only: sum_b b*B_b = sum_j 2^j Z_j + Tot
+//                     with Z_j = sum of buckets whose index has bit j set, computed as row /
+//                     column sums followed by bit-plane sums (16 lanes per output, tree depth
+//                     instead of the 2*2^(c-1) sequential additions of the CPU running sum).
+//   7. host           Horner over <= 256 bit positions on the (W x c) plane sums
+//                     (src/kzg/msm/variable_base.rs:168-175 is the window Horner).
+#include <algorithm>
+#include <vector>
+
+#include "ctx.hpp"
+#include "g1.cuh"
+#include "host_field.hpp"
+
+namespace gm {
+
+constexpr uint32_t KEY_INV = 0xffffffffu;
+constexpr int XYZZ_BYTES = 192;
+constexpr int AFF_BYTES = 96;
+
+// ------------------------------------------------------------------------------------------
+// digits
+// ------------------------------------------------------------------------------------------
+struct DigitIter {
+  uint32_t s[8];
+  uint32_t carry;
+  GM_DEV void init(const uint32_t* p, bool active, int mont) {
+    if (active) {
+      Fr v = fp_load<FrParams>(p);
+      if (mont) v = fp_from_mont<FrParams>(v);  // Fr::into_bigint
+#pragma unroll
+      for (int i = 0; i < 8; i++) s[i] = v.l[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) s[i] = 0;
+    }
+    carry = 0;
+  }
+  // next signed digit in [-2^(c-1), 2^(c-1)]; semantics of variable_base.rs:21-61 with
+  // c * W >= 256 so the top digit needs no special case
+  GM_DEV int32_t next(int c) {
+    uint32_t raw = s[0] & ((1u << c) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; i++) s[i] = (s[i] >> c) | (s[i + 1] << (32 - c));
+    s[7] >>= c;
+    uint32_t coef = raw + carry;
+    carry = (coef + (1u << (c - 1))) >> c;
+    return (int32_t)coef - (int32_t)(carry << c);
+  }
+};
+
+// One atomic per wave when every participating lane has the same key (the all-equal-scalars
+// case would otherwise serialise 64 same-address atomics per instruction).
+GM_DEV uint32_t wave_atomic_inc(uint32_t* arr, uint32_t key) {
+  const int lane = threadIdx.x & 63;
+  uint64_t valid = __ballot(key != KEY_INV);
+  if (valid == 0) return 0;
+  int first_lane = __ffsll((unsigned long long)valid) - 1;
+  uint32_t first = __shfl(key, first_lane);
+  uint64_t same = __ballot(key == first);
+  uint32_t pos = 0;
+  if (same == valid) {
+    uint32_t base = 0;
+    if (lane == first_lane) base = atomicAdd(arr + first, (uint32_t)__popcll((unsigned long long)same));
+    base = __shfl(base, first_lane);
+    pos = base + (uint32_t)__popcll((unsigned long long)(same & ((1ull << lane) - 1ull)));
+  } else if (key != KEY_INV) {
+    pos = atomicAdd(arr + key, 1u);
+  }
+  return pos;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int mont, int c,
+                                                    int W, uint32_t B, uint32_t* __restrict__ counts_or_cursor,
+                                                    uint64_t* __restrict__ entries) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool active = i < n;
+  DigitIter it;
+  it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
+  for (int w = 0; w < W; w++) {
+    int32_t d = it.next(c);
+    uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+    uint32_t key = (active && d != 0) ? (uint32_t)w * B + (mag - 1u) : KEY_INV;
+    uint32_t pos = wave_atomic_inc(counts_or_cursor, key);
+    if (SCATTER && key != KEY_INV) {
+      entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)i;
+    }
+  }
+}
+
+// exclusive scan of m counters by one 1024-thread block
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ counts, uint32_t m,
+                                               uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (m + 1023u) / 1024u;
+  const uint32_t lo = min(tid * chunk, m), hi = min(lo + chunk, m);
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += counts[i];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - s;
+  for (uint32_t i = lo; i < hi; i++) {
+    offsets[i] = run;
+    cursor[i] = run;
+    run += counts[i];
+  }
+  if (tid == 1023) offsets[m] = part[1023];
+}
+
+// ------------------------------------------------------------------------------------------
+// level 0: chunk-per-thread accumulation of sorted entries
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entries,
+                                              const uint32_t* __restrict__ total_ptr,
+                                              const uint8_t* __restrict__ bases, long long first, long long step,
+                                              uint32_t L, uint32_t* __restrict__ pk, uint8_t* __restrict__ pp,
+                                              uint8_t* __restrict__ buckets) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = *total_ptr;
+  const uint64_t start = (uint64_t)t * L;
+  uint32_t head_key = KEY_INV, tail_key = KEY_INV;
+  if (start < total) {
+    const uint64_t end = min(start + (uint64_t)L, total);
+    G1Xyzz acc = G1Xyzz::identity();
+    uint32_t cur = KEY_INV;
+    bool first_run = true;
+    for (uint64_t i = start; i < end; i++) {
+      const uint64_t e = entries[i];
+      const uint32_t key = (uint32_t)(e >> 32);
+      if (key != cur) {
+        if (cur != KEY_INV) {
+          if (first_run) {
+            head_key = cur;
+            g1_store_xyzz(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES, acc);
+            first_run = false;
+          } else {
+            g1_store_xyzz(buckets + (size_t)cur * XYZZ_BYTES, acc);  // interior run = whole bucket
+          }
+        }
+        cur = key;
+        acc = G1Xyzz::identity();
+      }
+      const long long idx = first + step * (long long)(e & 0x7fffffffull);
+      G1Affine p = g1_load_affine(bases + (size_t)idx * AFF_BYTES);
+      if ((e >> 31) & 1ull) p.y = fq_neg(p.y);
+      xyzz_madd(acc, p);
+    }
+    if (first_run) {
+      head_key = cur;
+      g1_store_xyzz(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES, acc);
+    } else {
+      tail_key = cur;
+      g1_store_xyzz(pp + (size_t)(2 * (size_t)t + 1) * XYZZ_BYTES, acc);
+    }
+  }
+  pk[2 * (size_t)t] = head_key;
+  pk[2 * (size_t)t + 1] = tail_key;
+}
+
+// ------------------------------------------------------------------------------------------
+// merge levels: one wave reduces 128 keyed slots (sorted by key, holes allowed) to <= 2
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_in, const uint8_t* __restrict__ pts_in,
+                                              uint32_t E, uint32_t* __restrict__ keys_out,
+                                              uint8_t* __restrict__ pts_out, uint8_t* __restrict__ buckets,
+                                              int final_level) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[128 * XYZZ_BYTES];
+  const int lane = threadIdx.x;
+  const uint32_t wave = blockIdx.x;
+  const uint32_t s0 = wave * 128u + 2u * lane;
+  uint32_t hk = s0 < E ? keys_in[s0] : KEY_INV;
+  uint32_t tk = s0 + 1 < E ? keys_in[s0 + 1] : KEY_INV;
+  uint32_t hs = 2 * lane, ts = 2 * lane + 1;  // LDS slot ids
+  if (hk != KEY_INV) g1_store_xyzz(lds + hs * XYZZ_BYTES, g1_load_xyzz(pts_in + (size_t)s0 * XYZZ_BYTES));
+  if (tk != KEY_INV) g1_store_xyzz(lds + ts * XYZZ_BYTES, g1_load_xyzz(pts_in + (size_t)(s0 + 1) * XYZZ_BYTES));
+  // a producer emits (head, INV) or (head, tail) or (INV, INV); normalise (INV, tail) defensively
+  if (hk == KEY_INV && tk != KEY_INV) {
+    hk = tk;
+    hs = ts;
+    tk = KEY_INV;
+  }
+  // equal head/tail keys cannot be produced, but merging them keeps the invariant "hk != tk"
+  __syncthreads();
+  if (hk != KEY_INV && hk == tk) {
+    G1Xyzz a = g1_load_xyzz(lds + hs * XYZZ_BYTES);
+    xyzz_add(a, g1_load_xyzz(lds + ts * XYZZ_BYTES));
+    g1_store_xyzz(lds + hs * XYZZ_BYTES, a);
+    tk = KEY_INV;
+  }
+  __syncthreads();
+
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t bhk = __shfl_down(hk, d), bhs = __shfl_down(hs, d);
+    const uint32_t btk = __shfl_down(tk, d), bts = __shfl_down(ts, d);
+    const bool act = (lane & (2 * d - 1)) == 0;
+    bool do_add = false;
+    uint32_t add_dst = 0, add_src = 0;
+    uint32_t f1k = KEY_INV, f1s = 0, f2k = KEY_INV, f2s = 0;  // runs that become interior
+    if (act && bhk != KEY_INV) {
+      if (hk == KEY_INV) {
+        hk = bhk; hs = bhs; tk = btk; ts = bts;
+      } else {
+        const bool a_two = tk != KEY_INV, b_two = btk != KEY_INV;
+        const uint32_t alk = a_two ? tk : hk, als = a_two ? ts : hs;
+        if (alk == bhk) {
+          do_add = true; add_dst = als; add_src = bhs;
+          if (b_two) {
+            if (a_two) { f1k = alk; f1s = als; }
+            tk = btk; ts = bts;
+          }
+        } else {
+          if (a_two) { f1k = tk; f1s = ts; }
+          if (b_two) { f2k = bhk; f2s = bhs; tk = btk; ts = bts; }
+          else { tk = bhk; ts = bhs; }
+        }
+      }
+    }
+    if (__any(do_add)) {
+      if (do_add) {
+        G1Xyzz a = g1_load_xyzz(lds + add_dst * XYZZ_BYTES);
+        xyzz_add(a, g1_load_xyzz(lds + add_src * XYZZ_BYTES));
+        g1_store_xyzz(lds + add_dst * XYZZ_BYTES, a);
+      }
+    }
+    if (f1k != KEY_INV) g1_store_xyzz(buckets + (size_t)f1k * XYZZ_BYTES, g1_load_xyzz(lds + f1s * XYZZ_BYTES));
+    if (f2k != KEY_INV) g1_store_xyzz(buckets + (size_t)f2k * XYZZ_BYTES, g1_load_xyzz(lds + f2s * XYZZ_BYTES));
+    __syncthreads();
+  }
+  if (lane == 0) {
+    if (final_level) {
+      if (hk != KEY_INV) g1_store_xyzz(buckets + (size_t)hk * XYZZ_BYTES, g1_load_xyzz(lds + hs * XYZZ_BYTES));
+      if (tk != KEY_INV) g1_store_xyzz(buckets + (size_t)tk * XYZZ_BYTES, g1_load_xyzz(lds + ts * XYZZ_BYTES));
+    } else {
+      keys_out[2 * (size_t)wave] = hk;
+      keys_out[2 * (size_t)wave + 1] = tk;
+      if (hk != KEY_INV) g1_store_xyzz(pts_out + (size_t)(2 * (size_t)wave) * XYZZ_BYTES, g1_load_xyzz(lds + hs * XYZZ_BYTES));
+      if (tk != KEY_INV) g1_store_xyzz(pts_out + (size_t)(2 * (size_t)wave + 1) * XYZZ_BYTES, g1_load_xyzz(lds + ts * XYZZ_BYTES));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bucket reduction by plain sums: 16 lanes per output element
+// ------------------------------------------------------------------------------------------
+enum { GS_ROW = 0, GS_COL = 1, GS_PLANE = 2 };
+struct GroupSumArgs {
+  int mode;
+  uint32_t n_out;      // number of outputs
+  uint32_t per_win;    // outputs per window
+  uint32_t win_stride; // input elements per window
+  uint32_t lo_bits;    // ROW/COL: a (low field width);   PLANE: nb (log2 of the per-window length)
+  uint32_t len;        // ROW: 2^a, COL: 2^h, PLANE: unused
+};
+
+GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
+  G1Xyzz r;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    r.x.l[i] = __shfl_xor(v.x.l[i], m);
+    r.y.l[i] = __shfl_xor(v.y.l[i], m);
+    r.zz.l[i] = __shfl_xor(v.zz.l[i], m);
+    r.zzz.l[i] = __shfl_xor(v.zzz.l[i], m);
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_group_sum(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                   GroupSumArgs a) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t o = gt >> 4, q = gt & 15u;
+  G1Xyzz acc = G1Xyzz::identity();
+  if (o < a.n_out) {
+    const uint32_t w = o / a.per_win, r = o % a.per_win;
+    const size_t base = (size_t)w * a.win_stride;
+    if (a.mode == GS_ROW) {
+      for (uint32_t e = q; e < a.len; e += 16) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)r << a.lo_bits) + e) * XYZZ_BYTES));
+    } else if (a.mode == GS_COL) {
+      for (uint32_t e = q; e < a.len; e += 16) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)e << a.lo_bits) + r) * XYZZ_BYTES));
+    } else {
+      const uint32_t nb = a.lo_bits;
+      if (r == nb) {  // total
+        for (uint32_t e = q; e < (1u << nb); e += 16) xyzz_add(acc, g1_load_xyzz(in + (base + e) * XYZZ_BYTES));
+      } else {        // elements whose bit r is set
+        const uint32_t half = nb ? (1u << (nb - 1)) : 0u;
+        for (uint32_t e = q; e < half; e += 16) {
+          uint32_t v = ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u));
+          xyzz_add(acc, g1_load_xyzz(in + (base + v) * XYZZ_BYTES));
+        }
+      }
+    }
+  }
+#pragma unroll 1
+  for (int m = 8; m >= 1; m >>= 1) {
+    G1Xyzz other = xyzz_shfl_xor(acc, m);
+    xyzz_add(acc, other);
+  }
+  if (o < a.n_out && q == 0) g1_store_xyzz(out + (size_t)o * XYZZ_BYTES, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// bases import / generation
+// ------------------------------------------------------------------------------------------
+// staging (stride >= 96, optional infinity flag at byte 96) -> packed 96-byte records
+__global__ void k_pack_bases(const uint8_t* __restrict__ src, size_t stride, size_t n, uint8_t* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(src + i * stride);
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst + i * AFF_BYTES);
+  bool inf = stride >= 97 && src[i * stride + 96] != 0;
+#pragma unroll
+  for (int k = 0; k < 24; k++) d[k] = inf ? 0u : s[k];
+}
+
+// out[i] = k_i * base via 32 windows of 8 bits against a (32 x 256)-entry affine table
+__global__ __launch_bounds__(256) void k_fixed_base_table(const uint8_t* __restrict__ base, uint8_t* __restrict__ table) {
+  // table[w][d] = d * 2^(8w) * base ; one thread per (w, d): double-and-add of the 13-bit... d*2^(8w)
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 32 * 256) return;
+  const uint32_t w = t >> 8, dgt = t & 255u;
+  G1Affine b = g1_load_affine(base);
+  G1Xyzz acc = G1Xyzz::identity();
+  // scalar = dgt << (8w): process bits of dgt from the top, then 8w doublings
+  for (int bit = 7; bit >= 0; bit--) {
+    acc = xyzz_dbl(acc);
+    if ((dgt >> bit) & 1u) xyzz_madd(acc, b);
+  }
+  for (uint32_t k = 0; k < 8 * w; k++) acc = xyzz_dbl(acc);
+  g1_store_xyzz(table + (size_t)t * XYZZ_BYTES, acc);
+}
+
+// Fq inversion by Fermat (a^(q-2)); used once per generated point
+GM_DEV Fq fq_inv(const Fq& a) {
+  // q - 2, little-endian 32-bit limbs
+  uint32_t e[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) e[i] = FqParams::MOD[i];
+  e[0] -= 2u;
+  Fq acc = Fq::one();
+  for (int i = 380; i >= 0; i--) {
+    acc = fq_sqr(acc);
+    if ((e[i >> 5] >> (i & 31)) & 1u) acc = fq_mul(acc, a);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void k_xyzz_to_affine(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Xyzz p = g1_load_xyzz(in + i * XYZZ_BYTES);
+  G1Affine a;
+  if (p.is_identity()) {
+    a.x = Fq::zero();
+    a.y = Fq::zero();
+  } else {
+    // x = X/ZZ, y = Y/ZZZ ; 1/ZZZ = inv, 1/ZZ = inv * ZZZ / ZZ ... use one inversion of ZZ*ZZZ
+    Fq t = fq_mul(p.zz, p.zzz);
+    Fq ti = fq_inv(t);
+    a.x = fq_mul(p.x, fq_mul(ti, p.zzz));
+    a.y = fq_mul(p.y, fq_mul(ti, p.zz));
+  }
+  g1_store_affine(out + i * AFF_BYTES, a);
+}
+
+// scalars canonical (mont = 0) or Montgomery; table in XYZZ; output affine
+__global__ __launch_bounds__(256) void k_fixed_base_mul(const uint32_t* __restrict__ scalars, int mont, size_t n,
+                                                        const uint8_t* __restrict__ table_aff, uint8_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr s = fp_load<FrParams>(scalars + 8 * i);
+  if (mont) s = fp_from_mont<FrParams>(s);
+  G1Xyzz acc = G1Xyzz::identity();
+  for (int w = 0; w < 32; w++) {
+    uint32_t dgt = (s.l[w >> 2] >> (8 * (w & 3))) & 255u;
+    if (dgt) {
+      G1Affine p = g1_load_affine(table_aff + ((size_t)w * 256 + dgt) * AFF_BYTES);
+      xyzz_madd(acc, p);
+    }
+  }
+  G1Affine a;
+  if (acc.is_identity()) {
+    a.x = Fq::zero();
+    a.y = Fq::zero();
+  } else {
+    Fq t = fq_mul(acc.zz, acc.zzz);
+    Fq ti = fq_inv(t);
+    a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
+    a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
+  }
+  g1_store_affine(out + i * AFF_BYTES, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int ceil_log2_sz(size_t n) {
+  int b = 0;
+  size_t v = n > 1 ? n - 1 : 0;
+  while (v) {
+    b++;
+    v >>= 1;
+  }
+  return b;
+}
+
+// window width: balances n*W mixed additions against W*2^(c-1) bucket work; tuned on MI355X
+static int choose_window(size_t n) {
+  int lg = ceil_log2_sz(n);
+  int c = lg - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  return c;
+}
+
+int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, int64_t step, const void* d_scalars,
+            int mont, size_t n, bool normalize, uint64_t out_jac[18]) {
+  gmh::G1 result = gmh::G1::identity();
+  if (n == 0) {
+    result.to_limbs(out_jac);
+    return GM_OK;
+  }
+  GM_CHECK(n < (1ull << 31), GM_EINVAL, "msm: n = %zu exceeds 2^31 - 1 pairs per call; chunk the stream", n);
+  {
+    int64_t last = first + step * (int64_t)(n - 1);
+    GM_CHECK(first >= 0 && last >= 0 && (size_t)first < nbases && (size_t)last < nbases, GM_EINVAL,
+             "msm: base range [%lld .. %lld] outside registered bases (len %zu)", (long long)first, (long long)last,
+             nbases);
+  }
+  std::lock_guard<std::mutex> lk(C->msm_mu);
+  MsmWorkspace& ws = C->msm;
+  hipStream_t st = C->stream;
+
+  const int c = C->msm_c_override ? C->msm_c_override : choose_window(n);
+  GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
+  const int W = (256 + c - 1) / c;
+  const uint32_t B = 1u << (c - 1);
+  const size_t nbuckets = (size_t)W * B;
+  const uint64_t N = (uint64_t)n * (uint64_t)W;
+  GM_CHECK(N < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)N);
+
+  // level-0 chunk length: keep >= 2 waves per SIMD when the problem is large enough
+  uint32_t L = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(4, (N + 131071) / 131072));
+  const uint64_t T0 = (N + L - 1) / L;
+  const uint64_t T0pad = (T0 + 255) / 256 * 256;
+  const uint64_t E1 = 2 * T0pad;
+
+  int rc;
+  if ((rc = ws.counts.ensure((nbuckets + 1) * 4))) return rc;
+  if ((rc = ws.offsets.ensure((nbuckets + 1) * 4))) return rc;
+  if ((rc = ws.cursor.ensure((nbuckets + 1) * 4))) return rc;
+  if ((rc = ws.entries.ensure(N * 8))) return rc;
+  if ((rc = ws.buckets.ensure(nbuckets * XYZZ_BYTES))) return rc;
+  if ((rc = ws.pk[0].ensure(E1 * 4))) return rc;
+  if ((rc = ws.pp[0].ensure(E1 * XYZZ_BYTES))) return rc;
+  const uint64_t E2 = 2 * ((E1 + 127) / 128);
+  if ((rc = ws.pk[1].ensure(E2 * 4))) return rc;
+  if ((rc = ws.pp[1].ensure(E2 * XYZZ_BYTES))) return rc;
+
+  const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
+  GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 1) * 4, st));
+  GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * XYZZ_BYTES, st));
+  const uint32_t dblocks = (uint32_t)((n + 255) / 256);
+  hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
+                     ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
+                     ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
+  hipLaunchKernelGGL(k_msm_digits<true>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
+                     ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
+  hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, ws.entries.as<uint64_t>(),
+                     ws.offsets.as<uint32_t>() + nbuckets, d_bases, (long long)first, (long long)step, L,
+                     ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
+  {
+    uint64_t E = E1;
+    int src = 0;
+    for (;;) {
+      uint32_t waves = (uint32_t)((E + 127) / 128);
+      int final_level = waves == 1;
+      hipLaunchKernelGGL(k_merge, dim3(waves), dim3(64), 0, st, ws.pk[src].as<uint32_t>(), ws.pp[src].as<uint8_t>(),
+                         (uint32_t)E, ws.pk[src ^ 1].as<uint32_t>(), ws.pp[src ^ 1].as<uint8_t>(),
+                         ws.buckets.as<uint8_t>(), final_level);
+      if (final_level) break;
+      E = 2ull * waves;
+      src ^= 1;
+    }
+  }
+
+  // bucket reduction: bits of the bucket index i = |d| - 1 (c - 1 bits) = (hi: h bits | lo: a bits)
+  const uint32_t nbits = (uint32_t)(c - 1);
+  const uint32_t a = nbits > 7 ? nbits / 2 : nbits;  // small tables: bit-planes straight from the buckets
+  const uint32_t h = nbits - a;
+  // plane layout per window: [col planes 0..a-1][row planes 0..h-1][tot]
+  const uint32_t planes_per_win = nbits + 1;
+  if ((rc = ws.planes.ensure((size_t)W * (planes_per_win + 1) * XYZZ_BYTES))) return rc;
+  const uint8_t* col_src = ws.buckets.as<uint8_t>();
+  uint32_t col_len_bits = a;
+  if (h > 0) {
+    if ((rc = ws.rows.ensure((size_t)W * (1u << h) * XYZZ_BYTES))) return rc;
+    if ((rc = ws.cols.ensure((size_t)W * (1u << a) * XYZZ_BYTES))) return rc;
+    GroupSumArgs ra{GS_ROW, (uint32_t)W << h, 1u << h, B, a, 1u << a};
+    hipLaunchKernelGGL(k_group_sum, dim3((ra.n_out * 16 + 255) / 256), dim3(256), 0, st, ws.buckets.as<uint8_t>(),
+                       ws.rows.as<uint8_t>(), ra);
+    GroupSumArgs ca{GS_COL, (uint32_t)W << a, 1u << a, B, a, 1u << h};
+    hipLaunchKernelGGL(k_group_sum, dim3((ca.n_out * 16 + 255) / 256), dim3(256), 0, st, ws.buckets.as<uint8_t>(),
+                       ws.cols.as<uint8_t>(), ca);
+    col_src = ws.cols.as<uint8_t>();
+  }
+  // planes over the column array (a bit-planes + total) and over the row array (h bit-planes + total)
+  uint8_t* planes = ws.planes.as<uint8_t>();
+  {
+    GroupSumArgs pa{GS_PLANE, (uint32_t)W * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0};
+    hipLaunchKernelGGL(k_group_sum, dim3((pa.n_out * 16 + 255) / 256), dim3(256), 0, st, col_src, planes, pa);
+  }
+  uint8_t* row_planes = planes + (size_t)W * (a + 1) * XYZZ_BYTES;
+  if (h > 0) {
+    GroupSumArgs pa{GS_PLANE, (uint32_t)W * (h + 1), h + 1, 1u << h, h, 0};
+    hipLaunchKernelGGL(k_group_sum, dim3((pa.n_out * 16 + 255) / 256), dim3(256), 0, st, ws.rows.as<uint8_t>(),
+                       row_planes, pa);
+  }
+  GM_HIP(hipGetLastError());
+  const size_t plane_count = (size_t)W * (a + 1) + (h > 0 ? (size_t)W * (h + 1) : 0);
+  const size_t plane_bytes = plane_count * XYZZ_BYTES;
+  if (ws.host_planes_cap < plane_bytes) {
+    if (ws.host_planes) (void)hipHostFree(ws.host_planes);
+    ws.host_planes = nullptr;
+    GM_HIP(hipHostMalloc((void**)&ws.host_planes, plane_bytes, hipHostMallocDefault));
+    ws.host_planes_cap = plane_bytes;
+  }
+  GM_HIP(hipMemcpyAsync(ws.host_planes, planes, plane_bytes, hipMemcpyDeviceToHost, st));
+  GM_HIP(hipStreamSynchronize(st));
+
+  // Horner over bit positions, windows high -> low (variable_base.rs:168-175 with the per-window
+  // weighted sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)
+  const uint64_t* hp = ws.host_planes;
+  auto col_plane = [&](int w, uint32_t j) { return gmh::xyzz_to_jac(hp + ((size_t)w * (a + 1) + j) * 24); };
+  auto row_plane = [&](int w, uint32_t j) {
+    return gmh::xyzz_to_jac(hp + ((size_t)W * (a + 1) + (size_t)w * (h + 1) + j) * 24);
+  };
+  for (int w = W - 1; w >= 0; w--) {
+    for (int j = c - 1; j >= 0; j--) {
+      result = result.dbl();
+      if ((uint32_t)j < nbits) {
+        gmh::G1 z = (uint32_t)j < a ? col_plane(w, (uint32_t)j) : row_plane(w, (uint32_t)j - a);
+        result = result.add(z);
+      }
+      if (j == 0) result = result.add(col_plane(w, a));  // Tot_w
+    }
+  }
+  if (normalize) result = result.normalized();
+  result.to_limbs(out_jac);
+  return GM_OK;
+}
+
+// ---- bases management -----------------------------------------------------------------------
+int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std::unique_ptr<Bases>& out) {
+  GM_CHECK(stride >= 96 && (stride % 8) == 0, GM_EINVAL, "bases: stride %zu must be >= 96 and a multiple of 8", stride);
+  auto b = std::make_unique<Bases>();
+  b->n = n;
+  if (n) {
+    GM_HIP(hipMalloc((void**)&b->d, n * AFF_BYTES));
+    if (stride == 96) {
+      GM_HIP(hipMemcpyAsync(b->d, bases, n * AFF_BYTES, hipMemcpyHostToDevice, C->stream));
+    } else {
+      uint8_t* stage = nullptr;
+      GM_HIP(hipMalloc((void**)&stage, n * stride));
+      GM_HIP(hipMemcpyAsync(stage, bases, n * stride, hipMemcpyHostToDevice, C->stream));
+      hipLaunchKernelGGL(k_pack_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C->stream, stage, stride, n, b->d);
+      GM_HIP(hipStreamSynchronize(C->stream));
+      GM_HIP(hipFree(stage));
+    }
+    GM_HIP(hipStreamSynchronize(C->stream));
+  }
+  out = std::move(b);
+  return GM_OK;
+}
+
+// fixed-base table (affine, 32 x 256 entries) for `base`
+static int build_fixed_table(Context* C, const uint64_t base_affine[12], uint8_t** table_aff) {
+  uint8_t *d_base = nullptr, *t_xyzz = nullptr;
+  GM_HIP(hipMalloc((void**)&d_base, AFF_BYTES));
+  GM_HIP(hipMalloc((void**)&t_xyzz, (size_t)32 * 256 * XYZZ_BYTES));
+  GM_HIP(hipMalloc((void**)table_aff, (size_t)32 * 256 * AFF_BYTES));
+  GM_HIP(hipMemcpyAsync(d_base, base_affine, AFF_BYTES, hipMemcpyHostToDevice, C->stream));
+  hipLaunchKernelGGL(k_fixed_base_table, dim3(32), dim3(256), 0, C->stream, d_base, t_xyzz);
+  hipLaunchKernelGGL(k_xyzz_to_affine, dim3(32), dim3(256), 0, C->stream, t_xyzz, (size_t)32 * 256, *table_aff);
+  GM_HIP(hipStreamSynchronize(C->stream));
+  GM_HIP(hipFree(d_base));
+  GM_HIP(hipFree(t_xyzz));
+  return GM_OK;
+}
+
+int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* d_scalars, int mont, size_t n,
+                        std::unique_ptr<Bases>& out) {
+  auto b = std::make_unique<Bases>();
+  b->n = n;
+  if (n) {
+    uint8_t* table = nullptr;
+    int rc = build_fixed_table(C, base_affine, &table);
+    if (rc) return rc;
+    GM_HIP(hipMalloc((void**)&b->d, n * AFF_BYTES));
+    hipLaunchKernelGGL(k_fixed_base_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C->stream,
+                       reinterpret_cast<const uint32_t*>(d_scalars), mont, n, table, b->d);
+    GM_HIP(hipStreamSynchronize(C->stream));
+    GM_HIP(hipFree(table));
+  }
+  out = std::move(b);
+  return GM_OK;
+}
+
+}  // namespace gm

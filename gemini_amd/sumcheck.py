@@ -1,0 +1,101 @@
+"""Host mirror of src/subprotocols/sumcheck: `trait Prover` (prover.rs:30-45), `TimeProver`
+(time_prover.rs:42-137) and the `Sumcheck::prove` round loop (proof.rs:36-66).  Each
+next_message is one fused fold+message kernel launch in libgemini_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .fr import FrVec
+
+
+class TimeProver:
+    def __init__(self, f, g, twist_mont):
+        """Witness::new + TimeProver::new: copies f and g (time_prover.rs:26-32, 57-67)."""
+        capi.ensure_init()
+        h = C.c_uint64()
+        tw = capi.u64(twist_mont).reshape(4)
+        if isinstance(f, FrVec) and isinstance(g, FrVec):
+            capi.check(capi.load().gm_sc_new_v(C.c_uint64(f.handle), C.c_uint64(g.handle), capi.ptr(tw), C.byref(h)))
+        else:
+            fm = capi.u64(f).reshape(-1, 4)
+            gm = capi.u64(g).reshape(-1, 4)
+            capi.check(capi.load().gm_sc_new(capi.ptr(fm), C.c_size_t(len(fm)), capi.ptr(gm), C.c_size_t(len(gm)), capi.ptr(tw), C.byref(h)))
+        self.handle = h.value
+
+    def next_message(self, verifier_message=None):
+        a = np.empty(4, dtype=np.uint64)
+        b = np.empty(4, dtype=np.uint64)
+        has = C.c_int()
+        ch = None if verifier_message is None else capi.ptr(capi.u64(verifier_message).reshape(4))
+        capi.check(capi.load().gm_sc_round(C.c_uint64(self.handle), ch, capi.ptr(a), capi.ptr(b), C.byref(has)))
+        return (a, b) if has.value else None
+
+    def fold(self, challenge):
+        capi.check(capi.load().gm_sc_fold(C.c_uint64(self.handle), capi.ptr(capi.u64(challenge).reshape(4))))
+
+    def rounds(self) -> int:
+        t = C.c_size_t()
+        capi.check(capi.load().gm_sc_rounds(C.c_uint64(self.handle), C.byref(t), None))
+        return t.value
+
+    def round(self) -> int:
+        r = C.c_size_t()
+        capi.check(capi.load().gm_sc_rounds(C.c_uint64(self.handle), None, C.byref(r)))
+        return r.value
+
+    def final_foldings(self):
+        f0 = np.empty(4, dtype=np.uint64)
+        g0 = np.empty(4, dtype=np.uint64)
+        has = C.c_int()
+        capi.check(capi.load().gm_sc_final(C.c_uint64(self.handle), capi.ptr(f0), capi.ptr(g0), C.byref(has)))
+        return (f0, g0) if has.value else None
+
+    def set_shard(self, pair_offset: int):
+        capi.check(capi.load().gm_sc_set_shard(C.c_uint64(self.handle), C.c_uint64(pair_offset)))
+
+    def free(self):
+        if self.handle:
+            capi.check(capi.load().gm_sc_free(C.c_uint64(self.handle)))
+            self.handle = 0
+
+
+class Sumcheck:
+    """src/subprotocols/sumcheck/proof.rs:19-31"""
+
+    def __init__(self, messages, challenges, rounds, final_foldings):
+        self.messages = messages
+        self.challenges = challenges
+        self.rounds = rounds
+        self.final_foldings = final_foldings
+
+    @staticmethod
+    def prove(transcript, prover) -> "Sumcheck":
+        """proof.rs:36-66.  `transcript` offers append_round_msg / append_fr / get_challenge."""
+        messages, challenges = [], []
+        verifier_message = None
+        while True:
+            message = prover.next_message(verifier_message)
+            if message is None:
+                break
+            transcript.append_round_msg(b"evaluations", message[0], message[1])
+            challenge = transcript.get_challenge(b"challenge")
+            verifier_message = challenge
+            messages.append(message)
+            challenges.append(challenge)
+        rounds = prover.rounds()
+        ff = prover.final_foldings()
+        transcript.append_fr(b"final-folding", ff[0])
+        transcript.append_fr(b"final-folding", ff[1])
+        return Sumcheck(messages, challenges, rounds, [ff])
+
+    @staticmethod
+    def new_time(transcript, f, g, twist_mont) -> "Sumcheck":
+        """proof.rs:125-130"""
+        prover = TimeProver(f, g, twist_mont)
+        try:
+            return Sumcheck.prove(transcript, prover)
+        finally:
+            prover.free()

@@ -1,0 +1,165 @@
+/*
+ * gemini_hip.h -- C ABI of libgemini_hip.so, the MI355X (gfx950) implementation of Gemini's
+ * prover hot path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * arkworks-rs/gemini checkout; ark-ec/ark-ff are third-party crates pinned in Cargo.lock:44-64).
+ * INTEGRATION.md shows the Rust `extern "C"` block and the feature-gated call sites.
+ *
+ * Conventions
+ *   - Fr elements: 4 x u64 little-endian limbs.  "mont" = Montgomery form a*2^256 mod r, exactly
+ *     the in-memory image of ark-ff `Fr` (zero-copy from `&[Fr]`).  "canonical" = the integer
+ *     itself, i.e. `Fr::into_bigint()` / `BigInt<4>`.
+ *   - G1 affine bases: x, y as 6 x u64 Montgomery limbs each (96 bytes).  `stride` >= 96; if
+ *     stride >= 97, byte 96 is ark-ec's `infinity: bool` (Rust `G1Affine` has stride 104).
+ *     With stride 96 the identity is encoded as x = y = 0.
+ *   - G1 results: Jacobian X, Y, Z (18 x u64, Montgomery) = the image of ark-ec
+ *     `Projective<g1::Config>`.  Results are normalised (Z = R, or (R, R, 0) for the identity)
+ *     so equal group elements always produce equal bytes.
+ *   - Return value: 0 = ok, negative = GM_E*.  Nothing throws or aborts across the boundary;
+ *     gm_last_error() gives a message for the calling thread.
+ *   - Ownership: the caller owns every host buffer for the duration of the call only; registered
+ *     bases and vectors are copied to device memory owned by the library until *_free.
+ *   - Threading: one process per GPU.  Calls on different handles may come from different
+ *     threads (sumcheck::prove_batch calls next_message on distinct provers concurrently,
+ *     src/subprotocols/sumcheck/proof.rs:85); calls on the same handle must be serialised.
+ */
+#ifndef GEMINI_HIP_H
+#define GEMINI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_OK 0
+#define GM_EINVAL (-1)    /* bad length / null pointer / bad stride */
+#define GM_ENOTINIT (-2)  /* gm_init not called */
+#define GM_EHANDLE (-3)   /* unknown or freed handle */
+#define GM_EHIP (-4)      /* HIP runtime error, see gm_last_error() */
+#define GM_ENOMEM (-5)
+#define GM_ESTATE (-6)    /* call sequence error (e.g. round message after the last round) */
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+/* Bind this process to GPU `device` (hipSetDevice) and create the library's streams. */
+int gm_init(int device);
+void gm_shutdown(void);
+const char* gm_last_error(void);
+/* ABI version, bumped on any signature change. */
+int gm_abi_version(void);
+
+/* ---- G1 multi-scalar multiplication ------------------------------------------------------- */
+/* Replaces VariableBaseMSM::msm_bigint(bases, bigints) of ark-ec 0.4.2 -- the function every
+ * MSM call site of the reference bottoms out in (src/kzg/time.rs:82,129; src/kzg/space.rs:52;
+ * ChunkedPippenger/HashMapPippenger flushes, in-tree copy src/kzg/msm/stream_pippenger.rs:180,250,264;
+ * algorithm statement src/kzg/msm/variable_base.rs:99-176).
+ * scalars: n x 4 u64 canonical (< r).  Like msm_unchecked, the caller passes n = min(lengths). */
+int gm_g1_msm(const void* bases, size_t base_stride, const uint64_t* scalars, size_t n, uint64_t out_jac[18]);
+
+/* SRS resident in HBM: replaces the `powers_of_g: Vec<G1Affine>` field of CommitterKey
+ * (src/kzg/time.rs:24-27) as the MSM operand.  The bases are copied; `handle` is opaque. */
+int gm_g1_bases_register(const void* bases, size_t base_stride, size_t n, uint64_t* handle);
+int gm_g1_bases_free(uint64_t handle);
+int gm_g1_bases_len(uint64_t handle, size_t* n);
+/* Copy registered bases back (96-byte stride): used by tests and by CommitterKey::index_by. */
+int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96);
+
+/* MSM against registered bases.  Pair i uses base[offset + i] (reversed = 0) or base[offset - i]
+ * (reversed = 1).  reversed/offset express CommitterKey::commit's prefix slice
+ * (src/kzg/time.rs:81-83) and CommitterKeyStream's Reverse(..) + advance_by alignment
+ * (src/kzg/space.rs:36-40,108-113,291-296) without moving the SRS. */
+int gm_g1_msm_h(uint64_t handle, size_t offset, int reversed, const uint64_t* scalars, size_t n, uint64_t out_jac[18]);
+
+/* Same, scalars taken from a device-resident Fr vector (see gm_fr_vec_*), elements
+ * [voffset, voffset + n).  The vector is in Montgomery form; into_bigint happens on device. */
+int gm_g1_msm_v(uint64_t bases_handle, size_t offset, int reversed, uint64_t vec_handle, size_t voffset, size_t n,
+                uint64_t out_jac[18]);
+
+/* Same, raw device pointer to n x 32-byte scalars already in HBM (mont != 0: Montgomery form).
+ * This is the entry bench.py times: inputs resident, result = 144 bytes. */
+int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
+                uint64_t out_jac[18]);
+
+/* Partial-result form for sharded MSMs: identical to gm_g1_msm_d but the
+ * result is NOT normalised, so ranks can all-gather 144-byte partial points and combine them
+ * with gm_g1_sum. */
+int gm_g1_msm_d_partial(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
+                        uint64_t out_jac[18]);
+/* out = normalise(sum of k Jacobian points): the local EC-add after the all-gather, and
+ * ChunkedPippenger's `result += chunk` (src/kzg/msm/stream_pippenger.rs:248-256). */
+int gm_g1_sum(const uint64_t* points_jac, size_t k, uint64_t out_jac[18]);
+
+/* Fixed-base generation on device: out[i] = scalars[i] * base (affine, 96-byte stride), registered
+ * directly as a bases handle.  Replaces FixedBase::msm + normalize_batch in CommitterKey::new
+ * (src/kzg/time.rs:49-59; setup, outside the prover timer) and builds benchmark inputs.
+ * scalars: n x 4 u64 canonical on the host. */
+int gm_g1_fixed_base_register(const uint64_t base_affine[12], const uint64_t* scalars, size_t n, uint64_t* handle);
+/* powers_of_g[i] = tau^i * g for i < n, entirely on device (tau canonical). */
+int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], size_t n, uint64_t* handle);
+
+/* Tuning knob (0 = automatic): window width c of the bucket method.  The result does not depend
+ * on it (tests sweep it). */
+int gm_set_msm_window(int c);
+
+/* ---- device-resident Fr vectors ------------------------------------------------------------ */
+/* Stand in for the `Vec<F>` values the time prover keeps in RAM (src/snark/time_prover.rs:32-106). */
+int gm_fr_vec_alloc(size_t n, uint64_t* handle);
+int gm_fr_vec_free(uint64_t handle);
+int gm_fr_vec_len(uint64_t handle, size_t* n);
+int gm_fr_vec_upload(uint64_t handle, size_t offset, const uint64_t* mont, size_t n);
+int gm_fr_vec_download(uint64_t handle, size_t offset, uint64_t* mont, size_t n);
+int gm_fr_vec_fill(uint64_t handle, const uint64_t value_mont[4]);
+/* raw device pointer (for torch.from_blob-style interop and RCCL); valid until free */
+int gm_fr_vec_ptr(uint64_t handle, void** dptr);
+/* shrink the logical length (DensePolynomial trims trailing zeros; fold halves lengths) */
+int gm_fr_vec_set_len(uint64_t handle, size_t n);
+
+/* ---- field vector helpers (src/misc.rs) ------------------------------------------------------ */
+/* out = [f[2i] + r * f[2i+1]], len ceil(n/2)                       src/misc.rs:52-56 */
+int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out);
+/* out = [1, x, x^2, ...]                                          src/misc.rs:59-65 */
+int gm_fr_powers(const uint64_t x_mont[4], size_t n, uint64_t out);
+/* out[sum b_j 2^j] = prod rho_j^{b_j}, len 2^k                    src/misc.rs:133-149 */
+int gm_fr_tensor(const uint64_t* rhos_mont, size_t k, uint64_t out);
+/* out = a . b elementwise (equal lengths, else GM_EINVAL)          src/misc.rs:205-208 */
+int gm_fr_hadamard(uint64_t a, uint64_t b, uint64_t out);
+/* result = sum_i a_i b_i                                           src/misc.rs:215-218 */
+int gm_fr_ip(uint64_t a, uint64_t b, uint64_t result_mont[4]);
+/* results[j] = sum_i p_i x_j^i for up to 3 points in one pass      src/misc.rs:194-199
+ * (tensorcheck evaluates every polynomial at beta^2, beta, -beta: tensorcheck/mod.rs:228-247) */
+int gm_fr_eval_le(uint64_t poly, const uint64_t* xs_mont, size_t npoints, uint64_t* results_mont);
+/* out = sum_j c_j p_j padded to the longest; logical length trimmed of high zeros
+ *                                                                  src/misc.rs:37-48 */
+int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, uint64_t out);
+/* quotient of f by the monic vanishing polynomial of `points` (degree k <= 3); rem gets k values.
+ * Replaces DensePolynomial::div in open_multi_points           src/kzg/time.rs:134-145 */
+int gm_fr_div_vanishing(uint64_t f, const uint64_t* points_mont, size_t k, uint64_t quotient, uint64_t* rem_mont);
+
+/* ---- sumcheck time prover --------------------------------------------------------------------- */
+/* Replaces TimeProver<F> behind `trait Prover<F>` (src/subprotocols/sumcheck/prover.rs:30-45,
+ * src/subprotocols/sumcheck/time_prover.rs:42-137).  f, g are copied (Witness::new copies too,
+ * time_prover.rs:26-32). */
+int gm_sc_new(const uint64_t* f_mont, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist_mont[4],
+              uint64_t* handle);
+/* from device vectors (copied), for a prover that keeps its state in HBM */
+int gm_sc_new_v(uint64_t f_vec, uint64_t g_vec, const uint64_t twist_mont[4], uint64_t* handle);
+/* next_message(verifier_message): challenge_or_null == NULL is `None`.  *has_msg = 0 means the
+ * reference returned None (round == tot_rounds).                     time_prover.rs:83-123 */
+int gm_sc_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg);
+/* Prover::fold                                                        time_prover.rs:75-80 */
+int gm_sc_fold(uint64_t handle, const uint64_t challenge_mont[4]);
+/* rounds() / round()                                                  time_prover.rs:125-131 */
+int gm_sc_rounds(uint64_t handle, size_t* tot_rounds, size_t* round);
+/* final_foldings(): *has = 0 if round != tot_rounds                   time_prover.rs:133-137 */
+int gm_sc_final(uint64_t handle, uint64_t f0_mont[4], uint64_t g0_mont[4], int* has);
+int gm_sc_free(uint64_t handle);
+/* partial-message form for sharded sumchecks: the shard holds pairs
+ * [pair_offset, pair_offset + len/2) of the global vectors; twist powers start at tau^(2*pair_offset) */
+int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEMINI_HIP_H */

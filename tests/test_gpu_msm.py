@@ -1,0 +1,225 @@
+"""GPU parity: G1 MSM through the C ABI vs the CPU restatement of the reference algorithm
+(oracle/gemini_oracle.c, itself pinned in test_oracle_pin.py).  Bit-exact after normalisation."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.util import assert_same_point, is_normalised, jac_to_affine_ints, rand_bases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import gemini_amd
+
+    gemini_amd.capi.init()
+    return gemini_amd
+
+
+def _set_window(gm, c):
+    gm.capi.check(gm.capi.load().gm_set_msm_window(C.c_int(c)))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 64, 100, 257, 1000, 4113])
+def test_msm_bigint_vs_oracle(gm, oracle, n):
+    """src/kzg/msm/variable_base.rs:179-215 (Pippenger == naive) with the oracle as the naive side."""
+    bases = rand_bases(oracle, 1000 + n, n)
+    sc = oracle.random_fr(2000 + n, n)
+    got = gm.VariableBaseMSM.msm_bigint(bases, sc)
+    assert is_normalised(oracle, got)
+    assert_same_point(oracle, got, oracle.msm_pippenger(bases, sc))
+
+
+def test_msm_special_scalars_and_points(gm, oracle, pyref):
+    n = 200
+    bases = rand_bases(oracle, 7, n)
+    sc = oracle.random_fr(8, n)
+    r = pyref.R_MOD
+    special = oracle.ints_to_limbs([0, 1, r - 1, 2, (1 << 254), (1 << 16) - 1, 1 << 16, (1 << 15), r - (1 << 15)], 4)
+    sc[: len(special)] = special
+    bases[20] = 0  # identity bases (CommitterKey::index_by creates them, src/kzg/time.rs:87)
+    bases[21] = 0
+    bases[31] = bases[30]  # equal points in different slots
+    neg = oracle.affine_to_ints(bases[40])
+    bases[41] = oracle.ints_to_affine((neg[0], (-neg[1]) % pyref.Q_MOD))  # P and -P
+    sc[41] = sc[40]
+    got = gm.VariableBaseMSM.msm_bigint(bases, sc)
+    assert_same_point(oracle, got, oracle.msm_pippenger(bases, sc))
+    # all-zero scalars and all-identity bases give the identity, encoded (R, R, 0)
+    z = gm.VariableBaseMSM.msm_bigint(bases, np.zeros_like(sc))
+    assert jac_to_affine_ints(oracle, z) is None and is_normalised(oracle, z)
+    z = gm.VariableBaseMSM.msm_bigint(np.zeros_like(bases), sc)
+    assert jac_to_affine_ints(oracle, z) is None
+    # empty input
+    z = gm.VariableBaseMSM.msm_bigint(bases[:0], sc[:0])
+    assert jac_to_affine_ints(oracle, z) is None
+
+
+@pytest.mark.parametrize("n", [64, 1000, 5000])
+def test_msm_all_equal_scalars(gm, oracle, n):
+    """dummy_r1cs makes every witness scalar equal (src/circuit.rs:349-365): one bucket per window."""
+    bases = rand_bases(oracle, 11, n)
+    e = oracle.random_fr(12, 1)[0]
+    sc = np.tile(e, (n, 1))
+    assert_same_point(oracle, gm.VariableBaseMSM.msm_bigint(bases, sc), oracle.msm_pippenger(bases, sc))
+
+
+@pytest.mark.parametrize("n", [64, 1000, 5000])
+def test_msm_all_equal_bases(gm, oracle, pyref, n):
+    """the elastic example makes every base the generator (examples/snark.rs:59-63): P + P inside buckets."""
+    g = oracle.g1_generator()
+    bases = np.tile(g, (n, 1))
+    sc = oracle.random_fr(13, n)
+    got = gm.VariableBaseMSM.msm_bigint(bases, sc)
+    total = sum(oracle.limbs_to_ints(sc)) % pyref.R_MOD
+    assert jac_to_affine_ints(oracle, got) == pyref.g1_mul(pyref.G1_GEN, total)
+    # and both degeneracies at once
+    e = oracle.random_fr(14, 1)[0]
+    got = gm.VariableBaseMSM.msm_bigint(bases, np.tile(e, (n, 1)))
+    assert jac_to_affine_ints(oracle, got) == pyref.g1_mul(pyref.G1_GEN, oracle.limbs_to_ints(e)[0] * n % pyref.R_MOD)
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_msm_window_independence(gm, oracle, c):
+    """the result is a group element: it cannot depend on the window width"""
+    n = 700
+    bases = rand_bases(oracle, 21, n)
+    sc = oracle.random_fr(22, n)
+    sc[0] = oracle.ints_to_limbs([0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000000], 4)[0]
+    exp = oracle.msm_pippenger(bases, sc)
+    try:
+        _set_window(gm, c)
+        assert_same_point(oracle, gm.VariableBaseMSM.msm_bigint(bases, sc), exp)
+    finally:
+        _set_window(gm, 0)
+
+
+def test_msm_rust_layout_and_unchecked(gm, oracle):
+    """stride-104 `G1Affine` records with the infinity flag; msm / msm_unchecked length semantics."""
+    n = 300
+    bases = rand_bases(oracle, 31, n)
+    sc = oracle.random_fr(32, n)
+    rust = np.zeros((n, 13), dtype=np.uint64)
+    rust[:, :12] = bases
+    rust[5, 12] = 1  # infinity = true, coordinates are then meaningless
+    rust[5, :12] = 0xDEADBEEF
+    ref = bases.copy()
+    ref[5] = 0
+    exp = oracle.msm_pippenger(ref, sc)
+    assert_same_point(oracle, gm.VariableBaseMSM.msm_bigint(rust, sc), exp)
+    mont = oracle.fr_to_mont(sc)
+    assert_same_point(oracle, gm.VariableBaseMSM.msm_unchecked(rust, mont), exp)
+    # msm_unchecked truncates to the shorter side; msm reports Err(min_len)
+    assert_same_point(oracle, gm.VariableBaseMSM.msm_unchecked(rust, mont[:250]), oracle.msm_pippenger(ref[:250], sc[:250]))
+    res, err = gm.VariableBaseMSM.msm(rust, mont[:250])
+    assert res is None and err == 250
+    res, err = gm.VariableBaseMSM.msm(rust, mont)
+    assert err is None
+    assert_same_point(oracle, res, exp)
+
+
+def test_registered_bases_offset_and_reverse(gm, oracle):
+    """CommitterKey::commit uses a prefix of powers_of_g (src/kzg/time.rs:81-83); CommitterKeyStream
+    walks Reverse(powers_of_g) after advance_by (src/kzg/space.rs:36-40,291-296)."""
+    n = 500
+    bases = rand_bases(oracle, 41, n)
+    sc = oracle.random_fr(42, 200)
+    reg = gm.G1Bases.register(bases)
+    try:
+        assert (reg.download() == bases).all()
+        assert_same_point(oracle, reg.msm_bigint(sc), oracle.msm_pippenger(bases[:200], sc))
+        assert_same_point(oracle, reg.msm_bigint(sc, offset=123), oracle.msm_pippenger(bases[123:323], sc))
+        rev = bases[::-1].copy()
+        skip = n - 200
+        # stream element k <-> array index n-1-(skip+k)
+        assert_same_point(oracle, reg.msm_bigint(sc, offset=n - 1 - skip, reversed_=True), oracle.msm_pippenger(rev[skip:], sc))
+        with pytest.raises(gm.capi.GeminiHipError):
+            reg.msm_bigint(sc, offset=400)
+    finally:
+        reg.free()
+
+
+def test_chunked_and_hashmap_pippenger(gm, oracle, pyref):
+    """time == space commitments (src/kzg/tests.rs:16-29) at the MSM level; stream_pippenger.rs:366-418"""
+    n = 150
+    bases = rand_bases(oracle, 51, n)
+    sc = oracle.random_fr(52, n)
+    full = oracle.msm_pippenger(bases, sc)
+    for buf in [1 << 20, 64, 7]:
+        p = gm.ChunkedPippenger(buf)
+        for b, s in zip(bases, sc):
+            p.add(b, s)
+        assert_same_point(oracle, p.finalize(), full)
+    dup = np.concatenate([bases, bases[:60]])
+    sc2 = np.concatenate([sc, oracle.random_fr(53, 60)])
+    mont = oracle.fr_to_mont(sc2)
+    exp = oracle.hashmap_pippenger(dup, mont, 1 << 20)
+    for cap in [1 << 20, 100, 16]:
+        p = gm.HashMapPippenger(cap)
+        for b, s in zip(dup, mont):
+            p.add(b, s)
+        assert_same_point(oracle, p.finalize(), exp)
+    # msm_chunks alignment (src/kzg/space.rs:36-40)
+    got = gm.msm_chunks(bases, oracle.fr_to_mont(sc[:100]))
+    assert_same_point(oracle, got, oracle.msm_chunks(bases, sc[:100]))
+
+
+def test_fixed_base_and_srs_generation(gm, oracle, pyref):
+    """CommitterKey::new's powers_of_g (src/kzg/time.rs:51-59) built on device"""
+    g = oracle.g1_generator()
+    ks = oracle.random_fr(61, 300)
+    ks[0] = 0
+    ks[1] = oracle.ints_to_limbs([1], 4)[0]
+    reg = gm.G1Bases.fixed_base(g, ks)
+    try:
+        assert (reg.download() == oracle.g1_fixed_base_mul(g, ks)).all()
+    finally:
+        reg.free()
+    tau = oracle.random_fr(62, 1)[0]
+    srs = gm.G1Bases.srs(g, tau, 257)
+    try:
+        t = oracle.limbs_to_ints(tau)[0]
+        pw = oracle.ints_to_limbs([pow(t, i, pyref.R_MOD) for i in range(257)], 4)
+        assert (srs.download() == oracle.g1_fixed_base_mul(g, pw)).all()
+    finally:
+        srs.free()
+
+
+def test_msm_2_16_vs_oracle(gm, oracle):
+    n = 1 << 16
+    bases = rand_bases(oracle, 71, n)
+    sc = oracle.random_fr(72, n)
+    assert_same_point(oracle, gm.VariableBaseMSM.msm_bigint(bases, sc), oracle.msm_pippenger(bases, sc))
+
+
+def test_msm_2_20_properties(gm, oracle, pyref):
+    """BASELINE config 2 size.  Size-independent properties: additivity over a split of the pairs,
+    linearity in the scalars, and the all-equal-scalar collapse sum_i e*P_i = e * sum_i P_i."""
+    n = 1 << 20
+    g = oracle.g1_generator()
+    ks = oracle.random_fr(81, n)
+    reg = gm.G1Bases.fixed_base(g, ks)
+    try:
+        a = oracle.random_fr(82, n)
+        full = reg.msm_bigint(a)
+        lo = reg.msm_bigint(a[: n // 2])
+        hi = reg.msm_bigint(a[n // 2:], offset=n // 2)
+        from gemini_amd.msm import g1_sum
+
+        assert (g1_sum(np.stack([lo, hi])) == full).all()
+        # discrete-log check: bases are k_i * G, so the MSM is (sum a_i k_i) * G
+        ai = oracle.limbs_to_ints(a[: 1 << 12])
+        ki = oracle.limbs_to_ints(ks[: 1 << 12])
+        small = reg.msm_bigint(a[: 1 << 12])
+        assert jac_to_affine_ints(oracle, small) == pyref.g1_mul(pyref.G1_GEN, sum(x * y for x, y in zip(ai, ki)) % pyref.R_MOD)
+        # all-equal scalars (the dummy_r1cs witness): e * sum P_i
+        e = oracle.random_fr(83, 1)[0]
+        ones = np.tile(oracle.ints_to_limbs([1], 4)[0], (n, 1))
+        s1 = reg.msm_bigint(ones)
+        se = reg.msm_bigint(np.tile(e, (n, 1)))
+        exp = oracle.g1_mul(oracle.g1_to_affine(s1), e)
+        assert_same_point(oracle, se, exp)
+    finally:
+        reg.free()

@@ -1,0 +1,162 @@
+"""GPU parity: sumcheck TimeProver (fused fold + message kernel) and the misc.rs vector helpers
+vs the CPU restatement.  Field arithmetic is exact, so every message must match bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import gemini_amd
+
+    gemini_amd.capi.init()
+    return gemini_amd
+
+
+def _mont(orc, ints):
+    return orc.fr_to_mont(orc.ints_to_limbs(ints, 4))
+
+
+def _run_both(gm, orc, f, g, tw, seed):
+    O = orc.TimeProver(f, g, tw)
+    G = gm.TimeProver(f, g, tw)
+    try:
+        assert G.rounds() == O.tot_rounds
+        ch = orc.fr_to_mont(orc.random_fr(seed, O.tot_rounds + 1))
+        vm = None
+        k = 0
+        while True:
+            mo = O.next_message(vm)
+            mg = G.next_message(vm)
+            if mo is None:
+                assert mg is None
+                break
+            assert G.final_foldings() is None or G.round() == G.rounds()
+            assert (mg[0] == mo[0]).all() and (mg[1] == mo[1]).all(), f"round {k}"
+            vm = ch[k]
+            k += 1
+        assert k == O.tot_rounds
+        fo, go = O.final_foldings()
+        fg, gg = G.final_foldings()
+        assert (fo == fg).all() and (go == gg).all()
+        # a further call keeps returning None (time_prover.rs test_trivial_prover)
+        assert G.next_message(None) is None
+    finally:
+        G.free()
+
+
+@pytest.mark.parametrize("nf,ng", [(2, 2), (3, 3), (30, 30), (93, 16), (16, 93), (17, 1), (1025, 1025), (4096, 4096), (5000, 777)])
+def test_time_prover_messages(gm, oracle, nf, ng):
+    """shapes from src/subprotocols/sumcheck/tests.rs:46,118-119,205 + odd / unequal lengths"""
+    f = oracle.fr_to_mont(oracle.random_fr(100 + nf, nf))
+    g = oracle.fr_to_mont(oracle.random_fr(200 + ng, ng))
+    tw = oracle.fr_to_mont(oracle.random_fr(300 + nf + ng, 1))[0]
+    _run_both(gm, oracle, f, g, tw, 400 + nf)
+
+
+def test_time_prover_dummy_r1cs_shape(gm, oracle):
+    """the benchmark instance: z_a = z_b = [1; n] with twist alpha (src/snark/time_prover.rs:52)"""
+    n = 1 << 14
+    one = _mont(oracle, [1])[0]
+    f = np.tile(one, (n, 1))
+    tw = oracle.fr_to_mont(oracle.random_fr(5, 1))[0]
+    _run_both(gm, oracle, f, f.copy(), tw, 6)
+
+
+def test_time_prover_2_18(gm, oracle):
+    n = 1 << 18
+    f = oracle.fr_to_mont(oracle.random_fr(7, n))
+    g = oracle.fr_to_mont(oracle.random_fr(8, n))
+    tw = oracle.fr_to_mont(oracle.random_fr(9, 1))[0]
+    _run_both(gm, oracle, f, g, tw, 10)
+
+
+def test_sumcheck_verifier_identity_2_20(gm, oracle, pyref):
+    """size-independent property at 2^20: each round's quadratic q(x) = a + b x + (claim - a) x^2
+    must satisfy q(rho) = next claim, ending at f0 * g0 (subclaim.rs:91-97)."""
+    n = 1 << 20
+    r = pyref.R_MOD
+    f = oracle.fr_to_mont(oracle.random_fr(11, n))
+    g = oracle.fr_to_mont(oracle.random_fr(12, n))
+    twi = oracle.limbs_to_ints(oracle.random_fr(13, 1))[0]
+    tw = _mont(oracle, [twi])[0]
+    # claim = sum f_i g_i tw^i via the library's own hadamard / powers / ip (checked elsewhere vs oracle)
+    pw = gm.powers(tw, n)
+    fv = gm.FrVec.from_host(f)
+    ft = gm.hadamard(fv, pw)
+    gv = gm.FrVec.from_host(g)
+    claim = gm.fr.fr_to_int(gm.ip(ft, gv))
+    P = gm.TimeProver(fv, gv, tw)
+    for v in (pw, fv, ft, gv):
+        v.free()
+    rho = oracle.limbs_to_ints(oracle.random_fr(14, 21))
+    vm = None
+    for k in range(20):
+        a, b = P.next_message(vm)
+        a, b = gm.fr.fr_to_int(a), gm.fr.fr_to_int(b)
+        c = (claim - a) % r
+        claim = (a + b * rho[k] + c * rho[k] * rho[k]) % r
+        vm = gm.fr.fr_from_int(rho[k])
+    assert P.next_message(vm) is None
+    f0, g0 = P.final_foldings()
+    assert gm.fr.fr_to_int(f0) * gm.fr.fr_to_int(g0) % r == claim
+    P.free()
+
+
+def test_vector_helpers_vs_oracle(gm, oracle):
+    n = 3001
+    f = oracle.fr_to_mont(oracle.random_fr(21, n))
+    g = oracle.fr_to_mont(oracle.random_fr(22, n))
+    x = oracle.fr_to_mont(oracle.random_fr(23, 3))
+    assert (gm.fold_polynomial(f, x[0]).to_host() == oracle.fold_polynomial(f, x[0])).all()
+    assert (gm.fold_polynomial(f[:1], x[0]).to_host() == oracle.fold_polynomial(f[:1], x[0])).all()
+    assert (gm.powers(x[0], n).to_host() == oracle.powers(x[0], n)).all()
+    assert (gm.hadamard(f, g).to_host() == oracle.hadamard(f, g)).all()
+    assert (gm.ip(f, g) == oracle.ip(f, g)).all()
+    ev = gm.evaluate_le(f, x)
+    for k in range(3):
+        assert (ev[k] == oracle.evaluate_le(f, x[k])).all()
+    assert (gm.evaluate_le(f[:1], x[:1])[0] == f[0]).all()
+    for k in [1, 2, 5, 12, 13]:
+        rhos = oracle.fr_to_mont(oracle.random_fr(30 + k, k))
+        assert (gm.tensor(rhos).to_host() == oracle.tensor(rhos)).all()
+    lc = gm.linear_combination([f, g[:1000], f[:5]], x)
+    assert (lc.to_host() == oracle.linear_combination([f, g[:1000], f[:5]], x)).all()
+    with pytest.raises(gm.capi.GeminiHipError):
+        gm.hadamard(f, g[:10])
+
+
+def test_reference_known_answers_on_gpu(gm, oracle):
+    """the reference's RNG-free tests, run through the device path:
+    src/misc.rs:402-422 (linear_combination), src/subprotocols/tensorcheck/mod.rs:388-398 (fold)."""
+    M = lambda v: _mont(oracle, v)
+    got = gm.linear_combination([M([100, 101, 102, 103]), M([100, 100, 100, 100])], M([1, 10]))
+    assert (got.to_host() == M([1100, 1101, 1102, 1103])).all()
+    assert len(gm.linear_combination([], np.empty((0, 4), dtype=np.uint64))) == 0
+    fold = gm.fold_polynomial(M([100, 101, 102, 103]), M([1])[0])
+    assert (fold.to_host() == M([201, 205])).all()
+    # trailing zeros are trimmed like DensePolynomial does
+    got = gm.linear_combination([M([5, 7, 0, 0]), M([1, 0, 0, 0])], M([1, 1]))
+    assert (got.to_host() == M([6, 7])).all()
+
+
+def test_div_vanishing_vs_oracle(gm, oracle, pyref):
+    """open_multi_points' quotient (src/kzg/time.rs:134-145) incl. the reference's known answer
+    f(53) remainder check of src/kzg/space.rs:334-355"""
+    from gemini_amd.fr import div_vanishing
+
+    for n in [7, 64, 65, 1000, 70000]:
+        f = oracle.fr_to_mont(oracle.random_fr(50 + n, n))
+        pts_i = oracle.limbs_to_ints(oracle.random_fr(60 + n, 3))
+        z = _mont(oracle, pyref.vanishing_polynomial(pts_i))
+        q_exp, _ = oracle.poly_div_monic(f, z)
+        q, _ = div_vanishing(f, _mont(oracle, pts_i))
+        assert (q.to_host() == q_exp).all(), n
+    f = _mont(oracle, [24, 7, 73, 3, 88, 80, 80])
+    beta = 53
+    pts = [beta * beta, beta, pyref.R_MOD - beta]
+    q, _ = div_vanishing(f, _mont(oracle, pts))
+    q_exp, rem = oracle.poly_div_monic(f, _mont(oracle, pyref.vanishing_polynomial(pts)))
+    assert (q.to_host() == q_exp).all()
+    assert oracle.limbs_to_ints(oracle.fr_from_mont(oracle.evaluate_le(rem, _mont(oracle, [beta])[0]))) == [1807299544171]

@@ -74,6 +74,18 @@ __global__ void k_fq_mul(const uint32_t* a, const uint32_t* b, uint32_t* out, in
   for (int i = 0; i < iters; i++) { x = fp_mul<FqParams>(x, y); }
   fp_store<FqParams>(out + 12 * t, x);
 }
+__global__ void k_fq_mul_cios(const uint32_t* a, const uint32_t* b, uint32_t* out, int iters) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq x = fp_load<FqParams>(a + 12 * t), y = fp_load<FqParams>(b + 12 * t);
+  for (int i = 0; i < iters; i++) { x = fp_mul_cios<FqParams>(x, y); }
+  fp_store<FqParams>(out + 12 * t, x);
+}
+__global__ void k_fr_mul_cios(const uint32_t* a, const uint32_t* b, uint32_t* out, int iters) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  Fr x = fp_load<FrParams>(a + 8 * t), y = fp_load<FrParams>(b + 8 * t);
+  for (int i = 0; i < iters; i++) { x = fp_mul_cios<FrParams>(x, y); }
+  fp_store<FrParams>(out + 8 * t, x);
+}
 __global__ void k_fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* out, int iters) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   Fr x = fp_load<FrParams>(a + 8 * t), y = fp_load<FrParams>(b + 8 * t);
@@ -121,10 +133,20 @@ int main(int argc, char** argv) {
     uint32_t *da, *db, *dc; CK(hipMalloc(&da, 48 * n)); CK(hipMalloc(&db, 48 * n)); CK(hipMalloc(&dc, 48 * n));
     CK(hipMemcpy(da, ha.data(), 48 * n, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), 48 * n, hipMemcpyHostToDevice));
     int fi = 200;
+    uint32_t* dd; CK(hipMalloc(&dd, 48 * n));
+    std::vector<uint32_t> h1(12 * n), h2(12 * n);
     float ms = timeit([&] { k_fq_mul<<<blocks, threads>>>(da, db, dc, fi); });
-    printf("fq_mul            %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
+    printf("fq_mul (asm FIPS) %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
+    ms = timeit([&] { k_fq_mul_cios<<<blocks, threads>>>(da, db, dd, fi); });
+    printf("fq_mul (C CIOS)   %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
+    CK(hipMemcpy(h1.data(), dc, 48 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dd, 48 * n, hipMemcpyDeviceToHost));
+    printf("fq asm == cios: %s\n", h1 == h2 ? "yes" : "NO");
     ms = timeit([&] { k_fr_mul<<<blocks, threads>>>(da, db, dc, fi); });
-    printf("fr_mul            %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
+    printf("fr_mul (asm FIPS) %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
+    ms = timeit([&] { k_fr_mul_cios<<<blocks, threads>>>(da, db, dd, fi); });
+    printf("fr_mul (C CIOS)   %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
+    CK(hipMemcpy(h1.data(), dc, 32 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dd, 32 * n, hipMemcpyDeviceToHost));
+    printf("fr asm == cios: %s\n", std::equal(h1.begin(), h1.begin() + 8 * n, h2.begin()) ? "yes" : "NO");
     ms = timeit([&] { k_fq_add<<<blocks, threads>>>(da, db, dc, fi); });
     printf("fq_add+sub        %8.3f ms  %8.2f Gpair/s\n", ms, (double)n * fi / ms / 1e6);
   }
