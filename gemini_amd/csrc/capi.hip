@@ -38,6 +38,32 @@ void DevBuf::release() {
   cap = 0;
 }
 
+void Profiler::begin(int stage, hipStream_t st) {
+  if (!on) return;
+  if (!have_events) {
+    for (auto& e : ev) (void)hipEventCreate(&e);
+    have_events = true;
+  }
+  (void)hipEventRecord(ev[2 * stage], st);
+}
+void Profiler::end(int stage, hipStream_t st) {
+  if (!on) return;
+  (void)hipEventRecord(ev[2 * stage + 1], st);
+  pending[stage] = true;
+}
+void Profiler::collect() {
+  if (!on) return;
+  for (int s = 0; s < PROF_NSTAGES; s++) {
+    if (!pending[s]) continue;
+    float t = 0;
+    if (hipEventElapsedTime(&t, ev[2 * s], ev[2 * s + 1]) == hipSuccess) {
+      ms[s] += t;
+      count[s] += 1;
+    }
+    pending[s] = false;
+  }
+}
+
 static Context* g_ctx = nullptr;
 static std::mutex g_ctx_mu;
 Context* context() { return g_ctx; }
@@ -148,6 +174,26 @@ void gm_shutdown(void) {
   (void)hipStreamDestroy(C->stream);
   delete C;
   g_ctx = nullptr;
+}
+
+int gm_prof_enable(int on) {
+  GM_CTX();
+  C->prof.on = on != 0;
+  for (int s = 0; s < PROF_NSTAGES; s++) {
+    C->prof.ms[s] = 0;
+    C->prof.count[s] = 0;
+    C->prof.pending[s] = false;
+  }
+  return GM_OK;
+}
+int gm_prof_read(double* ms_out, uint64_t* count_out, int n) {
+  GM_CTX();
+  GM_CHECK(n >= 0 && n <= PROF_NSTAGES, GM_EINVAL, "prof_read: n = %d, at most %d stages", n, (int)PROF_NSTAGES);
+  for (int s = 0; s < n; s++) {
+    if (ms_out) ms_out[s] = C->prof.ms[s];
+    if (count_out) count_out[s] = C->prof.count[s];
+  }
+  return GM_OK;
 }
 
 int gm_set_msm_window(int c) {

@@ -75,8 +75,23 @@ struct MsmWorkspace {
   size_t host_planes_cap = 0;
 };
 
+// per-stage kernel timing with HIP events on the library's own stream (bench.py's roofline leg)
+enum ProfStage { PROF_DIGITS = 0, PROF_SCAN, PROF_SCATTER, PROF_ACC0, PROF_MERGE, PROF_REDUCE, PROF_SC_ROUND, PROF_NSTAGES };
+struct Profiler {
+  bool on = false;
+  hipEvent_t ev[2 * PROF_NSTAGES];
+  bool have_events = false;
+  bool pending[PROF_NSTAGES] = {};
+  double ms[PROF_NSTAGES] = {};
+  uint64_t count[PROF_NSTAGES] = {};
+  void begin(int stage, hipStream_t st);
+  void end(int stage, hipStream_t st);
+  void collect();  // after a stream sync
+};
+
 struct Context {
   int device = -1;
+  Profiler prof;
   hipStream_t stream = nullptr;
   std::mutex mu;       // guards handle tables
   std::mutex msm_mu;   // MSM workspace is single-flight (the reference's MSM calls are sequential)

@@ -56,8 +56,9 @@ struct DigitIter {
     }
     carry = 0;
   }
-  // next signed digit in [-2^(c-1), 2^(c-1)]; semantics of variable_base.rs:21-61 with
-  // c * W >= 256 so the top digit needs no special case
+  // next signed digit in [-2^(c-1), 2^(c-1)]; semantics of variable_base.rs:21-61.  With
+  // c * W >= 256 the top window's raw value is < 2^(c-1), so after the caller folds the final
+  // carry back in (variable_base.rs:58) the top digit is still within the bucket range.
   GM_DEV int32_t next(int c) {
     uint32_t raw = s[0] & ((1u << c) - 1u);
 #pragma unroll
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__
   it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
   for (int w = 0; w < W; w++) {
     int32_t d = it.next(c);
+    if (w == W - 1) d += (int32_t)(it.carry << c);  // variable_base.rs:58: digits[last] += carry << w
     uint32_t mag = (uint32_t)(d < 0 ? -d : d);
     uint32_t key = (active && d != 0) ? (uint32_t)w * B + (mag - 1u) : KEY_INV;
     uint32_t pos = wave_atomic_inc(counts_or_cursor, key);
@@ -487,15 +489,25 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 1) * 4, st));
   GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * XYZZ_BYTES, st));
   const uint32_t dblocks = (uint32_t)((n + 255) / 256);
+  Profiler& pf = C->prof;
+  pf.begin(PROF_DIGITS, st);
   hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
                      ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
+  pf.end(PROF_DIGITS, st);
+  pf.begin(PROF_SCAN, st);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
                      ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
+  pf.end(PROF_SCAN, st);
+  pf.begin(PROF_SCATTER, st);
   hipLaunchKernelGGL(k_msm_digits<true>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
                      ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
+  pf.end(PROF_SCATTER, st);
+  pf.begin(PROF_ACC0, st);
   hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, ws.entries.as<uint64_t>(),
                      ws.offsets.as<uint32_t>() + nbuckets, d_bases, (long long)first, (long long)step, L,
                      ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
+  pf.end(PROF_ACC0, st);
+  pf.begin(PROF_MERGE, st);
   {
     uint64_t E = E1;
     int src = 0;
@@ -511,6 +523,8 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
     }
   }
 
+  pf.end(PROF_MERGE, st);
+  pf.begin(PROF_REDUCE, st);
   // bucket reduction: bits of the bucket index i = |d| - 1 (c - 1 bits) = (hi: h bits | lo: a bits)
   const uint32_t nbits = (uint32_t)(c - 1);
   const uint32_t a = nbits > 7 ? nbits / 2 : nbits;  // small tables: bit-planes straight from the buckets
@@ -543,6 +557,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
     hipLaunchKernelGGL(k_group_sum, dim3((pa.n_out * 16 + 255) / 256), dim3(256), 0, st, ws.rows.as<uint8_t>(),
                        row_planes, pa);
   }
+  pf.end(PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
   const size_t plane_count = (size_t)W * (a + 1) + (h > 0 ? (size_t)W * (h + 1) : 0);
   const size_t plane_bytes = plane_count * XYZZ_BYTES;
@@ -554,6 +569,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   }
   GM_HIP(hipMemcpyAsync(ws.host_planes, planes, plane_bytes, hipMemcpyDeviceToHost, st));
   GM_HIP(hipStreamSynchronize(st));
+  pf.collect();
 
   // Horner over bit positions, windows high -> low (variable_base.rs:168-175 with the per-window
   // weighted sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)

@@ -103,6 +103,15 @@ int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], si
  * on it (tests sweep it). */
 int gm_set_msm_window(int c);
 
+/* Per-stage device timing (HIP events on the library's stream).  Stages, in order:
+ * 0 digits+histogram, 1 scan, 2 scatter, 3 bucket accumulate (k_acc0), 4 partial merge,
+ * 5 bucket reduce, 6 sumcheck round.  gm_prof_enable(1) resets and starts accumulating;
+ * gm_prof_read returns total milliseconds and launch-group counts per stage.  No reference
+ * counterpart (the reference only has start_timer!/end_timer! spans, src/snark/time_prover.rs:23). */
+#define GM_PROF_NSTAGES 7
+int gm_prof_enable(int on);
+int gm_prof_read(double* ms_out, uint64_t* count_out, int n);
+
 /* ---- device-resident Fr vectors ------------------------------------------------------------ */
 /* Stand in for the `Vec<F>` values the time prover keeps in RAM (src/snark/time_prover.rs:32-106). */
 int gm_fr_vec_alloc(size_t n, uint64_t* handle);
