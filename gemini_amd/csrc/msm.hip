@@ -111,15 +111,45 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__
   }
 }
 
-// exclusive scan of m counters by one 1024-thread block
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ counts, uint32_t m,
-                                               uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
+// exclusive scan of m counters in three launches: per-block sums (4096 counters per block),
+// a single-block scan of the block sums, then the local scans with the block offsets applied
+constexpr uint32_t SCAN_PER_THREAD = 16;
+constexpr uint32_t SCAN_PER_BLOCK = 256 * SCAN_PER_THREAD;
+
+GM_DEV uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* lds /* 256 */, uint32_t* total) {
+  const uint32_t tid = threadIdx.x;
+  lds[tid] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t x = tid >= d ? lds[tid - d] : 0;
+    __syncthreads();
+    lds[tid] += x;
+    __syncthreads();
+  }
+  if (total) *total = lds[255];
+  return lds[tid] - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_block_sums(const uint32_t* __restrict__ counts, uint32_t m,
+                                                         uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t lds[256];
+  const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t s = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) s += base + k < m ? counts[base + k] : 0u;
+  uint32_t total;
+  block_exclusive_scan_256(s, lds, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t* __restrict__ block_sums, uint32_t nb,
+                                                   uint32_t* __restrict__ total_out) {
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
-  const uint32_t chunk = (m + 1023u) / 1024u;
-  const uint32_t lo = min(tid * chunk, m), hi = min(lo + chunk, m);
+  const uint32_t chunk = (nb + 1023u) / 1024u;
+  const uint32_t lo = min(tid * chunk, nb), hi = min(lo + chunk, nb);
   uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += counts[i];
+  for (uint32_t i = lo; i < hi; i++) s += block_sums[i];
   part[tid] = s;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -130,11 +160,34 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
   }
   uint32_t run = part[tid] - s;
   for (uint32_t i = lo; i < hi; i++) {
-    offsets[i] = run;
-    cursor[i] = run;
-    run += counts[i];
+    uint32_t c = block_sums[i];
+    block_sums[i] = run;
+    run += c;
   }
-  if (tid == 1023) offsets[m] = part[1023];
+  if (tid == 1023) *total_out = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ counts, uint32_t m,
+                                                    const uint32_t* __restrict__ block_sums,
+                                                    uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t lds[256];
+  const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  uint32_t v[SCAN_PER_THREAD];
+  uint32_t s = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+    v[k] = base + k < m ? counts[base + k] : 0u;
+    s += v[k];
+  }
+  uint32_t run = block_exclusive_scan_256(s, lds, nullptr) + block_sums[blockIdx.x];
+#pragma unroll
+  for (uint32_t k = 0; k < SCAN_PER_THREAD; k++) {
+    if (base + k < m) {
+      offsets[base + k] = run;
+      cursor[base + k] = run;
+    }
+    run += v[k];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -219,6 +272,31 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
   }
   __syncthreads();
 
+  // step 0: every lane boundary at once.  In the common case each producer's last run continues
+  // into the next producer's first run and ends there; when both neighbours hold two runs the
+  // merged run is bounded on both sides and therefore a complete bucket.  This removes the
+  // boundary additions from all six tree steps below (they then only carry keys).
+  {
+    const uint32_t nhk = __shfl_down(hk, 1), nhs = __shfl_down(hs, 1), ntk = __shfl_down(tk, 1);
+    const uint32_t ptk = __shfl_up(tk, 1);
+    const bool give = lane < 63 && tk != KEY_INV && ntk != KEY_INV && nhk == tk;   // my tail + next head
+    const bool taken = lane > 0 && tk != KEY_INV && ptk != KEY_INV && ptk == hk;   // my head consumed by prev
+    if (__any(give)) {
+      if (give) {
+        G1Xyzz a = g1_load_xyzz(lds + ts * XYZZ_BYTES);
+        xyzz_add(a, g1_load_xyzz(lds + nhs * XYZZ_BYTES));
+        g1_store_xyzz(buckets + (size_t)tk * XYZZ_BYTES, a);
+      }
+    }
+    __syncthreads();
+    if (taken) {  // drop my head: (head, tail) -> (tail, INV)
+      hk = tk; hs = ts; tk = KEY_INV;
+    }
+    if (give) {   // drop my tail (after `taken` so a lane that does both ends up empty)
+      if (taken) { hk = KEY_INV; } else { tk = KEY_INV; }
+    }
+  }
+
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t bhk = __shfl_down(hk, d), bhs = __shfl_down(hs, d);
     const uint32_t btk = __shfl_down(tk, d), bts = __shfl_down(ts, d);
@@ -274,6 +352,8 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
 // ------------------------------------------------------------------------------------------
 enum { GS_ROW = 0, GS_COL = 1, GS_PLANE = 2 };
 struct GroupSumArgs {
+  const uint8_t* in;
+  uint8_t* out;
   int mode;
   uint32_t n_out;      // number of outputs
   uint32_t per_win;    // outputs per window
@@ -294,9 +374,14 @@ GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_group_sum(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                   GroupSumArgs a) {
-  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+// two independent jobs per launch (blocks [0, blocks0) run a0, the rest a1) so the row and column
+// passes -- and later the two bit-plane passes -- overlap instead of serialising their latency
+__global__ __launch_bounds__(256) void k_group_sum(GroupSumArgs a0, GroupSumArgs a1, uint32_t blocks0) {
+  const bool second = blockIdx.x >= blocks0;
+  const GroupSumArgs& a = second ? a1 : a0;
+  const uint8_t* __restrict__ in = a.in;
+  uint8_t* __restrict__ out = a.out;
+  const uint32_t gt = (blockIdx.x - (second ? blocks0 : 0u)) * blockDim.x + threadIdx.x;
   const uint32_t o = gt >> 4, q = gt & 15u;
   G1Xyzz acc = G1Xyzz::identity();
   if (o < a.n_out) {
@@ -477,6 +562,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   if ((rc = ws.counts.ensure((nbuckets + 1) * 4))) return rc;
   if ((rc = ws.offsets.ensure((nbuckets + 1) * 4))) return rc;
   if ((rc = ws.cursor.ensure((nbuckets + 1) * 4))) return rc;
+  if ((rc = ws.misc.ensure((nbuckets / SCAN_PER_BLOCK + 2) * 4))) return rc;
   if ((rc = ws.entries.ensure(N * 8))) return rc;
   if ((rc = ws.buckets.ensure(nbuckets * XYZZ_BYTES))) return rc;
   if ((rc = ws.pk[0].ensure(E1 * 4))) return rc;
@@ -495,8 +581,15 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
                      ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
   pf.end(PROF_DIGITS, st);
   pf.begin(PROF_SCAN, st);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
-                     ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
+  {
+    const uint32_t nb = (uint32_t)((nbuckets + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
+                       ws.misc.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, ws.misc.as<uint32_t>(), nb,
+                       ws.offsets.as<uint32_t>() + nbuckets);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
+                       ws.misc.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
+  }
   pf.end(PROF_SCAN, st);
   pf.begin(PROF_SCATTER, st);
   hipLaunchKernelGGL(k_msm_digits<true>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
@@ -534,28 +627,25 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   if ((rc = ws.planes.ensure((size_t)W * (planes_per_win + 1) * XYZZ_BYTES))) return rc;
   const uint8_t* col_src = ws.buckets.as<uint8_t>();
   uint32_t col_len_bits = a;
+  auto gs_blocks = [](const GroupSumArgs& g) { return (g.n_out * 16 + 255) / 256; };
+  GroupSumArgs none{};
+  none.n_out = 0;
   if (h > 0) {
     if ((rc = ws.rows.ensure((size_t)W * (1u << h) * XYZZ_BYTES))) return rc;
     if ((rc = ws.cols.ensure((size_t)W * (1u << a) * XYZZ_BYTES))) return rc;
-    GroupSumArgs ra{GS_ROW, (uint32_t)W << h, 1u << h, B, a, 1u << a};
-    hipLaunchKernelGGL(k_group_sum, dim3((ra.n_out * 16 + 255) / 256), dim3(256), 0, st, ws.buckets.as<uint8_t>(),
-                       ws.rows.as<uint8_t>(), ra);
-    GroupSumArgs ca{GS_COL, (uint32_t)W << a, 1u << a, B, a, 1u << h};
-    hipLaunchKernelGGL(k_group_sum, dim3((ca.n_out * 16 + 255) / 256), dim3(256), 0, st, ws.buckets.as<uint8_t>(),
-                       ws.cols.as<uint8_t>(), ca);
+    GroupSumArgs ra{ws.buckets.as<uint8_t>(), ws.rows.as<uint8_t>(), GS_ROW, (uint32_t)W << h, 1u << h, B, a, 1u << a};
+    GroupSumArgs ca{ws.buckets.as<uint8_t>(), ws.cols.as<uint8_t>(), GS_COL, (uint32_t)W << a, 1u << a, B, a, 1u << h};
+    hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(ra) + gs_blocks(ca)), dim3(256), 0, st, ra, ca, gs_blocks(ra));
     col_src = ws.cols.as<uint8_t>();
   }
   // planes over the column array (a bit-planes + total) and over the row array (h bit-planes + total)
   uint8_t* planes = ws.planes.as<uint8_t>();
-  {
-    GroupSumArgs pa{GS_PLANE, (uint32_t)W * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0};
-    hipLaunchKernelGGL(k_group_sum, dim3((pa.n_out * 16 + 255) / 256), dim3(256), 0, st, col_src, planes, pa);
-  }
   uint8_t* row_planes = planes + (size_t)W * (a + 1) * XYZZ_BYTES;
-  if (h > 0) {
-    GroupSumArgs pa{GS_PLANE, (uint32_t)W * (h + 1), h + 1, 1u << h, h, 0};
-    hipLaunchKernelGGL(k_group_sum, dim3((pa.n_out * 16 + 255) / 256), dim3(256), 0, st, ws.rows.as<uint8_t>(),
-                       row_planes, pa);
+  {
+    GroupSumArgs pc{col_src, planes, GS_PLANE, (uint32_t)W * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0};
+    GroupSumArgs pr = none;
+    if (h > 0) pr = GroupSumArgs{ws.rows.as<uint8_t>(), row_planes, GS_PLANE, (uint32_t)W * (h + 1), h + 1, 1u << h, h, 0};
+    hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(pc) + (h > 0 ? gs_blocks(pr) : 0)), dim3(256), 0, st, pc, pr, gs_blocks(pc));
   }
   pf.end(PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
