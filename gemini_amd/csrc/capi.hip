@@ -120,6 +120,7 @@ int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]);
 int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results);
 int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out);
 int fr_fill(Context* C, FrVec* v, const uint64_t val[4]);
+int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y);
 int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k, FrVec* q, uint64_t* rem_out);
 
 }  // namespace gm
@@ -164,6 +165,11 @@ void gm_shutdown(void) {
   for (auto& kv : C->vecs)
     if (kv.second->d) (void)hipFree(kv.second->d);
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
+  for (auto& kv : C->matrices) {
+    if (kv.second->rowptr) (void)hipFree(kv.second->rowptr);
+    if (kv.second->cols) (void)hipFree(kv.second->cols);
+    if (kv.second->vals) (void)hipFree(kv.second->vals);
+  }
   MsmWorkspace& w = C->msm;
   for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
                     &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc})
@@ -472,6 +478,60 @@ int gm_fr_div_vanishing(uint64_t f, const uint64_t* points_mont, size_t k, uint6
   GM_VEC(vf, f, "fr_div_vanishing");
   GM_VEC(vq, quotient, "fr_div_vanishing");
   return fr_div_linear_factors(C, vf, points_mont, k, vq, rem_mont);
+}
+
+// ---- sparse matrices (R1CS) -------------------------------------------------------------------
+int gm_spm_register(const uint64_t* rowptr, const uint32_t* cols, const uint64_t* vals_mont, size_t nrows, size_t ncols,
+                    size_t nnz, uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(rowptr && handle && ((cols && vals_mont) || nnz == 0), GM_EINVAL, "spm_register: null pointer");
+  GM_CHECK(rowptr[0] == 0 && rowptr[nrows] == nnz, GM_EINVAL, "spm_register: rowptr must run from 0 to nnz");
+  for (size_t k = 0; k < nnz; k++) GM_CHECK(cols[k] < ncols, GM_EINVAL, "spm_register: column %u >= %zu", cols[k], ncols);
+  auto M = std::make_unique<SparseMatrix>();
+  M->nrows = nrows;
+  M->ncols = ncols;
+  M->nnz = nnz;
+  GM_HIP(hipMalloc((void**)&M->rowptr, (nrows + 1) * 8));
+  GM_HIP(hipMemcpyAsync(M->rowptr, rowptr, (nrows + 1) * 8, hipMemcpyHostToDevice, C->stream));
+  if (nnz) {
+    GM_HIP(hipMalloc((void**)&M->cols, nnz * 4));
+    GM_HIP(hipMalloc((void**)&M->vals, nnz * 32));
+    GM_HIP(hipMemcpyAsync(M->cols, cols, nnz * 4, hipMemcpyHostToDevice, C->stream));
+    GM_HIP(hipMemcpyAsync(M->vals, vals_mont, nnz * 32, hipMemcpyHostToDevice, C->stream));
+  }
+  GM_HIP(hipStreamSynchronize(C->stream));
+  std::lock_guard<std::mutex> lk(C->mu);
+  *handle = C->next_handle++;
+  C->matrices[*handle] = std::move(M);
+  return GM_OK;
+}
+int gm_spm_free(uint64_t handle) {
+  GM_CTX();
+  std::unique_ptr<SparseMatrix> M;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->matrices.find(handle);
+    GM_CHECK(it != C->matrices.end(), GM_EHANDLE, "spm_free: unknown handle %llu", (unsigned long long)handle);
+    M = std::move(it->second);
+    C->matrices.erase(it);
+  }
+  if (M->rowptr) (void)hipFree(M->rowptr);
+  if (M->cols) (void)hipFree(M->cols);
+  if (M->vals) (void)hipFree(M->vals);
+  return GM_OK;
+}
+int gm_spm_mul(uint64_t matrix, uint64_t x, uint64_t y) {
+  GM_CTX();
+  SparseMatrix* M;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->matrices.find(matrix);
+    GM_CHECK(it != C->matrices.end(), GM_EHANDLE, "spm_mul: unknown matrix handle %llu", (unsigned long long)matrix);
+    M = it->second.get();
+  }
+  GM_VEC(vx, x, "spm_mul");
+  GM_VEC(vy, y, "spm_mul");
+  return spm_mul(C, M, vx, vy);
 }
 
 // ---- sumcheck ---------------------------------------------------------------------------------

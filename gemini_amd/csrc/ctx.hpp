@@ -55,6 +55,14 @@ struct FrVec {
   size_t len = 0;
 };
 
+// CSR sparse matrix resident in HBM (`Matrix<F> = Vec<Vec<(F, usize)>>`, src/circuit.rs:43)
+struct SparseMatrix {
+  uint64_t* rowptr = nullptr;  // nrows + 1
+  uint32_t* cols = nullptr;    // nnz
+  uint8_t* vals = nullptr;     // nnz x 32 bytes Montgomery
+  size_t nrows = 0, ncols = 0, nnz = 0;
+};
+
 struct Sumcheck {
   // ping-pong state of TimeProver (src/subprotocols/sumcheck/time_prover.rs:42-52)
   uint8_t* f[2] = {nullptr, nullptr};
@@ -99,6 +107,7 @@ struct Context {
   std::unordered_map<uint64_t, std::unique_ptr<Bases>> bases;
   std::unordered_map<uint64_t, std::unique_ptr<FrVec>> vecs;
   std::unordered_map<uint64_t, std::unique_ptr<Sumcheck>> provers;
+  std::unordered_map<uint64_t, std::unique_ptr<SparseMatrix>> matrices;
   MsmWorkspace msm;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results

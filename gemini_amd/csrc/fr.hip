@@ -374,6 +374,22 @@ __global__ __launch_bounds__(256) void k_div_phase3(const uint8_t* __restrict__ 
   }
 }
 
+// y[i] = sum_k vals[k] * x[cols[k]] over row i of a CSR matrix       src/misc.rs:100-110
+// (product_matrix_vector; the reference skips the multiplication when the coefficient is one,
+// which cannot change the value)
+__global__ __launch_bounds__(256) void k_spmv(const uint64_t* __restrict__ rowptr, const uint32_t* __restrict__ cols,
+                                              const uint8_t* __restrict__ vals, size_t nrows,
+                                              const uint8_t* __restrict__ x, size_t nx, uint8_t* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = Fr::zero();
+    for (uint64_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+      Fr xv = fr_load_or_zero(x, cols[k], nx);
+      acc = fr_add(acc, fr_mul(fp_load<FrParams>(vals + k * FR_BYTES), xv));
+    }
+    fp_store<FrParams>(y + i * FR_BYTES, acc);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
@@ -687,6 +703,17 @@ int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVe
   GM_HIP(hipStreamSynchronize(C->stream));
   out->len = n;
   return fr_trim(C, out);
+}
+
+int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y) {
+  GM_CHECK(y->cap >= M->nrows, GM_EINVAL, "spm_mul: output capacity %zu < %zu rows", y->cap, M->nrows);
+  GM_CHECK(y != x, GM_EINVAL, "spm_mul: output must not alias the input");
+  if (M->nrows)
+    hipLaunchKernelGGL(k_spmv, dim3(grid_for(M->nrows)), dim3(256), 0, C->stream, M->rowptr, M->cols, M->vals, M->nrows, x->d, x->len, y->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  y->len = M->nrows;
+  return GM_OK;
 }
 
 int fr_fill(Context* C, FrVec* v, const uint64_t val[4]) {

@@ -92,10 +92,24 @@ class Sumcheck:
         return Sumcheck(messages, challenges, rounds, [ff])
 
     @staticmethod
-    def new_time(transcript, f, g, twist_mont) -> "Sumcheck":
+    def prove_native(transcript, prover: "TimeProver") -> "Sumcheck":
+        """the same round loop run inside the library (gm_sumcheck_prove): no Python per round"""
+        cap = prover.rounds() + 1
+        msgs = np.zeros((cap, 8), dtype=np.uint64)
+        chs = np.zeros((cap, 4), dtype=np.uint64)
+        ff = np.zeros(8, dtype=np.uint64)
+        k = C.c_size_t()
+        capi.check(capi.load().gm_sumcheck_prove(C.c_uint64(transcript.handle), C.c_uint64(prover.handle), capi.ptr(msgs), capi.ptr(chs),
+                                                 C.c_size_t(cap), capi.ptr(ff), C.byref(k)))
+        n = k.value
+        return Sumcheck([(msgs[i, :4].copy(), msgs[i, 4:].copy()) for i in range(n)], [chs[i].copy() for i in range(n)], prover.rounds(),
+                        [(ff[:4].copy(), ff[4:].copy())])
+
+    @staticmethod
+    def new_time(transcript, f, g, twist_mont, native: bool = True) -> "Sumcheck":
         """proof.rs:125-130"""
         prover = TimeProver(f, g, twist_mont)
         try:
-            return Sumcheck.prove(transcript, prover)
+            return Sumcheck.prove_native(transcript, prover) if native else Sumcheck.prove(transcript, prover)
         finally:
             prover.free()

@@ -146,6 +146,15 @@ int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, 
  * Replaces DensePolynomial::div in open_multi_points           src/kzg/time.rs:134-145 */
 int gm_fr_div_vanishing(uint64_t f, const uint64_t* points_mont, size_t k, uint64_t quotient, uint64_t* rem_mont);
 
+/* ---- sparse R1CS matrices ------------------------------------------------------------------------ */
+/* `Matrix<F> = Vec<Vec<(F, usize)>>` (src/circuit.rs:43) as CSR, copied to HBM once.  gm_spm_mul is
+ * product_matrix_vector (src/misc.rs:100-110): y = M x.  Registering the TRANSPOSE turns the
+ * abc_tensored scatter-add of src/snark/time_prover.rs:63-81 into three products M^T r. */
+int gm_spm_register(const uint64_t* rowptr, const uint32_t* cols, const uint64_t* vals_mont, size_t nrows, size_t ncols,
+                    size_t nnz, uint64_t* handle);
+int gm_spm_free(uint64_t handle);
+int gm_spm_mul(uint64_t matrix, uint64_t x, uint64_t y);
+
 /* ---- sumcheck time prover --------------------------------------------------------------------- */
 /* Replaces TimeProver<F> behind `trait Prover<F>` (src/subprotocols/sumcheck/prover.rs:30-45,
  * src/subprotocols/sumcheck/time_prover.rs:42-137).  f, g are copied (Witness::new copies too,
@@ -167,6 +176,26 @@ int gm_sc_free(uint64_t handle);
 /* partial-message form for sharded sumchecks: the shard holds pairs
  * [pair_offset, pair_offset + len/2) of the global vectors; twist powers start at tau^(2*pair_offset) */
 int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset);
+
+/* ---- Fiat-Shamir transcript (host; no GPU needed) ------------------------------------------------ */
+/* merlin::Transcript::new(label) (merlin 3.0.0, Cargo.lock:606-608); the prover uses
+ * Transcript::new(PROTOCOL_NAME) with PROTOCOL_NAME = b"GEMINI-v0" (src/lib.rs:74). */
+int gm_transcript_new(const uint8_t* label, size_t len, uint64_t* handle);
+int gm_transcript_free(uint64_t handle);
+/* Transcript::append_message / challenge_bytes */
+int gm_transcript_append_message(uint64_t handle, const uint8_t* label, size_t llen, const uint8_t* msg, size_t mlen);
+int gm_transcript_challenge_bytes(uint64_t handle, const uint8_t* label, size_t llen, uint8_t* out, size_t n);
+/* GeminiTranscript::append_serializable (src/transcript.rs:16-24) for `count` consecutive Fr
+ * (an Fr, a RoundMsg(a, b), an [F; 2]) and for G1 elements (Commitment; with_len != 0 prefixes the
+ * u64 length like Vec<Commitment>). */
+int gm_transcript_append_fr(uint64_t handle, const uint8_t* label, size_t llen, const uint64_t* mont, size_t count);
+int gm_transcript_append_g1(uint64_t handle, const uint8_t* label, size_t llen, const uint64_t* jac, size_t count, int with_len);
+/* GeminiTranscript::get_challenge::<Fr> (src/transcript.rs:26-34) */
+int gm_transcript_challenge_fr(uint64_t handle, const uint8_t* label, size_t llen, uint64_t out_mont[4]);
+/* Sumcheck::prove round loop (src/subprotocols/sumcheck/proof.rs:36-66) over a gm_sc_* prover.
+ * messages: cap_rounds x 8 u64 (a || b), challenges: cap_rounds x 4, final_foldings: f0 || g0. */
+int gm_sumcheck_prove(uint64_t transcript, uint64_t prover, uint64_t* messages, uint64_t* challenges, size_t cap_rounds,
+                      uint64_t final_foldings[8], size_t* rounds_out);
 
 #ifdef __cplusplus
 }

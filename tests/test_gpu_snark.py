@@ -1,0 +1,120 @@
+"""GPU parity for the callers of the hot path: KZG CommitterKey
+(src/kzg/time.rs) and the snark time prover (src/snark/time_prover.rs) through the device path vs
+the CPU restatement (oracle/snark_ref.py), transcript included."""
+import numpy as np
+import pytest
+
+from tests.util import jac_to_affine_ints
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import gemini_amd
+
+    gemini_amd.capi.init()
+    return gemini_amd
+
+
+def _M(orc, ints):
+    return orc.fr_to_mont(orc.ints_to_limbs(ints, 4))
+
+
+def test_committer_key_vs_oracle(gm, oracle, pyref):
+    """src/kzg/time.rs tests (:162-211) + src/kzg/tests.rs:16-59 shape: commit / open /
+    open_multi_points / batch_open_multi_points against the restatement."""
+    from gemini_amd.kzg import CommitterKey
+    from oracle import snark_ref as sr
+
+    tau = oracle.limbs_to_ints(oracle.random_fr(1, 1))[0]
+    ck = CommitterKey.new(200, 3, oracle.ints_to_limbs([tau], 4)[0])
+    srs = sr.srs(tau, 201)
+    assert len(ck.powers_of_g) == 201
+    assert (ck.powers_of_g.download() == srs).all()
+    poly = oracle.limbs_to_ints(oracle.random_fr(2, 101))
+    pm = _M(oracle, poly)
+    assert jac_to_affine_ints(oracle, ck.commit(pm)) == sr.commit(srs, poly)
+    # trivial commitment test (:174-190): f = x + x^2, alpha = 0 -> evaluation 0
+    ev, proof = ck.open(_M(oracle, [0, 1, 1]), _M(oracle, [0])[0])
+    assert not ev.any()
+    q, _ = pyref.poly_divmod([0, 1, 1], [0, 1])
+    assert jac_to_affine_ints(oracle, proof) == sr.commit(srs, q)
+    # open at a random point: evaluation == polynomial.evaluate (:193-211)
+    a = oracle.limbs_to_ints(oracle.random_fr(3, 1))[0]
+    ev, proof = ck.open(pm, _M(oracle, [a])[0])
+    assert gm.fr.fr_to_int(ev) == pyref.evaluate_le(poly, a)
+    q, _ = pyref.poly_divmod(poly, pyref.vanishing_polynomial([a]))
+    assert jac_to_affine_ints(oracle, proof) == sr.commit(srs, q)
+    pts = [a * a % pyref.R_MOD, a, (-a) % pyref.R_MOD]
+    assert jac_to_affine_ints(oracle, ck.open_multi_points(pm, _M(oracle, pts))) == sr.open_multi_points(srs, poly, pts)
+    polys = [oracle.limbs_to_ints(oracle.random_fr(10 + k, n)) for k, n in enumerate([101, 50, 25, 7])]
+    chal = oracle.limbs_to_ints(oracle.random_fr(4, 1))[0]
+    got = ck.batch_open_multi_points([_M(oracle, p) for p in polys], _M(oracle, pts), _M(oracle, [chal])[0])
+    assert jac_to_affine_ints(oracle, got) == sr.batch_open_multi_points(srs, polys, pts, chal)
+    batch = ck.batch_commit([_M(oracle, p) for p in polys])
+    assert [jac_to_affine_ints(oracle, c) for c in batch] == [sr.commit(srs, p) for p in polys]
+
+
+@pytest.mark.parametrize("logn", [3, 6, 9])
+def test_snark_time_prover_dummy_r1cs(gm, oracle, pyref, logn):
+    """examples/snark.rs:69-79 (time_snark_main) at small sizes: every proof element, i.e. every
+    commitment and every sumcheck message, equals the restatement's -- which also fixes every
+    Fiat-Shamir challenge in between."""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+    from oracle import snark_ref as sr
+
+    n = 1 << logn
+    e = oracle.limbs_to_ints(oracle.random_fr(100 + logn, 1))[0]
+    tau = oracle.limbs_to_ints(oracle.random_fr(200 + logn, 1))[0]
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])  # examples/snark.rs:75
+    r1cs = dummy_r1cs(e, n)
+    proof = Proof.new_time(r1cs, ck)
+    exp = sr.snark_new_time(sr.dummy_r1cs(e, n), sr.srs(tau, 2 * n + 1))
+    I = gm.fr.fr_to_int
+    assert jac_to_affine_ints(oracle, proof.witness_commitment) == exp["witness_commitment"]
+    assert I(proof.zc_alpha) == exp["zc_alpha"]
+    for got, want in ((proof.first_sumcheck_msgs, exp["first_sumcheck_msgs"]), (proof.second_sumcheck_msgs, exp["second_sumcheck_msgs"])):
+        assert [(I(a), I(b)) for a, b in got[0]] == want[0]
+        assert (I(got[1][0][0]), I(got[1][0][1])) == want[1]
+    tc, etc = proof.tensorcheck_proof, exp["tensorcheck_proof"]
+    assert [jac_to_affine_ints(oracle, c) for c in tc.folded_polynomials_commitments] == etc["folded_polynomials_commitments"]
+    assert [[I(x) for x in e2] for e2 in tc.folded_polynomials_evaluations] == etc["folded_polynomials_evaluations"]
+    assert [[I(x) for x in e3] for e3 in tc.base_polynomials_evaluations] == etc["base_polynomials_evaluations"]
+    assert jac_to_affine_ints(oracle, tc.evaluation_proof) == etc["evaluation_proof"]
+    # proof shape of src/snark/mod.rs:76-82 at this size
+    assert len(proof.first_sumcheck_msgs[0]) == logn and len(tc.folded_polynomials_commitments) == logn - 1
+    r1cs.free()
+
+
+def test_snark_time_prover_general_r1cs(gm, oracle, pyref):
+    """a non-diagonal instance: random sparse A, B and C chosen so that Az . Bz = Cz row by row"""
+    from gemini_amd.circuit import R1cs, SparseMatrix
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+    from oracle import snark_ref as sr
+
+    n = 32
+    rng = pyref.SplitMix64(77)
+    R = pyref.R_MOD
+    z = [rng.fr() for _ in range(n)]
+    mk = lambda: [[(rng.fr(), int(rng.next() % n)) for _ in range(1 + int(rng.next() % 3))] for _ in range(n)]
+    a, b = mk(), mk()
+    za, zb = sr.matvec(a, z), sr.matvec(b, z)
+    c = [[(za[i] * zb[i] % R * pow(z[i], -1, R) % R, i)] for i in range(n)]
+    inst = {"a": a, "b": b, "c": c, "z": z, "w": z[1:], "x": z[:1]}
+    tau = rng.fr()
+    exp = sr.snark_new_time(inst, sr.srs(tau, 2 * n + 1))
+    M = lambda v: gm.fr.fr_from_int(v)
+    dev = lambda rows: [[(M(v), col) for v, col in row] for row in rows]
+    mats = [SparseMatrix.from_rows(dev(m), n) for m in (a, b, c)] + [SparseMatrix.from_rows(dev(m), n, transpose=True) for m in (a, b, c)]
+    r1cs = R1cs(*mats, gm.FrVec.from_host(_M(oracle, z)), gm.FrVec.from_host(_M(oracle, z[1:])), gm.FrVec.from_host(_M(oracle, z[:1])))
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    proof = Proof.new_time(r1cs, ck)
+    I = gm.fr.fr_to_int
+    assert jac_to_affine_ints(oracle, proof.witness_commitment) == exp["witness_commitment"]
+    assert [(I(x), I(y)) for x, y in proof.second_sumcheck_msgs[0]] == exp["second_sumcheck_msgs"][0]
+    assert jac_to_affine_ints(oracle, proof.tensorcheck_proof.evaluation_proof) == exp["tensorcheck_proof"]["evaluation_proof"]
+    r1cs.free()
