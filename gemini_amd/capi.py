@@ -29,7 +29,7 @@ SYMBOLS = [
     "gm_fr_lincomb", "gm_fr_div_vanishing",
     "gm_spm_register", "gm_spm_free", "gm_spm_mul",
     "gm_sc_new", "gm_sc_new_v", "gm_sc_round", "gm_sc_fold", "gm_sc_rounds", "gm_sc_final", "gm_sc_free",
-    "gm_sc_set_shard",
+    "gm_sc_set_shard", "gm_sc_lens", "gm_sc_download",
     "gm_transcript_new", "gm_transcript_free", "gm_transcript_append_message", "gm_transcript_challenge_bytes",
     "gm_transcript_append_fr", "gm_transcript_append_g1", "gm_transcript_challenge_fr", "gm_sumcheck_prove",
 ]

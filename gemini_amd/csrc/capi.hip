@@ -575,6 +575,25 @@ int gm_sc_final(uint64_t handle, uint64_t f0_mont[4], uint64_t g0_mont[4], int* 
   GM_SC(S, handle, "sc_final");
   return sc_final(C, S, f0_mont, g0_mont, has);
 }
+// current vectors of the prover (after the folds so far): lengths, then the elements
+int gm_sc_lens(uint64_t handle, size_t* nf, size_t* ng, uint64_t twist_mont[4]) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_lens");
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (nf) *nf = S->nf;
+  if (ng) *ng = S->ng;
+  if (twist_mont) memcpy(twist_mont, S->twist, 32);
+  return GM_OK;
+}
+int gm_sc_download(uint64_t handle, uint64_t* f_mont, uint64_t* g_mont) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_download");
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (f_mont && S->nf) GM_HIP(hipMemcpyAsync(f_mont, S->f[S->cur], S->nf * 32, hipMemcpyDeviceToHost, C->stream));
+  if (g_mont && S->ng) GM_HIP(hipMemcpyAsync(g_mont, S->g[S->cur], S->ng * 32, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
 int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset) {
   GM_CTX();
   GM_SC(S, handle, "sc_set_shard");

@@ -53,6 +53,16 @@ class TimeProver:
         capi.check(capi.load().gm_sc_final(C.c_uint64(self.handle), capi.ptr(f0), capi.ptr(g0), C.byref(has)))
         return (f0, g0) if has.value else None
 
+    def state(self):
+        """(f, g, twist) as they stand after the folds so far (TimeProver's pub fields)"""
+        nf, ng = C.c_size_t(), C.c_size_t()
+        tw = np.empty(4, dtype=np.uint64)
+        capi.check(capi.load().gm_sc_lens(C.c_uint64(self.handle), C.byref(nf), C.byref(ng), capi.ptr(tw)))
+        f = np.empty((nf.value, 4), dtype=np.uint64)
+        g = np.empty((ng.value, 4), dtype=np.uint64)
+        capi.check(capi.load().gm_sc_download(C.c_uint64(self.handle), capi.ptr(f), capi.ptr(g)))
+        return f, g, tw
+
     def set_shard(self, pair_offset: int):
         capi.check(capi.load().gm_sc_set_shard(C.c_uint64(self.handle), C.c_uint64(pair_offset)))
 

@@ -176,6 +176,10 @@ int gm_sc_free(uint64_t handle);
 /* partial-message form for sharded sumchecks: the shard holds pairs
  * [pair_offset, pair_offset + len/2) of the global vectors; twist powers start at tau^(2*pair_offset) */
 int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset);
+/* current state of the prover (TimeProver's pub fields f, g, twist: time_prover.rs:42-52): lengths and
+ * twist, then the vectors themselves -- used when sharded provers hand their tails to one rank */
+int gm_sc_lens(uint64_t handle, size_t* nf, size_t* ng, uint64_t twist_mont[4]);
+int gm_sc_download(uint64_t handle, uint64_t* f_mont, uint64_t* g_mont);
 
 /* ---- Fiat-Shamir transcript (host; no GPU needed) ------------------------------------------------ */
 /* merlin::Transcript::new(label) (merlin 3.0.0, Cargo.lock:606-608); the prover uses
