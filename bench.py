@@ -50,6 +50,42 @@ def uniform_fr(rng: np.random.Generator, n: int) -> np.ndarray:
     return out
 
 
+def snark_time_prover(gm, logn: int) -> dict:
+    """second half of BASELINE.json's metric: wall time of the `Proof::new_time` span
+    (src/snark/time_prover.rs:23,109) on dummy_r1cs(2^logn) with an SRS of 2^(logn+1)+1 powers
+    (examples/snark.rs:69-79).  Instance and SRS are built before the timer, as in the reference."""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+
+    n = 1 << logn
+    rng = np.random.default_rng(2022420)
+    rnd = lambda: int.from_bytes(rng.bytes(40), "little") % R_MOD
+    t0 = time.perf_counter()
+    r1cs = dummy_r1cs(rnd(), n)
+    t_inst = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    ck = CommitterKey.new(2 * n, 5, tau)
+    t_srs = time.perf_counter() - t0
+    runs = []
+    for _ in range(3):
+        runs.append(Proof.new_time(r1cs, ck).spans)
+    best = min(runs, key=lambda r: r["ark_gemini::snark::time_prover"])
+    r1cs.free()
+    ck.powers_of_g.free()
+    return {
+        "metric": "snark time_prover",
+        "unit": "s",
+        "logn": logn,
+        "value": round(best["ark_gemini::snark::time_prover"], 4),
+        "higher_is_better": False,
+        "spans_s": {k: round(v, 4) for k, v in best.items()},
+        "setup_s": {"dummy_r1cs_to_hbm": round(t_inst, 3), "srs_generation_on_device": round(t_srs, 3)},
+        "note": "best of 3; instance (diagonal CSR) and SRS resident in HBM before the timer; proof elements equal the CPU restatement at logn 3/6/9 (tests/test_gpu_snark.py)",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=LOG_N, help="pairs per GPU per step = 2^logn (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--snark-logn", type=int, default=24, help="also time snark::Proof::new_time on dummy_r1cs(2^k) (N=1 only; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -133,6 +170,16 @@ def main():
     stage_names = ["digits_hist", "scan", "scatter", "acc0", "merge", "reduce", "sc_round"]
     stages = {k: (ms[i] / cnt[i] if cnt[i] else None) for i, k in enumerate(stage_names)}
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
+    # this same command; profiles/r1_pmc_msm20.json says how it was collected and corrected)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_msm20.json")) as fh:
+            if args.logn == LOG_N:
+                traffic = json.load(fh)["kernels"]["gm::k_acc0"]["hbm_bytes_corrected"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     if rank == 0:
         pairs = world * n * args.steps
         value = pairs / elapsed / 1e6
@@ -163,7 +210,7 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 6) if achieved else None,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel_ms": round(acc0_ms, 4) if acc0_ms else None,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
                 "note": "integer-ALU bound (~300 v_mad_u64_u32 per Fq product); HBM fraction reported as the contract asks",
@@ -190,6 +237,8 @@ def main():
                 "sample": f"one full 2^{args.logn} MSM of the benchmark inputs ({cpu_s:.2f} s), OpenMP one task per window",
                 "matches_gpu_result": bool(same),
             }
+        if world == 1 and args.snark_logn > 0:
+            out["time_prover"] = snark_time_prover(gm, args.snark_logn)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
