@@ -38,6 +38,52 @@ void DevBuf::release() {
   cap = 0;
 }
 
+int DevPool::alloc(size_t bytes, void** p, size_t* cap) {
+  if (bytes == 0) {
+    *p = nullptr;
+    *cap = 0;
+    return GM_OK;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = free_list.lower_bound(bytes);
+    if (it != free_list.end() && it->first <= bytes + bytes / 2 + 4096) {
+      *p = it->second;
+      *cap = it->first;
+      pooled_bytes -= it->first;
+      free_list.erase(it);
+      return GM_OK;
+    }
+  }
+  size_t want = (bytes + 4095) & ~(size_t)4095;
+  hipError_t e = hipMalloc(p, want);
+  if (e == hipErrorOutOfMemory) {  // give cached blocks back and retry once
+    release_all();
+    e = hipMalloc(p, want);
+  }
+  GM_HIP(e);
+  *cap = want;
+  return GM_OK;
+}
+void DevPool::free(void* p, size_t cap) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (pooled_bytes + cap <= MAX_POOLED) {
+      free_list.emplace(cap, p);
+      pooled_bytes += cap;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+void DevPool::release_all() {
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& kv : free_list) (void)hipFree(kv.second);
+  free_list.clear();
+  pooled_bytes = 0;
+}
+
 void Profiler::begin(int stage, hipStream_t st) {
   if (!on) return;
   if (!have_events) {
@@ -164,6 +210,7 @@ void gm_shutdown(void) {
     if (kv.second->d) (void)hipFree(kv.second->d);
   for (auto& kv : C->vecs)
     if (kv.second->d) (void)hipFree(kv.second->d);
+  C->pool.release_all();
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
   for (auto& kv : C->matrices) {
     if (kv.second->rowptr) (void)hipFree(kv.second->rowptr);
@@ -363,7 +410,10 @@ int gm_fr_vec_alloc(size_t n, uint64_t* handle) {
   auto v = std::make_unique<FrVec>();
   v->cap = n;
   v->len = n;
-  if (n) GM_HIP(hipMalloc((void**)&v->d, n * 32));
+  size_t cap_bytes = 0;
+  int rc = C->pool.alloc(n * 32, (void**)&v->d, &cap_bytes);
+  if (rc) return rc;
+  v->cap_bytes = cap_bytes;
   *handle = put_vec(std::move(v));
   return GM_OK;
 }
@@ -377,7 +427,9 @@ int gm_fr_vec_free(uint64_t handle) {
     v = std::move(it->second);
     C->vecs.erase(it);
   }
-  if (v->d) GM_HIP(hipFree(v->d));
+  // stream-ordered reuse is safe: every kernel of this library runs on C->stream and entry points
+  // return after synchronising it
+  C->pool.free(v->d, v->cap_bytes);
   return GM_OK;
 }
 #define GM_VEC(var, h, who)                  \

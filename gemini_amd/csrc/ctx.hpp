@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -53,6 +54,7 @@ struct FrVec {
   uint8_t* d = nullptr;  // cap x 32 bytes, Montgomery
   size_t cap = 0;
   size_t len = 0;
+  size_t cap_bytes = 0;  // size of the pooled allocation behind d
 };
 
 // CSR sparse matrix resident in HBM (`Matrix<F> = Vec<Vec<(F, usize)>>`, src/circuit.rs:43)
@@ -67,6 +69,7 @@ struct Sumcheck {
   // ping-pong state of TimeProver (src/subprotocols/sumcheck/time_prover.rs:42-52)
   uint8_t* f[2] = {nullptr, nullptr};
   uint8_t* g[2] = {nullptr, nullptr};
+  size_t fcap[2] = {0, 0}, gcap[2] = {0, 0};  // pooled allocation sizes
   int cur = 0;
   size_t nf = 0, ng = 0;
   uint64_t twist[4];  // Montgomery
@@ -97,8 +100,21 @@ struct Profiler {
   void collect();  // after a stream sync
 };
 
+// Caching allocator for device vectors: the prover allocates and drops O(100) multi-hundred-MB
+// vectors per proof; hipMalloc/hipFree are synchronous and cost milliseconds at that size.
+struct DevPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_list;  // capacity -> pointer
+  size_t pooled_bytes = 0;
+  static constexpr size_t MAX_POOLED = (size_t)96 << 30;
+  int alloc(size_t bytes, void** p, size_t* cap);
+  void free(void* p, size_t cap);
+  void release_all();
+};
+
 struct Context {
   int device = -1;
+  DevPool pool;
   Profiler prof;
   hipStream_t stream = nullptr;
   std::mutex mu;       // guards handle tables

@@ -493,10 +493,11 @@ int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_
   S->ng = ng;
   memcpy(S->twist, twist, 32);
   S->tot_rounds = ceil_log2_sz(nf > ng ? nf : ng);  // time_prover.rs:35-38
-  GM_HIP(hipMalloc((void**)&S->f[0], nf * FR_BYTES));
-  GM_HIP(hipMalloc((void**)&S->f[1], ((nf + 1) / 2) * FR_BYTES));
-  GM_HIP(hipMalloc((void**)&S->g[0], ng * FR_BYTES));
-  GM_HIP(hipMalloc((void**)&S->g[1], ((ng + 1) / 2) * FR_BYTES));
+  int rc;
+  if ((rc = C->pool.alloc(nf * FR_BYTES, (void**)&S->f[0], &S->fcap[0]))) return rc;
+  if ((rc = C->pool.alloc(((nf + 1) / 2) * FR_BYTES, (void**)&S->f[1], &S->fcap[1]))) return rc;
+  if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g[0], &S->gcap[0]))) return rc;
+  if ((rc = C->pool.alloc(((ng + 1) / 2) * FR_BYTES, (void**)&S->g[1], &S->gcap[1]))) return rc;
   GM_HIP(hipMalloc((void**)&S->partials, 512 * 2 * FR_BYTES));
   GM_HIP(hipHostMalloc((void**)&S->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
   hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -508,9 +509,12 @@ int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_
 }
 
 void sc_destroy(Sumcheck* S) {
+  Context* C = context();
   for (int i = 0; i < 2; i++) {
-    if (S->f[i]) (void)hipFree(S->f[i]);
-    if (S->g[i]) (void)hipFree(S->g[i]);
+    if (C) {
+      C->pool.free(S->f[i], S->fcap[i]);
+      C->pool.free(S->g[i], S->gcap[i]);
+    }
   }
   if (S->partials) (void)hipFree(S->partials);
   if (S->host_partials) (void)hipHostFree(S->host_partials);

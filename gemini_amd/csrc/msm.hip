@@ -26,6 +26,7 @@
 //   7. host           Horner over <= 256 bit positions on the (W x c) plane sums
 //                     (src/kzg/msm/variable_base.rs:168-175 is the window Horner).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "ctx.hpp"
@@ -360,6 +361,7 @@ struct GroupSumArgs {
   uint32_t win_stride; // input elements per window
   uint32_t lo_bits;    // ROW/COL: a (low field width);   PLANE: nb (log2 of the per-window length)
   uint32_t len;        // ROW: 2^a, COL: 2^h, PLANE: unused
+  uint32_t lpo_shift;  // lanes per output = 2^lpo_shift (4..6): more lanes = shorter dependent chains
 };
 
 GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
@@ -382,22 +384,23 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumArgs a0, GroupSumArgs
   const uint8_t* __restrict__ in = a.in;
   uint8_t* __restrict__ out = a.out;
   const uint32_t gt = (blockIdx.x - (second ? blocks0 : 0u)) * blockDim.x + threadIdx.x;
-  const uint32_t o = gt >> 4, q = gt & 15u;
+  const uint32_t lpo = 1u << a.lpo_shift;
+  const uint32_t o = gt >> a.lpo_shift, q = gt & (lpo - 1u);
   G1Xyzz acc = G1Xyzz::identity();
   if (o < a.n_out) {
     const uint32_t w = o / a.per_win, r = o % a.per_win;
     const size_t base = (size_t)w * a.win_stride;
     if (a.mode == GS_ROW) {
-      for (uint32_t e = q; e < a.len; e += 16) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)r << a.lo_bits) + e) * XYZZ_BYTES));
+      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)r << a.lo_bits) + e) * XYZZ_BYTES));
     } else if (a.mode == GS_COL) {
-      for (uint32_t e = q; e < a.len; e += 16) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)e << a.lo_bits) + r) * XYZZ_BYTES));
+      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)e << a.lo_bits) + r) * XYZZ_BYTES));
     } else {
       const uint32_t nb = a.lo_bits;
       if (r == nb) {  // total
-        for (uint32_t e = q; e < (1u << nb); e += 16) xyzz_add(acc, g1_load_xyzz(in + (base + e) * XYZZ_BYTES));
+        for (uint32_t e = q; e < (1u << nb); e += lpo) xyzz_add(acc, g1_load_xyzz(in + (base + e) * XYZZ_BYTES));
       } else {        // elements whose bit r is set
         const uint32_t half = nb ? (1u << (nb - 1)) : 0u;
-        for (uint32_t e = q; e < half; e += 16) {
+        for (uint32_t e = q; e < half; e += lpo) {
           uint32_t v = ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u));
           xyzz_add(acc, g1_load_xyzz(in + (base + v) * XYZZ_BYTES));
         }
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumArgs a0, GroupSumArgs
     }
   }
 #pragma unroll 1
-  for (int m = 8; m >= 1; m >>= 1) {
+  for (int m = (int)(lpo >> 1); m >= 1; m >>= 1) {
     G1Xyzz other = xyzz_shfl_xor(acc, m);
     xyzz_add(acc, other);
   }
@@ -553,7 +556,9 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   GM_CHECK(N < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)N);
 
   // level-0 chunk length: keep >= 2 waves per SIMD when the problem is large enough
+  static const int L_env = getenv("GM_MSM_L") ? atoi(getenv("GM_MSM_L")) : 0;  // tuning override
   uint32_t L = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(4, (N + 131071) / 131072));
+  if (L_env > 0) L = (uint32_t)L_env;
   const uint64_t T0 = (N + L - 1) / L;
   const uint64_t T0pad = (T0 + 255) / 256 * 256;
   const uint64_t E1 = 2 * T0pad;
@@ -627,14 +632,16 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   if ((rc = ws.planes.ensure((size_t)W * (planes_per_win + 1) * XYZZ_BYTES))) return rc;
   const uint8_t* col_src = ws.buckets.as<uint8_t>();
   uint32_t col_len_bits = a;
-  auto gs_blocks = [](const GroupSumArgs& g) { return (g.n_out * 16 + 255) / 256; };
+  static const int lpo1 = getenv("GM_MSM_LPO1") ? atoi(getenv("GM_MSM_LPO1")) : 5;
+  static const int lpo2 = getenv("GM_MSM_LPO2") ? atoi(getenv("GM_MSM_LPO2")) : 4;
+  auto gs_blocks = [](const GroupSumArgs& g) { return (uint32_t)((((uint64_t)g.n_out << g.lpo_shift) + 255) / 256); };
   GroupSumArgs none{};
   none.n_out = 0;
   if (h > 0) {
     if ((rc = ws.rows.ensure((size_t)W * (1u << h) * XYZZ_BYTES))) return rc;
     if ((rc = ws.cols.ensure((size_t)W * (1u << a) * XYZZ_BYTES))) return rc;
-    GroupSumArgs ra{ws.buckets.as<uint8_t>(), ws.rows.as<uint8_t>(), GS_ROW, (uint32_t)W << h, 1u << h, B, a, 1u << a};
-    GroupSumArgs ca{ws.buckets.as<uint8_t>(), ws.cols.as<uint8_t>(), GS_COL, (uint32_t)W << a, 1u << a, B, a, 1u << h};
+    GroupSumArgs ra{ws.buckets.as<uint8_t>(), ws.rows.as<uint8_t>(), GS_ROW, (uint32_t)W << h, 1u << h, B, a, 1u << a, (uint32_t)lpo1};
+    GroupSumArgs ca{ws.buckets.as<uint8_t>(), ws.cols.as<uint8_t>(), GS_COL, (uint32_t)W << a, 1u << a, B, a, 1u << h, (uint32_t)lpo1};
     hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(ra) + gs_blocks(ca)), dim3(256), 0, st, ra, ca, gs_blocks(ra));
     col_src = ws.cols.as<uint8_t>();
   }
@@ -642,9 +649,9 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   uint8_t* planes = ws.planes.as<uint8_t>();
   uint8_t* row_planes = planes + (size_t)W * (a + 1) * XYZZ_BYTES;
   {
-    GroupSumArgs pc{col_src, planes, GS_PLANE, (uint32_t)W * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0};
+    GroupSumArgs pc{col_src, planes, GS_PLANE, (uint32_t)W * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0, (uint32_t)lpo2};
     GroupSumArgs pr = none;
-    if (h > 0) pr = GroupSumArgs{ws.rows.as<uint8_t>(), row_planes, GS_PLANE, (uint32_t)W * (h + 1), h + 1, 1u << h, h, 0};
+    if (h > 0) pr = GroupSumArgs{ws.rows.as<uint8_t>(), row_planes, GS_PLANE, (uint32_t)W * (h + 1), h + 1, 1u << h, h, 0, (uint32_t)lpo2};
     hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(pc) + (h > 0 ? gs_blocks(pr) : 0)), dim3(256), 0, st, pc, pr, gs_blocks(pc));
   }
   pf.end(PROF_REDUCE, st);

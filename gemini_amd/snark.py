@@ -33,6 +33,7 @@ class Proof:
         z_b = r1cs.b.mul(r1cs.z)
         z_c = r1cs.c.mul(r1cs.z)
         transcript = Transcript(PROTOCOL_NAME)
+        spans["product_matrix_vector x3"] = time.perf_counter() - t_all
 
         t0 = time.perf_counter()
         witness_commitment = ck.commit(r1cs.w)  # :42
@@ -46,6 +47,7 @@ class Proof:
         first_proof = Sumcheck.new_time(transcript, z_a, z_b, alpha)  # :52
         spans["First sumcheck"] = time.perf_counter() - t0
 
+        t0 = time.perf_counter()
         b_challenges = tensor(np.stack(first_proof.challenges))  # :56-58
         c_challenges = powers(alpha, len(b_challenges))
         a_challenges = hadamard(b_challenges, c_challenges)
@@ -63,6 +65,7 @@ class Proof:
         abc_tensored.set_len(len(r1cs.z))
         for v in (ta, tb, tc, a_challenges, b_challenges, c_challenges):
             v.free()
+        spans["tensor/powers/hadamard/abc_tensored"] = time.perf_counter() - t0
 
         t0 = time.perf_counter()
         second_proof = Sumcheck.new_time(transcript, abc_tensored, r1cs.z, fr_from_int(1))  # :84-89
