@@ -633,7 +633,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   const uint8_t* col_src = ws.buckets.as<uint8_t>();
   uint32_t col_len_bits = a;
   static const int lpo1 = getenv("GM_MSM_LPO1") ? atoi(getenv("GM_MSM_LPO1")) : 5;
-  static const int lpo2 = getenv("GM_MSM_LPO2") ? atoi(getenv("GM_MSM_LPO2")) : 4;
+  static const int lpo2 = getenv("GM_MSM_LPO2") ? atoi(getenv("GM_MSM_LPO2")) : 5;
   auto gs_blocks = [](const GroupSumArgs& g) { return (uint32_t)((((uint64_t)g.n_out << g.lpo_shift) + 255) / 256); };
   GroupSumArgs none{};
   none.n_out = 0;
