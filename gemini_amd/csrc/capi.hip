@@ -218,7 +218,7 @@ void gm_shutdown(void) {
     if (kv.second->vals) (void)hipFree(kv.second->vals);
   }
   MsmWorkspace& w = C->msm;
-  for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
+  for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.tmp_entries, &w.sortmeta, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
                     &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc})
     b->release();
   if (w.host_planes) (void)hipHostFree(w.host_planes);

@@ -81,7 +81,7 @@ struct Sumcheck {
 };
 
 struct MsmWorkspace {
-  DevBuf scalars, counts, offsets, cursor, entries, buckets, pk[2], pp[2], rows, cols, planes, misc;
+  DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
   uint64_t* host_planes = nullptr;  // pinned staging for the D2H of window bit-planes
   size_t host_planes_cap = 0;
 };

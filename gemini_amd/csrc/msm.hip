@@ -27,6 +27,7 @@
 //                     (src/kzg/msm/variable_base.rs:168-175 is the window Horner).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "ctx.hpp"
@@ -109,6 +110,167 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__
     if (SCATTER && key != KEY_INV) {
       entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)i;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Two-pass MSD counting sort with block-local aggregation in LDS.
+//
+// The per-entry global atomics of k_msm_digits cost one L2 atomic + one scattered 8-byte write per
+// (scalar, window) pair.  Here every block first counts its tile in LDS, reserves contiguous
+// output ranges with ONE global atomic per non-empty bin, and ranks its entries with LDS atomics:
+//   pass 1  bin = key >> FB  (window, high bucket bits; G = W * 2^(c-1-FB) <= 4096 bins)
+//   pass 2  bin = key & (2^FB - 1) inside one coarse group, blocks own (group, chunk) pairs
+// Global atomics drop from n*W to ~(n*W / tile) * bins; writes of a block to one bin are contiguous.
+// Skewed inputs (all-equal scalars) only serialise LDS atomics inside a block.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t SORT_TS = 1024;     // scalars per block in pass 1
+constexpr uint32_t SORT_CH = 16384;    // entries per block in pass 2
+constexpr uint32_t SORT_GMAX = 4096;   // coarse bins
+constexpr uint32_t SORT_FMAX = 1024;   // fine bins
+
+struct SortGeom {
+  int c, W;
+  uint32_t B, FB, G;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg,
+                                               uint32_t* __restrict__ gcount_or_cursor, uint64_t* __restrict__ tmp) {
+  __shared__ uint32_t cnt[SORT_GMAX];
+  __shared__ uint32_t base[SCATTER ? SORT_GMAX : 1];
+  for (uint32_t g = threadIdx.x; g < sg.G; g += 256) cnt[g] = 0;
+  __syncthreads();
+  const uint32_t first = blockIdx.x * SORT_TS;
+  for (uint32_t s = threadIdx.x; s < SORT_TS; s += 256) {
+    const uint32_t i = first + s;
+    const bool active = i < n;
+    DigitIter it;
+    it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
+    for (int w = 0; w < sg.W; w++) {
+      int32_t d = it.next(sg.c);
+      if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
+      if (active && d != 0) {
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        atomicAdd(&cnt[((uint32_t)w * sg.B + (mag - 1u)) >> sg.FB], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (!SCATTER) {
+    for (uint32_t g = threadIdx.x; g < sg.G; g += 256)
+      if (cnt[g]) atomicAdd(gcount_or_cursor + g, cnt[g]);
+    return;
+  }
+  for (uint32_t g = threadIdx.x; g < sg.G; g += 256) {
+    const uint32_t k = cnt[g];
+    if (SCATTER) base[g] = k ? atomicAdd(gcount_or_cursor + g, k) : 0u;
+    cnt[g] = 0;
+  }
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < SORT_TS; s += 256) {
+    const uint32_t i = first + s;
+    const bool active = i < n;
+    DigitIter it;
+    it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
+    for (int w = 0; w < sg.W; w++) {
+      int32_t d = it.next(sg.c);
+      if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
+      if (active && d != 0) {
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint32_t key = (uint32_t)w * sg.B + (mag - 1u);
+        const uint32_t g = key >> sg.FB;
+        const uint32_t r = atomicAdd(&cnt[g], 1u);
+        tmp[(SCATTER ? base[g] : 0u) + r] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)i;
+      }
+    }
+  }
+}
+
+// exclusive scan of the G coarse counters + prefix of the pass-2 block counts (one block)
+__global__ __launch_bounds__(1024) void k_sort1_scan(const uint32_t* __restrict__ gcount, uint32_t G,
+                                                     uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor,
+                                                     uint32_t* __restrict__ blkoff) {
+  __shared__ uint32_t a[1024], b[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (G + 1023u) / 1024u;  // <= 4
+  uint32_t v[4], nb[4], sa = 0, sb = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t g = tid * per + k;
+    v[k] = g < G ? gcount[g] : 0u;
+    nb[k] = (v[k] + SORT_CH - 1u) / SORT_CH;
+    sa += v[k];
+    sb += nb[k];
+  }
+  a[tid] = sa;
+  b[tid] = sb;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t xa = tid >= d ? a[tid - d] : 0, xb = tid >= d ? b[tid - d] : 0;
+    __syncthreads();
+    a[tid] += xa;
+    b[tid] += xb;
+    __syncthreads();
+  }
+  uint32_t ra = a[tid] - sa, rb = b[tid] - sb;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t g = tid * per + k;
+    if (g < G) {
+      goff[g] = ra;
+      gcursor[g] = ra;
+      blkoff[g] = rb;
+    }
+    ra += v[k];
+    rb += nb[k];
+  }
+  if (tid == 1023) {
+    goff[G] = a[1023];
+    blkoff[G] = b[1023];
+  }
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_sort2(const uint64_t* __restrict__ tmp, const uint32_t* __restrict__ goff,
+                                               const uint32_t* __restrict__ blkoff, SortGeom sg,
+                                               uint32_t* __restrict__ counts_or_cursor, uint64_t* __restrict__ entries) {
+  __shared__ uint32_t cnt[SORT_FMAX];
+  __shared__ uint32_t base[SCATTER ? SORT_FMAX : 1];
+  __shared__ uint32_t s_g;
+  const uint32_t nf = 1u << sg.FB;
+  if (blockIdx.x >= blkoff[sg.G]) return;
+  if (threadIdx.x == 0) {  // largest g with blkoff[g] <= blockIdx.x
+    uint32_t lo = 0, hi = sg.G;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (blkoff[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    s_g = lo;
+  }
+  for (uint32_t f = threadIdx.x; f < nf; f += 256) cnt[f] = 0;
+  __syncthreads();
+  const uint32_t g = s_g;
+  const uint32_t chunk = blockIdx.x - blkoff[g];
+  const uint32_t lo = goff[g] + chunk * SORT_CH;
+  const uint32_t hi = min(lo + SORT_CH, goff[g + 1]);
+  const uint32_t mask = nf - 1u;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[(uint32_t)(tmp[i] >> 32) & mask], 1u);
+  __syncthreads();
+  if (!SCATTER) {
+    for (uint32_t f = threadIdx.x; f < nf; f += 256)
+      if (cnt[f]) atomicAdd(counts_or_cursor + ((size_t)g << sg.FB) + f, cnt[f]);
+    return;
+  }
+  for (uint32_t f = threadIdx.x; f < nf; f += 256) {
+    const uint32_t k = cnt[f];
+    if (SCATTER) base[f] = k ? atomicAdd(counts_or_cursor + ((size_t)g << sg.FB) + f, k) : 0u;
+    cnt[f] = 0;
+  }
+  __syncthreads();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const uint64_t e = tmp[i];
+    const uint32_t f = (uint32_t)(e >> 32) & mask;
+    const uint32_t r = atomicAdd(&cnt[f], 1u);
+    entries[(SCATTER ? base[f] : 0u) + r] = e;
   }
 }
 
@@ -581,12 +743,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * XYZZ_BYTES, st));
   const uint32_t dblocks = (uint32_t)((n + 255) / 256);
   Profiler& pf = C->prof;
-  pf.begin(PROF_DIGITS, st);
-  hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
-                     ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
-  pf.end(PROF_DIGITS, st);
-  pf.begin(PROF_SCAN, st);
-  {
+  auto run_scan = [&]() {
     const uint32_t nb = (uint32_t)((nbuckets + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
                        ws.misc.as<uint32_t>());
@@ -594,12 +751,50 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
                        ws.offsets.as<uint32_t>() + nbuckets);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
                        ws.misc.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
+  };
+  static const bool sort_atomic = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
+  if (sort_atomic) {
+    pf.begin(PROF_DIGITS, st);
+    hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
+                       ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
+    pf.end(PROF_DIGITS, st);
+    pf.begin(PROF_SCAN, st);
+    run_scan();
+    pf.end(PROF_SCAN, st);
+    pf.begin(PROF_SCATTER, st);
+    hipLaunchKernelGGL(k_msm_digits<true>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
+                       ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
+    pf.end(PROF_SCATTER, st);
+  } else {
+    SortGeom sg;
+    sg.c = c;
+    sg.W = W;
+    sg.B = B;
+    sg.FB = std::min<uint32_t>((uint32_t)(c - 1), 10u);
+    sg.G = (uint32_t)(nbuckets >> sg.FB);
+    GM_CHECK(sg.G <= SORT_GMAX, GM_EINVAL, "msm: %u coarse sort bins exceed %u (window %d too wide for this sort)", sg.G, SORT_GMAX, c);
+    if ((rc = ws.tmp_entries.ensure(N * 8))) return rc;
+    if ((rc = ws.sortmeta.ensure((size_t)(4 * (sg.G + 1)) * 4))) return rc;
+    uint32_t* gcount = ws.sortmeta.as<uint32_t>();
+    uint32_t* goff = gcount + (sg.G + 1);
+    uint32_t* gcursor = goff + (sg.G + 1);
+    uint32_t* blkoff = gcursor + (sg.G + 1);
+    GM_HIP(hipMemsetAsync(gcount, 0, (sg.G + 1) * 4, st));
+    const uint32_t b1 = (uint32_t)((n + SORT_TS - 1) / SORT_TS);
+    const uint32_t b2 = (uint32_t)(N / SORT_CH + sg.G + 1);
+    pf.begin(PROF_DIGITS, st);
+    hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcount, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(k_sort1_scan, dim3(1), dim3(1024), 0, st, gcount, sg.G, goff, gcursor, blkoff);
+    hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>());
+    pf.end(PROF_DIGITS, st);
+    pf.begin(PROF_SCATTER, st);
+    hipLaunchKernelGGL(k_sort2<false>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
+                       ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
+    run_scan();
+    hipLaunchKernelGGL(k_sort2<true>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
+                       ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
+    pf.end(PROF_SCATTER, st);
   }
-  pf.end(PROF_SCAN, st);
-  pf.begin(PROF_SCATTER, st);
-  hipLaunchKernelGGL(k_msm_digits<true>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
-                     ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
-  pf.end(PROF_SCATTER, st);
   pf.begin(PROF_ACC0, st);
   hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, ws.entries.as<uint64_t>(),
                      ws.offsets.as<uint32_t>() + nbuckets, d_bases, (long long)first, (long long)step, L,
