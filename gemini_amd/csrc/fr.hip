@@ -5,6 +5,7 @@
 // a wave moves 2 KiB per load instruction.  These kernels are HBM-streaming work with ~10
 // modular multiplications per 384 bytes moved (sumcheck round); the arithmetic is the
 // 8-limb product-scanning multiplier of field.cuh.
+#include <algorithm>
 #include <vector>
 
 #include "ctx.hpp"
@@ -770,7 +771,31 @@ int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k
     const size_t nch = (n + DIV_K - 1) / DIV_K, nseg = (nch + seg - 1) / seg;
     hipLaunchKernelGGL(k_div_phase1, dim3(grid_for(nch)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums);
     hipLaunchKernelGGL(k_div_phase2a, dim3(grid_for(nseg)), dim3(256), 0, C->stream, sums, nch, seg, (const uint32_t*)(base + 32), seg_sums);
-    hipLaunchKernelGGL(k_div_phase2b, dim3(1), dim3(64), 0, C->stream, seg_sums, nseg, seg, nch, mt, carry);
+    {
+      // phase 2b on the host: nseg (<= n/4096) sequential steps of a first-order recurrence cost
+      // microseconds on a CPU core and milliseconds on a single GPU lane
+      std::vector<uint64_t> hs(nseg * 4), hc(nseg * 4);
+      GM_HIP(hipMemcpyAsync(hs.data(), seg_sums, nseg * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+      GM_HIP(hipStreamSynchronize(C->stream));
+      gmh::Fr acc = gmh::Fr::zero();
+      auto mpow = [&](size_t e) {
+        gmh::Fr r = gmh::Fr::one(), b = m;
+        while (e) {
+          if (e & 1) r = r * b;
+          b = b.sqr();
+          e >>= 1;
+        }
+        return r;
+      };
+      const gmh::Fr mseg = mpow(seg);
+      for (size_t sgi = nseg; sgi-- > 0;) {
+        acc.to_limbs(hc.data() + 4 * sgi);
+        const size_t len = std::min(seg, nch - sgi * seg);
+        acc = acc * (len == seg ? mseg : mpow(len)) + gmh::Fr::from_limbs(hs.data() + 4 * sgi);
+      }
+      GM_HIP(hipMemcpyAsync(carry, hc.data(), nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
+      GM_HIP(hipStreamSynchronize(C->stream));  // hc goes out of scope
+    }
     hipLaunchKernelGGL(k_div_phase3, dim3(grid_for(nch)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums, carry, seg, mt, dst,
                        base + 128 + j * 32);
     GM_HIP(hipGetLastError());

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <vector>
 #include "../gemini_amd/csrc/field.cuh"
+#include "../gemini_amd/csrc/field30.cuh"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -86,6 +87,25 @@ __global__ void k_fr_mul_cios(const uint32_t* a, const uint32_t* b, uint32_t* ou
   for (int i = 0; i < iters; i++) { x = fp_mul_cios<FrParams>(x, y); }
   fp_store<FrParams>(out + 8 * t, x);
 }
+__global__ void k_fq30_mul(const uint32_t* a, const uint32_t* b, uint32_t* out, int iters) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq30 x = fq30_unpack(fp_load<FqParams>(a + 12 * t)), y = fq30_unpack(fp_load<FqParams>(b + 12 * t));
+  for (int i = 0; i < iters; i++) { x = fq30_mul(x, y); }
+  fp_store<FqParams>(out + 12 * t, fq30_pack(x));
+}
+// one product both ways: out32 = a*b*2^-384 (canonical), out30 = (a*b*2^-390) * 2^6 canonicalised
+__global__ void k_fq30_check(const uint32_t* a, const uint32_t* b, uint32_t* out32, uint32_t* out30) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq x = fp_load<FqParams>(a + 12 * t), y = fp_load<FqParams>(b + 12 * t);
+  fp_cond_sub<FqParams>(x, 0); fp_cond_sub<FqParams>(y, 0);
+  fp_store<FqParams>(out32 + 12 * t, fp_mul<FqParams>(x, y));
+  Fq30 r = fq30_mul(fq30_unpack(x), fq30_unpack(y));
+  const Fq30 c396 = {{0x3480cb7fu, 0x3e0c0000u, 0x2042b126u, 0x3f337aafu, 0x3de4b4d1u, 0x1e015cf1u, 0x005c540du, 0x3467b19au, 0x352a6da3u, 0x19d89d19u, 0x2fb9afe6u, 0x3848c817u, 0x0009772fu}};
+  r = fq30_mul(r, c396);
+  Fq p = fq30_pack(r);
+  fp_cond_sub<FqParams>(p, 0); fp_cond_sub<FqParams>(p, 0);
+  fp_store<FqParams>(out30 + 12 * t, p);
+}
 __global__ void k_fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* out, int iters) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   Fr x = fp_load<FrParams>(a + 8 * t), y = fp_load<FrParams>(b + 8 * t);
@@ -141,6 +161,11 @@ int main(int argc, char** argv) {
     printf("fq_mul (C CIOS)   %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
     CK(hipMemcpy(h1.data(), dc, 48 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dd, 48 * n, hipMemcpyDeviceToHost));
     printf("fq asm == cios: %s\n", h1 == h2 ? "yes" : "NO");
+    ms = timeit([&] { k_fq30_mul<<<blocks, threads>>>(da, db, dc, fi); });
+    printf("fq30_mul (13x30)  %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
+    k_fq30_check<<<blocks, threads>>>(da, db, dc, dd);
+    CK(hipMemcpy(h1.data(), dc, 48 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dd, 48 * n, hipMemcpyDeviceToHost));
+    printf("fq30 * 2^6 == fq32: %s\n", h1 == h2 ? "yes" : "NO");
     ms = timeit([&] { k_fr_mul<<<blocks, threads>>>(da, db, dc, fi); });
     printf("fr_mul (asm FIPS) %8.3f ms  %8.2f Gmul/s\n", ms, (double)n * fi / ms / 1e6);
     ms = timeit([&] { k_fr_mul_cios<<<blocks, threads>>>(da, db, dd, fi); });
