@@ -152,6 +152,7 @@ uint64_t put_prover(std::unique_ptr<Sumcheck> p) {
 int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std::unique_ptr<Bases>& out);
 int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* d_scalars, int mont, size_t n,
                         std::unique_ptr<Bases>& out);
+int bases_precompute(Context* C, Bases* b, int c);
 int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_t ng, bool src_is_device,
               const uint64_t twist[4], uint64_t* handle);
 void sc_destroy(Sumcheck* S);
@@ -206,8 +207,10 @@ void gm_shutdown(void) {
   if (!g_ctx) return;
   Context* C = g_ctx;
   (void)hipStreamSynchronize(C->stream);
-  for (auto& kv : C->bases)
+  for (auto& kv : C->bases) {
+    if (kv.second->table) (void)hipFree(kv.second->table);
     if (kv.second->d) (void)hipFree(kv.second->d);
+  }
   for (auto& kv : C->vecs)
     if (kv.second->d) (void)hipFree(kv.second->d);
   C->pool.release_all();
@@ -277,8 +280,16 @@ int gm_g1_bases_free(uint64_t handle) {
     b = std::move(it->second);
     C->bases.erase(it);
   }
+  if (b->table) (void)hipFree(b->table);
   if (b->d) GM_HIP(hipFree(b->d));
   return GM_OK;
+}
+
+int gm_g1_bases_precompute(uint64_t handle, int c) {
+  GM_CTX();
+  Bases* b = find_bases(handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "bases_precompute: unknown handle %llu", (unsigned long long)handle);
+  return bases_precompute(C, b, c);
 }
 
 int gm_g1_bases_len(uint64_t handle, size_t* n) {
@@ -309,7 +320,7 @@ static int msm_host_scalars(Context* C, Bases* b, size_t offset, int reversed, c
     if ((rc = C->msm.scalars.ensure(n * 32 + 32))) return rc;
     if (n) GM_HIP(hipMemcpyAsync(C->msm.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
   }
-  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, C->msm.scalars.p, 0, n, true, out_jac);
+  return msm_run(C, b, (int64_t)offset, reversed ? -1 : 1, C->msm.scalars.p, 0, n, true, out_jac);
 }
 
 int gm_g1_msm(const void* bases, size_t base_stride, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
@@ -339,7 +350,7 @@ int gm_g1_msm_v(uint64_t bases_handle, size_t offset, int reversed, uint64_t vec
   FrVec* v = find_vec(vec_handle);
   GM_CHECK(v != nullptr, GM_EHANDLE, "msm_v: unknown vector handle %llu", (unsigned long long)vec_handle);
   GM_CHECK(voffset + n <= v->len, GM_EINVAL, "msm_v: range [%zu, %zu) outside vector of length %zu", voffset, voffset + n, v->len);
-  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, v->d + voffset * 32, 1, n, true, out_jac);
+  return msm_run(C, b, (int64_t)offset, reversed ? -1 : 1, v->d + voffset * 32, 1, n, true, out_jac);
 }
 
 int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
@@ -348,7 +359,7 @@ int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* 
   Bases* b = find_bases(bases_handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "msm_d: unknown bases handle %llu", (unsigned long long)bases_handle);
   GM_CHECK(out_jac != nullptr && (d_scalars != nullptr || n == 0), GM_EINVAL, "msm_d: null pointer");
-  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, d_scalars, mont, n, true, out_jac);
+  return msm_run(C, b, (int64_t)offset, reversed ? -1 : 1, d_scalars, mont, n, true, out_jac);
 }
 
 int gm_g1_msm_d_partial(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
@@ -357,7 +368,7 @@ int gm_g1_msm_d_partial(uint64_t bases_handle, size_t offset, int reversed, cons
   Bases* b = find_bases(bases_handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "msm_d_partial: unknown bases handle %llu", (unsigned long long)bases_handle);
   GM_CHECK(out_jac != nullptr && (d_scalars != nullptr || n == 0), GM_EINVAL, "msm_d_partial: null pointer");
-  return msm_run(C, b->d, b->n, (int64_t)offset, reversed ? -1 : 1, d_scalars, mont, n, false, out_jac);
+  return msm_run(C, b, (int64_t)offset, reversed ? -1 : 1, d_scalars, mont, n, false, out_jac);
 }
 
 int gm_g1_sum(const uint64_t* points_jac, size_t k, uint64_t out_jac[18]) {

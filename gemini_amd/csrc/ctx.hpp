@@ -48,6 +48,10 @@ struct DevBuf {
 struct Bases {
   uint8_t* d = nullptr;  // n x 96 bytes: x, y Montgomery; identity = all zero
   size_t n = 0;
+  // optional fixed-base window tables: table[w * n + i] = 2^(tab_c * w) * base[i], w < tab_W
+  // (table row 0 is a copy of d so one pointer serves every window)
+  uint8_t* table = nullptr;
+  int tab_c = 0, tab_W = 0;
 };
 
 struct FrVec {
@@ -145,7 +149,7 @@ uint64_t put_prover(std::unique_ptr<Sumcheck> p);
   GM_CHECK(C != nullptr, GM_ENOTINIT, "gm_init has not been called")
 
 // MSM engine (msm.hip)
-int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, int64_t step, const void* d_scalars,
-            int mont, size_t n, bool normalize, uint64_t out_jac[18]);
+int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
+            bool normalize, uint64_t out_jac[18]);
 
 }  // namespace gm

@@ -132,7 +132,9 @@ constexpr uint32_t SORT_FMAX = 1024;   // fine bins
 struct SortGeom {
   int c, W;
   uint32_t B, FB, G;
+  int shared;  // 1: fixed-base tables in use -> one bucket set for all windows, window index rides in the entry
 };
+constexpr int ENTRY_W_SHIFT = 26;  // entry idx field: pair index in bits 0..25, window in bits 26..30 (tables only)
 
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg,
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
       if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
       if (active && d != 0) {
         const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        atomicAdd(&cnt[((uint32_t)w * sg.B + (mag - 1u)) >> sg.FB], 1u);
+        atomicAdd(&cnt[((sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u)) >> sg.FB], 1u);
       }
     }
   }
@@ -178,10 +180,11 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
       if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
       if (active && d != 0) {
         const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        const uint32_t key = (uint32_t)w * sg.B + (mag - 1u);
+        const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
         const uint32_t g = key >> sg.FB;
         const uint32_t r = atomicAdd(&cnt[g], 1u);
-        tmp[(SCATTER ? base[g] : 0u) + r] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)i;
+        const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : i;
+        tmp[(SCATTER ? base[g] : 0u) + r] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
       }
     }
   }
@@ -359,8 +362,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 __global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entries,
                                               const uint32_t* __restrict__ total_ptr,
                                               const uint8_t* __restrict__ bases, long long first, long long step,
-                                              uint32_t L, uint32_t* __restrict__ pk, uint8_t* __restrict__ pp,
-                                              uint8_t* __restrict__ buckets) {
+                                              long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
+                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = *total_ptr;
   const uint64_t start = (uint64_t)t * L;
@@ -386,7 +389,13 @@ __global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entri
         cur = key;
         acc = G1Xyzz::identity();
       }
-      const long long idx = first + step * (long long)(e & 0x7fffffffull);
+      long long idx;
+      if (tab_stride) {  // fixed-base tables: row = window, column = pair
+        const uint32_t lo = (uint32_t)e & 0x7fffffffu;
+        idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
+      } else {
+        idx = first + step * (long long)(e & 0x7fffffffull);
+      }
       G1Affine p = g1_load_affine(bases + (size_t)idx * AFF_BYTES);
       if ((e >> 31) & 1ull) p.y = fq_neg(p.y);
       xyzz_madd(acc, p);
@@ -669,6 +678,26 @@ __global__ __launch_bounds__(256) void k_fixed_base_mul(const uint32_t* __restri
   g1_store_affine(out + i * AFF_BYTES, a);
 }
 
+// table[(w + 1) * n + i] = 2^c * table[w * n + i]: c doublings and one normalisation per point
+__global__ __launch_bounds__(256) void k_table_next(const uint8_t* __restrict__ prev, uint8_t* __restrict__ next, size_t n, int c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p = g1_load_affine(prev + i * AFF_BYTES);
+  G1Xyzz acc = G1Xyzz::from_affine(p);
+  for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
+  G1Affine a;
+  if (acc.is_identity()) {
+    a.x = Fq::zero();
+    a.y = Fq::zero();
+  } else {
+    Fq t = fq_mul(acc.zz, acc.zzz);
+    Fq ti = fq_inv(t);
+    a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
+    a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
+  }
+  g1_store_affine(next + i * AFF_BYTES, a);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -691,8 +720,9 @@ static int choose_window(size_t n) {
   return c;
 }
 
-int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, int64_t step, const void* d_scalars,
-            int mont, size_t n, bool normalize, uint64_t out_jac[18]) {
+int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
+            bool normalize, uint64_t out_jac[18]) {
+  const size_t nbases = bases->n;
   gmh::G1 result = gmh::G1::identity();
   if (n == 0) {
     result.to_limbs(out_jac);
@@ -709,11 +739,18 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   MsmWorkspace& ws = C->msm;
   hipStream_t st = C->stream;
 
-  const int c = C->msm_c_override ? C->msm_c_override : choose_window(n);
+  // fixed-base tables (gm_g1_bases_precompute) serve large MSMs; small ones are latency-bound and
+  // cheaper with few buckets
+  static const size_t tab_min = getenv("GM_MSM_TABLE_MIN") ? (size_t)atoll(getenv("GM_MSM_TABLE_MIN")) : ((size_t)1 << 17);
+  const bool use_table = bases->table != nullptr && !C->msm_c_override && n >= tab_min && n < ((size_t)1 << ENTRY_W_SHIFT);
+  const int c = use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
   const int W = (256 + c - 1) / c;
   const uint32_t B = 1u << (c - 1);
-  const size_t nbuckets = (size_t)W * B;
+  const int Wb = use_table ? 1 : W;  // bucket sets
+  const size_t nbuckets = (size_t)Wb * B;
+  const uint8_t* d_bases = use_table ? bases->table : bases->d;
+  const long long tab_stride = use_table ? (long long)bases->n : 0;
   const uint64_t N = (uint64_t)n * (uint64_t)W;
   GM_CHECK(N < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)N);
 
@@ -752,7 +789,8 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets,
                        ws.misc.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
   };
-  static const bool sort_atomic = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
+  static const bool sort_atomic_env = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
+  const bool sort_atomic = sort_atomic_env && !use_table;
   if (sort_atomic) {
     pf.begin(PROF_DIGITS, st);
     hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
@@ -770,6 +808,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
     sg.c = c;
     sg.W = W;
     sg.B = B;
+    sg.shared = use_table ? 1 : 0;
     sg.FB = std::min<uint32_t>((uint32_t)(c - 1), 10u);
     sg.G = (uint32_t)(nbuckets >> sg.FB);
     GM_CHECK(sg.G <= SORT_GMAX, GM_EINVAL, "msm: %u coarse sort bins exceed %u (window %d too wide for this sort)", sg.G, SORT_GMAX, c);
@@ -797,7 +836,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   }
   pf.begin(PROF_ACC0, st);
   hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, ws.entries.as<uint64_t>(),
-                     ws.offsets.as<uint32_t>() + nbuckets, d_bases, (long long)first, (long long)step, L,
+                     ws.offsets.as<uint32_t>() + nbuckets, d_bases, (long long)first, (long long)step, tab_stride, L,
                      ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
   pf.end(PROF_ACC0, st);
   pf.begin(PROF_MERGE, st);
@@ -824,7 +863,7 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   const uint32_t h = nbits - a;
   // plane layout per window: [col planes 0..a-1][row planes 0..h-1][tot]
   const uint32_t planes_per_win = nbits + 1;
-  if ((rc = ws.planes.ensure((size_t)W * (planes_per_win + 1) * XYZZ_BYTES))) return rc;
+  if ((rc = ws.planes.ensure((size_t)Wb * (planes_per_win + 1) * XYZZ_BYTES))) return rc;
   const uint8_t* col_src = ws.buckets.as<uint8_t>();
   uint32_t col_len_bits = a;
   static const int lpo1 = getenv("GM_MSM_LPO1") ? atoi(getenv("GM_MSM_LPO1")) : 5;
@@ -833,25 +872,25 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   GroupSumArgs none{};
   none.n_out = 0;
   if (h > 0) {
-    if ((rc = ws.rows.ensure((size_t)W * (1u << h) * XYZZ_BYTES))) return rc;
-    if ((rc = ws.cols.ensure((size_t)W * (1u << a) * XYZZ_BYTES))) return rc;
-    GroupSumArgs ra{ws.buckets.as<uint8_t>(), ws.rows.as<uint8_t>(), GS_ROW, (uint32_t)W << h, 1u << h, B, a, 1u << a, (uint32_t)lpo1};
-    GroupSumArgs ca{ws.buckets.as<uint8_t>(), ws.cols.as<uint8_t>(), GS_COL, (uint32_t)W << a, 1u << a, B, a, 1u << h, (uint32_t)lpo1};
+    if ((rc = ws.rows.ensure((size_t)Wb * (1u << h) * XYZZ_BYTES))) return rc;
+    if ((rc = ws.cols.ensure((size_t)Wb * (1u << a) * XYZZ_BYTES))) return rc;
+    GroupSumArgs ra{ws.buckets.as<uint8_t>(), ws.rows.as<uint8_t>(), GS_ROW, (uint32_t)Wb << h, 1u << h, B, a, 1u << a, (uint32_t)lpo1};
+    GroupSumArgs ca{ws.buckets.as<uint8_t>(), ws.cols.as<uint8_t>(), GS_COL, (uint32_t)Wb << a, 1u << a, B, a, 1u << h, (uint32_t)lpo1};
     hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(ra) + gs_blocks(ca)), dim3(256), 0, st, ra, ca, gs_blocks(ra));
     col_src = ws.cols.as<uint8_t>();
   }
   // planes over the column array (a bit-planes + total) and over the row array (h bit-planes + total)
   uint8_t* planes = ws.planes.as<uint8_t>();
-  uint8_t* row_planes = planes + (size_t)W * (a + 1) * XYZZ_BYTES;
+  uint8_t* row_planes = planes + (size_t)Wb * (a + 1) * XYZZ_BYTES;
   {
-    GroupSumArgs pc{col_src, planes, GS_PLANE, (uint32_t)W * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0, (uint32_t)lpo2};
+    GroupSumArgs pc{col_src, planes, GS_PLANE, (uint32_t)Wb * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0, (uint32_t)lpo2};
     GroupSumArgs pr = none;
-    if (h > 0) pr = GroupSumArgs{ws.rows.as<uint8_t>(), row_planes, GS_PLANE, (uint32_t)W * (h + 1), h + 1, 1u << h, h, 0, (uint32_t)lpo2};
+    if (h > 0) pr = GroupSumArgs{ws.rows.as<uint8_t>(), row_planes, GS_PLANE, (uint32_t)Wb * (h + 1), h + 1, 1u << h, h, 0, (uint32_t)lpo2};
     hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(pc) + (h > 0 ? gs_blocks(pr) : 0)), dim3(256), 0, st, pc, pr, gs_blocks(pc));
   }
   pf.end(PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
-  const size_t plane_count = (size_t)W * (a + 1) + (h > 0 ? (size_t)W * (h + 1) : 0);
+  const size_t plane_count = (size_t)Wb * (a + 1) + (h > 0 ? (size_t)Wb * (h + 1) : 0);
   const size_t plane_bytes = plane_count * XYZZ_BYTES;
   if (ws.host_planes_cap < plane_bytes) {
     if (ws.host_planes) (void)hipHostFree(ws.host_planes);
@@ -868,9 +907,9 @@ int msm_run(Context* C, const uint8_t* d_bases, size_t nbases, int64_t first, in
   const uint64_t* hp = ws.host_planes;
   auto col_plane = [&](int w, uint32_t j) { return gmh::xyzz_to_jac(hp + ((size_t)w * (a + 1) + j) * 24); };
   auto row_plane = [&](int w, uint32_t j) {
-    return gmh::xyzz_to_jac(hp + ((size_t)W * (a + 1) + (size_t)w * (h + 1) + j) * 24);
+    return gmh::xyzz_to_jac(hp + ((size_t)Wb * (a + 1) + (size_t)w * (h + 1) + j) * 24);
   };
-  for (int w = W - 1; w >= 0; w--) {
+  for (int w = Wb - 1; w >= 0; w--) {
     for (int j = c - 1; j >= 0; j--) {
       result = result.dbl();
       if ((uint32_t)j < nbits) {
@@ -920,6 +959,31 @@ static int build_fixed_table(Context* C, const uint64_t base_affine[12], uint8_t
   GM_HIP(hipStreamSynchronize(C->stream));
   GM_HIP(hipFree(d_base));
   GM_HIP(hipFree(t_xyzz));
+  return GM_OK;
+}
+
+// gm_g1_bases_precompute
+int bases_precompute(Context* C, Bases* b, int c) {
+  if (c == 0) c = 20;
+  GM_CHECK(c >= 8 && c <= 22, GM_EINVAL, "bases_precompute: window %d outside [8, 22]", c);
+  GM_CHECK(b->n >= 1 && b->n < ((size_t)1 << ENTRY_W_SHIFT), GM_EINVAL, "bases_precompute: %zu bases (need 1 .. 2^26 - 1)", b->n);
+  const int W = (256 + c - 1) / c;
+  std::lock_guard<std::mutex> lk(C->msm_mu);
+  if (b->table) {
+    (void)hipFree(b->table);
+    b->table = nullptr;
+  }
+  uint8_t* t = nullptr;
+  GM_HIP(hipMalloc((void**)&t, (size_t)W * b->n * AFF_BYTES));
+  GM_HIP(hipMemcpyAsync(t, b->d, b->n * AFF_BYTES, hipMemcpyDeviceToDevice, C->stream));
+  for (int w = 0; w + 1 < W; w++)
+    hipLaunchKernelGGL(k_table_next, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, C->stream,
+                       t + (size_t)w * b->n * AFF_BYTES, t + (size_t)(w + 1) * b->n * AFF_BYTES, b->n, c);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  b->table = t;
+  b->tab_c = c;
+  b->tab_W = W;
   return GM_OK;
 }
 

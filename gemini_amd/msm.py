@@ -53,6 +53,11 @@ class G1Bases:
                                                   C.c_size_t(n), C.byref(h)))
         return cls(h.value, n)
 
+    def precompute(self, c: int = 0):
+        """build the fixed-base window tables (gm_g1_bases_precompute); setup, outside any prover timer"""
+        capi.check(capi.load().gm_g1_bases_precompute(C.c_uint64(self.handle), C.c_int(c)))
+        return self
+
     def download(self, offset: int = 0, n: int | None = None) -> np.ndarray:
         n = self.n - offset if n is None else n
         out = np.empty((n, 12), dtype=np.uint64)

@@ -66,6 +66,15 @@ int gm_g1_bases_len(uint64_t handle, size_t* n);
 /* Copy registered bases back (96-byte stride): used by tests and by CommitterKey::index_by. */
 int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96);
 
+/* Fixed-base window tables for a registered SRS: table[w][i] = 2^(c*w) * base[i] for w < ceil(256/c),
+ * kept in HBM (W x n x 96 bytes -- 40 GB for the 2^25-point SRS of `snark -i 24`; this is what 288 GB
+ * per GPU buys).  Afterwards MSMs of >= 2^17 pairs against this handle use ONE bucket set shared by
+ * all windows: c = 20 instead of 16 (13 instead of 16 base additions per pair), no per-window bucket
+ * reduction and c instead of 256 doublings at the end.  Results are identical (tests compare both
+ * paths).  Setup cost is comparable to generating the SRS; like CommitterKey::new it is outside the
+ * prover timer.  c = 0 picks the default (20).  No reference counterpart: ark-ec recomputes. */
+int gm_g1_bases_precompute(uint64_t handle, int c);
+
 /* MSM against registered bases.  Pair i uses base[offset + i] (reversed = 0) or base[offset - i]
  * (reversed = 1).  reversed/offset express CommitterKey::commit's prefix slice
  * (src/kzg/time.rs:81-83) and CommitterKeyStream's Reverse(..) + advance_by alignment

@@ -223,3 +223,30 @@ def test_msm_2_20_properties(gm, oracle, pyref):
         assert_same_point(oracle, se, exp)
     finally:
         reg.free()
+
+
+def test_fixed_base_tables_same_results(gm, oracle):
+    """gm_g1_bases_precompute: MSMs through the shared-bucket / table path equal the plain path and the
+    oracle, incl. offset / reversed addressing, all-equal scalars and identity bases."""
+    import os
+
+    n = 6000
+    bases = rand_bases(oracle, 91, n)
+    bases[17] = 0
+    sc = oracle.random_fr(92, n)
+    reg = gm.G1Bases.register(bases)
+    try:
+        plain = reg.msm_bigint(sc)
+        for c in (8, 13, 20):
+            reg.precompute(c)
+            os.environ["GM_MSM_TABLE_MIN"] = "1"  # read once per process: set before the first table MSM
+            got = reg.msm_bigint(sc)
+            assert (got == plain).all(), c
+            assert_same_point(oracle, got, oracle.msm_pippenger(bases, sc))
+            assert_same_point(oracle, reg.msm_bigint(sc[:1000], offset=321), oracle.msm_pippenger(bases[321:1321], sc[:1000]))
+            rev = bases[::-1].copy()
+            assert_same_point(oracle, reg.msm_bigint(sc[:1000], offset=n - 1 - 500, reversed_=True), oracle.msm_pippenger(rev[500:1500], sc[:1000]))
+            e = np.tile(oracle.random_fr(93, 1)[0], (n, 1))
+            assert_same_point(oracle, reg.msm_bigint(e), oracle.msm_pippenger(bases, e))
+    finally:
+        reg.free()
