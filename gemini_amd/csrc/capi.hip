@@ -252,6 +252,12 @@ int gm_prof_read(double* ms_out, uint64_t* count_out, int n) {
   return GM_OK;
 }
 
+int gm_set_msm_table_min(size_t n) {
+  GM_CTX();
+  C->msm_table_min = n;
+  return GM_OK;
+}
+
 int gm_set_msm_window(int c) {
   GM_CTX();
   GM_CHECK(c == 0 || (c >= 2 && c <= 22), GM_EINVAL, "gm_set_msm_window: c = %d not in {0} u [2, 22]", c);

@@ -132,6 +132,7 @@ struct Context {
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
   int msm_c_override = 0;
+  size_t msm_table_min = (size_t)1 << 17;  // smallest MSM that uses fixed-base tables when present
   int cu_count = 256;
 };
 

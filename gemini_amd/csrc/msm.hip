@@ -373,8 +373,19 @@ __global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entri
     G1Xyzz acc = G1Xyzz::identity();
     uint32_t cur = KEY_INV;
     bool first_run = true;
+    // No software prefetch here: hipcc must drain vmcnt before every call of the out-of-line Fq
+    // multiplier, so an early-issued gather cannot overlap the addition inside one wave (measured:
+    // no change).  The second resident wave per SIMD hides the gather latency instead.
     for (uint64_t i = start; i < end; i++) {
       const uint64_t e = entries[i];
+      long long idx;
+      if (tab_stride) {  // fixed-base tables: row = window, column = pair
+        const uint32_t lo = (uint32_t)e & 0x7fffffffu;
+        idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
+      } else {
+        idx = first + step * (long long)(e & 0x7fffffffull);
+      }
+      G1Affine p = g1_load_affine(bases + (size_t)idx * AFF_BYTES);
       const uint32_t key = (uint32_t)(e >> 32);
       if (key != cur) {
         if (cur != KEY_INV) {
@@ -389,14 +400,6 @@ __global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entri
         cur = key;
         acc = G1Xyzz::identity();
       }
-      long long idx;
-      if (tab_stride) {  // fixed-base tables: row = window, column = pair
-        const uint32_t lo = (uint32_t)e & 0x7fffffffu;
-        idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
-      } else {
-        idx = first + step * (long long)(e & 0x7fffffffull);
-      }
-      G1Affine p = g1_load_affine(bases + (size_t)idx * AFF_BYTES);
       if ((e >> 31) & 1ull) p.y = fq_neg(p.y);
       xyzz_madd(acc, p);
     }
@@ -741,7 +744,7 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
 
   // fixed-base tables (gm_g1_bases_precompute) serve large MSMs; small ones are latency-bound and
   // cheaper with few buckets
-  static const size_t tab_min = getenv("GM_MSM_TABLE_MIN") ? (size_t)atoll(getenv("GM_MSM_TABLE_MIN")) : ((size_t)1 << 17);
+  const size_t tab_min = C->msm_table_min;
   const bool use_table = bases->table != nullptr && !C->msm_c_override && n >= tab_min && n < ((size_t)1 << ENTRY_W_SHIFT);
   const int c = use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);

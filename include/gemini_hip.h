@@ -111,6 +111,9 @@ int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], si
 /* Tuning knob (0 = automatic): window width c of the bucket method.  The result does not depend
  * on it (tests sweep it). */
 int gm_set_msm_window(int c);
+/* Smallest pair count for which an MSM uses the fixed-base tables of its handle (default 2^17:
+ * below that the MSM is latency-bound and few buckets win).  Tuning/test knob. */
+int gm_set_msm_table_min(size_t n);
 
 /* Per-stage device timing (HIP events on the library's stream).  Stages, in order:
  * 0 digits+histogram, 1 scan, 2 scatter, 3 bucket accumulate (k_acc0), 4 partial merge,

@@ -228,18 +228,16 @@ def test_msm_2_20_properties(gm, oracle, pyref):
 def test_fixed_base_tables_same_results(gm, oracle):
     """gm_g1_bases_precompute: MSMs through the shared-bucket / table path equal the plain path and the
     oracle, incl. offset / reversed addressing, all-equal scalars and identity bases."""
-    import os
-
     n = 6000
     bases = rand_bases(oracle, 91, n)
     bases[17] = 0
     sc = oracle.random_fr(92, n)
     reg = gm.G1Bases.register(bases)
+    gm.capi.check(gm.capi.load().gm_set_msm_table_min(C.c_size_t(1)))
     try:
         plain = reg.msm_bigint(sc)
         for c in (8, 13, 20):
             reg.precompute(c)
-            os.environ["GM_MSM_TABLE_MIN"] = "1"  # read once per process: set before the first table MSM
             got = reg.msm_bigint(sc)
             assert (got == plain).all(), c
             assert_same_point(oracle, got, oracle.msm_pippenger(bases, sc))
@@ -249,4 +247,5 @@ def test_fixed_base_tables_same_results(gm, oracle):
             e = np.tile(oracle.random_fr(93, 1)[0], (n, 1))
             assert_same_point(oracle, reg.msm_bigint(e), oracle.msm_pippenger(bases, e))
     finally:
+        gm.capi.check(gm.capi.load().gm_set_msm_table_min(C.c_size_t(1 << 17)))
         reg.free()
