@@ -523,19 +523,33 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
 }
 
 // ------------------------------------------------------------------------------------------
-// bucket reduction by plain sums: 16 lanes per output element
+// bucket reduction by plain sums, several lanes per output element
+//
+// sum_b b*B_b over one bucket set = sum_j 2^j Z_j + Tot, Z_j = sum of the buckets whose index
+// (|digit| - 1) has bit j set.  The index is split into up to three digit fields of <= 7 bits; the
+// per-field marginals Y_k[v] = sum of buckets whose k-th field equals v are produced by strided
+// plain sums (one or two levels), and the Z_j are bit-plane sums over the small Y_k arrays.  Every
+// sum is over <= 128 elements, done by 2^lpo_shift lanes per output (sequential part + shuffle
+// tree), so the dependent-addition depth is ~20 instead of 2*2^(c-1) for the CPU's running sum
+// (variable_base.rs:140-166), at 2-3x its work.
 // ------------------------------------------------------------------------------------------
-enum { GS_ROW = 0, GS_COL = 1, GS_PLANE = 2 };
+enum { GS_STRIDED = 0, GS_PLANE = 1 };
 struct GroupSumArgs {
   const uint8_t* in;
   uint8_t* out;
   int mode;
-  uint32_t n_out;      // number of outputs
-  uint32_t per_win;    // outputs per window
-  uint32_t win_stride; // input elements per window
-  uint32_t lo_bits;    // ROW/COL: a (low field width);   PLANE: nb (log2 of the per-window length)
-  uint32_t len;        // ROW: 2^a, COL: 2^h, PLANE: unused
-  uint32_t lpo_shift;  // lanes per output = 2^lpo_shift (4..6): more lanes = shorter dependent chains
+  uint32_t n_out;       // number of outputs (all bucket sets)
+  uint32_t per_win;     // outputs per bucket set
+  uint32_t win_stride;  // input elements per bucket set
+  // GS_STRIDED: out[w][r] = sum_{e < len} in[w*win_stride + (r / n_lo)*s_hi + (r % n_lo)*s_lo + e*s_e]
+  uint32_t n_lo, s_hi, s_lo, s_e, len;
+  // GS_PLANE: input length 2^nb per set; r < nb: elements with bit r set; r == nb: all elements
+  uint32_t nb;
+  uint32_t lpo_shift;   // lanes per output = 2^lpo_shift
+};
+struct GroupSumJobs {
+  GroupSumArgs j[3];
+  uint32_t blk_end[3];  // cumulative block counts
 };
 
 GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
@@ -550,26 +564,26 @@ GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
   return r;
 }
 
-// two independent jobs per launch (blocks [0, blocks0) run a0, the rest a1) so the row and column
-// passes -- and later the two bit-plane passes -- overlap instead of serialising their latency
-__global__ __launch_bounds__(256) void k_group_sum(GroupSumArgs a0, GroupSumArgs a1, uint32_t blocks0) {
-  const bool second = blockIdx.x >= blocks0;
-  const GroupSumArgs& a = second ? a1 : a0;
+// up to three independent jobs per launch so that passes of the same level overlap instead of
+// serialising their (latency-bound) depth
+__global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
+  const int job = blockIdx.x < J.blk_end[0] ? 0 : (blockIdx.x < J.blk_end[1] ? 1 : 2);
+  const GroupSumArgs& a = J.j[job];
+  const uint32_t blk0 = job == 0 ? 0u : J.blk_end[job - 1];
   const uint8_t* __restrict__ in = a.in;
   uint8_t* __restrict__ out = a.out;
-  const uint32_t gt = (blockIdx.x - (second ? blocks0 : 0u)) * blockDim.x + threadIdx.x;
+  const uint32_t gt = (blockIdx.x - blk0) * blockDim.x + threadIdx.x;
   const uint32_t lpo = 1u << a.lpo_shift;
   const uint32_t o = gt >> a.lpo_shift, q = gt & (lpo - 1u);
   G1Xyzz acc = G1Xyzz::identity();
   if (o < a.n_out) {
     const uint32_t w = o / a.per_win, r = o % a.per_win;
     const size_t base = (size_t)w * a.win_stride;
-    if (a.mode == GS_ROW) {
-      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)r << a.lo_bits) + e) * XYZZ_BYTES));
-    } else if (a.mode == GS_COL) {
-      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, g1_load_xyzz(in + (base + ((size_t)e << a.lo_bits) + r) * XYZZ_BYTES));
+    if (a.mode == GS_STRIDED) {
+      const size_t b0 = base + (size_t)(r / a.n_lo) * a.s_hi + (size_t)(r % a.n_lo) * a.s_lo;
+      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, g1_load_xyzz(in + (b0 + (size_t)e * a.s_e) * XYZZ_BYTES));
     } else {
-      const uint32_t nb = a.lo_bits;
+      const uint32_t nb = a.nb;
       if (r == nb) {  // total
         for (uint32_t e = q; e < (1u << nb); e += lpo) xyzz_add(acc, g1_load_xyzz(in + (base + e) * XYZZ_BYTES));
       } else {        // elements whose bit r is set
@@ -860,40 +874,95 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
 
   pf.end(PROF_MERGE, st);
   pf.begin(PROF_REDUCE, st);
-  // bucket reduction: bits of the bucket index i = |d| - 1 (c - 1 bits) = (hi: h bits | lo: a bits)
+  // bucket reduction (see k_group_sum): index bits split into m <= 3 fields w0 (low), w1, w2
   const uint32_t nbits = (uint32_t)(c - 1);
-  const uint32_t a = nbits > 7 ? nbits / 2 : nbits;  // small tables: bit-planes straight from the buckets
-  const uint32_t h = nbits - a;
-  // plane layout per window: [col planes 0..a-1][row planes 0..h-1][tot]
-  const uint32_t planes_per_win = nbits + 1;
-  if ((rc = ws.planes.ensure((size_t)Wb * (planes_per_win + 1) * XYZZ_BYTES))) return rc;
-  const uint8_t* col_src = ws.buckets.as<uint8_t>();
-  uint32_t col_len_bits = a;
-  static const int lpo1 = getenv("GM_MSM_LPO1") ? atoi(getenv("GM_MSM_LPO1")) : 5;
-  static const int lpo2 = getenv("GM_MSM_LPO2") ? atoi(getenv("GM_MSM_LPO2")) : 5;
-  auto gs_blocks = [](const GroupSumArgs& g) { return (uint32_t)((((uint64_t)g.n_out << g.lpo_shift) + 255) / 256); };
-  GroupSumArgs none{};
-  none.n_out = 0;
-  if (h > 0) {
-    if ((rc = ws.rows.ensure((size_t)Wb * (1u << h) * XYZZ_BYTES))) return rc;
-    if ((rc = ws.cols.ensure((size_t)Wb * (1u << a) * XYZZ_BYTES))) return rc;
-    GroupSumArgs ra{ws.buckets.as<uint8_t>(), ws.rows.as<uint8_t>(), GS_ROW, (uint32_t)Wb << h, 1u << h, B, a, 1u << a, (uint32_t)lpo1};
-    GroupSumArgs ca{ws.buckets.as<uint8_t>(), ws.cols.as<uint8_t>(), GS_COL, (uint32_t)Wb << a, 1u << a, B, a, 1u << h, (uint32_t)lpo1};
-    hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(ra) + gs_blocks(ca)), dim3(256), 0, st, ra, ca, gs_blocks(ra));
-    col_src = ws.cols.as<uint8_t>();
+  uint32_t wf[3] = {0, 0, 0};
+  int m;
+  if (nbits <= 7) {
+    m = 1;
+    wf[0] = nbits;
+  } else if (nbits <= 14) {
+    m = 2;
+    wf[0] = nbits / 2;
+    wf[1] = nbits - wf[0];
+  } else {
+    m = 3;
+    wf[0] = nbits / 3;
+    wf[1] = (nbits - wf[0]) / 2;
+    wf[2] = nbits - wf[0] - wf[1];
   }
-  // planes over the column array (a bit-planes + total) and over the row array (h bit-planes + total)
+  // lanes per output: enough lanes to put ~2^17 threads in flight (2 waves per SIMD), never more than
+  // the element count; few lanes keep the work near the minimum (the shuffle tree runs on every lane)
+  auto lpo_for = [](uint32_t len, uint32_t n_out) {
+    uint32_t s = 0;
+    while (s < 5 && (1u << s) < len && ((uint64_t)n_out << s) < (1u << 17)) s++;
+    return s;
+  };
+  auto strided = [&](const uint8_t* in, uint8_t* out, uint32_t win_in, uint32_t n_hi, uint32_t n_lo, uint32_t s_hi, uint32_t s_lo,
+                     uint32_t s_e, uint32_t len) {
+    GroupSumArgs g{};
+    g.in = in; g.out = out; g.mode = GS_STRIDED;
+    g.per_win = n_hi * n_lo; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = win_in;
+    g.n_lo = n_lo; g.s_hi = s_hi; g.s_lo = s_lo; g.s_e = s_e; g.len = len; g.lpo_shift = lpo_for(len, g.n_out);
+    return g;
+  };
+  auto plane = [&](const uint8_t* in, uint8_t* out, uint32_t nb) {
+    GroupSumArgs g{};
+    g.in = in; g.out = out; g.mode = GS_PLANE;
+    g.per_win = nb + 1; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = 1u << nb; g.nb = nb;
+    g.lpo_shift = lpo_for(nb ? (1u << (nb - 1)) : 1u, g.n_out);
+    return g;
+  };
+  auto launch = [&](std::initializer_list<GroupSumArgs> jobs) {
+    GroupSumJobs J{};
+    uint32_t tot = 0;
+    int k = 0;
+    for (const GroupSumArgs& g : jobs) {
+      J.j[k] = g;
+      tot += (uint32_t)((((uint64_t)g.n_out << g.lpo_shift) + 255) / 256);
+      J.blk_end[k] = tot;
+      k++;
+    }
+    for (; k < 3; k++) J.blk_end[k] = tot;
+    hipLaunchKernelGGL(k_group_sum, dim3(tot), dim3(256), 0, st, J);
+  };
+  // plane output layout: field k occupies Wb * (wf[k] + 1) records starting at plane_off[k]
+  size_t plane_off[3], plane_count = 0;
+  for (int k = 0; k < m; k++) {
+    plane_off[k] = plane_count;
+    plane_count += (size_t)Wb * (wf[k] + 1);
+  }
+  if ((rc = ws.planes.ensure(plane_count * XYZZ_BYTES))) return rc;
   uint8_t* planes = ws.planes.as<uint8_t>();
-  uint8_t* row_planes = planes + (size_t)Wb * (a + 1) * XYZZ_BYTES;
-  {
-    GroupSumArgs pc{col_src, planes, GS_PLANE, (uint32_t)Wb * (col_len_bits + 1), col_len_bits + 1, 1u << col_len_bits, col_len_bits, 0, (uint32_t)lpo2};
-    GroupSumArgs pr = none;
-    if (h > 0) pr = GroupSumArgs{ws.rows.as<uint8_t>(), row_planes, GS_PLANE, (uint32_t)Wb * (h + 1), h + 1, 1u << h, h, 0, (uint32_t)lpo2};
-    hipLaunchKernelGGL(k_group_sum, dim3(gs_blocks(pc) + (h > 0 ? gs_blocks(pr) : 0)), dim3(256), 0, st, pc, pr, gs_blocks(pc));
+  const uint8_t* X = ws.buckets.as<uint8_t>();
+  const uint32_t n0 = 1u << wf[0], n1 = 1u << wf[1], n2 = 1u << wf[2];
+  if (m == 1) {
+    launch({plane(X, planes, wf[0])});
+  } else if (m == 2) {
+    // Y1[d1] = sum_{d0} X (rows), Y0[d0] = sum_{d1} X (columns)
+    if ((rc = ws.rows.ensure((size_t)Wb * (n0 + n1) * XYZZ_BYTES))) return rc;
+    uint8_t* Y0 = ws.rows.as<uint8_t>();
+    uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ_BYTES;
+    launch({strided(X, Y1, B, 1, n1, 0, n0, 1, n0), strided(X, Y0, B, 1, n0, 0, 1, n0, n1)});
+    launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1])});
+  } else {
+    // level 1: A[d2][d1] = sum_{d0} X, Bm[d2][d0] = sum_{d1} X
+    if ((rc = ws.rows.ensure((size_t)Wb * ((size_t)n2 * n1 + (size_t)n2 * n0) * XYZZ_BYTES))) return rc;
+    if ((rc = ws.cols.ensure((size_t)Wb * (n0 + n1 + n2) * XYZZ_BYTES))) return rc;
+    uint8_t* A = ws.rows.as<uint8_t>();
+    uint8_t* Bm = A + (size_t)Wb * n2 * n1 * XYZZ_BYTES;
+    uint8_t* Y0 = ws.cols.as<uint8_t>();
+    uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ_BYTES;
+    uint8_t* Y2 = Y1 + (size_t)Wb * n1 * XYZZ_BYTES;
+    launch({strided(X, A, B, n2, n1, n1 * n0, n0, 1, n0), strided(X, Bm, B, n2, n0, n1 * n0, 1, n0, n1)});
+    // level 2: Y2[d2] = sum_{d1} A, Y1[d1] = sum_{d2} A, Y0[d0] = sum_{d2} Bm
+    launch({strided(A, Y2, n2 * n1, 1, n2, 0, n1, 1, n1), strided(A, Y1, n2 * n1, 1, n1, 0, 1, n1, n2),
+            strided(Bm, Y0, n2 * n0, 1, n0, 0, 1, n0, n2)});
+    launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1]),
+            plane(Y2, planes + plane_off[2] * XYZZ_BYTES, wf[2])});
   }
   pf.end(PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
-  const size_t plane_count = (size_t)Wb * (a + 1) + (h > 0 ? (size_t)Wb * (h + 1) : 0);
   const size_t plane_bytes = plane_count * XYZZ_BYTES;
   if (ws.host_planes_cap < plane_bytes) {
     if (ws.host_planes) (void)hipHostFree(ws.host_planes);
@@ -905,21 +974,25 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
   GM_HIP(hipStreamSynchronize(st));
   pf.collect();
 
-  // Horner over bit positions, windows high -> low (variable_base.rs:168-175 with the per-window
-  // weighted sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)
+  // Horner over bit positions, bucket sets high -> low (variable_base.rs:168-175 with the weighted
+  // bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)
   const uint64_t* hp = ws.host_planes;
-  auto col_plane = [&](int w, uint32_t j) { return gmh::xyzz_to_jac(hp + ((size_t)w * (a + 1) + j) * 24); };
-  auto row_plane = [&](int w, uint32_t j) {
-    return gmh::xyzz_to_jac(hp + ((size_t)Wb * (a + 1) + (size_t)w * (h + 1) + j) * 24);
+  auto plane_at = [&](int w, int field, uint32_t j) {
+    return gmh::xyzz_to_jac(hp + (plane_off[field] + (size_t)w * (wf[field] + 1) + j) * 24);
   };
   for (int w = Wb - 1; w >= 0; w--) {
     for (int j = c - 1; j >= 0; j--) {
       result = result.dbl();
       if ((uint32_t)j < nbits) {
-        gmh::G1 z = (uint32_t)j < a ? col_plane(w, (uint32_t)j) : row_plane(w, (uint32_t)j - a);
-        result = result.add(z);
+        int field = 0;
+        uint32_t jj = (uint32_t)j;
+        while (jj >= wf[field]) {
+          jj -= wf[field];
+          field++;
+        }
+        result = result.add(plane_at(w, field, jj));
       }
-      if (j == 0) result = result.add(col_plane(w, a));  // Tot_w
+      if (j == 0) result = result.add(plane_at(w, 0, wf[0]));  // Tot_w
     }
   }
   if (normalize) result = result.normalized();
