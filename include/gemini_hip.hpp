@@ -1,0 +1,330 @@
+// gemini_hip.hpp -- header-only C++ host layer over the C ABI (gemini_hip.h), mirroring the
+// reference's Rust interface for the hot path: same names, argument meaning and failure
+// behaviour (the reference panics -> these throw gm::Error).  This is what a C++ embedder links;
+// the Rust shim of INTEGRATION.md has the same shape.
+//
+//   gm::VariableBaseMSM::{msm, msm_unchecked, msm_bigint}   ark-ec 0.4.2 (in-tree: src/kzg/msm/variable_base.rs)
+//   gm::ChunkedPippenger / gm::HashMapPippenger             src/kzg/msm/stream_pippenger.rs:143-271
+//   gm::CommitterKey::{commit, batch_commit}                src/kzg/time.rs:81-107
+//   gm::TimeProver (trait Prover)                           src/subprotocols/sumcheck/prover.rs:30-45
+//   gm::Transcript (GeminiTranscript over merlin)           src/transcript.rs:8-34
+//   gm::Sumcheck::{prove, new_time}                         src/subprotocols/sumcheck/proof.rs:36-66,125-130
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gemini_hip.h"
+
+namespace gm {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) {
+  if (rc != GM_OK) throw Error(rc, gm_last_error());
+}
+inline void init(int device = 0) { check(gm_init(device)); }
+
+using Fr = std::array<uint64_t, 4>;        // Montgomery limbs (ark-ff memory image)
+using BigInt = std::array<uint64_t, 4>;    // canonical integer (Fr::into_bigint)
+using G1Projective = std::array<uint64_t, 18>;  // Jacobian X, Y, Z
+struct G1Affine {                          // Rust layout: x, y, infinity (104-byte stride)
+  uint64_t x[6], y[6];
+  uint64_t infinity;  // bool at byte 96, padded
+};
+static_assert(sizeof(G1Affine) == 104, "G1Affine must match the 104-byte Rust record");
+
+inline G1Projective g1_zero() {
+  G1Projective z;
+  check(gm_g1_sum(nullptr, 0, z.data()));
+  return z;
+}
+inline G1Projective g1_add(const G1Projective& a, const G1Projective& b) {
+  uint64_t two[36];
+  memcpy(two, a.data(), 144);
+  memcpy(two + 18, b.data(), 144);
+  G1Projective r;
+  check(gm_g1_sum(two, 2, r.data()));
+  return r;
+}
+
+struct VariableBaseMSM {
+  static G1Projective msm_bigint(const std::vector<G1Affine>& bases, const std::vector<BigInt>& bigints) {
+    size_t n = bases.size() < bigints.size() ? bases.size() : bigints.size();
+    G1Projective out;
+    check(gm_g1_msm(bases.data(), sizeof(G1Affine), n ? bigints[0].data() : nullptr, n, out.data()));
+    return out;
+  }
+  // silently truncates to the shorter input (src/kzg/time.rs:82)
+  static G1Projective msm_unchecked(const std::vector<G1Affine>& bases, const std::vector<Fr>& scalars) {
+    size_t n = bases.size() < scalars.size() ? bases.size() : scalars.size();
+    G1Projective out;
+    if (n == 0) return g1_zero();
+    uint64_t hb = 0, hv = 0;
+    check(gm_g1_bases_register(bases.data(), sizeof(G1Affine), n, &hb));
+    int rc = gm_fr_vec_alloc(n, &hv);
+    if (!rc) rc = gm_fr_vec_upload(hv, 0, scalars[0].data(), n);
+    if (!rc) rc = gm_g1_msm_v(hb, 0, 0, hv, 0, n, out.data());  // into_bigint happens on the device
+    if (hv) gm_fr_vec_free(hv);
+    gm_g1_bases_free(hb);
+    check(rc);
+    return out;
+  }
+  // Ok(result) or Err(min_len): std::pair<optional<result>, size_t>
+  static std::pair<std::optional<G1Projective>, size_t> msm(const std::vector<G1Affine>& bases, const std::vector<Fr>& scalars) {
+    if (bases.size() != scalars.size()) return {std::nullopt, bases.size() < scalars.size() ? bases.size() : scalars.size()};
+    return {msm_unchecked(bases, scalars), 0};
+  }
+};
+
+// src/kzg/msm/stream_pippenger.rs:209-271
+class ChunkedPippenger {
+ public:
+  explicit ChunkedPippenger(size_t max_msm_buffer) : buf_size_(max_msm_buffer), result_(g1_zero()) {
+    scalars_.reserve(max_msm_buffer);
+    bases_.reserve(max_msm_buffer);
+  }
+  static ChunkedPippenger with_size(size_t buf_size) { return ChunkedPippenger(buf_size); }
+  void add(const G1Affine& base, const BigInt& scalar) {
+    scalars_.push_back(scalar);
+    bases_.push_back(base);
+    if (scalars_.size() == buf_size_) flush();
+  }
+  G1Projective finalize() {
+    if (!scalars_.empty()) flush();
+    return result_;
+  }
+
+ private:
+  void flush() {
+    result_ = g1_add(result_, VariableBaseMSM::msm_bigint(bases_, scalars_));
+    scalars_.clear();
+    bases_.clear();
+  }
+  size_t buf_size_;
+  std::vector<BigInt> scalars_;
+  std::vector<G1Affine> bases_;
+  G1Projective result_;
+};
+
+// src/kzg/msm/stream_pippenger.rs:143-206: scalars of equal bases are added in Fr before the MSM
+class HashMapPippenger {
+ public:
+  explicit HashMapPippenger(size_t max_msm_buffer) : cap_(max_msm_buffer), result_(g1_zero()) {}
+  void add(const G1Affine& base, const Fr& scalar) {
+    Key k;
+    memcpy(k.data(), &base, 104);
+    auto it = buffer_.find(k);
+    if (it == buffer_.end()) {
+      buffer_.emplace(k, scalar);
+    } else {
+      it->second = fr_add(it->second, scalar);
+    }
+    if (buffer_.size() == cap_) flush();
+  }
+  G1Projective finalize() {
+    if (!buffer_.empty()) flush();
+    return result_;
+  }
+
+ private:
+  using Key = std::array<uint64_t, 13>;
+  static Fr fr_add(const Fr& a, const Fr& b) {  // modular addition of Montgomery residues
+    static const uint64_t R[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+    Fr r;
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; i++) {
+      c += (unsigned __int128)a[i] + b[i];
+      r[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    bool ge = c != 0;
+    if (!ge) {
+      ge = true;
+      for (int i = 3; i >= 0; i--) {
+        if (r[i] != R[i]) {
+          ge = r[i] > R[i];
+          break;
+        }
+      }
+    }
+    if (ge) {
+      unsigned __int128 br = 0;
+      for (int i = 0; i < 4; i++) {
+        unsigned __int128 d = (unsigned __int128)r[i] - R[i] - (uint64_t)br;
+        r[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+      }
+    }
+    return r;
+  }
+  void flush() {
+    std::vector<G1Affine> bases;
+    std::vector<Fr> scalars;
+    for (auto& kv : buffer_) {
+      G1Affine b;
+      memcpy(&b, kv.first.data(), 104);
+      bases.push_back(b);
+      scalars.push_back(kv.second);
+    }
+    result_ = g1_add(result_, VariableBaseMSM::msm_unchecked(bases, scalars));
+    buffer_.clear();
+  }
+  size_t cap_;
+  std::map<Key, Fr> buffer_;
+  G1Projective result_;
+};
+
+// SRS resident in HBM + the commit path of src/kzg/time.rs:81-107
+class CommitterKey {
+ public:
+  explicit CommitterKey(const std::vector<G1Affine>& powers_of_g) : n_(powers_of_g.size()) {
+    check(gm_g1_bases_register(powers_of_g.data(), sizeof(G1Affine), n_, &h_));
+  }
+  ~CommitterKey() {
+    if (h_) gm_g1_bases_free(h_);
+  }
+  CommitterKey(const CommitterKey&) = delete;
+  CommitterKey& operator=(const CommitterKey&) = delete;
+  G1Projective commit(const std::vector<Fr>& polynomial) const {
+    size_t n = polynomial.size() < n_ ? polynomial.size() : n_;
+    if (n == 0) return g1_zero();
+    uint64_t hv = 0;
+    check(gm_fr_vec_alloc(n, &hv));
+    G1Projective out;
+    int rc = gm_fr_vec_upload(hv, 0, polynomial[0].data(), n);
+    if (!rc) rc = gm_g1_msm_v(h_, 0, 0, hv, 0, n, out.data());
+    gm_fr_vec_free(hv);
+    check(rc);
+    return out;
+  }
+  std::vector<G1Projective> batch_commit(const std::vector<std::vector<Fr>>& polynomials) const {
+    std::vector<G1Projective> out;
+    for (auto& p : polynomials) out.push_back(commit(p));
+    return out;
+  }
+
+ private:
+  uint64_t h_ = 0;
+  size_t n_;
+};
+
+struct RoundMsg {
+  Fr a, b;
+};
+
+// trait Prover, src/subprotocols/sumcheck/prover.rs:30-45 / time_prover.rs:42-137
+class TimeProver {
+ public:
+  TimeProver(const std::vector<Fr>& f, const std::vector<Fr>& g, const Fr& twist) {
+    check(gm_sc_new(f.empty() ? nullptr : f[0].data(), f.size(), g.empty() ? nullptr : g[0].data(), g.size(), twist.data(), &h_));
+  }
+  ~TimeProver() {
+    if (h_) gm_sc_free(h_);
+  }
+  TimeProver(const TimeProver&) = delete;
+  TimeProver& operator=(const TimeProver&) = delete;
+  std::optional<RoundMsg> next_message(const std::optional<Fr>& verifier_message) {
+    RoundMsg m;
+    int has = 0;
+    check(gm_sc_round(h_, verifier_message ? verifier_message->data() : nullptr, m.a.data(), m.b.data(), &has));
+    if (!has) return std::nullopt;
+    return m;
+  }
+  void fold(const Fr& challenge) { check(gm_sc_fold(h_, challenge.data())); }
+  size_t rounds() const {
+    size_t t = 0;
+    check(gm_sc_rounds(h_, &t, nullptr));
+    return t;
+  }
+  size_t round() const {
+    size_t r = 0;
+    check(gm_sc_rounds(h_, nullptr, &r));
+    return r;
+  }
+  std::optional<std::array<Fr, 2>> final_foldings() const {
+    std::array<Fr, 2> ff;
+    int has = 0;
+    check(gm_sc_final(h_, ff[0].data(), ff[1].data(), &has));
+    if (!has) return std::nullopt;
+    return ff;
+  }
+  uint64_t handle() const { return h_; }
+
+ private:
+  uint64_t h_ = 0;
+};
+
+// merlin::Transcript + GeminiTranscript, src/transcript.rs
+class Transcript {
+ public:
+  explicit Transcript(const std::string& label = "GEMINI-v0") { check(gm_transcript_new((const uint8_t*)label.data(), label.size(), &h_)); }
+  ~Transcript() {
+    if (h_) gm_transcript_free(h_);
+  }
+  Transcript(const Transcript&) = delete;
+  Transcript& operator=(const Transcript&) = delete;
+  void append_message(const std::string& label, const std::vector<uint8_t>& msg) {
+    check(gm_transcript_append_message(h_, (const uint8_t*)label.data(), label.size(), msg.data(), msg.size()));
+  }
+  void append_serializable(const std::string& label, const Fr& x) { check(gm_transcript_append_fr(h_, (const uint8_t*)label.data(), label.size(), x.data(), 1)); }
+  void append_serializable(const std::string& label, const RoundMsg& m) {
+    uint64_t ab[8];
+    memcpy(ab, m.a.data(), 32);
+    memcpy(ab + 4, m.b.data(), 32);
+    check(gm_transcript_append_fr(h_, (const uint8_t*)label.data(), label.size(), ab, 2));
+  }
+  void append_serializable(const std::string& label, const G1Projective& c) {
+    check(gm_transcript_append_g1(h_, (const uint8_t*)label.data(), label.size(), c.data(), 1, 0));
+  }
+  Fr get_challenge(const std::string& label) {
+    Fr r;
+    check(gm_transcript_challenge_fr(h_, (const uint8_t*)label.data(), label.size(), r.data()));
+    return r;
+  }
+  uint64_t handle() const { return h_; }
+
+ private:
+  uint64_t h_ = 0;
+};
+
+// src/subprotocols/sumcheck/proof.rs:19-66,125-130
+struct Sumcheck {
+  std::vector<RoundMsg> messages;
+  std::vector<Fr> challenges;
+  size_t rounds = 0;
+  std::vector<std::array<Fr, 2>> final_foldings;
+
+  static Sumcheck prove(Transcript& transcript, TimeProver& prover) {
+    Sumcheck s;
+    std::optional<Fr> verifier_message;
+    while (auto message = prover.next_message(verifier_message)) {
+      transcript.append_serializable("evaluations", *message);
+      Fr challenge = transcript.get_challenge("challenge");
+      verifier_message = challenge;
+      s.messages.push_back(*message);
+      s.challenges.push_back(challenge);
+    }
+    s.rounds = prover.rounds();
+    auto ff = prover.final_foldings();
+    if (!ff) throw Error(GM_ESTATE, "final foldings unavailable");
+    s.final_foldings.push_back(*ff);
+    transcript.append_serializable("final-folding", (*ff)[0]);
+    transcript.append_serializable("final-folding", (*ff)[1]);
+    return s;
+  }
+  static Sumcheck new_time(Transcript& transcript, const std::vector<Fr>& f, const std::vector<Fr>& g, const Fr& twist) {
+    TimeProver prover(f, g, twist);
+    return prove(transcript, prover);
+  }
+};
+
+}  // namespace gm
