@@ -11,5 +11,5 @@ path: every MSM, sumcheck round and vector pass is a call into the library.
 from . import capi  # noqa: F401
 from .msm import VariableBaseMSM, ChunkedPippenger, HashMapPippenger, G1Bases, msm_chunks  # noqa: F401
 from .fr import FrVec, fold_polynomial, powers, tensor, hadamard, ip, evaluate_le, linear_combination  # noqa: F401
-from .sumcheck import TimeProver, Sumcheck  # noqa: F401
+from .sumcheck import TimeProver, SpaceProver, ElasticProver, Sumcheck  # noqa: F401
 from .transcript import Transcript, PROTOCOL_NAME  # noqa: F401

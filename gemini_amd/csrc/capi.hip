@@ -159,6 +159,13 @@ void sc_destroy(Sumcheck* S);
 int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
 int sc_fold(Context* C, Sumcheck* S, const uint64_t challenge[4]);
 int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has);
+int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream, size_t ng, bool src_is_device,
+              const uint64_t twist[4], uint64_t* handle);
+void sp_destroy(Context* C, SpaceProver* S);
+int sp_fold(Context* C, SpaceProver* S, const uint64_t challenge[4]);
+int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
+int sp_final(Context* C, SpaceProver* S, uint64_t f0[4], uint64_t g0[4], int* has);
+int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle);
 int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out);
 int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out);
 int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out);
@@ -215,6 +222,7 @@ void gm_shutdown(void) {
     if (kv.second->d) (void)hipFree(kv.second->d);
   C->pool.release_all();
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
+  for (auto& kv : C->space_provers) sp_destroy(C, kv.second.get());
   for (auto& kv : C->matrices) {
     if (kv.second->rowptr) (void)hipFree(kv.second->rowptr);
     if (kv.second->cols) (void)hipFree(kv.second->cols);
@@ -669,6 +677,65 @@ int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset) {
   S->pair_offset = pair_offset;
   return GM_OK;
 }
+// ---- space prover --------------------------------------------------------------------------------
+static SpaceProver* find_sp(Context* C, uint64_t h) {
+  std::lock_guard<std::mutex> lk(C->mu);
+  auto it = C->space_provers.find(h);
+  return it == C->space_provers.end() ? nullptr : it->second.get();
+}
+#define GM_SP(var, h, who)                     \
+  SpaceProver* var = find_sp(C, h);            \
+  GM_CHECK(var != nullptr, GM_EHANDLE, who ": unknown space prover handle %llu", (unsigned long long)(h))
+
+int gm_sp_new(const uint64_t* f_stream_mont, size_t nf, const uint64_t* g_stream_mont, size_t ng, const uint64_t twist_mont[4],
+              uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(f_stream_mont && g_stream_mont && twist_mont && handle, GM_EINVAL, "sp_new: null pointer");
+  return sp_create(C, f_stream_mont, nf, g_stream_mont, ng, false, twist_mont, handle);
+}
+int gm_sp_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg) {
+  GM_CTX();
+  GM_SP(S, handle, "sp_round");
+  GM_CHECK(a_mont && b_mont && has_msg, GM_EINVAL, "sp_round: null pointer");
+  return sp_round(C, S, challenge_or_null, a_mont, b_mont, has_msg);
+}
+int gm_sp_fold(uint64_t handle, const uint64_t challenge_mont[4]) {
+  GM_CTX();
+  GM_SP(S, handle, "sp_fold");
+  return sp_fold(C, S, challenge_mont);
+}
+int gm_sp_rounds(uint64_t handle, size_t* tot_rounds, size_t* round) {
+  GM_CTX();
+  GM_SP(S, handle, "sp_rounds");
+  if (tot_rounds) *tot_rounds = S->tot_rounds;
+  if (round) *round = S->round;
+  return GM_OK;
+}
+int gm_sp_final(uint64_t handle, uint64_t f0_mont[4], uint64_t g0_mont[4], int* has) {
+  GM_CTX();
+  GM_SP(S, handle, "sp_final");
+  return sp_final(C, S, f0_mont, g0_mont, has);
+}
+int gm_sp_to_time(uint64_t handle, uint64_t* time_handle) {
+  GM_CTX();
+  GM_SP(S, handle, "sp_to_time");
+  GM_CHECK(time_handle != nullptr, GM_EINVAL, "sp_to_time: null pointer");
+  return sp_to_time(C, S, time_handle);
+}
+int gm_sp_free(uint64_t handle) {
+  GM_CTX();
+  std::unique_ptr<SpaceProver> p;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->space_provers.find(handle);
+    GM_CHECK(it != C->space_provers.end(), GM_EHANDLE, "sp_free: unknown handle %llu", (unsigned long long)handle);
+    p = std::move(it->second);
+    C->space_provers.erase(it);
+  }
+  sp_destroy(C, p.get());
+  return GM_OK;
+}
+
 int gm_sc_free(uint64_t handle) {
   GM_CTX();
   std::unique_ptr<Sumcheck> p;

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "../../include/gemini_hip.h"
 
@@ -84,6 +85,22 @@ struct Sumcheck {
   std::mutex mu;
 };
 
+struct SpaceProver {
+  // src/subprotocols/sumcheck/space_prover.rs:20-40: the witness streams (big-endian, never modified),
+  // the challenges and the twisted challenges
+  uint8_t* f = nullptr;
+  uint8_t* g = nullptr;
+  size_t nf = 0, ng = 0, fcap = 0, gcap = 0;
+  std::vector<uint64_t> challenges, twisted;  // 4 limbs each, Montgomery
+  uint64_t twist[4];
+  size_t round = 0, tot_rounds = 0;
+  DevBuf tables;
+  uint8_t *wf_lo = nullptr, *wf_hi = nullptr, *wg_lo = nullptr, *wg_hi = nullptr;
+  uint8_t* partials = nullptr;
+  uint64_t* host_partials = nullptr;
+  std::mutex mu;
+};
+
 struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
   uint64_t* host_planes = nullptr;  // pinned staging for the D2H of window bit-planes
@@ -128,6 +145,7 @@ struct Context {
   std::unordered_map<uint64_t, std::unique_ptr<FrVec>> vecs;
   std::unordered_map<uint64_t, std::unique_ptr<Sumcheck>> provers;
   std::unordered_map<uint64_t, std::unique_ptr<SparseMatrix>> matrices;
+  std::unordered_map<uint64_t, std::unique_ptr<SpaceProver>> space_provers;
   MsmWorkspace msm;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results

@@ -392,6 +392,89 @@ __global__ __launch_bounds__(256) void k_spmv(const uint64_t* __restrict__ rowpt
 }
 
 // ------------------------------------------------------------------------------------------
+// space prover (src/subprotocols/sumcheck/space_prover.rs): nothing but the ORIGINAL big-endian
+// streams and the challenges is kept; every message is recomputed from the streams.
+// After k folds the folded vector is F[m] = sum_{u < 2^k} f_le[m 2^k + u] w_u with
+// w = tensor(challenges) (misc.rs:133-149) -- so a message is a pass over the streams that
+// dots each group of 2^k originals with the tensor weights (two half tables lo/hi), no folded
+// vector is ever materialised.  f_le[i] = stream[n - 1 - i] (Reverse, src/iterable/slice.rs:17-39).
+// ------------------------------------------------------------------------------------------
+struct SpArgs {
+  const uint8_t* f;  // streams, big-endian
+  const uint8_t* g;
+  size_t nf, ng;
+  const uint8_t* wf_lo;  // tensor(twisted challenges): lo table (2^klo) and hi table (2^(k-klo))
+  const uint8_t* wf_hi;
+  const uint8_t* wg_lo;  // tensor(challenges)
+  const uint8_t* wg_hi;
+  uint32_t k, klo;
+  uint32_t tau[8];
+  PowTable tau2;
+  uint32_t log_threads;
+  size_t npairs;
+};
+
+GM_DEV Fr sp_folded(const uint8_t* stream, size_t n, const uint8_t* lo, const uint8_t* hi, uint32_t k, uint32_t klo, size_t m) {
+  // F[m] over the little-endian view; elements past the end are zero
+  const size_t span = (size_t)1 << k;
+  const size_t first = m << k;
+  Fr acc = Fr::zero();
+  if (first >= n) return acc;
+  const size_t last = min(first + span, n);
+  const size_t lomask = ((size_t)1 << klo) - 1;
+  for (size_t i = first; i < last; i++) {
+    const size_t u = i - first;
+    Fr v = fp_load<FrParams>(stream + (n - 1 - i) * FR_BYTES);
+    if (k > 0) {
+      v = fr_mul(v, fp_load<FrParams>(lo + (u & lomask) * FR_BYTES));
+      if (k > klo) v = fr_mul(v, fp_load<FrParams>(hi + (u >> klo) * FR_BYTES));
+    }
+    acc = fr_add(acc, v);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void k_sp_message(SpArgs A, uint8_t* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
+  const size_t T = (size_t)1 << A.log_threads;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Fr tau, tw = Fr::one(), step;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    tau.l[i] = A.tau[i];
+    step.l[i] = A.tau2.p[A.log_threads][i];
+  }
+  Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
+  if (t < A.npairs) tw = pow_from_table(A.tau2, t);
+  for (size_t j = t; j < A.npairs; j += T) {
+    Fr fe = sp_folded(A.f, A.nf, A.wf_lo, A.wf_hi, A.k, A.klo, 2 * j);
+    Fr fo = sp_folded(A.f, A.nf, A.wf_lo, A.wf_hi, A.k, A.klo, 2 * j + 1);
+    Fr ge = sp_folded(A.g, A.ng, A.wg_lo, A.wg_hi, A.k, A.klo, 2 * j);
+    Fr go = sp_folded(A.g, A.ng, A.wg_lo, A.wg_hi, A.k, A.klo, 2 * j + 1);
+    Fr u = fr_mul(fe, tw), w = fr_mul(fo, tw);
+    acc[0] = fr_add(acc[0], fr_mul(u, ge));
+    acc[1] = fr_add(acc[1], fr_mul(u, go));
+    acc[2] = fr_add(acc[2], fr_mul(w, ge));
+    tw = fr_mul(tw, step);
+  }
+  block_sum<3>(acc, lds);
+  if (threadIdx.x == 0) {
+    Fr b = fr_add(acc[1], fr_mul(tau, acc[2]));
+    fp_store<FrParams>(partials + ((size_t)blockIdx.x * 2) * FR_BYTES, acc[0]);
+    fp_store<FrParams>(partials + ((size_t)blockIdx.x * 2 + 1) * FR_BYTES, b);
+  }
+}
+
+// out[m] = F[m] for m < nout: materialises the folded vector (TimeProver::from(&SpaceProver),
+// space_prover.rs:269-307) in little-endian order
+__global__ __launch_bounds__(256) void k_sp_materialize(const uint8_t* __restrict__ stream, size_t n, const uint8_t* __restrict__ lo,
+                                                        const uint8_t* __restrict__ hi, uint32_t k, uint32_t klo, size_t nout,
+                                                        uint8_t* __restrict__ out) {
+  for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < nout; m += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + m * FR_BYTES, sp_folded(stream, n, lo, hi, k, klo, m));
+}
+
+// ------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------
 static void make_pow_table(const gmh::Fr& x, PowTable& t) {
@@ -557,6 +640,189 @@ int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has) 
   GM_HIP(hipMemcpyAsync(g0, S->g[S->cur], FR_BYTES, hipMemcpyDeviceToHost, C->stream));
   GM_HIP(hipStreamSynchronize(C->stream));
   *has = 1;
+  return GM_OK;
+}
+
+// ---- space prover -------------------------------------------------------------------------------
+static int sp_tables(Context* C, SpaceProver* S, uint32_t* klo_out) {
+  // tensor half tables for the challenges so far: [twisted lo | twisted hi | plain lo | plain hi]
+  const uint32_t k = (uint32_t)S->challenges.size() / 4;
+  const uint32_t klo = k < 10 ? k : 10, khi = k - klo;
+  *klo_out = klo;
+  if (k == 0) return GM_OK;
+  GM_CHECK(khi <= 20, GM_EINVAL, "space prover: %u folds exceed the supported 30 (switch to the time prover, elastic_prover.rs:44-57)", k);
+  const size_t nlo = (size_t)1 << klo, nhi = (size_t)1 << khi;
+  int rc = S->tables.ensure((2 * k * 4 * 8) + 2 * (nlo + nhi) * FR_BYTES + 256);
+  if (rc) return rc;
+  uint8_t* base = S->tables.as<uint8_t>();
+  uint8_t* ch_t = base;                     // k twisted challenges
+  uint8_t* ch_p = base + (size_t)k * 32;    // k plain challenges
+  uint8_t* tabs = base + (size_t)2 * k * 32;
+  GM_HIP(hipMemcpyAsync(ch_t, S->twisted.data(), (size_t)k * 32, hipMemcpyHostToDevice, C->stream));
+  GM_HIP(hipMemcpyAsync(ch_p, S->challenges.data(), (size_t)k * 32, hipMemcpyHostToDevice, C->stream));
+  S->wf_lo = tabs;
+  S->wf_hi = tabs + nlo * FR_BYTES;
+  S->wg_lo = tabs + (nlo + nhi) * FR_BYTES;
+  S->wg_hi = tabs + (2 * nlo + nhi) * FR_BYTES;
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nlo)), dim3(256), 0, C->stream, (const uint32_t*)ch_t, klo, S->wf_lo);
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nhi)), dim3(256), 0, C->stream, (const uint32_t*)(ch_t + (size_t)klo * 32), khi, S->wf_hi);
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nlo)), dim3(256), 0, C->stream, (const uint32_t*)ch_p, klo, S->wg_lo);
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nhi)), dim3(256), 0, C->stream, (const uint32_t*)(ch_p + (size_t)klo * 32), khi, S->wg_hi);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+
+static size_t ceil_shift(size_t n, uint32_t k) { return k >= 63 ? (n ? 1 : 0) : (n + (((size_t)1 << k) - 1)) >> k; }
+
+int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream, size_t ng, bool src_is_device,
+              const uint64_t twist[4], uint64_t* handle) {
+  GM_CHECK(nf >= 1 && ng >= 1, GM_EINVAL, "space prover: empty streams");
+  auto S = std::make_unique<SpaceProver>();
+  S->nf = nf;
+  S->ng = ng;
+  memcpy(S->twist, twist, 32);
+  S->tot_rounds = ceil_log2_sz(nf < ng ? nf : ng);  // space_prover.rs:74-77: log2(min(len))
+  int rc;
+  if ((rc = C->pool.alloc(nf * FR_BYTES, (void**)&S->f, &S->fcap))) return rc;
+  if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g, &S->gcap))) return rc;
+  GM_HIP(hipMalloc((void**)&S->partials, 512 * 2 * FR_BYTES));
+  GM_HIP(hipHostMalloc((void**)&S->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
+  hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  GM_HIP(hipMemcpyAsync(S->f, f_stream, nf * FR_BYTES, kind, C->stream));
+  GM_HIP(hipMemcpyAsync(S->g, g_stream, ng * FR_BYTES, kind, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  std::lock_guard<std::mutex> lk(C->mu);
+  *handle = C->next_handle++;
+  C->space_provers[*handle] = std::move(S);
+  return GM_OK;
+}
+
+void sp_destroy(Context* C, SpaceProver* S) {
+  if (C) {
+    C->pool.free(S->f, S->fcap);
+    C->pool.free(S->g, S->gcap);
+  }
+  S->tables.release();
+  if (S->partials) (void)hipFree(S->partials);
+  if (S->host_partials) (void)hipHostFree(S->host_partials);
+}
+
+// Prover::fold for the space prover: store the randomness aside        space_prover.rs:245-249
+static void sp_push(SpaceProver* S, const uint64_t r[4]) {
+  gmh::Fr rr = gmh::Fr::from_limbs(r), tw = gmh::Fr::from_limbs(S->twist);
+  gmh::Fr rt = rr * tw;
+  S->challenges.insert(S->challenges.end(), r, r + 4);
+  S->twisted.insert(S->twisted.end(), rt.l, rt.l + 4);
+  tw.sqr().to_limbs(S->twist);
+}
+
+int sp_fold(Context*, SpaceProver* S, const uint64_t challenge[4]) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  sp_push(S, challenge);
+  return GM_OK;
+}
+
+// SpaceProver::next_message                                             space_prover.rs:117-240
+int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a_out[4], uint64_t b_out[4], int* has_msg) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_CHECK(S->round <= S->tot_rounds, GM_ESTATE, "More rounds than needed.");
+  if (challenge) sp_push(S, challenge);
+  if (S->round == S->tot_rounds) {
+    *has_msg = 0;
+    return GM_OK;
+  }
+  uint32_t klo = 0;
+  int rc = sp_tables(C, S, &klo);
+  if (rc) return rc;
+  SpArgs A;
+  memset(&A, 0, sizeof A);
+  A.f = S->f;
+  A.g = S->g;
+  A.nf = S->nf;
+  A.ng = S->ng;
+  A.wf_lo = S->wf_lo;
+  A.wf_hi = S->wf_hi;
+  A.wg_lo = S->wg_lo;
+  A.wg_hi = S->wg_hi;
+  A.k = (uint32_t)S->challenges.size() / 4;
+  A.klo = klo;
+  gmh::Fr tau = gmh::Fr::from_limbs(S->twist);
+  memcpy(A.tau, tau.l, 32);
+  make_pow_table(tau.sqr(), A.tau2);
+  const size_t nfk = ceil_shift(S->nf, A.k), ngk = ceil_shift(S->ng, A.k);
+  const size_t pf = (nfk + 1) / 2, pg = (ngk + 1) / 2;
+  A.npairs = pf < pg ? pf : pg;  // the streams are aligned at the low end (space_prover.rs:141-153)
+  uint32_t lt = 8;
+  while (lt < 17 && ((size_t)1 << lt) < A.npairs) lt++;
+  A.log_threads = lt;
+  const unsigned blocks = (unsigned)(((size_t)1 << lt) / 256);
+  hipLaunchKernelGGL(k_sp_message, dim3(blocks), dim3(256), 0, C->stream, A, S->partials);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  gmh::Fr a = gmh::Fr::zero(), b = gmh::Fr::zero();
+  for (unsigned i = 0; i < blocks; i++) {
+    a = a + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8);
+    b = b + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8 + 4);
+  }
+  a.to_limbs(a_out);
+  b.to_limbs(b_out);
+  S->round += 1;
+  *has_msg = 1;
+  return GM_OK;
+}
+
+// folded vectors of the current round, little-endian, into fresh pooled buffers
+static int sp_materialize(Context* C, SpaceProver* S, uint8_t** f_out, size_t* nf_out, size_t* fcap, uint8_t** g_out, size_t* ng_out,
+                          size_t* gcap) {
+  uint32_t klo = 0;
+  int rc = sp_tables(C, S, &klo);
+  if (rc) return rc;
+  const uint32_t k = (uint32_t)S->challenges.size() / 4;
+  *nf_out = ceil_shift(S->nf, k);
+  *ng_out = ceil_shift(S->ng, k);
+  if ((rc = C->pool.alloc(*nf_out * FR_BYTES, (void**)f_out, fcap))) return rc;
+  if ((rc = C->pool.alloc(*ng_out * FR_BYTES, (void**)g_out, gcap))) return rc;
+  hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(*nf_out)), dim3(256), 0, C->stream, S->f, S->nf, S->wf_lo, S->wf_hi, k, klo, *nf_out, *f_out);
+  hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(*ng_out)), dim3(256), 0, C->stream, S->g, S->ng, S->wg_lo, S->wg_hi, k, klo, *ng_out, *g_out);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
+
+int sp_final(Context* C, SpaceProver* S, uint64_t f0[4], uint64_t g0[4], int* has) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (S->round != S->tot_rounds) {
+    *has = 0;
+    return GM_OK;
+  }
+  uint8_t *f, *g;
+  size_t nf, ng, fc, gc;
+  int rc = sp_materialize(C, S, &f, &nf, &fc, &g, &ng, &gc);
+  if (rc) return rc;
+  GM_HIP(hipMemcpyAsync(f0, f, FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipMemcpyAsync(g0, g, FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  C->pool.free(f, fc);
+  C->pool.free(g, gc);
+  *has = 1;
+  return GM_OK;
+}
+
+// From<&SpaceProver> for TimeProver                                      space_prover.rs:269-307
+int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  auto T = std::make_unique<Sumcheck>();
+  int rc = sp_materialize(C, S, &T->f[0], &T->nf, &T->fcap[0], &T->g[0], &T->ng, &T->gcap[0]);
+  if (rc) return rc;
+  if ((rc = C->pool.alloc(((T->nf + 1) / 2) * FR_BYTES, (void**)&T->f[1], &T->fcap[1]))) return rc;
+  if ((rc = C->pool.alloc(((T->ng + 1) / 2) * FR_BYTES, (void**)&T->g[1], &T->gcap[1]))) return rc;
+  GM_HIP(hipMalloc((void**)&T->partials, 512 * 2 * FR_BYTES));
+  GM_HIP(hipHostMalloc((void**)&T->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
+  memcpy(T->twist, S->twist, 32);
+  T->round = S->round;  // "copy other informations such us round(s) and twist"
+  T->tot_rounds = S->tot_rounds;
+  *time_handle = put_prover(std::move(T));
   return GM_OK;
 }
 

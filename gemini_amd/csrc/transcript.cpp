@@ -303,4 +303,71 @@ int gm_sumcheck_prove(uint64_t transcript, uint64_t prover, uint64_t* messages, 
   return GM_OK;
 }
 
+// Sumcheck::prove_batch (src/subprotocols/sumcheck/proof.rs:69-122): k provers of possibly different
+// lengths run in lock-step for max(rounds) + 1 rounds; coefficients c_j are drawn first
+// (b"batch-sumcheck"); a prover that has run out contributes (f0 * g0, 0); the round message is
+// sum_j c_j * m_j.  The reference maps provers over rayon (:85); their device kernels are
+// independent launches here.  messages: cap_rounds x 8, challenges: cap_rounds x 4,
+// final_foldings: k x 8 (lhs || rhs per prover).
+int gm_sumcheck_prove_batch(uint64_t transcript, const uint64_t* provers, size_t k, uint64_t* messages, uint64_t* challenges,
+                            size_t cap_rounds, uint64_t* final_foldings, size_t* rounds_out) {
+  T_CHECK(provers && messages && challenges && final_foldings && rounds_out && k >= 1, GM_EINVAL, "sumcheck_prove_batch: bad arguments");
+  size_t rounds = 0;
+  for (size_t j = 0; j < k; j++) {
+    size_t t = 0;
+    int rc = gm_sc_rounds(provers[j], &t, nullptr);
+    if (rc) return rc;
+    if (t > rounds) rounds = t;
+  }
+  rounds += 1;  // "+1 to get the final foldings"
+  T_CHECK(rounds <= cap_rounds, GM_EINVAL, "sumcheck_prove_batch: %zu rounds exceed capacity %zu", rounds, cap_rounds);
+  std::vector<gmh::Fr> coeff(k);
+  for (size_t j = 0; j < k; j++) {
+    uint64_t c[4];
+    int rc = gm_transcript_challenge_fr(transcript, (const uint8_t*)"batch-sumcheck", 14, c);
+    if (rc) return rc;
+    coeff[j] = gmh::Fr::from_limbs(c);
+  }
+  const uint64_t* vm = nullptr;
+  for (size_t r = 0; r < rounds; r++) {
+    gmh::Fr ma = gmh::Fr::zero(), mb = gmh::Fr::zero();
+    for (size_t j = 0; j < k; j++) {
+      uint64_t a[4], b[4];
+      int has = 0;
+      int rc = gm_sc_round(provers[j], vm, a, b, &has);
+      if (rc) return rc;
+      gmh::Fr fa, fb;
+      if (has) {
+        fa = gmh::Fr::from_limbs(a);
+        fb = gmh::Fr::from_limbs(b);
+      } else {
+        uint64_t f0[4], g0[4];
+        int hf = 0;
+        if ((rc = gm_sc_final(provers[j], f0, g0, &hf))) return rc;
+        T_CHECK(hf, GM_ESTATE, "If next_message is None, we expect final foldings to be available");
+        fa = gmh::Fr::from_limbs(f0) * gmh::Fr::from_limbs(g0);
+        fb = gmh::Fr::zero();
+      }
+      ma = ma + fa * coeff[j];
+      mb = mb + fb * coeff[j];
+    }
+    ma.to_limbs(messages + 8 * r);
+    mb.to_limbs(messages + 8 * r + 4);
+    int rc = gm_transcript_append_fr(transcript, (const uint8_t*)"evaluations", 11, messages + 8 * r, 2);
+    if (rc) return rc;
+    if ((rc = gm_transcript_challenge_fr(transcript, (const uint8_t*)"challenge", 9, challenges + 4 * r))) return rc;
+    vm = challenges + 4 * r;
+  }
+  for (size_t j = 0; j < k; j++) {
+    int has = 0;
+    int rc = gm_sc_final(provers[j], final_foldings + 8 * j, final_foldings + 8 * j + 4, &has);
+    if (rc) return rc;
+    T_CHECK(has, GM_ESTATE, "sumcheck_prove_batch: final foldings unavailable for prover %zu", j);
+    if ((rc = gm_transcript_append_fr(transcript, (const uint8_t*)"final-folding-lhs", 17, final_foldings + 8 * j, 1))) return rc;
+    if ((rc = gm_transcript_append_fr(transcript, (const uint8_t*)"final-folding-rhs", 17, final_foldings + 8 * j + 4, 1))) return rc;
+  }
+  *rounds_out = rounds;
+  return GM_OK;
+}
+
 }  // extern "C"

@@ -72,6 +72,110 @@ class TimeProver:
             self.handle = 0
 
 
+SPACE_TIME_THRESHOLD = 22  # src/lib.rs:76
+
+
+class SpaceProver:
+    """src/subprotocols/sumcheck/space_prover.rs: keeps the big-endian streams and the challenges only;
+    every message is recomputed from the streams on the device (gm_sp_*)."""
+
+    def __init__(self, f_stream, g_stream, twist_mont):
+        capi.ensure_init()
+        fm = capi.u64(f_stream).reshape(-1, 4)
+        gm_ = capi.u64(g_stream).reshape(-1, 4)
+        h = C.c_uint64()
+        capi.check(capi.load().gm_sp_new(capi.ptr(fm), C.c_size_t(len(fm)), capi.ptr(gm_), C.c_size_t(len(gm_)),
+                                         capi.ptr(capi.u64(twist_mont).reshape(4)), C.byref(h)))
+        self.handle = h.value
+
+    def next_message(self, verifier_message=None):
+        a = np.empty(4, dtype=np.uint64)
+        b = np.empty(4, dtype=np.uint64)
+        has = C.c_int()
+        ch = None if verifier_message is None else capi.ptr(capi.u64(verifier_message).reshape(4))
+        capi.check(capi.load().gm_sp_round(C.c_uint64(self.handle), ch, capi.ptr(a), capi.ptr(b), C.byref(has)))
+        return (a, b) if has.value else None
+
+    def fold(self, challenge):
+        capi.check(capi.load().gm_sp_fold(C.c_uint64(self.handle), capi.ptr(capi.u64(challenge).reshape(4))))
+
+    def rounds(self) -> int:
+        t = C.c_size_t()
+        capi.check(capi.load().gm_sp_rounds(C.c_uint64(self.handle), C.byref(t), None))
+        return t.value
+
+    def round(self) -> int:
+        r = C.c_size_t()
+        capi.check(capi.load().gm_sp_rounds(C.c_uint64(self.handle), None, C.byref(r)))
+        return r.value
+
+    def final_foldings(self):
+        f0 = np.empty(4, dtype=np.uint64)
+        g0 = np.empty(4, dtype=np.uint64)
+        has = C.c_int()
+        capi.check(capi.load().gm_sp_final(C.c_uint64(self.handle), capi.ptr(f0), capi.ptr(g0), C.byref(has)))
+        return (f0, g0) if has.value else None
+
+    def to_time_prover(self) -> "TimeProver":
+        """TimeProver::from(&SpaceProver) (space_prover.rs:269-307)"""
+        h = C.c_uint64()
+        capi.check(capi.load().gm_sp_to_time(C.c_uint64(self.handle), C.byref(h)))
+        tp = TimeProver.__new__(TimeProver)
+        tp.handle = h.value
+        return tp
+
+    def free(self):
+        if self.handle:
+            capi.check(capi.load().gm_sp_free(C.c_uint64(self.handle)))
+            self.handle = 0
+
+
+class ElasticProver:
+    """src/subprotocols/sumcheck/elastic_prover.rs: a SpaceProver that turns into a TimeProver when
+    fewer than SPACE_TIME_THRESHOLD rounds remain."""
+
+    def __init__(self, f_stream, g_stream, twist_mont):
+        self.space = SpaceProver(f_stream, g_stream, twist_mont)
+        self.time = None
+
+    def _cur(self):
+        return self.time if self.time is not None else self.space
+
+    def next_message(self, verifier_message=None):
+        # `Prover::next_message` of each variant folds first; the elastic switch lives in fold (:44-57)
+        if verifier_message is not None and self.time is None:
+            self.fold(verifier_message)
+            verifier_message = None
+        return self._cur().next_message(verifier_message)
+
+    def fold(self, challenge):
+        if self.time is None:
+            p = self.space
+            if p.rounds() - p.round() < SPACE_TIME_THRESHOLD:
+                self.time = p.to_time_prover()
+                self.time.fold(challenge)
+                p.free()
+            else:
+                p.fold(challenge)
+        else:
+            self.time.fold(challenge)
+
+    def rounds(self) -> int:
+        return self._cur().rounds()
+
+    def round(self) -> int:
+        return self._cur().round()
+
+    def final_foldings(self):
+        return self._cur().final_foldings()
+
+    def free(self):
+        if self.time is not None:
+            self.time.free()
+        if self.space.handle:
+            self.space.free()
+
+
 class Sumcheck:
     """src/subprotocols/sumcheck/proof.rs:19-31"""
 
@@ -114,6 +218,40 @@ class Sumcheck:
         n = k.value
         return Sumcheck([(msgs[i, :4].copy(), msgs[i, 4:].copy()) for i in range(n)], [chs[i].copy() for i in range(n)], prover.rounds(),
                         [(ff[:4].copy(), ff[4:].copy())])
+
+    @staticmethod
+    def new_space(transcript, f_stream, g_stream, twist_mont) -> "Sumcheck":
+        """proof.rs:133-142"""
+        prover = SpaceProver(f_stream, g_stream, twist_mont)
+        try:
+            return Sumcheck.prove(transcript, prover)
+        finally:
+            prover.free()
+
+    @staticmethod
+    def new_elastic(transcript, f_stream, g_stream, twist_mont) -> "Sumcheck":
+        """proof.rs:145-154"""
+        prover = ElasticProver(f_stream, g_stream, twist_mont)
+        try:
+            return Sumcheck.prove(transcript, prover)
+        finally:
+            prover.free()
+
+    @staticmethod
+    def prove_batch(transcript, provers) -> "Sumcheck":
+        """proof.rs:69-122 (run inside the library: gm_sumcheck_prove_batch)"""
+        k = len(provers)
+        cap = max(p.rounds() for p in provers) + 1
+        msgs = np.zeros((cap, 8), dtype=np.uint64)
+        chs = np.zeros((cap, 4), dtype=np.uint64)
+        ff = np.zeros((k, 8), dtype=np.uint64)
+        handles = np.array([p.handle for p in provers], dtype=np.uint64)
+        r = C.c_size_t()
+        capi.check(capi.load().gm_sumcheck_prove_batch(C.c_uint64(transcript.handle), capi.ptr(handles), C.c_size_t(k), capi.ptr(msgs), capi.ptr(chs),
+                                                       C.c_size_t(cap), capi.ptr(ff), C.byref(r)))
+        n = r.value
+        return Sumcheck([(msgs[i, :4].copy(), msgs[i, 4:].copy()) for i in range(n)], [chs[i].copy() for i in range(n)], n,
+                        [(ff[j, :4].copy(), ff[j, 4:].copy()) for j in range(k)])
 
     @staticmethod
     def new_time(transcript, f, g, twist_mont, native: bool = True) -> "Sumcheck":

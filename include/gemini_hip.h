@@ -193,6 +193,22 @@ int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset);
 int gm_sc_lens(uint64_t handle, size_t* nf, size_t* ng, uint64_t twist_mont[4]);
 int gm_sc_download(uint64_t handle, uint64_t* f_mont, uint64_t* g_mont);
 
+/* ---- sumcheck space prover / elastic hand-off --------------------------------------------------- */
+/* Replaces SpaceProver<F, S1, S2> behind `trait Prover<F>` (src/subprotocols/sumcheck/space_prover.rs).
+ * f_stream / g_stream are the BIG-ENDIAN coefficient streams the reference consumes (Reverse(slice),
+ * src/iterable/slice.rs:17-39).  Only the streams and the challenges are kept; every message is
+ * recomputed from the streams (:117-240).  rounds = ceil(log2(min(len))) as in :74-77.
+ * gm_sp_to_time is `TimeProver::from(&SpaceProver)` (:269-307), the switch ElasticProver::fold makes
+ * when rounds - round < SPACE_TIME_THRESHOLD = 22 (elastic_prover.rs:44-57, src/lib.rs:76). */
+int gm_sp_new(const uint64_t* f_stream_mont, size_t nf, const uint64_t* g_stream_mont, size_t ng, const uint64_t twist_mont[4],
+              uint64_t* handle);
+int gm_sp_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg);
+int gm_sp_fold(uint64_t handle, const uint64_t challenge_mont[4]);
+int gm_sp_rounds(uint64_t handle, size_t* tot_rounds, size_t* round);
+int gm_sp_final(uint64_t handle, uint64_t f0_mont[4], uint64_t g0_mont[4], int* has);
+int gm_sp_to_time(uint64_t handle, uint64_t* time_handle);
+int gm_sp_free(uint64_t handle);
+
 /* ---- Fiat-Shamir transcript (host; no GPU needed) ------------------------------------------------ */
 /* merlin::Transcript::new(label) (merlin 3.0.0, Cargo.lock:606-608); the prover uses
  * Transcript::new(PROTOCOL_NAME) with PROTOCOL_NAME = b"GEMINI-v0" (src/lib.rs:74). */
@@ -212,6 +228,11 @@ int gm_transcript_challenge_fr(uint64_t handle, const uint8_t* label, size_t lle
  * messages: cap_rounds x 8 u64 (a || b), challenges: cap_rounds x 4, final_foldings: f0 || g0. */
 int gm_sumcheck_prove(uint64_t transcript, uint64_t prover, uint64_t* messages, uint64_t* challenges, size_t cap_rounds,
                       uint64_t final_foldings[8], size_t* rounds_out);
+
+/* Sumcheck::prove_batch (src/subprotocols/sumcheck/proof.rs:69-122) over k gm_sc_* provers.
+ * messages: cap_rounds x 8, challenges: cap_rounds x 4, final_foldings: k x 8 (lhs || rhs). */
+int gm_sumcheck_prove_batch(uint64_t transcript, const uint64_t* provers, size_t k, uint64_t* messages, uint64_t* challenges,
+                            size_t cap_rounds, uint64_t* final_foldings, size_t* rounds_out);
 
 #ifdef __cplusplus
 }

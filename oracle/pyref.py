@@ -633,6 +633,34 @@ def sumcheck_prove(transcript: GeminiTranscript, prover):
     return messages, challenges, ff
 
 
+def sumcheck_prove_batch(transcript: GeminiTranscript, provers):
+    """src/subprotocols/sumcheck/proof.rs:69-122"""
+    rounds = max(p.tot_rounds for p in provers) + 1
+    coefficients = [transcript.get_challenge(b"batch-sumcheck") for _ in provers]
+    messages, challenges = [], []
+    vm = None
+    for _ in range(rounds):
+        a = b = 0
+        for p, c in zip(provers, coefficients):
+            m = p.next_message(vm)
+            if m is None:
+                ff = p.final_foldings()
+                m = (ff[0] * ff[1] % R_MOD, 0)
+            a = (a + m[0] * c) % R_MOD
+            b = (b + m[1] * c) % R_MOD
+        transcript.append_round_msg(b"evaluations", a, b)
+        vm = transcript.get_challenge(b"challenge")
+        messages.append((a, b))
+        challenges.append(vm)
+    finals = []
+    for p in provers:
+        ff = p.final_foldings()
+        transcript.append_fr(b"final-folding-lhs", ff[0])
+        transcript.append_fr(b"final-folding-rhs", ff[1])
+        finals.append(ff)
+    return messages, challenges, finals
+
+
 # ----------------------------------------------------------------------------
 # Deterministic test-input generator shared by oracle, tests and bench
 # (the reference draws from ark_std::test_rng(), which is not reproducible without Rust)

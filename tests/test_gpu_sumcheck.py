@@ -160,3 +160,109 @@ def test_div_vanishing_vs_oracle(gm, oracle, pyref):
     q_exp, rem = oracle.poly_div_monic(f, _mont(oracle, pyref.vanishing_polynomial(pts)))
     assert (q.to_host() == q_exp).all()
     assert oracle.limbs_to_ints(oracle.fr_from_mont(oracle.evaluate_le(rem, _mont(oracle, [beta])[0]))) == [1807299544171]
+
+
+def test_prove_and_prove_batch_vs_restatement(gm, oracle, pyref):
+    """Sumcheck::prove (proof.rs:36-66) and prove_batch (:69-122; shapes of sumcheck/tests.rs:141-200):
+    messages, challenges and final foldings equal the Python restatement over the same transcript."""
+    I = lambda a: oracle.limbs_to_ints(oracle.fr_from_mont(np.asarray(a).reshape(-1, 4)))
+    shapes = [(64, 64), (17, 5), (128, 128), (2, 2)]
+    fs = [oracle.fr_to_mont(oracle.random_fr(700 + i, nf)) for i, (nf, _) in enumerate(shapes)]
+    gs = [oracle.fr_to_mont(oracle.random_fr(800 + i, ng)) for i, (_, ng) in enumerate(shapes)]
+    tws = oracle.fr_to_mont(oracle.random_fr(900, len(shapes)))
+    # single prove, both the Python round loop and the in-library loop
+    for native in (False, True):
+        t = gm.Transcript()
+        sc = gm.Sumcheck.new_time(t, fs[0], gs[0], tws[0], native=native)
+        tr = pyref.GeminiTranscript(pyref.PROTOCOL_NAME)
+        m, c, ff = pyref.sumcheck_prove(tr, pyref.TimeProver(I(fs[0]), I(gs[0]), I(tws[0])[0]))
+        assert [(I(a)[0], I(b)[0]) for a, b in sc.messages] == m
+        assert [I(x)[0] for x in sc.challenges] == c
+        assert (I(sc.final_foldings[0][0])[0], I(sc.final_foldings[0][1])[0]) == ff
+        assert I(t.get_challenge(b"next"))[0] == tr.get_challenge(b"next")
+        t.free()
+    # batch
+    t = gm.Transcript()
+    provers = [gm.TimeProver(f, g, tw) for f, g, tw in zip(fs, gs, tws)]
+    sc = gm.Sumcheck.prove_batch(t, provers)
+    tr = pyref.GeminiTranscript(pyref.PROTOCOL_NAME)
+    m, c, finals = pyref.sumcheck_prove_batch(tr, [pyref.TimeProver(I(f), I(g), I(tw)[0]) for f, g, tw in zip(fs, gs, tws)])
+    assert sc.rounds == 8 == len(m)  # max rounds (7) + 1
+    assert [(I(a)[0], I(b)[0]) for a, b in sc.messages] == m
+    assert [I(x)[0] for x in sc.challenges] == c
+    assert [(I(a)[0], I(b)[0]) for a, b in sc.final_foldings] == finals
+    assert I(t.get_challenge(b"next"))[0] == tr.get_challenge(b"next")
+    for p in provers:
+        p.free()
+    t.free()
+
+
+def _msgs_equal(m1, m2):
+    return all((a1 == a2).all() and (b1 == b2).all() for (a1, b1), (a2, b2) in zip(m1, m2)) and len(m1) == len(m2)
+
+
+def test_messages_consistency_space_time(gm, oracle):
+    """src/subprotocols/sumcheck/tests.rs:42-87: space prover (big-endian streams) == time prover, message by
+    message and as whole proofs; also vs the CPU restatement."""
+    n = 30  # DensePolynomial::rand(29)
+    f = oracle.fr_to_mont(oracle.random_fr(41, n))
+    g = oracle.fr_to_mont(oracle.random_fr(42, n))
+    one = oracle.fr_to_mont(oracle.ints_to_limbs([1], 4))[0]
+    tw = one
+    tp = gm.TimeProver(f, g, tw)
+    sp = gm.SpaceProver(f[::-1].copy(), g[::-1].copy(), tw)
+    O = oracle.TimeProver(f, g, tw)
+    for vm in (None, oracle.fr_to_mont(oracle.random_fr(43, 1))[0], one):
+        ms, mt, mo = sp.next_message(vm), tp.next_message(vm), O.next_message(vm)
+        assert (ms[0] == mt[0]).all() and (ms[1] == mt[1]).all()
+        assert (ms[0] == mo[0]).all() and (ms[1] == mo[1]).all()
+    tp.free()
+    sp.free()
+    for twist in (one, oracle.fr_to_mont(oracle.random_fr(44, 1))[0]):
+        ts, tt = gm.Transcript(), gm.Transcript()
+        space_proof = gm.Sumcheck.new_space(ts, f[::-1].copy(), g[::-1].copy(), twist)
+        time_proof = gm.Sumcheck.new_time(tt, f, g, twist)
+        assert _msgs_equal(space_proof.messages, time_proof.messages)
+        assert all((x == y).all() for x, y in zip(space_proof.challenges, time_proof.challenges))
+        assert (space_proof.final_foldings[0][0] == time_proof.final_foldings[0][0]).all()
+        assert (space_proof.final_foldings[0][1] == time_proof.final_foldings[0][1]).all()
+        ts.free()
+        tt.free()
+
+
+def test_consistency_elastic(gm, oracle):
+    """tests.rs:90-111: elastic == time.  With 30 coefficients the switch happens at the first fold;
+    a 2^12-long instance with a lowered threshold exercises several space rounds before the hand-off."""
+    import gemini_amd.sumcheck as S
+
+    for n, thr in ((30, 22), (1 << 12, 8), (3000, 6)):
+        f = oracle.fr_to_mont(oracle.random_fr(51 + n, n))
+        g = oracle.fr_to_mont(oracle.random_fr(52 + n, n))
+        tw = oracle.fr_to_mont(oracle.random_fr(53 + n, 1))[0]
+        old = S.SPACE_TIME_THRESHOLD
+        S.SPACE_TIME_THRESHOLD = thr
+        try:
+            te, tt = gm.Transcript(), gm.Transcript()
+            elastic = gm.Sumcheck.new_elastic(te, f[::-1].copy(), g[::-1].copy(), tw)
+            time_proof = gm.Sumcheck.new_time(tt, f, g, tw)
+            assert _msgs_equal(elastic.messages, time_proof.messages), n
+            assert (elastic.final_foldings[0][0] == time_proof.final_foldings[0][0]).all()
+            assert (elastic.final_foldings[0][1] == time_proof.final_foldings[0][1]).all()
+            te.free()
+            tt.free()
+        finally:
+            S.SPACE_TIME_THRESHOLD = old
+
+
+def test_space_prover_different_lengths(gm, oracle):
+    """tests.rs:114-138: f of 93 and g of 16 coefficients, first message equal"""
+    f = oracle.fr_to_mont(oracle.random_fr(61, 93))
+    g = oracle.fr_to_mont(oracle.random_fr(62, 16))
+    tw = oracle.fr_to_mont(oracle.ints_to_limbs([1], 4))[0]
+    tp = gm.TimeProver(f, g, tw)
+    sp = gm.SpaceProver(f[::-1].copy(), g[::-1].copy(), tw)
+    ms, mt = sp.next_message(None), tp.next_message(None)
+    assert (ms[0] == mt[0]).all() and (ms[1] == mt[1]).all()
+    assert sp.rounds() == 4 and tp.rounds() == 7  # log2(min) vs log2(max), as in the reference
+    tp.free()
+    sp.free()
