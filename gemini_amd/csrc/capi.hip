@@ -174,6 +174,7 @@ int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]);
 int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results);
 int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out);
 int fr_fill(Context* C, FrVec* v, const uint64_t val[4]);
+int fr_reverse(Context* C, FrVec* in, FrVec* out);
 int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y);
 int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k, FrVec* q, uint64_t* rem_out);
 
@@ -506,6 +507,12 @@ int gm_fr_vec_fill(uint64_t handle, const uint64_t value_mont[4]) {
   return fr_fill(C, v, value_mont);
 }
 
+int gm_fr_reverse(uint64_t in, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vi, in, "fr_reverse");
+  GM_VEC(vo, out, "fr_reverse");
+  return fr_reverse(C, vi, vo);
+}
 int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out) {
   GM_CTX();
   GM_VEC(vf, f, "fr_fold");

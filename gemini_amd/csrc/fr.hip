@@ -295,6 +295,12 @@ __global__ __launch_bounds__(256) void k_high_nonzero(const uint8_t* __restrict_
   if (best) atomicMax(result, best);
 }
 
+// out[i] = in[n - 1 - i]: big-endian stream <-> little-endian coefficient vector (Reverse, src/iterable/slice.rs:17-39)
+__global__ void k_reverse(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + i * FR_BYTES, fp_load<FrParams>(in + (n - 1 - i) * FR_BYTES));
+}
+
 __global__ void k_fill(uint8_t* __restrict__ v, size_t n, const uint32_t* __restrict__ val) {
   Fr x = fp_load<FrParams>(val);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -984,6 +990,16 @@ int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y) {
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
   y->len = M->nrows;
+  return GM_OK;
+}
+
+int fr_reverse(Context* C, FrVec* in, FrVec* out) {
+  GM_CHECK(out->cap >= in->len, GM_EINVAL, "reverse: output capacity %zu < %zu", out->cap, in->len);
+  GM_CHECK(out != in, GM_EINVAL, "reverse: output must not alias the input");
+  if (in->len) hipLaunchKernelGGL(k_reverse, dim3(grid_for(in->len)), dim3(256), 0, C->stream, in->d, in->len, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = in->len;
   return GM_OK;
 }
 

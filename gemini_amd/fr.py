@@ -101,6 +101,18 @@ def _as_vec(x):
     return (x, False) if isinstance(x, FrVec) else (FrVec.from_host(x), True)
 
 
+def reverse(v) -> FrVec:
+    """Reverse(slice): big-endian stream <-> little-endian coefficient vector (src/iterable/slice.rs:17-39)"""
+    vv, tmp = _as_vec(v)
+    out = FrVec.alloc(len(vv))
+    try:
+        capi.check(capi.load().gm_fr_reverse(C.c_uint64(vv.handle), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
 def fold_polynomial(f, r_mont) -> FrVec:
     """src/misc.rs:52-56"""
     fv, tmp = _as_vec(f)

@@ -5,7 +5,8 @@ from __future__ import annotations
 import numpy as np
 
 from . import capi
-from .fr import FrVec, _as_vec, div_vanishing, fr_from_int, linear_combination, powers
+from .fr import FrVec, R_MOD, _as_vec, div_vanishing, fold_polynomial, fr_from_int, fr_to_int, linear_combination, powers, reverse
+from .msm import g1_sum, g1_zero
 from .msm import G1Bases
 
 # BLS12-381 G1 generator, Montgomery limbs (the reference draws g = G1::rand(rng), src/kzg/time.rs:54)
@@ -88,3 +89,177 @@ class CommitterKey:
             return self.open_multi_points(batched, pts)
         finally:
             batched.free()
+
+
+class FoldedPolynomialTree:
+    """src/subprotocols/sumcheck/streams.rs:13-37: a big-endian coefficient stream plus folding challenges;
+    level i (1..depth) is the stream folded with challenges[0..i)."""
+
+    def __init__(self, coefficients_stream, challenges_mont):
+        self.coefficients = coefficients_stream
+        self.challenges = [capi.u64(c).reshape(4) for c in challenges_mont]
+
+    def depth(self) -> int:
+        return len(self.challenges)
+
+    def __len__(self) -> int:
+        return len(self.coefficients)
+
+
+def _newton_to_monomial_be(rem_newton, points_int):
+    """f mod prod (x - p_j) from the successive-division remainders r_j (Newton form), returned
+    big-endian like the `state` deque of src/kzg/space.rs:145-163"""
+    coeffs = [0] * len(points_int)
+    basis = [1]  # prod_{t<j} (x - p_t), little-endian
+    for j, r in enumerate(rem_newton):
+        rj = fr_to_int(r)
+        for d, b in enumerate(basis):
+            coeffs[d] = (coeffs[d] + rj * b) % R_MOD
+        nxt = [0] * (len(basis) + 1)
+        for d, b in enumerate(basis):
+            nxt[d] = (nxt[d] - points_int[j] * b) % R_MOD
+            nxt[d + 1] = (nxt[d + 1] + b) % R_MOD
+        basis = nxt
+    return np.stack([fr_from_int(c) for c in reversed(coeffs)])
+
+
+class CommitterKeyStream:
+    """src/kzg/space.rs:59-69.  `powers_of_g` is the big-endian stream Reverse(time key's powers)
+    (:287-296); in HBM the SRS stays in time order and the stream view is the `reversed` addressing
+    of gm_g1_msm_*.  Polynomials are big-endian coefficient streams (numpy arrays or FrVec)."""
+
+    def __init__(self, powers_of_g: G1Bases, max_eval_points: int):
+        self.powers_of_g = powers_of_g
+        self._max_eval_points = max_eval_points
+
+    @classmethod
+    def from_committer_key(cls, ck: "CommitterKey") -> "CommitterKeyStream":
+        return cls(ck.powers_of_g, ck.max_eval_points())
+
+    def as_committer_key(self, max_degree: int) -> "CommitterKey":
+        """:77-92 (keeps the first max_degree powers; shares the resident SRS)"""
+        assert max_degree <= len(self.powers_of_g)
+        return CommitterKey(self.powers_of_g, self._max_eval_points)
+
+    def _msm_stream(self, scalars_stream: FrVec, first_stream_pos: int, chunk: int) -> np.ndarray:
+        """sum over stream positions: pair k = (base_stream[first_stream_pos + k], scalars_stream[k]),
+        flushed every `chunk` pairs like ChunkedPippenger / msm_chunks"""
+        n = len(self.powers_of_g)
+        total = len(scalars_stream)
+        result = g1_zero()
+        for off in range(0, total, chunk):
+            m = min(chunk, total - off)
+            part = self.powers_of_g.msm_vec(scalars_stream, n=m, voffset=off, offset=n - 1 - (first_stream_pos + off), reversed_=True)
+            result = g1_sum(np.stack([result, part]))
+        return result
+
+    def commit(self, polynomial_stream) -> np.ndarray:
+        """:169-177 -> msm_chunks (:22-55): skip len(powers) - len(poly) bases, 2^20-pair MSMs, summed"""
+        v, tmp = _as_vec(polynomial_stream)
+        try:
+            assert len(self.powers_of_g) >= len(v)
+            return self._msm_stream(v, len(self.powers_of_g) - len(v), 1 << 20)
+        finally:
+            if tmp:
+                v.free()
+
+    def open(self, polynomial_stream, alpha_mont, max_msm_buffer: int):
+        """:95-125 -> (evaluation, proof): pairs (base_i, previous_i), previous_{i+1} = previous_i*alpha + c_i"""
+        v, tmp = _as_vec(polynomial_stream)
+        le = reverse(v)
+        try:
+            q, rem = div_vanishing(le, capi.u64(alpha_mont).reshape(1, 4))
+            # stream-order scalars: [0, q_{d-1}, ..., q_0]
+            qs = FrVec.alloc(len(v))
+            qs.fill(fr_from_int(0))
+            if len(q):
+                qr = reverse(q)
+                import ctypes as C
+
+                host = qr.to_host()
+                capi.check(capi.load().gm_fr_vec_upload(C.c_uint64(qs.handle), C.c_size_t(1), capi.ptr(host), C.c_size_t(len(host))))
+                qr.free()
+            proof = self._msm_stream(qs, len(self.powers_of_g) - len(v), max_msm_buffer)
+            q.free()
+            qs.free()
+            return rem[0], proof
+        finally:
+            le.free()
+            if tmp:
+                v.free()
+
+    def open_multi_points(self, polynomial_stream, points_mont, max_msm_buffer: int):
+        """:128-166 -> (remainder (big-endian, len(points) values), proof)"""
+        v, tmp = _as_vec(polynomial_stream)
+        pts = capi.u64(points_mont).reshape(-1, 4)
+        le = reverse(v)
+        try:
+            q, rem = div_vanishing(le, pts)
+            remainder = _newton_to_monomial_be(rem, [fr_to_int(p) for p in pts])
+            qs = reverse(q)
+            proof = self._msm_stream(qs, len(self.powers_of_g) - len(v) + len(pts), max_msm_buffer)
+            q.free()
+            qs.free()
+            return remainder, proof
+        finally:
+            le.free()
+            if tmp:
+                v.free()
+
+    def _foldings_le(self, polynomials: FoldedPolynomialTree):
+        v, tmp = _as_vec(polynomials.coefficients)
+        cur = reverse(v)
+        if tmp:
+            v.free()
+        out = []
+        first = cur
+        for ch in polynomials.challenges:
+            cur = fold_polynomial(cur, ch)
+            out.append(cur)
+        first.free()
+        return out
+
+    def commit_folding(self, polynomials: FoldedPolynomialTree, max_msm_buffer: int) -> list:
+        """:192-223: one ChunkedPippenger of size max_msm_buffer / depth per folding level"""
+        n = polynomials.depth()
+        levels = self._foldings_le(polynomials)
+        out = []
+        for lvl in levels:
+            s = reverse(lvl)
+            out.append(self._msm_stream(s, len(self.powers_of_g) - len(s), max(1, max_msm_buffer // n)))
+            s.free()
+            lvl.free()
+        return out
+
+    def open_folding(self, polynomials: FoldedPolynomialTree, points_mont, etas_mont, max_msm_buffer: int):
+        """:229-285 -> (remainders per level (big-endian), proof = sum_i etas[i-1] * commit(quotient_i)).
+        The reference merges equal bases in a HashMapPippenger; on the device that is the linear
+        combination of the quotients followed by one (chunked) MSM."""
+        pts = capi.u64(points_mont).reshape(-1, 4)
+        etas = capi.u64(etas_mont).reshape(-1, 4)
+        pts_int = [fr_to_int(p) for p in pts]
+        levels = self._foldings_le(polynomials)
+        quotients, remainders = [], []
+        for lvl in levels:
+            if len(lvl) > len(pts):
+                q, rem = div_vanishing(lvl, pts)
+                remainders.append(_newton_to_monomial_be(rem, pts_int))
+            else:  # shorter than the divisor: quotient empty, remainder = the polynomial, zero padded at the top
+                q = FrVec.alloc(0)
+                host = lvl.to_host()
+                pad = np.zeros((len(pts) - len(host), 4), dtype=np.uint64)
+                remainders.append(np.concatenate([pad, host[::-1]]))
+            quotients.append(q)
+            lvl.free()
+        batched = linear_combination(quotients, etas[: len(quotients)])
+        for q in quotients:
+            q.free()
+        if len(batched) == 0:
+            batched.free()
+            return remainders, g1_zero()
+        s = reverse(batched)
+        # bases: tau^j for coefficient j -> stream position n - len(batched)
+        proof = self._msm_stream(s, len(self.powers_of_g) - len(s), max_msm_buffer)
+        s.free()
+        batched.free()
+        return remainders, proof

@@ -118,3 +118,75 @@ def test_snark_time_prover_general_r1cs(gm, oracle, pyref):
     assert [(I(x), I(y)) for x, y in proof.second_sumcheck_msgs[0]] == exp["second_sumcheck_msgs"][0]
     assert jac_to_affine_ints(oracle, proof.tensorcheck_proof.evaluation_proof) == exp["tensorcheck_proof"]["evaluation_proof"]
     r1cs.free()
+
+
+def test_committer_key_stream_consistency(gm, oracle, pyref):
+    """src/kzg/tests.rs:16-59 (time == space commitments and openings), src/kzg/space.rs:313-387
+    (open_multi_points incl. the 1807299544171 known answer), commit_folding / open_folding vs the
+    time-side equivalents."""
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream, FoldedPolynomialTree
+    from oracle import snark_ref as sr
+
+    I = gm.fr.fr_to_int
+    tau = oracle.limbs_to_ints(oracle.random_fr(71, 1))[0]
+    time_ck = CommitterKey.new(200, 3, oracle.ints_to_limbs([tau], 4)[0])
+    space_ck = CommitterKeyStream.from_committer_key(time_ck)
+    srs = sr.srs(tau, 201)
+    assert len(space_ck.powers_of_g) == len(time_ck.powers_of_g)  # test_srs
+    # test_commitment_consistency (d = 15) and a longer one
+    for d, seed in ((15, 72), (100, 73)):
+        poly = oracle.fr_to_mont(oracle.random_fr(seed, d + 1))
+        stream = poly[::-1].copy()  # Reverse(polynomial.coeffs())
+        tc, scm = time_ck.commit(poly), space_ck.commit(stream)
+        assert (tc == scm).all()
+        # test_open_consistency
+        alpha = oracle.fr_to_mont(oracle.random_fr(seed + 10, 1))[0]
+        te, tp = time_ck.open(poly, alpha)
+        se, sp = space_ck.open(stream, alpha, 1 << 20)
+        assert (te == se).all() and (tp == sp).all()
+        se2, sp2 = space_ck.open(stream, alpha, 7)  # tiny buffer: many ChunkedPippenger flushes
+        assert (te == se2).all() and (tp == sp2).all()
+    # space.rs test_open_multi_points
+    f_be = [80, 80, 88, 3, 73, 7, 24]
+    stream = oracle.fr_to_mont(oracle.ints_to_limbs(f_be, 4))
+    beta = 53
+    M = lambda v: oracle.fr_to_mont(oracle.ints_to_limbs(v, 4))
+    rem, _ = space_ck.open_multi_points(stream, M([beta * beta, beta, pyref.R_MOD - beta]), 1 << 20)
+    assert pyref.evaluate_be([I(x) for x in rem], beta) == 1807299544171
+    rem1, _ = space_ck.open_multi_points(stream, M([beta]), 1 << 20)
+    assert len(rem1) == 1
+    poly_i = oracle.limbs_to_ints(oracle.random_fr(74, 101))
+    poly = M(poly_i)
+    stream = poly[::-1].copy()
+    b = oracle.limbs_to_ints(oracle.random_fr(75, 1))[0]
+    _, proof_batch = space_ck.open_multi_points(stream, M([b]), 1 << 20)
+    _, proof_single = space_ck.open(stream, M([b])[0], 1 << 20)
+    assert (proof_batch == proof_single).all()
+    pts = [b, pyref.R_MOD - b, b * b % pyref.R_MOD]
+    rem, proof = space_ck.open_multi_points(stream, M(pts), 1 << 20)
+    rem_i = [I(x) for x in rem]
+    for p in pts:
+        assert pyref.evaluate_be(rem_i, p) == pyref.evaluate_le(poly_i, p)
+    assert (proof == time_ck.open_multi_points(poly, M(pts))).all()
+    # commit_folding: level i = commitment of the i-fold folding
+    chal_i = oracle.limbs_to_ints(oracle.random_fr(76, 6))
+    tree = FoldedPolynomialTree(stream, M(chal_i))
+    got = space_ck.commit_folding(tree, 1 << 20)
+    cur = poly_i
+    folds = []
+    for c in chal_i:
+        cur = pyref.fold_polynomial(cur, c)
+        folds.append(cur)
+    assert [jac_to_affine_ints(oracle, x) for x in got] == [sr.commit(srs, f) for f in folds]
+    assert [jac_to_affine_ints(oracle, x) for x in space_ck.commit_folding(tree, 12)] == [sr.commit(srs, f) for f in folds]
+    # open_folding: proof = commit(sum_i eta_i * quotient_i), remainders evaluate like the foldings
+    etas = oracle.limbs_to_ints(oracle.random_fr(77, 6))
+    rems, proof = space_ck.open_folding(tree, M(pts), M(etas), 1 << 20)
+    z = pyref.vanishing_polynomial(pts)
+    quots = [pyref.poly_divmod(f, z)[0] for f in folds]
+    assert jac_to_affine_ints(oracle, proof) == sr.commit(srs, pyref.linear_combination(quots, etas))
+    for f, r in zip(folds, rems):
+        r_i = [I(x) for x in r]
+        assert len(r_i) == 3
+        for p in pts:
+            assert pyref.evaluate_be(r_i, p) == pyref.evaluate_le(f, p)
