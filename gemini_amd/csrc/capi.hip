@@ -153,6 +153,13 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
 int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* d_scalars, int mont, size_t n,
                         std::unique_ptr<Bases>& out);
 int bases_precompute(Context* C, Bases* b, int c);
+int sc_set_herring(Sumcheck* S, int on);
+int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist[4],
+               uint64_t* handle);
+void hg1_destroy(Context* C, HerringG1* H);
+int hg1_fold(Context* C, HerringG1* H, const uint64_t r[4]);
+int hg1_round(Context* C, HerringG1* H, const uint64_t* challenge, uint64_t a_jac[18], uint64_t b_jac[18], int* has_msg);
+int hg1_final(Context* C, HerringG1* H, uint64_t f0_jac[18], uint64_t g0[4], int* has);
 int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_t ng, bool src_is_device,
               const uint64_t twist[4], uint64_t* handle);
 void sc_destroy(Sumcheck* S);
@@ -224,6 +231,7 @@ void gm_shutdown(void) {
   C->pool.release_all();
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
   for (auto& kv : C->space_provers) sp_destroy(C, kv.second.get());
+  for (auto& kv : C->herring_g1) hg1_destroy(C, kv.second.get());
   for (auto& kv : C->matrices) {
     if (kv.second->rowptr) (void)hipFree(kv.second->rowptr);
     if (kv.second->cols) (void)hipFree(kv.second->cols);
@@ -684,6 +692,63 @@ int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset) {
   S->pair_offset = pair_offset;
   return GM_OK;
 }
+// ---- herring provers -------------------------------------------------------------------------------
+int gm_sc_set_herring(uint64_t handle, int on) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_set_herring");
+  return sc_set_herring(S, on);
+}
+static HerringG1* find_hg1(Context* C, uint64_t h) {
+  std::lock_guard<std::mutex> lk(C->mu);
+  auto it = C->herring_g1.find(h);
+  return it == C->herring_g1.end() ? nullptr : it->second.get();
+}
+#define GM_HG1(var, h, who)                   \
+  HerringG1* var = find_hg1(C, h);            \
+  GM_CHECK(var != nullptr, GM_EHANDLE, who ": unknown herring G1 prover handle %llu", (unsigned long long)(h))
+int gm_hg1_new(const void* f_bases, size_t base_stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist_mont[4],
+               uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(f_bases && g_mont && twist_mont && handle, GM_EINVAL, "hg1_new: null pointer");
+  return hg1_create(C, f_bases, base_stride, nf, g_mont, ng, twist_mont, handle);
+}
+int gm_hg1_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_jac[18], uint64_t b_jac[18], int* has_msg) {
+  GM_CTX();
+  GM_HG1(H, handle, "hg1_round");
+  GM_CHECK(a_jac && b_jac && has_msg, GM_EINVAL, "hg1_round: null pointer");
+  return hg1_round(C, H, challenge_or_null, a_jac, b_jac, has_msg);
+}
+int gm_hg1_fold(uint64_t handle, const uint64_t challenge_mont[4]) {
+  GM_CTX();
+  GM_HG1(H, handle, "hg1_fold");
+  return hg1_fold(C, H, challenge_mont);
+}
+int gm_hg1_rounds(uint64_t handle, size_t* tot_rounds, size_t* round) {
+  GM_CTX();
+  GM_HG1(H, handle, "hg1_rounds");
+  if (tot_rounds) *tot_rounds = H->tot_rounds;
+  if (round) *round = H->round;
+  return GM_OK;
+}
+int gm_hg1_final(uint64_t handle, uint64_t f0_jac[18], uint64_t g0_mont[4], int* has) {
+  GM_CTX();
+  GM_HG1(H, handle, "hg1_final");
+  return hg1_final(C, H, f0_jac, g0_mont, has);
+}
+int gm_hg1_free(uint64_t handle) {
+  GM_CTX();
+  std::unique_ptr<HerringG1> p;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->herring_g1.find(handle);
+    GM_CHECK(it != C->herring_g1.end(), GM_EHANDLE, "hg1_free: unknown handle %llu", (unsigned long long)handle);
+    p = std::move(it->second);
+    C->herring_g1.erase(it);
+  }
+  hg1_destroy(C, p.get());
+  return GM_OK;
+}
+
 // ---- space prover --------------------------------------------------------------------------------
 static SpaceProver* find_sp(Context* C, uint64_t h) {
   std::lock_guard<std::mutex> lk(C->mu);

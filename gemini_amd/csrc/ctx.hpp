@@ -80,6 +80,7 @@ struct Sumcheck {
   uint64_t twist[4];  // Montgomery
   size_t round = 0, tot_rounds = 0;
   uint64_t pair_offset = 0;  // shard origin (gm_sc_set_shard)
+  bool herring = false;      // herring FModule prover: messages carry no twist (src/herring/time_prover.rs:91-123)
   uint8_t* partials = nullptr;   // per-block (a, b) partial sums
   uint64_t* host_partials = nullptr;  // pinned
   std::mutex mu;
@@ -98,6 +99,20 @@ struct SpaceProver {
   uint8_t *wf_lo = nullptr, *wf_hi = nullptr, *wg_lo = nullptr, *wg_hi = nullptr;
   uint8_t* partials = nullptr;
   uint64_t* host_partials = nullptr;
+  std::mutex mu;
+};
+
+// herring TimeProver over G1Module (Lhs = G1, Rhs = F, Target = G1): src/herring/module.rs:81-102
+struct HerringG1 {
+  uint8_t* f[2] = {nullptr, nullptr};  // affine points, 96 B each
+  uint8_t* g[2] = {nullptr, nullptr};  // Fr
+  size_t fcap[2] = {0, 0}, gcap[2] = {0, 0};
+  int cur = 0;
+  size_t nf = 0, ng = 0;
+  uint64_t twist[4];
+  size_t round = 0, tot_rounds = 0;
+  uint8_t* tmp = nullptr;  // compacted scalars
+  size_t tmpcap = 0;
   std::mutex mu;
 };
 
@@ -146,6 +161,7 @@ struct Context {
   std::unordered_map<uint64_t, std::unique_ptr<Sumcheck>> provers;
   std::unordered_map<uint64_t, std::unique_ptr<SparseMatrix>> matrices;
   std::unordered_map<uint64_t, std::unique_ptr<SpaceProver>> space_provers;
+  std::unordered_map<uint64_t, std::unique_ptr<HerringG1>> herring_g1;
   MsmWorkspace msm;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results

@@ -295,6 +295,12 @@ __global__ __launch_bounds__(256) void k_high_nonzero(const uint8_t* __restrict_
   if (best) atomicMax(result, best);
 }
 
+// out[i] = in[start + i * stride]
+__global__ void k_fr_stride(const uint8_t* __restrict__ in, size_t start, size_t stride, size_t count, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + i * FR_BYTES, fp_load<FrParams>(in + (start + i * stride) * FR_BYTES));
+}
+
 // out[i] = in[n - 1 - i]: big-endian stream <-> little-endian coefficient vector (Reverse, src/iterable/slice.rs:17-39)
 __global__ void k_reverse(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -503,6 +509,9 @@ static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr
   gmh::Fr tau = gmh::Fr::from_limbs(S->twist);
   gmh::Fr tau_msg = fold ? tau.sqr() : tau;
   gmh::Fr rho_tau = rho * tau;
+  // herring's bilinear-module prover uses the twist only when folding; its message is the plain
+  // a = <f_e, g_e>, b = <f_e, g_o> + <f_o, g_e> (src/herring/time_prover.rs:104-117)
+  if (S->herring) tau_msg = gmh::Fr::one();
   A.f_in = S->f[S->cur];
   A.g_in = S->g[S->cur];
   A.f_out = S->f[S->cur ^ 1];
@@ -559,7 +568,7 @@ static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr
     S->cur ^= 1;
     S->nf = (S->nf + 1) / 2;
     S->ng = (S->ng + 1) / 2;
-    gmh::Fr t2 = tau.sqr();
+    gmh::Fr t2 = tau.sqr();  // the real twist, also for herring
     t2.to_limbs(S->twist);
     S->pair_offset = S->pair_offset / 2;
   }
@@ -627,6 +636,15 @@ int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], 
   }
   S->round += 1;
   *has_msg = 1;
+  return GM_OK;
+}
+
+int sc_set_herring(Sumcheck* S, int on) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_CHECK(S->round == 0, GM_ESTATE, "sc_set_herring: must be called before the first round");
+  S->herring = on != 0;
+  // herring::Witness::required_rounds uses the SHORTER vector (src/herring/time_prover.rs:36-39)
+  S->tot_rounds = ceil_log2_sz(on ? (S->nf < S->ng ? S->nf : S->ng) : (S->nf > S->ng ? S->nf : S->ng));
   return GM_OK;
 }
 
@@ -829,6 +847,23 @@ int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle) {
   T->round = S->round;  // "copy other informations such us round(s) and twist"
   T->tot_rounds = S->tot_rounds;
   *time_handle = put_prover(std::move(T));
+  return GM_OK;
+}
+
+static int upload_small(Context* C, const void* src, size_t bytes, uint8_t** dptr);
+int fr_stride_raw(Context* C, const uint8_t* in, size_t start, size_t stride, size_t count, uint8_t* out) {
+  if (count) hipLaunchKernelGGL(k_fr_stride, dim3(grid_for(count)), dim3(256), 0, C->stream, in, start, stride, count, out);
+  GM_HIP(hipGetLastError());
+  return GM_OK;
+}
+int fr_fold_raw(Context* C, const uint8_t* f, size_t n, const uint64_t r[4], uint8_t* out) {
+  uint8_t* dr;
+  int rc = upload_small(C, r, 32, &dr);
+  if (rc) return rc;
+  const size_t m = (n + 1) / 2;
+  if (m) hipLaunchKernelGGL(k_fold, dim3(grid_for(m)), dim3(256), 0, C->stream, f, n, (const uint32_t*)dr, out);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
 

@@ -695,6 +695,36 @@ __global__ __launch_bounds__(256) void k_fixed_base_mul(const uint32_t* __restri
   g1_store_affine(out + i * AFF_BYTES, a);
 }
 
+// herring split_fold over G1 (src/herring/time_prover.rs:72-76): out[i] = P[2i] + s * P[2i+1], affine out.
+// s: canonical scalar, 8 x u32.  One thread per output: double-and-add, then one inversion.
+__global__ __launch_bounds__(256) void k_g1_split_fold(const uint8_t* __restrict__ in, size_t n, const uint32_t* __restrict__ s8,
+                                                       uint8_t* __restrict__ out) {
+  const size_t m = (n + 1) / 2;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  G1Affine lo = g1_load_affine(in + (2 * i) * AFF_BYTES);
+  G1Xyzz acc = G1Xyzz::identity();
+  if (2 * i + 1 < n) {
+    G1Affine hi = g1_load_affine(in + (2 * i + 1) * AFF_BYTES);
+    for (int bit = 254; bit >= 0; bit--) {
+      acc = xyzz_dbl(acc);
+      if ((s8[bit >> 5] >> (bit & 31)) & 1u) xyzz_madd(acc, hi);
+    }
+  }
+  xyzz_madd(acc, lo);
+  G1Affine a;
+  if (acc.is_identity()) {
+    a.x = Fq::zero();
+    a.y = Fq::zero();
+  } else {
+    Fq t = fq_mul(acc.zz, acc.zzz);
+    Fq ti = fq_inv(t);
+    a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
+    a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
+  }
+  g1_store_affine(out + i * AFF_BYTES, a);
+}
+
 // table[(w + 1) * n + i] = 2^c * table[w * n + i]: c doublings and one normalisation per point
 __global__ __launch_bounds__(256) void k_table_next(const uint8_t* __restrict__ prev, uint8_t* __restrict__ next, size_t n, int c) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1035,6 +1065,124 @@ static int build_fixed_table(Context* C, const uint64_t base_affine[12], uint8_t
   GM_HIP(hipStreamSynchronize(C->stream));
   GM_HIP(hipFree(d_base));
   GM_HIP(hipFree(t_xyzz));
+  return GM_OK;
+}
+
+// ---- herring TimeProver over G1Module (src/herring/time_prover.rs:42-137, module.rs:81-102) ------
+int fr_stride_raw(Context* C, const uint8_t* in, size_t start, size_t stride, size_t count, uint8_t* out);
+int fr_fold_raw(Context* C, const uint8_t* f, size_t n, const uint64_t r[4], uint8_t* out);
+
+int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist[4],
+               uint64_t* handle) {
+  GM_CHECK(nf >= 1 && ng >= 1, GM_EINVAL, "herring G1 prover: empty vectors");
+  std::unique_ptr<Bases> b;
+  int rc = bases_from_host(C, f_bases, stride, nf, b);
+  if (rc) return rc;
+  auto H = std::make_unique<HerringG1>();
+  H->nf = nf;
+  H->ng = ng;
+  H->f[0] = b->d;  // take ownership of the packed copy
+  b->d = nullptr;
+  GM_HIP(hipMalloc((void**)&H->f[1], ((nf + 1) / 2) * AFF_BYTES));
+  if ((rc = C->pool.alloc(ng * 32, (void**)&H->g[0], &H->gcap[0]))) return rc;
+  if ((rc = C->pool.alloc(((ng + 1) / 2) * 32, (void**)&H->g[1], &H->gcap[1]))) return rc;
+  if ((rc = C->pool.alloc(((ng + 1) / 2) * 32 + 32, (void**)&H->tmp, &H->tmpcap))) return rc;
+  GM_HIP(hipMemcpyAsync(H->g[0], g_mont, ng * 32, hipMemcpyHostToDevice, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  memcpy(H->twist, twist, 32);
+  size_t mn = nf < ng ? nf : ng;
+  H->tot_rounds = (size_t)ceil_log2_sz(mn);  // Witness::required_rounds: log2(min(len)) (time_prover.rs:36-39)
+  std::lock_guard<std::mutex> lk(C->mu);
+  *handle = C->next_handle++;
+  C->herring_g1[*handle] = std::move(H);
+  return GM_OK;
+}
+
+void hg1_destroy(Context* C, HerringG1* H) {
+  for (int i = 0; i < 2; i++) {
+    if (H->f[i]) (void)hipFree(H->f[i]);
+    if (C) C->pool.free(H->g[i], H->gcap[i]);
+  }
+  if (C) C->pool.free(H->tmp, H->tmpcap);
+}
+
+static int hg1_fold_locked(Context* C, HerringG1* H, const uint64_t r[4]) {
+  gmh::Fr rr = gmh::Fr::from_limbs(r), tw = gmh::Fr::from_limbs(H->twist);
+  gmh::Fr rt = rr * tw;
+  uint64_t canon[4];
+  rt.to_canonical(canon);  // scalar multiplication wants the integer
+  int rc = C->msm.misc.ensure(64);
+  if (rc) return rc;
+  GM_HIP(hipMemcpyAsync(C->msm.misc.p, canon, 32, hipMemcpyHostToDevice, C->stream));
+  const size_t m = (H->nf + 1) / 2;
+  hipLaunchKernelGGL(k_g1_split_fold, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, C->stream, H->f[H->cur], H->nf,
+                     C->msm.misc.as<uint32_t>(), H->f[H->cur ^ 1]);
+  GM_HIP(hipGetLastError());
+  if ((rc = fr_fold_raw(C, H->g[H->cur], H->ng, r, H->g[H->cur ^ 1]))) return rc;
+  H->cur ^= 1;
+  H->nf = m;
+  H->ng = (H->ng + 1) / 2;
+  tw.sqr().to_limbs(H->twist);
+  return GM_OK;
+}
+
+int hg1_fold(Context* C, HerringG1* H, const uint64_t r[4]) {
+  std::lock_guard<std::mutex> lk(H->mu);
+  return hg1_fold_locked(C, H, r);
+}
+
+// next_message: a = <f_even, g_even>, b = <f_even, g_odd> + <f_odd, g_even>, each an MSM (module.rs:91-101)
+int hg1_round(Context* C, HerringG1* H, const uint64_t* challenge, uint64_t a_jac[18], uint64_t b_jac[18], int* has_msg) {
+  std::lock_guard<std::mutex> lk(H->mu);
+  GM_CHECK(H->round <= H->tot_rounds, GM_ESTATE, "More rounds than needed.");
+  int rc;
+  if (challenge && (rc = hg1_fold_locked(C, H, challenge))) return rc;
+  if (H->round == H->tot_rounds) {
+    *has_msg = 0;
+    return GM_OK;
+  }
+  Bases fb;
+  fb.d = H->f[H->cur];
+  fb.n = H->nf;
+  const uint8_t* g = H->g[H->cur];
+  const size_t fe = (H->nf + 1) / 2, fo = H->nf / 2, ge = (H->ng + 1) / 2, go = H->ng / 2;
+  auto ip = [&](int f_first, size_t fcount, size_t g_first, size_t gcount, uint64_t out[18]) -> int {
+    const size_t cnt = fcount < gcount ? fcount : gcount;  // zip
+    int r2 = fr_stride_raw(C, g, g_first, 2, cnt, H->tmp);
+    if (r2) return r2;
+    return msm_run(C, &fb, f_first, 2, H->tmp, 1, cnt, true, out);
+  };
+  uint64_t b1[18], b2[18];
+  if ((rc = ip(0, fe, 0, ge, a_jac))) return rc;
+  if ((rc = ip(0, fe, 1, go, b1))) return rc;
+  if ((rc = ip(1, fo, 0, ge, b2))) return rc;
+  gmh::G1 bsum = gmh::G1::from_limbs(b1).add(gmh::G1::from_limbs(b2)).normalized();
+  bsum.to_limbs(b_jac);
+  H->round += 1;
+  *has_msg = 1;
+  return GM_OK;
+}
+
+int hg1_final(Context* C, HerringG1* H, uint64_t f0_jac[18], uint64_t g0[4], int* has) {
+  std::lock_guard<std::mutex> lk(H->mu);
+  if (H->round != H->tot_rounds) {
+    *has = 0;
+    return GM_OK;
+  }
+  uint64_t aff[12];
+  GM_HIP(hipMemcpyAsync(aff, H->f[H->cur], AFF_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipMemcpyAsync(g0, H->g[H->cur], 32, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  gmh::G1 p = gmh::G1::identity();
+  bool zero = true;
+  for (int i = 0; i < 12; i++) zero &= aff[i] == 0;
+  if (!zero) {
+    p.x = gmh::Fq::from_limbs(aff);
+    p.y = gmh::Fq::from_limbs(aff + 6);
+    p.z = gmh::Fq::one();
+  }
+  p.to_limbs(f0_jac);
+  *has = 1;
   return GM_OK;
 }
 

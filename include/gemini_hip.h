@@ -211,6 +211,24 @@ int gm_sp_final(uint64_t handle, uint64_t f0_mont[4], uint64_t g0_mont[4], int* 
 int gm_sp_to_time(uint64_t handle, uint64_t* time_handle);
 int gm_sp_free(uint64_t handle);
 
+/* ---- herring: sumcheck over a bilinear module (src/herring) --------------------------------------- */
+/* FModule (F x F -> F, module.rs:127-146): the gm_sc_* prover with herring semantics -- the twist is
+ * used when folding only, the message is a = <f_e, g_e>, b = <f_e, g_o> + <f_o, g_e>
+ * (src/herring/time_prover.rs:91-123) and rounds = ceil(log2(min(len))) (:36-39).  Call right after
+ * gm_sc_new. */
+int gm_sc_set_herring(uint64_t handle, int on);
+/* G1Module (G1 x F -> G1, module.rs:81-102): f is a vector of G1 points (affine records as in
+ * gm_g1_bases_register), g a vector of Fr.  Each message is three device MSMs over the even/odd
+ * halves (`M::ip` = msm_unchecked); fold is split_fold (time_prover.rs:72-76): f'[i] = f[2i] +
+ * (r*twist) f[2i+1] on the device, g folds in Fr.  Messages / final f are normalised Jacobian. */
+int gm_hg1_new(const void* f_bases, size_t base_stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist_mont[4],
+               uint64_t* handle);
+int gm_hg1_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_jac[18], uint64_t b_jac[18], int* has_msg);
+int gm_hg1_fold(uint64_t handle, const uint64_t challenge_mont[4]);
+int gm_hg1_rounds(uint64_t handle, size_t* tot_rounds, size_t* round);
+int gm_hg1_final(uint64_t handle, uint64_t f0_jac[18], uint64_t g0_mont[4], int* has);
+int gm_hg1_free(uint64_t handle);
+
 /* ---- Fiat-Shamir transcript (host; no GPU needed) ------------------------------------------------ */
 /* merlin::Transcript::new(label) (merlin 3.0.0, Cargo.lock:606-608); the prover uses
  * Transcript::new(PROTOCOL_NAME) with PROTOCOL_NAME = b"GEMINI-v0" (src/lib.rs:74). */

@@ -633,6 +633,56 @@ def sumcheck_prove(transcript: GeminiTranscript, prover):
     return messages, challenges, ff
 
 
+class HerringTimeProver:
+    """src/herring/time_prover.rs:42-137 over a bilinear module given by (p, add, zero, scale_lhs):
+    module "F":  Lhs = Rhs = Target = Fr (ints);   module "G1": Lhs = Target = G1 affine points, Rhs = Fr."""
+
+    def __init__(self, module, f, g, twist):
+        self.module = module
+        self.f = list(f)
+        self.g = [x % R_MOD for x in g]
+        self.twist = twist % R_MOD
+        self.round = 0
+        self.tot_rounds = ceil_log2(min(len(self.f), len(self.g)))  # :36-39
+
+    def _ip(self, lhs, rhs):
+        if self.module == "F":
+            return sum(a * b for a, b in zip(lhs, rhs)) % R_MOD
+        return msm_naive(list(lhs)[: len(list(rhs))] if False else list(lhs), list(rhs))
+
+    def _split_fold_lhs(self, r):
+        out = []
+        for i in range(0, len(self.f), 2):
+            lo = self.f[i]
+            hi = self.f[i + 1] if i + 1 < len(self.f) else None
+            if self.module == "F":
+                out.append((lo + (hi or 0) * r) % R_MOD)
+            else:
+                out.append(g1_add(lo, g1_mul(hi, r)) if hi is not None else lo)
+        return out
+
+    def fold(self, r):  # :82-88
+        self.f = self._split_fold_lhs(r * self.twist % R_MOD)
+        self.g = fold_polynomial(self.g, r)
+        self.twist = self.twist * self.twist % R_MOD
+
+    def next_message(self, vm=None):  # :91-123
+        if vm is not None:
+            self.fold(vm)
+        if self.round == self.tot_rounds:
+            return None
+        fe, fo = self.f[0::2], self.f[1::2]
+        ge, go = self.g[0::2], self.g[1::2]
+        a = self._ip(fe, ge)
+        b1, b2 = self._ip(fe, go), self._ip(fo, ge)
+        b = (b1 + b2) % R_MOD if self.module == "F" else g1_add(b1, b2)
+        self.round += 1
+        return (a, b)
+
+    def final_foldings(self):
+        return (self.f[0], self.g[0]) if self.round == self.tot_rounds else None
+
+
 def sumcheck_prove_batch(transcript: GeminiTranscript, provers):
     """src/subprotocols/sumcheck/proof.rs:69-122"""
     rounds = max(p.tot_rounds for p in provers) + 1

@@ -266,3 +266,62 @@ def test_space_prover_different_lengths(gm, oracle):
     assert sp.rounds() == 4 and tp.rounds() == 7  # log2(min) vs log2(max), as in the reference
     tp.free()
     sp.free()
+
+
+def test_herring_fmodule_prover(gm, oracle, pyref):
+    """src/herring/time_prover.rs over FModule (module.rs:127-146): twist-free messages, twisted folds"""
+    from gemini_amd.herring import FModuleTimeProver
+
+    I = lambda a: oracle.limbs_to_ints(oracle.fr_from_mont(np.asarray(a).reshape(-1, 4)))
+    for nf, ng in ((64, 64), (33, 33), (100, 17)):
+        f = oracle.fr_to_mont(oracle.random_fr(1100 + nf, nf))
+        g = oracle.fr_to_mont(oracle.random_fr(1200 + ng, ng))
+        tw = oracle.fr_to_mont(oracle.random_fr(1300, 1))[0]
+        ch = oracle.fr_to_mont(oracle.random_fr(1400, 10))
+        G = FModuleTimeProver(f, g, tw)
+        P = pyref.HerringTimeProver("F", I(f), I(g), I(tw)[0])
+        assert G.rounds() == P.tot_rounds
+        vm_g = vm_p = None
+        k = 0
+        while True:
+            mg, mp = G.next_message(vm_g), P.next_message(vm_p)
+            if mp is None:
+                assert mg is None
+                break
+            assert (I(mg[0])[0], I(mg[1])[0]) == mp, (nf, ng, k)
+            vm_g, vm_p = ch[k], I(ch[k])[0]
+            k += 1
+        fg, fp = G.final_foldings(), P.final_foldings()
+        assert (I(fg[0])[0], I(fg[1])[0]) == fp
+        G.free()
+
+
+def test_herring_g1module_prover(gm, oracle, pyref):
+    """src/herring/time_prover.rs over G1Module (module.rs:81-102): messages are MSMs over the even/odd
+    halves, fold is split_fold on G1 (P_even + (r*twist) P_odd)"""
+    from gemini_amd.herring import G1ModuleTimeProver
+    from tests.util import jac_to_affine_ints, rand_bases
+
+    I = lambda a: oracle.limbs_to_ints(oracle.fr_from_mont(np.asarray(a).reshape(-1, 4)))
+    for n in (16, 11):
+        pts_arr = rand_bases(oracle, 1500 + n, n)
+        pts = [oracle.affine_to_ints(p) for p in pts_arr]
+        g = oracle.fr_to_mont(oracle.random_fr(1600 + n, n))
+        tw = oracle.fr_to_mont(oracle.random_fr(1700, 1))[0]
+        ch = oracle.fr_to_mont(oracle.random_fr(1800, 6))
+        G = G1ModuleTimeProver(pts_arr, g, tw)
+        P = pyref.HerringTimeProver("G1", pts, I(g), I(tw)[0])
+        assert G.rounds() == P.tot_rounds
+        vm_g = vm_p = None
+        k = 0
+        while True:
+            mg, mp = G.next_message(vm_g), P.next_message(vm_p)
+            if mp is None:
+                assert mg is None
+                break
+            assert (jac_to_affine_ints(oracle, mg[0]), jac_to_affine_ints(oracle, mg[1])) == mp, (n, k)
+            vm_g, vm_p = ch[k], I(ch[k])[0]
+            k += 1
+        fg, fp = G.final_foldings(), P.final_foldings()
+        assert (jac_to_affine_ints(oracle, fg[0]), I(fg[1])[0]) == fp
+        G.free()
