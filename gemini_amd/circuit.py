@@ -88,3 +88,24 @@ def dummy_r1cs(e_canonical: int, n: int) -> R1cs:
     x = FrVec.alloc(1)
     x.fill(em)
     return R1cs(d, d, d, d, d, d, z, w, x)
+
+
+class R1csStream:
+    """src/circuit.rs R1csStream: the same instance as big-endian streams (Reverse(..) of z, witness,
+    z_a, z_b, z_c: src/snark/tests.rs:38-52) plus the matrices the MatrixTensor streams walk.  On the
+    device the streams are reversed vectors and `MatrixTensor` is a product with the transposed CSR."""
+
+    def __init__(self, r1cs: R1cs):
+        from .fr import reverse
+
+        self.at, self.bt, self.ct = r1cs.at, r1cs.bt, r1cs.ct
+        z_a, z_b, z_c = r1cs.a.mul(r1cs.z), r1cs.b.mul(r1cs.z), r1cs.c.mul(r1cs.z)
+        self.z = reverse(r1cs.z)
+        self.witness = reverse(r1cs.w)
+        self.z_a, self.z_b, self.z_c = reverse(z_a), reverse(z_b), reverse(z_c)
+        for v in (z_a, z_b, z_c):
+            v.free()
+
+    def free(self):
+        for v in (self.z, self.witness, self.z_a, self.z_b, self.z_c):
+            v.free()

@@ -190,3 +190,55 @@ def test_committer_key_stream_consistency(gm, oracle, pyref):
         assert len(r_i) == 3
         for p in pts:
             assert pyref.evaluate_be(r_i, p) == pyref.evaluate_le(f, p)
+
+
+@pytest.mark.parametrize("kind", ["dummy", "general"])
+def test_snark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
+    """src/snark/tests.rs:14-57 (test_snark_consistency): assert_eq!(time_proof, space_proof) -- every
+    commitment, sumcheck message, evaluation and the opening proof of Proof::new_elastic equal those of
+    Proof::new_time (max_msm_buffer = 20 forces many Pippenger flushes, as in the reference test)."""
+    import gemini_amd.sumcheck as S
+    from gemini_amd.circuit import R1cs, R1csStream, SparseMatrix, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from gemini_amd.snark import Proof
+
+    rng = pyref.SplitMix64(4242)
+    if kind == "dummy":
+        n = 64
+        r1cs = dummy_r1cs(rng.fr(), n)
+    else:
+        n = 16
+        R = pyref.R_MOD
+        z = [rng.fr() for _ in range(n)]
+        mk = lambda: [[(rng.fr(), int(rng.next() % n)) for _ in range(1 + int(rng.next() % 3))] for _ in range(n)]
+        a, b = mk(), mk()
+        matvec = lambda rows: [sum(v * z[c] for v, c in row) % R for row in rows]
+        za, zb = matvec(a), matvec(b)
+        c = [[(za[i] * zb[i] % R * pow(z[i], -1, R) % R, i)] for i in range(n)]
+        dev = lambda rows: [[(gm.fr.fr_from_int(v), col) for v, col in row] for row in rows]
+        mats = [SparseMatrix.from_rows(dev(m), n) for m in (a, b, c)] + [SparseMatrix.from_rows(dev(m), n, transpose=True) for m in (a, b, c)]
+        M = lambda v: oracle.fr_to_mont(oracle.ints_to_limbs(v, 4))
+        r1cs = R1cs(*mats, gm.FrVec.from_host(M(z)), gm.FrVec.from_host(M(z[1:])), gm.FrVec.from_host(M(z[:1])))
+    ck = CommitterKey.new(2 * n, 3, oracle.random_fr(4243, 1)[0])
+    time_proof = Proof.new_time(r1cs, ck)
+    stream = R1csStream(r1cs)
+    old = S.SPACE_TIME_THRESHOLD
+    S.SPACE_TIME_THRESHOLD = 3  # make the elastic provers spend rounds in the space prover at this size
+    try:
+        space_proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 20)
+    finally:
+        S.SPACE_TIME_THRESHOLD = old
+    eq = lambda x, y: bool((np.asarray(x) == np.asarray(y)).all())
+    assert eq(time_proof.witness_commitment, space_proof.witness_commitment)
+    assert eq(time_proof.zc_alpha, space_proof.zc_alpha)
+    for tm, sm in ((time_proof.first_sumcheck_msgs, space_proof.first_sumcheck_msgs), (time_proof.second_sumcheck_msgs, space_proof.second_sumcheck_msgs)):
+        assert len(tm[0]) == len(sm[0]) and all(eq(x[0], y[0]) and eq(x[1], y[1]) for x, y in zip(tm[0], sm[0]))
+        assert eq(tm[1][0][0], sm[1][0][0]) and eq(tm[1][0][1], sm[1][0][1])
+    tt, st = time_proof.tensorcheck_proof, space_proof.tensorcheck_proof
+    assert len(tt.folded_polynomials_commitments) == len(st.folded_polynomials_commitments)
+    assert all(eq(x, y) for x, y in zip(tt.folded_polynomials_commitments, st.folded_polynomials_commitments))
+    assert all(eq(x, y) for x, y in zip(tt.folded_polynomials_evaluations, st.folded_polynomials_evaluations))
+    assert all(eq(x, y) for x, y in zip(tt.base_polynomials_evaluations, st.base_polynomials_evaluations))
+    assert eq(tt.evaluation_proof, st.evaluation_proof)
+    stream.free()
+    r1cs.free()
