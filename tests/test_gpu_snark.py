@@ -84,8 +84,10 @@ def test_snark_time_prover_dummy_r1cs(gm, oracle, pyref, logn):
     assert [[I(x) for x in e2] for e2 in tc.folded_polynomials_evaluations] == etc["folded_polynomials_evaluations"]
     assert [[I(x) for x in e3] for e3 in tc.base_polynomials_evaluations] == etc["base_polynomials_evaluations"]
     assert jac_to_affine_ints(oracle, tc.evaluation_proof) == etc["evaluation_proof"]
-    # proof shape of src/snark/mod.rs:76-82 at this size
+    # proof shape of src/snark/mod.rs:76-82 at this size, and the compressed size examples/snark.rs:96 prints:
+    # 48 + 32 + 2*(8 + 64 logn + 8 + 64) + (8 + 48 (logn-1)) + (8 + 64 (logn-1)) + 48 + (8 + 96)  (= 6056 at logn 24)
     assert len(proof.first_sumcheck_msgs[0]) == logn and len(tc.folded_polynomials_commitments) == logn - 1
+    assert proof.compressed_size() == 48 + 32 + 2 * (8 + 64 * logn + 8 + 64) + (8 + 48 * (logn - 1)) + (8 + 64 * (logn - 1)) + 48 + (8 + 96)
     r1cs.free()
 
 

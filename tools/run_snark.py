@@ -38,6 +38,7 @@ def main():
     for _ in range(args.repeat):
         proof = Proof.new_time(r1cs, ck)
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
+        out["proof_size_B"] = proof.compressed_size()  # examples/snark.rs:96 "proof-size {}B"
     out["time_prover_s"] = min(r["ark_gemini::snark::time_prover"] for r in out["runs"])
     print(json.dumps(out))
 
