@@ -153,6 +153,7 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
 int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* d_scalars, int mont, size_t n,
                         std::unique_ptr<Bases>& out);
 int bases_precompute(Context* C, Bases* b, int c);
+int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out96);
 int sc_set_herring(Sumcheck* S, int on);
 int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist[4],
                uint64_t* handle);
@@ -328,11 +329,7 @@ int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96) 
   Bases* b = find_bases(handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "bases_download: unknown handle %llu", (unsigned long long)handle);
   GM_CHECK(offset + n <= b->n, GM_EINVAL, "bases_download: range [%zu, %zu) outside %zu bases", offset, offset + n, b->n);
-  if (n) {
-    GM_HIP(hipMemcpyAsync(out96, b->d + offset * 96, n * 96, hipMemcpyDeviceToHost, C->stream));
-    GM_HIP(hipStreamSynchronize(C->stream));
-  }
-  return GM_OK;
+  return bases_export(C, b, offset, n, out96);
 }
 
 static int msm_host_scalars(Context* C, Bases* b, size_t offset, int reversed, const uint64_t* scalars, size_t n,

@@ -11,46 +11,92 @@
 // Replaces: `Projective<P>::add_assign(&Affine)` / `add_assign(&Projective)` /
 // `double_in_place` of ark-ec 0.4.2 as used by VariableBaseMSM::msm_bigint
 // (in-tree statement: src/kzg/msm/variable_base.rs:125-175).
+//
+// Coordinate arithmetic goes through the `FqE` element layer below.  GM_FQ30 = 0 (default, what ships)
+// is the 12 x 32-bit canonical representation of field.cuh.  GM_FQ30 = 1 is the EXPERIMENTAL
+// 13 x 30-bit lazy-carry representation of field30.cuh (one v_mad_u64_u32 per partial product,
+// Montgomery factor 2^390, loose values): its multiplier is 22 % faster in isolation, but inside
+// k_acc0 the 13-limb elements push the kernel to the 256-VGPR cap (AGPR traffic) and it measured
+// 30 % SLOWER end to end, with a parity mismatch still open -- it is not built by default.
+// With GM_FQ30 = 1 every device-resident coordinate (bases, buckets, partials, tables) is stored as
+// a * 2^390 mod q in the same 12 x u32 packed, fully reduced record; conversion from / to ark-ff's
+// a * 2^384 happens once at the boundary (k_pack_bases, k_export_bases, host plane conversion).
 #pragma once
 #include "field.cuh"
+#include "field30.cuh"
+
+#ifndef GM_FQ30
+#define GM_FQ30 0
+#endif
 
 namespace gm {
 
-// Fq multiplication is ~700 instructions; inlining ten of them per point addition blows the
-// 64 KiB instruction cache, so the group law calls one shared out-of-line copy.
-__device__ __noinline__ Fq fq_mul_fn(const Fq a, const Fq b) { return fp_mul<FqParams>(a, b); }
-
-#ifndef GM_FQ_MUL_INLINE
-#define GM_FQ_MUL_INLINE 0
-#endif
-GM_DEV Fq fq_mul(const Fq& a, const Fq& b) {
-#if GM_FQ_MUL_INLINE
-  return fp_mul<FqParams>(a, b);
-#else
-  return fq_mul_fn(a, b);
-#endif
+#if GM_FQ30
+// ---- element layer: 13 x 30-bit, loose.  Bounds (multiples of q) are tracked in the comments of the
+// group law: products are < 2q whenever bound(a) * bound(b) <= 512, fqe_sub<K> needs b < K q.
+using FqE = Fq30;
+__device__ __noinline__ Fq30 fq30_mul_fn(const Fq30 a, const Fq30 b) { return fq30_mul(a, b); }
+GM_DEV FqE fq_mul(const FqE& a, const FqE& b) { return fq30_mul_fn(a, b); }
+GM_DEV FqE fq_sqr(const FqE& a) { return fq30_mul_fn(a, a); }
+GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fq30_add(a, b); }
+GM_DEV FqE fq_dbl(const FqE& a) { return fq30_add(a, a); }
+template <int K>
+GM_DEV FqE fq_sub(const FqE& a, const FqE& b) { return fq30_sub<K>(a, b); }
+GM_DEV FqE fq_neg_canonical(const FqE& y) { return fq30_sub<1>(FqE::zero(), y); }  // y < q (as loaded)
+GM_DEV bool fq_is_zero_mod(const FqE& a) { return fq30_is_zero_modq(a); }
+GM_DEV bool fq_is_exact_zero(const FqE& a) { return a.is_exact_zero(); }
+GM_DEV FqE fqe_zero() { return FqE::zero(); }
+GM_DEV FqE fqe_one() { return fq30_const(Fq30Consts::ONE); }
+GM_DEV FqE fqe_load(const void* p) { return fq30_unpack(fp_load<FqParams>(p)); }
+GM_DEV void fqe_store(void* p, const FqE& a) {
+  fp_store<FqParams>(p, fq30_pack(fq30_canonical_tail(fq30_mul_fn(a, fq30_const(Fq30Consts::ONE)))));
 }
-GM_DEV Fq fq_sqr(const Fq& a) { return fq_mul(a, a); }
-GM_DEV Fq fq_add(const Fq& a, const Fq& b) { return fp_add<FqParams>(a, b); }
-GM_DEV Fq fq_sub(const Fq& a, const Fq& b) { return fp_sub<FqParams>(a, b); }
-GM_DEV Fq fq_dbl(const Fq& a) { return fp_add<FqParams>(a, a); }
-GM_DEV Fq fq_neg(const Fq& a) { return fp_neg<FqParams>(a); }
+constexpr int FQE_LIMBS = 13;
+// ark-ff form (a * 2^384) <-> device form (a * 2^390)
+GM_DEV FqE fqe_import(const Fq& ark) { return fq30_mul_fn(fq30_unpack(ark), fq30_const(Fq30Consts::CIN)); }
+GM_DEV Fq fqe_export(const FqE& dev) {
+  FqE t = fq30_mul_fn(dev, fq30_const(Fq30Consts::COUT));
+  return fq30_pack(fq30_canonical_tail(fq30_mul_fn(t, fq30_const(Fq30Consts::ONE))));
+}
+#else
+using FqE = Fq;
+__device__ __noinline__ Fq fq_mul_fn(const Fq a, const Fq b) { return fp_mul<FqParams>(a, b); }
+GM_DEV FqE fq_mul(const FqE& a, const FqE& b) { return fq_mul_fn(a, b); }
+GM_DEV FqE fq_sqr(const FqE& a) { return fq_mul_fn(a, a); }
+GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fp_add<FqParams>(a, b); }
+GM_DEV FqE fq_dbl(const FqE& a) { return fp_add<FqParams>(a, a); }
+template <int K>
+GM_DEV FqE fq_sub(const FqE& a, const FqE& b) { return fp_sub<FqParams>(a, b); }
+GM_DEV FqE fq_neg_canonical(const FqE& y) { return fp_neg<FqParams>(y); }
+GM_DEV bool fq_is_zero_mod(const FqE& a) { return a.is_zero(); }
+GM_DEV bool fq_is_exact_zero(const FqE& a) { return a.is_zero(); }
+GM_DEV FqE fqe_zero() { return Fq::zero(); }
+GM_DEV FqE fqe_one() { return Fq::one(); }
+GM_DEV FqE fqe_load(const void* p) { return fp_load<FqParams>(p); }
+GM_DEV void fqe_store(void* p, const FqE& a) { fp_store<FqParams>(p, a); }
+constexpr int FQE_LIMBS = 12;
+GM_DEV FqE fqe_import(const Fq& ark) { return ark; }
+GM_DEV Fq fqe_export(const FqE& dev) { return dev; }
+#endif
 
 // Affine point, identity encoded as (0, 0) -- not on y^2 = x^3 + 4, hence unambiguous.
+// Coordinates of a loaded point are fully reduced (< q).
 struct G1Affine {
-  Fq x, y;
-  GM_DEV bool is_identity() const { return x.is_zero() && y.is_zero(); }
+  FqE x, y;
+  GM_DEV bool is_identity() const { return fq_is_exact_zero(x) && fq_is_exact_zero(y); }
 };
 
+// Invariants kept by every routine below (GM_FQ30): x < 8q, y < 4q, zz, zzz < 2q; the identity is the
+// all-zero record (zz == 0 exactly -- a non-identity point never has zz = 0 mod q).
 struct G1Xyzz {
-  Fq x, y, zz, zzz;
-  GM_DEV bool is_identity() const { return zz.is_zero(); }
+  FqE x, y, zz, zzz;
+  GM_DEV bool is_identity() const { return fq_is_exact_zero(zz); }
   static GM_DEV G1Xyzz identity() {
     G1Xyzz r;
-    r.x = Fq::zero();
-    r.y = Fq::zero();
-    r.zz = Fq::zero();
-    r.zzz = Fq::zero();
+    r.x = fqe_zero();
+    r.y = fqe_zero();
+    r.zz = fqe_zero();
+    r.zzz = fqe_zero();
     return r;
   }
   static GM_DEV G1Xyzz from_affine(const G1Affine& p) {
@@ -58,36 +104,24 @@ struct G1Xyzz {
     if (p.is_identity()) return identity();
     r.x = p.x;
     r.y = p.y;
-    r.zz = Fq::one();
-    r.zzz = Fq::one();
+    r.zz = fqe_one();
+    r.zzz = fqe_one();
     return r;
   }
 };
 
-// Jacobian (X, Y, Z): what ark-ec `Projective<P>` holds and what crosses the C ABI.
-struct G1Jac {
-  Fq x, y, z;
-};
-
-GM_DEV G1Affine g1_neg(const G1Affine& p) {
-  G1Affine r;
-  r.x = p.x;
-  r.y = fq_neg(p.y);
-  return r;
-}
-
 // 2 * (affine p), EFD mdbl-2008-s (a = 0)
 GM_DEV G1Xyzz xyzz_dbl_affine(const G1Affine& p) {
-  if (p.is_identity() || p.y.is_zero()) return G1Xyzz::identity();
+  if (p.is_identity() || fq_is_exact_zero(p.y)) return G1Xyzz::identity();
   G1Xyzz r;
-  Fq u = fq_dbl(p.y);
-  Fq v = fq_sqr(u);
-  Fq w = fq_mul(u, v);
-  Fq s = fq_mul(p.x, v);
-  Fq xx = fq_sqr(p.x);
-  Fq m = fq_add(fq_dbl(xx), xx);
-  r.x = fq_sub(fq_sqr(m), fq_dbl(s));
-  r.y = fq_sub(fq_mul(m, fq_sub(s, r.x)), fq_mul(w, p.y));
+  FqE u = fq_dbl(p.y);                                   // < 2q
+  FqE v = fq_sqr(u);                                     // < 2q
+  FqE w = fq_mul(u, v);                                  // < 2q
+  FqE s = fq_mul(p.x, v);                                // < 2q
+  FqE xx = fq_sqr(p.x);                                  // < 2q
+  FqE m = fq_add(fq_dbl(xx), xx);                        // < 6q
+  r.x = fq_sub<4>(fq_sqr(m), fq_dbl(s));                 // 2s < 4q        -> < 6q
+  r.y = fq_sub<2>(fq_mul(m, fq_sub<8>(s, r.x)), fq_mul(w, p.y));  // (s - x3) < 10q, 6*10 <= 512 -> < 4q
   r.zz = v;
   r.zzz = w;
   return r;
@@ -95,16 +129,16 @@ GM_DEV G1Xyzz xyzz_dbl_affine(const G1Affine& p) {
 
 // 2 * p, EFD dbl-2008-s-1 (a = 0)
 GM_DEV G1Xyzz xyzz_dbl(const G1Xyzz& p) {
-  if (p.is_identity() || p.y.is_zero()) return G1Xyzz::identity();
+  if (p.is_identity() || fq_is_zero_mod(p.y)) return G1Xyzz::identity();
   G1Xyzz r;
-  Fq u = fq_dbl(p.y);
-  Fq v = fq_sqr(u);
-  Fq w = fq_mul(u, v);
-  Fq s = fq_mul(p.x, v);
-  Fq xx = fq_sqr(p.x);
-  Fq m = fq_add(fq_dbl(xx), xx);
-  r.x = fq_sub(fq_sqr(m), fq_dbl(s));
-  r.y = fq_sub(fq_mul(m, fq_sub(s, r.x)), fq_mul(w, p.y));
+  FqE u = fq_dbl(p.y);                                   // < 8q
+  FqE v = fq_sqr(u);                                     // 64 <= 512 -> < 2q
+  FqE w = fq_mul(u, v);                                  // < 2q
+  FqE s = fq_mul(p.x, v);                                // 8*2 -> < 2q
+  FqE xx = fq_sqr(p.x);                                  // 64 -> < 2q
+  FqE m = fq_add(fq_dbl(xx), xx);                        // < 6q
+  r.x = fq_sub<4>(fq_sqr(m), fq_dbl(s));                 // < 6q
+  r.y = fq_sub<2>(fq_mul(m, fq_sub<8>(s, r.x)), fq_mul(w, p.y));  // w*y: 2*4 -> < 2q   -> y3 < 4q
   r.zz = fq_mul(v, p.zz);
   r.zzz = fq_mul(w, p.zzz);
   return r;
@@ -117,23 +151,23 @@ GM_DEV void xyzz_madd(G1Xyzz& acc, const G1Affine& q) {
     acc = G1Xyzz::from_affine(q);
     return;
   }
-  Fq u2 = fq_mul(q.x, acc.zz);
-  Fq s2 = fq_mul(q.y, acc.zzz);
-  Fq p = fq_sub(u2, acc.x);
-  Fq r = fq_sub(s2, acc.y);
-  if (p.is_zero()) {
-    if (r.is_zero()) {
+  FqE u2 = fq_mul(q.x, acc.zz);                          // < 2q
+  FqE s2 = fq_mul(q.y, acc.zzz);                         // < 2q
+  FqE p = fq_sub<8>(u2, acc.x);                          // acc.x < 8q      -> < 10q
+  FqE r = fq_sub<4>(s2, acc.y);                          // acc.y < 4q      -> < 6q
+  if (fq_is_zero_mod(p)) {
+    if (fq_is_zero_mod(r)) {
       acc = xyzz_dbl_affine(q);
     } else {
       acc = G1Xyzz::identity();
     }
     return;
   }
-  Fq pp = fq_sqr(p);
-  Fq ppp = fq_mul(p, pp);
-  Fq qq = fq_mul(acc.x, pp);
-  Fq x3 = fq_sub(fq_sub(fq_sqr(r), ppp), fq_dbl(qq));
-  Fq y3 = fq_sub(fq_mul(r, fq_sub(qq, x3)), fq_mul(acc.y, ppp));
+  FqE pp = fq_sqr(p);                                    // 100 <= 512 -> < 2q
+  FqE ppp = fq_mul(p, pp);                               // < 2q
+  FqE qq = fq_mul(acc.x, pp);                            // 8*2 -> < 2q
+  FqE x3 = fq_sub<4>(fq_sub<2>(fq_sqr(r), ppp), fq_dbl(qq));  // (r^2 - ppp) < 4q, 2qq < 4q -> < 8q
+  FqE y3 = fq_sub<2>(fq_mul(r, fq_sub<8>(qq, x3)), fq_mul(acc.y, ppp));  // (qq - x3) < 10q, 6*10; 4*2 -> < 4q
   acc.zz = fq_mul(acc.zz, pp);
   acc.zzz = fq_mul(acc.zzz, ppp);
   acc.x = x3;
@@ -147,73 +181,71 @@ GM_DEV void xyzz_add(G1Xyzz& acc, const G1Xyzz& q) {
     acc = q;
     return;
   }
-  Fq u1 = fq_mul(acc.x, q.zz);
-  Fq u2 = fq_mul(q.x, acc.zz);
-  Fq s1 = fq_mul(acc.y, q.zzz);
-  Fq s2 = fq_mul(q.y, acc.zzz);
-  Fq p = fq_sub(u2, u1);
-  Fq r = fq_sub(s2, s1);
-  if (p.is_zero()) {
-    if (r.is_zero()) {
+  FqE u1 = fq_mul(acc.x, q.zz);                          // 8*2 -> < 2q
+  FqE u2 = fq_mul(q.x, acc.zz);
+  FqE s1 = fq_mul(acc.y, q.zzz);                         // 4*2
+  FqE s2 = fq_mul(q.y, acc.zzz);
+  FqE p = fq_sub<2>(u2, u1);                             // < 4q
+  FqE r = fq_sub<2>(s2, s1);                             // < 4q
+  if (fq_is_zero_mod(p)) {
+    if (fq_is_zero_mod(r)) {
       acc = xyzz_dbl(acc);
     } else {
       acc = G1Xyzz::identity();
     }
     return;
   }
-  Fq pp = fq_sqr(p);
-  Fq ppp = fq_mul(p, pp);
-  Fq qq = fq_mul(u1, pp);
-  Fq x3 = fq_sub(fq_sub(fq_sqr(r), ppp), fq_dbl(qq));
-  Fq y3 = fq_sub(fq_mul(r, fq_sub(qq, x3)), fq_mul(s1, ppp));
+  FqE pp = fq_sqr(p);
+  FqE ppp = fq_mul(p, pp);
+  FqE qq = fq_mul(u1, pp);
+  FqE x3 = fq_sub<4>(fq_sub<2>(fq_sqr(r), ppp), fq_dbl(qq));  // < 8q
+  FqE y3 = fq_sub<2>(fq_mul(r, fq_sub<8>(qq, x3)), fq_mul(s1, ppp));  // < 4q
   acc.zz = fq_mul(fq_mul(acc.zz, q.zz), pp);
   acc.zzz = fq_mul(fq_mul(acc.zzz, q.zzz), ppp);
   acc.x = x3;
   acc.y = y3;
 }
 
-// XYZZ -> Jacobian without inversion: (X*ZZ, Y*ZZZ, ZZ) represents the same point
-// (x = X*ZZ / ZZ^2, y = Y*ZZZ / ZZ^3 using ZZ^3 = ZZZ^2).  Identity -> (1, 1, 0) like ark-ec.
-GM_DEV G1Jac xyzz_to_jac(const G1Xyzz& p) {
-  G1Jac r;
-  if (p.is_identity()) {
-    r.x = Fq::one();
-    r.y = Fq::one();
-    r.z = Fq::zero();
-    return r;
-  }
-  r.x = fq_mul(p.x, p.zz);
-  r.y = fq_mul(p.y, p.zzz);
-  r.z = p.zz;
-  return r;
-}
-
-// 96-byte affine / 192-byte XYZZ memory images (AoS, 16-byte aligned -> dwordx4 accesses)
+// 96-byte affine / 192-byte XYZZ memory images (AoS, 16-byte aligned -> dwordx4 accesses); values at
+// rest are fully reduced
 GM_DEV G1Affine g1_load_affine(const void* p) {
   G1Affine r;
-  r.x = fp_load<FqParams>(p);
-  r.y = fp_load<FqParams>(reinterpret_cast<const char*>(p) + 48);
+  r.x = fqe_load(p);
+  r.y = fqe_load(reinterpret_cast<const char*>(p) + 48);
   return r;
 }
 GM_DEV void g1_store_affine(void* p, const G1Affine& a) {
-  fp_store<FqParams>(p, a.x);
-  fp_store<FqParams>(reinterpret_cast<char*>(p) + 48, a.y);
+  fqe_store(p, a.x);
+  fqe_store(reinterpret_cast<char*>(p) + 48, a.y);
 }
 GM_DEV G1Xyzz g1_load_xyzz(const void* p) {
   const char* c = reinterpret_cast<const char*>(p);
   G1Xyzz r;
-  r.x = fp_load<FqParams>(c);
-  r.y = fp_load<FqParams>(c + 48);
-  r.zz = fp_load<FqParams>(c + 96);
-  r.zzz = fp_load<FqParams>(c + 144);
+  r.x = fqe_load(c);
+  r.y = fqe_load(c + 48);
+  r.zz = fqe_load(c + 96);
+  r.zzz = fqe_load(c + 144);
   return r;
 }
-GM_DEV void g1_store_xyzz(void* p, const G1Xyzz& a) {
+#if GM_FQ30
+__device__ __noinline__  // canonicalisation makes the store path long: keep one out-of-line copy
+#else
+GM_DEV
+#endif
+void g1_store_xyzz(void* p, const G1Xyzz a) {
   char* c = reinterpret_cast<char*>(p);
-  fp_store<FqParams>(c, a.x);
-  fp_store<FqParams>(c + 48, a.y);
-  fp_store<FqParams>(c + 96, a.zz);
-  fp_store<FqParams>(c + 144, a.zzz);
+  if (a.is_identity()) {  // keep the all-zero encoding exact
+    const Fq z = Fq::zero();
+    fp_store<FqParams>(c, z);
+    fp_store<FqParams>(c + 48, z);
+    fp_store<FqParams>(c + 96, z);
+    fp_store<FqParams>(c + 144, z);
+    return;
+  }
+  fqe_store(c, a.x);
+  fqe_store(c + 48, a.y);
+  fqe_store(c + 96, a.zz);
+  fqe_store(c + 144, a.zzz);
 }
 
 }  // namespace gm

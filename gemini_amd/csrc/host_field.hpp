@@ -244,6 +244,31 @@ struct G1 {
   }
 };
 
+// Device-resident Fq values are a * 2^390 mod q (g1.cuh, GM_FQ30); ark-ff's form is a * 2^384.
+// x_ark = x_dev * 2^-6: as a Montgomery (R = 2^384) operand that constant is 2^378.
+#ifndef GM_FQ30
+#define GM_FQ30 0
+#endif
+static inline Fq fq_from_device(const u64* p) {
+  Fq v = Fq::from_limbs(p);
+#if GM_FQ30
+  static const u64 K[6] = {0, 0, 0, 0, 0, 0x0400000000000000ULL};
+  return v * Fq::from_limbs(K);
+#else
+  return v;
+#endif
+}
+// XYZZ record in device form -> Jacobian in ark-ff form
+static inline G1 xyzz_to_jac_dev(const u64* p) {
+  Fq X = fq_from_device(p), Y = fq_from_device(p + 6), ZZ = fq_from_device(p + 12), ZZZ = fq_from_device(p + 18);
+  if (ZZ.is_zero()) return G1::identity();
+  G1 r;
+  r.x = X * ZZ;
+  r.y = Y * ZZZ;
+  r.z = ZZ;
+  return r;
+}
+
 // extended Jacobian (X, Y, ZZ, ZZZ) -> Jacobian, mirrors device xyzz_to_jac
 static inline G1 xyzz_to_jac(const u64* p) {
   Fq X = Fq::from_limbs(p), Y = Fq::from_limbs(p + 6), ZZ = Fq::from_limbs(p + 12), ZZZ = Fq::from_limbs(p + 18);

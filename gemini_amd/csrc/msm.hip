@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entri
         cur = key;
         acc = G1Xyzz::identity();
       }
-      if ((e >> 31) & 1ull) p.y = fq_neg(p.y);
+      if ((e >> 31) & 1ull) p.y = fq_neg_canonical(p.y);
       xyzz_madd(acc, p);
     }
     if (first_run) {
@@ -555,7 +555,7 @@ struct GroupSumJobs {
 GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
   G1Xyzz r;
 #pragma unroll
-  for (int i = 0; i < 12; i++) {
+  for (int i = 0; i < FQE_LIMBS; i++) {
     r.x.l[i] = __shfl_xor(v.x.l[i], m);
     r.y.l[i] = __shfl_xor(v.y.l[i], m);
     r.zz.l[i] = __shfl_xor(v.zz.l[i], m);
@@ -606,15 +606,31 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
 // ------------------------------------------------------------------------------------------
 // bases import / generation
 // ------------------------------------------------------------------------------------------
-// staging (stride >= 96, optional infinity flag at byte 96) -> packed 96-byte records
+// staging (stride >= 96, optional infinity flag at byte 96, ark-ff Montgomery form) -> packed 96-byte
+// records in the device form (see g1.cuh: a * 2^390 with GM_FQ30)
 __global__ void k_pack_bases(const uint8_t* __restrict__ src, size_t stride, size_t n, uint8_t* __restrict__ dst) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t* s = reinterpret_cast<const uint32_t*>(src + i * stride);
-  uint32_t* d = reinterpret_cast<uint32_t*>(dst + i * AFF_BYTES);
   bool inf = stride >= 97 && src[i * stride + 96] != 0;
+  Fq x, y;
 #pragma unroll
-  for (int k = 0; k < 24; k++) d[k] = inf ? 0u : s[k];
+  for (int k = 0; k < 12; k++) {
+    x.l[k] = inf ? 0u : s[k];
+    y.l[k] = inf ? 0u : s[12 + k];
+  }
+  G1Affine a;
+  a.x = fqe_import(x);
+  a.y = fqe_import(y);
+  g1_store_affine(dst + i * AFF_BYTES, a);
+}
+// device form -> ark-ff Montgomery form, 96-byte records (gm_g1_bases_download)
+__global__ void k_export_bases(const uint8_t* __restrict__ src, size_t n, uint8_t* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine a = g1_load_affine(src + i * AFF_BYTES);
+  fp_store<FqParams>(dst + i * AFF_BYTES, fqe_export(a.x));
+  fp_store<FqParams>(dst + i * AFF_BYTES + 48, fqe_export(a.y));
 }
 
 // out[i] = k_i * base via 32 windows of 8 bits against a (32 x 256)-entry affine table
@@ -635,13 +651,13 @@ __global__ __launch_bounds__(256) void k_fixed_base_table(const uint8_t* __restr
 }
 
 // Fq inversion by Fermat (a^(q-2)); used once per generated point
-GM_DEV Fq fq_inv(const Fq& a) {
+GM_DEV FqE fq_inv(const FqE& a) {
   // q - 2, little-endian 32-bit limbs
   uint32_t e[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) e[i] = FqParams::MOD[i];
   e[0] -= 2u;
-  Fq acc = Fq::one();
+  FqE acc = fqe_one();
   for (int i = 380; i >= 0; i--) {
     acc = fq_sqr(acc);
     if ((e[i >> 5] >> (i & 31)) & 1u) acc = fq_mul(acc, a);
@@ -655,12 +671,12 @@ __global__ __launch_bounds__(256) void k_xyzz_to_affine(const uint8_t* __restric
   G1Xyzz p = g1_load_xyzz(in + i * XYZZ_BYTES);
   G1Affine a;
   if (p.is_identity()) {
-    a.x = Fq::zero();
-    a.y = Fq::zero();
+    a.x = fqe_zero();
+    a.y = fqe_zero();
   } else {
     // x = X/ZZ, y = Y/ZZZ ; 1/ZZZ = inv, 1/ZZ = inv * ZZZ / ZZ ... use one inversion of ZZ*ZZZ
-    Fq t = fq_mul(p.zz, p.zzz);
-    Fq ti = fq_inv(t);
+    FqE t = fq_mul(p.zz, p.zzz);
+    FqE ti = fq_inv(t);
     a.x = fq_mul(p.x, fq_mul(ti, p.zzz));
     a.y = fq_mul(p.y, fq_mul(ti, p.zz));
   }
@@ -684,11 +700,11 @@ __global__ __launch_bounds__(256) void k_fixed_base_mul(const uint32_t* __restri
   }
   G1Affine a;
   if (acc.is_identity()) {
-    a.x = Fq::zero();
-    a.y = Fq::zero();
+    a.x = fqe_zero();
+    a.y = fqe_zero();
   } else {
-    Fq t = fq_mul(acc.zz, acc.zzz);
-    Fq ti = fq_inv(t);
+    FqE t = fq_mul(acc.zz, acc.zzz);
+    FqE ti = fq_inv(t);
     a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
     a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
   }
@@ -714,11 +730,11 @@ __global__ __launch_bounds__(256) void k_g1_split_fold(const uint8_t* __restrict
   xyzz_madd(acc, lo);
   G1Affine a;
   if (acc.is_identity()) {
-    a.x = Fq::zero();
-    a.y = Fq::zero();
+    a.x = fqe_zero();
+    a.y = fqe_zero();
   } else {
-    Fq t = fq_mul(acc.zz, acc.zzz);
-    Fq ti = fq_inv(t);
+    FqE t = fq_mul(acc.zz, acc.zzz);
+    FqE ti = fq_inv(t);
     a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
     a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
   }
@@ -734,11 +750,11 @@ __global__ __launch_bounds__(256) void k_table_next(const uint8_t* __restrict__ 
   for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
   G1Affine a;
   if (acc.is_identity()) {
-    a.x = Fq::zero();
-    a.y = Fq::zero();
+    a.x = fqe_zero();
+    a.y = fqe_zero();
   } else {
-    Fq t = fq_mul(acc.zz, acc.zzz);
-    Fq ti = fq_inv(t);
+    FqE t = fq_mul(acc.zz, acc.zzz);
+    FqE ti = fq_inv(t);
     a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
     a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
   }
@@ -1008,7 +1024,7 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
   // bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)
   const uint64_t* hp = ws.host_planes;
   auto plane_at = [&](int w, int field, uint32_t j) {
-    return gmh::xyzz_to_jac(hp + (plane_off[field] + (size_t)w * (wf[field] + 1) + j) * 24);
+    return gmh::xyzz_to_jac_dev(hp + (plane_off[field] + (size_t)w * (wf[field] + 1) + j) * 24);
   };
   for (int w = Wb - 1; w >= 0; w--) {
     for (int j = c - 1; j >= 0; j--) {
@@ -1037,9 +1053,7 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
   b->n = n;
   if (n) {
     GM_HIP(hipMalloc((void**)&b->d, n * AFF_BYTES));
-    if (stride == 96) {
-      GM_HIP(hipMemcpyAsync(b->d, bases, n * AFF_BYTES, hipMemcpyHostToDevice, C->stream));
-    } else {
+    {
       uint8_t* stage = nullptr;
       GM_HIP(hipMalloc((void**)&stage, n * stride));
       GM_HIP(hipMemcpyAsync(stage, bases, n * stride, hipMemcpyHostToDevice, C->stream));
@@ -1053,13 +1067,32 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
   return GM_OK;
 }
 
+int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out96) {
+  if (n == 0) return GM_OK;
+  uint8_t* tmp = nullptr;
+  GM_HIP(hipMalloc((void**)&tmp, n * AFF_BYTES));
+  hipLaunchKernelGGL(k_export_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C->stream, b->d + offset * AFF_BYTES, n, tmp);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipMemcpyAsync(out96, tmp, n * AFF_BYTES, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  GM_HIP(hipFree(tmp));
+  return GM_OK;
+}
+
 // fixed-base table (affine, 32 x 256 entries) for `base`
 static int build_fixed_table(Context* C, const uint64_t base_affine[12], uint8_t** table_aff) {
   uint8_t *d_base = nullptr, *t_xyzz = nullptr;
   GM_HIP(hipMalloc((void**)&d_base, AFF_BYTES));
   GM_HIP(hipMalloc((void**)&t_xyzz, (size_t)32 * 256 * XYZZ_BYTES));
   GM_HIP(hipMalloc((void**)table_aff, (size_t)32 * 256 * AFF_BYTES));
-  GM_HIP(hipMemcpyAsync(d_base, base_affine, AFF_BYTES, hipMemcpyHostToDevice, C->stream));
+  {
+    uint8_t* stage = nullptr;
+    GM_HIP(hipMalloc((void**)&stage, AFF_BYTES));
+    GM_HIP(hipMemcpyAsync(stage, base_affine, AFF_BYTES, hipMemcpyHostToDevice, C->stream));
+    hipLaunchKernelGGL(k_pack_bases, dim3(1), dim3(64), 0, C->stream, stage, (size_t)AFF_BYTES, (size_t)1, d_base);
+    GM_HIP(hipStreamSynchronize(C->stream));
+    GM_HIP(hipFree(stage));
+  }
   hipLaunchKernelGGL(k_fixed_base_table, dim3(32), dim3(256), 0, C->stream, d_base, t_xyzz);
   hipLaunchKernelGGL(k_xyzz_to_affine, dim3(32), dim3(256), 0, C->stream, t_xyzz, (size_t)32 * 256, *table_aff);
   GM_HIP(hipStreamSynchronize(C->stream));
@@ -1177,8 +1210,8 @@ int hg1_final(Context* C, HerringG1* H, uint64_t f0_jac[18], uint64_t g0[4], int
   bool zero = true;
   for (int i = 0; i < 12; i++) zero &= aff[i] == 0;
   if (!zero) {
-    p.x = gmh::Fq::from_limbs(aff);
-    p.y = gmh::Fq::from_limbs(aff + 6);
+    p.x = gmh::fq_from_device(aff);
+    p.y = gmh::fq_from_device(aff + 6);
     p.z = gmh::Fq::one();
   }
   p.to_limbs(f0_jac);
