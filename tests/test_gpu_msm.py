@@ -249,3 +249,34 @@ def test_fixed_base_tables_same_results(gm, oracle):
     finally:
         gm.capi.check(gm.capi.load().gm_set_msm_table_min(C.c_size_t(1 << 17)))
         reg.free()
+
+
+def test_msm_2_24_properties(gm, oracle, pyref):
+    """`snark -i 24` size (BASELINE config 3: the witness commitment is a 2^24 - 1 pair MSM with all-equal
+    scalars).  Size-independent properties only: additivity over a split, the all-equal collapse
+    sum_i e*P_i = e * sum_i P_i, and the discrete-log identity on a prefix."""
+    from gemini_amd.msm import g1_sum
+
+    n = 1 << 24
+    g = oracle.g1_generator()
+    rng = np.random.default_rng(2424)
+    import bench
+
+    ks = bench.uniform_fr(rng, n)
+    reg = gm.G1Bases.fixed_base(g, ks)
+    try:
+        a = bench.uniform_fr(rng, n)
+        full = reg.msm_bigint(a)
+        third = n // 3
+        parts = [reg.msm_bigint(a[:third]), reg.msm_bigint(a[third:2 * third], offset=third), reg.msm_bigint(a[2 * third:], offset=2 * third)]
+        assert (g1_sum(np.stack(parts)) == full).all()
+        m = 1 << 11
+        ai, ki = oracle.limbs_to_ints(a[:m]), oracle.limbs_to_ints(ks[:m])
+        assert jac_to_affine_ints(oracle, reg.msm_bigint(a[:m])) == pyref.g1_mul(pyref.G1_GEN, sum(x * y for x, y in zip(ai, ki)) % pyref.R_MOD)
+        e = oracle.random_fr(2425, 1)[0]
+        ones = np.tile(oracle.ints_to_limbs([1], 4)[0], (n - 1, 1))
+        s1 = reg.msm_bigint(ones)
+        se = reg.msm_bigint(np.tile(e, (n - 1, 1)))  # the dummy_r1cs witness commitment shape
+        assert_same_point(oracle, se, oracle.g1_mul(oracle.g1_to_affine(s1), e))
+    finally:
+        reg.free()
