@@ -105,10 +105,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # test hooks (not used by the driver): GM_BENCH_BACKEND=gloo + GM_BENCH_SINGLE_DEVICE=1 run the
+    # N > 1 code path with every rank on GPU 0 of a one-GPU box (collectives on CPU tensors)
+    backend = os.environ.get("GM_BENCH_BACKEND", "nccl")
+    if os.environ.get("GM_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     import gemini_amd as gm
     from gemini_amd.msm import g1_sum
@@ -132,14 +141,14 @@ def main():
     host_scalars = [uniform_fr(rng, n) for _ in range(2)]
     dev_scalars = [torch.from_numpy(s.view(np.int64)).cuda() for s in host_scalars]
     torch.cuda.synchronize()
-    gather = torch.empty((world, 18), dtype=torch.int64, device="cuda") if world > 1 else None
+    gather = torch.empty((world, 18), dtype=torch.int64, device=coll_dev) if world > 1 else None
 
     def step(i: int) -> np.ndarray:
         d = dev_scalars[i & 1]
         part = bases.msm_device(d.data_ptr(), n, mont=False, partial=world > 1)
         if world == 1:
             return part
-        mine = torch.from_numpy(part.view(np.int64)).cuda()
+        mine = torch.from_numpy(part.view(np.int64)).to(coll_dev)
         dist.all_gather_into_tensor(gather.view(-1), mine)
         return g1_sum(gather.cpu().numpy().view(np.uint64))
 
@@ -160,7 +169,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
