@@ -783,8 +783,31 @@ static int choose_window(size_t n) {
   return c;
 }
 
+static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
+                       bool normalize, uint64_t out_jac[18]);
+
+// Calls larger than 2^26 pairs are split into 2^26-pair MSMs whose results are added on the host --
+// the same composition ChunkedPippenger / msm_chunks use (src/kzg/space.rs:41-53), with the chunk
+// sized for the device (entry indices are 26 + 5 bits; n * windows must stay below 2^32).
 int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
             bool normalize, uint64_t out_jac[18]) {
+  const size_t CH = (size_t)1 << 26;
+  if (n <= CH) return msm_run_one(C, bases, first, step, d_scalars, mont, n, normalize, out_jac);
+  gmh::G1 acc = gmh::G1::identity();
+  for (size_t off = 0; off < n; off += CH) {
+    const size_t m = n - off < CH ? n - off : CH;
+    uint64_t part[18];
+    int rc = msm_run_one(C, bases, first + step * (int64_t)off, step, reinterpret_cast<const uint8_t*>(d_scalars) + off * 32, mont, m, false, part);
+    if (rc) return rc;
+    acc = acc.add(gmh::G1::from_limbs(part));
+  }
+  if (normalize) acc = acc.normalized();
+  acc.to_limbs(out_jac);
+  return GM_OK;
+}
+
+static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
+                       bool normalize, uint64_t out_jac[18]) {
   const size_t nbases = bases->n;
   gmh::G1 result = gmh::G1::identity();
   if (n == 0) {
