@@ -325,3 +325,55 @@ def test_herring_g1module_prover(gm, oracle, pyref):
         fg, fp = G.final_foldings(), P.final_foldings()
         assert (jac_to_affine_ints(oracle, fg[0]), I(fg[1])[0]) == fp
         G.free()
+
+
+def test_sharded_prover_on_device(gm, oracle, pyref):
+    """contiguous even-aligned shards, each with its twist origin tau^(2*first pair)
+    (gm_sc_set_shard); the shard messages add up to the unsharded prover's message in every round while
+    the shards stay pair-aligned, and the gathered tail continues identically."""
+    N = 1 << 12
+    f = oracle.fr_to_mont(oracle.random_fr(2001, N))
+    g = oracle.fr_to_mont(oracle.random_fr(2002, N))
+    tw = oracle.fr_to_mont(oracle.random_fr(2003, 1))[0]
+    ch = oracle.fr_to_mont(oracle.random_fr(2004, 13))
+    I = lambda a: oracle.limbs_to_ints(oracle.fr_from_mont(np.asarray(a).reshape(-1, 4)))
+    for world in (2, 4):
+        per = N // world
+        shards = [gm.TimeProver(f[r * per:(r + 1) * per], g[r * per:(r + 1) * per], tw) for r in range(world)]
+        for r, s in enumerate(shards):
+            s.set_shard(r * per // 2)
+        ref = gm.TimeProver(f, g, tw)
+        vm = None
+        rounds_sharded = 0
+        cur = per
+        while cur >= 4:  # shards stay pair-aligned while their length is a multiple of 4 before a fold
+            mr = ref.next_message(vm)
+            ms = [s.next_message(vm) for s in shards]
+            tot = [sum(I(m[i])[0] for m in ms) % pyref.R_MOD for i in range(2)]
+            assert tot == [I(mr[0])[0], I(mr[1])[0]], (world, rounds_sharded)
+            vm = ch[rounds_sharded]
+            rounds_sharded += 1
+            cur //= 2
+        # hand-off: apply the pending fold shard-locally, gather, continue on one prover
+        for s in shards:
+            s.fold(vm)
+        ref_m = ref.next_message(vm)
+        states = [s.state() for s in shards]
+        fs = np.concatenate([st[0] for st in states])
+        gs = np.concatenate([st[1] for st in states])
+        tail = gm.TimeProver(fs, gs, states[0][2])
+        mt = tail.next_message(None)
+        assert (mt[0] == ref_m[0]).all() and (mt[1] == ref_m[1]).all()
+        k = rounds_sharded
+        while True:
+            vm = ch[k]
+            k += 1
+            a, b = ref.next_message(vm), tail.next_message(vm)
+            if a is None:
+                assert b is None
+                break
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        fa, fb = ref.final_foldings(), tail.final_foldings()
+        assert (fa[0] == fb[0]).all() and (fa[1] == fb[1]).all()
+        for s in shards + [ref, tail]:
+            s.free()
