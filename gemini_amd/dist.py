@@ -135,3 +135,80 @@ class ShardedTimeProver:
 
     def free(self):
         self.local.free()
+
+
+class ShardedCommitterKey:
+    """`CommitterKey` (src/kzg/time.rs:24-27) with powers_of_g[lo, hi) resident on this rank: the
+    "independent MSM chunks shard across the GPUs, final reduce of partial G1 points" of the north star.
+    Polynomials are replicated (every rank runs the same field arithmetic); each commitment is one local
+    MSM over the rank's slice + one 144-byte all-gather + EC add, so `Proof.new_time(r1cs, key)` runs
+    unchanged on N GPUs.
+
+    local_msm(polynomial, a, b) -> (18,) Jacobian of sum_{a <= i < b} polynomial[i] * powers_of_g[i];
+    by default the HIP MSM over the resident slice (gemini_amd.msm.G1Bases)."""
+
+    def __init__(self, local_powers, lo: int, n_global: int, max_eval_points: int, local_msm=None):
+        self.powers_of_g = local_powers
+        self.lo, self.hi = lo, lo + len(local_powers)
+        self.n_global = n_global
+        self._max_eval_points = max_eval_points
+        self._local_msm = local_msm or self._hip_msm
+
+    @classmethod
+    def new(cls, max_degree: int, max_eval_points: int, tau_canonical, rank: int, world: int, g_affine=None) -> "ShardedCommitterKey":
+        """src/kzg/time.rs:49-72, each rank generating only its slice: base tau^lo * g, ratio tau"""
+        from .kzg import g1_generator_mont
+        from .msm import G1Bases
+
+        n = max_degree + 1
+        lo, hi = shard_range(n, rank, world)
+        g = g1_generator_mont() if g_affine is None else g_affine
+        tau = _to_int(np.asarray(tau_canonical, dtype=np.uint64))
+        first = G1Bases.fixed_base(g, np.array([_to_limbs(pow(tau, lo, R_MOD))], dtype=np.uint64))
+        base = first.download()[0]
+        first.free()
+        return cls(G1Bases.srs(base, tau_canonical, hi - lo), lo, n, max_eval_points)
+
+    def max_eval_points(self) -> int:
+        return self._max_eval_points
+
+    def _hip_msm(self, polynomial, a: int, b: int) -> np.ndarray:
+        from .fr import _as_vec
+        from .msm import g1_zero
+
+        if b <= a:
+            return g1_zero()
+        v, tmp = _as_vec(polynomial)
+        try:
+            return self.powers_of_g.msm_vec(v, n=b - a, voffset=a, offset=a - self.lo)
+        finally:
+            if tmp:
+                v.free()
+
+    def partial(self, polynomial) -> np.ndarray:
+        """this rank's share of commit(polynomial)"""
+        n = min(len(polynomial), self.n_global)
+        return self._local_msm(polynomial, min(self.lo, n), min(self.hi, n))
+
+    def commit(self, polynomial) -> np.ndarray:
+        return g1_sum(all_gather_u64(self.partial(polynomial)))
+
+    def batch_commit(self, polynomials) -> list:
+        """one all-gather for the whole batch (k x 144 bytes)"""
+        polys = list(polynomials)
+        if not polys:
+            return []
+        parts = all_gather_u64(np.stack([self.partial(p) for p in polys]))  # (world, k, 18)
+        return [g1_sum(parts[:, k]) for k in range(len(polys))]
+
+    # the openings are commitments to quotients computed (replicated) on every rank: same code as the
+    # single-GPU key, with `commit` above
+    def open_multi_points(self, polynomial, eval_points_mont):
+        from .kzg import CommitterKey
+
+        return CommitterKey.open_multi_points(self, polynomial, eval_points_mont)
+
+    def batch_open_multi_points(self, polynomials, eval_points_mont, eval_chal_mont):
+        from .kzg import CommitterKey
+
+        return CommitterKey.batch_open_multi_points(self, polynomials, eval_points_mont, eval_chal_mont)

@@ -244,3 +244,49 @@ def test_snark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
     assert eq(tt.evaluation_proof, st.evaluation_proof)
     stream.free()
     r1cs.free()
+
+
+def test_sharded_committer_key_single_process(gm, oracle, pyref):
+    """north star: the KZG key shards by powers across GPUs.  Here both shards live on the one GPU:
+    each rank-local slice is generated from (tau^lo g, tau) and equals the slice of the full key; the
+    partial commitments add up (gm_g1_sum) to the full key's commitment; with a world of one
+    (gloo, single rank) Proof.new_time over the sharded key gives the byte-identical proof."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.dist import ShardedCommitterKey
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.msm import g1_sum
+    from gemini_amd.snark import Proof
+
+    tau_l = oracle.random_fr(77, 1)[0]
+    n = 1 << 10
+    ck = CommitterKey.new(2 * n, 5, tau_l)
+    full = ck.powers_of_g.download()
+    shards = [ShardedCommitterKey.new(2 * n, 5, tau_l, r, 3) for r in range(3)]
+    assert [s.lo for s in shards] == [0, 683, 1366] and shards[-1].hi == 2 * n + 1
+    for s in shards:
+        assert (s.powers_of_g.download() == full[s.lo:s.hi]).all()
+    for m in (2 * n + 1, 1500, 700, 5, 0):
+        poly = oracle.fr_to_mont(oracle.random_fr(100 + m, m)) if m else np.empty((0, 4), dtype=np.uint64)
+        want = ck.commit(poly)
+        got = g1_sum(np.stack([s.partial(poly) for s in shards]))
+        assert (got == want).all(), m
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        one = ShardedCommitterKey.new(2 * n, 5, tau_l, 0, 1)
+        r1cs = dummy_r1cs(12345, n)
+        a = Proof.new_time(r1cs, ck).serialize_compressed()
+        b = Proof.new_time(r1cs, one).serialize_compressed()
+        assert a == b
+    finally:
+        dist.destroy_process_group()

@@ -104,6 +104,25 @@ def _worker(rank, world, port, q):
             k += 1
         fr_, fs_ = ref.final_foldings(), sp.final_foldings()
         ok_sc &= bool((fr_[0] == fs_[0]).all() and (fr_[1] == fs_[1]).all()) and sp.replicated
+
+        # ---- KZG key sharded by powers: commit / batch_commit = local MSM + all-gather + EC add
+        n_srs = 600
+        srs = orc.g1_fixed_base_mul(orc.g1_generator(), orc.ints_to_limbs([pow(7, i, P.R_MOD) for i in range(n_srs)], 4))
+        lo, hi = gd.shard_range(n_srs, rank, world)
+
+        def local_msm(poly, a, b):
+            if b <= a:
+                from gemini_amd.msm import g1_zero
+
+                return g1_zero()
+            return orc.msm_pippenger(srs[a:b], orc.fr_from_mont(poly[a:b]))
+
+        key = gd.ShardedCommitterKey(srs[lo:hi], lo, n_srs, 3, local_msm=local_msm)
+        polys = [orc.fr_to_mont(orc.random_fr(20 + k, m)) for k, m in enumerate((600, 250, 700, 1))]
+        aff = lambda j: orc.affine_to_ints(orc.g1_to_affine(j))
+        want = [aff(orc.msm_pippenger(srs[: min(len(p_), n_srs)], orc.fr_from_mont(p_[:n_srs]))) for p_ in polys]
+        ok_msm &= [aff(c) for c in key.batch_commit(polys)] == want
+        ok_msm &= aff(key.commit(polys[1])) == want[1]
         q.put((rank, ok_msm, ok_sc, k))
     finally:
         dist.destroy_process_group()
