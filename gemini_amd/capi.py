@@ -23,6 +23,8 @@ SYMBOLS = [
     "gm_g1_msm", "gm_g1_bases_register", "gm_g1_bases_free", "gm_g1_bases_len", "gm_g1_bases_download", "gm_g1_bases_precompute",
     "gm_g1_msm_h", "gm_g1_msm_v", "gm_g1_msm_d", "gm_g1_msm_d_partial", "gm_g1_sum",
     "gm_g1_fixed_base_register", "gm_g1_srs_register", "gm_set_msm_window", "gm_set_msm_table_min", "gm_prof_enable", "gm_prof_read",
+    "gm_idx_register", "gm_idx_free", "gm_fr_gather", "gm_fr_alg_hash", "gm_fr_plookup_set", "gm_fr_add_scalar", "gm_fr_shift_monic",
+    "gm_fr_acc_product",
     "gm_fr_vec_alloc", "gm_fr_vec_free", "gm_fr_vec_len", "gm_fr_vec_upload", "gm_fr_vec_download",
     "gm_fr_vec_fill", "gm_fr_vec_ptr", "gm_fr_vec_set_len",
     "gm_fr_reverse", "gm_fr_fold", "gm_fr_powers", "gm_fr_tensor", "gm_fr_hadamard", "gm_fr_ip", "gm_fr_eval_le",

@@ -13,6 +13,7 @@ from .fr import FrVec, R_MOD, fr_from_int
 class SparseMatrix:
     def __init__(self, handle: int, nrows: int, ncols: int):
         self.handle, self.nrows, self.ncols = handle, nrows, ncols
+        self.csr = None
 
     @classmethod
     def from_csr(cls, rowptr, cols, vals_mont, nrows: int, ncols: int) -> "SparseMatrix":
@@ -23,7 +24,9 @@ class SparseMatrix:
         h = C.c_uint64()
         capi.check(capi.load().gm_spm_register(capi.ptr(rowptr), capi.ptr(cols), capi.ptr(vals), C.c_size_t(nrows), C.c_size_t(ncols),
                                                C.c_size_t(len(cols)), C.byref(h)))
-        return cls(h.value, nrows, ncols)
+        m = cls(h.value, nrows, ncols)
+        m.csr = (rowptr, cols, vals)  # host copy (the preprocessing SNARK's joint matrices are built from it)
+        return m
 
     @classmethod
     def from_rows(cls, rows, ncols: int, transpose: bool = False) -> "SparseMatrix":

@@ -185,6 +185,12 @@ int fr_fill(Context* C, FrVec* v, const uint64_t val[4]);
 int fr_reverse(Context* C, FrVec* in, FrVec* out);
 int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y);
 int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k, FrVec* q, uint64_t* rem_out);
+int fr_gather(Context* C, FrVec* src, const IdxVec* index, FrVec* out);
+int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4], FrVec* out);
+int fr_plookup_set(Context* C, FrVec* v, const uint64_t y[4], const uint64_t z[4], FrVec* out);
+int fr_add_scalar(Context* C, FrVec* v, const uint64_t y[4], FrVec* out);
+int fr_shift_monic(Context* C, FrVec* v, FrVec* out);
+int fr_acc_product(Context* C, FrVec* v, FrVec* out);
 
 }  // namespace gm
 
@@ -233,6 +239,8 @@ void gm_shutdown(void) {
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
   for (auto& kv : C->space_provers) sp_destroy(C, kv.second.get());
   for (auto& kv : C->herring_g1) hg1_destroy(C, kv.second.get());
+  for (auto& kv : C->indices)
+    if (kv.second->d) (void)hipFree(kv.second->d);
   for (auto& kv : C->matrices) {
     if (kv.second->rowptr) (void)hipFree(kv.second->rowptr);
     if (kv.second->cols) (void)hipFree(kv.second->cols);
@@ -567,6 +575,86 @@ int gm_fr_div_vanishing(uint64_t f, const uint64_t* points_mont, size_t k, uint6
   GM_VEC(vf, f, "fr_div_vanishing");
   GM_VEC(vq, quotient, "fr_div_vanishing");
   return fr_div_linear_factors(C, vf, points_mont, k, vq, rem_mont);
+}
+
+// ---- index vectors + entry-product / plookup builders (psnark) ----------------------------------
+int gm_idx_register(const uint32_t* index, size_t n, uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(handle && (index || n == 0), GM_EINVAL, "idx_register: null pointer");
+  auto I = std::make_unique<IdxVec>();
+  I->n = n;
+  uint32_t mx = 0;
+  for (size_t k = 0; k < n; k++) mx = index[k] > mx ? index[k] : mx;
+  I->max_plus_1 = n ? (size_t)mx + 1 : 0;
+  if (n) {
+    GM_HIP(hipMalloc((void**)&I->d, n * 4));
+    GM_HIP(hipMemcpyAsync(I->d, index, n * 4, hipMemcpyHostToDevice, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+  }
+  std::lock_guard<std::mutex> lk(C->mu);
+  *handle = C->next_handle++;
+  C->indices[*handle] = std::move(I);
+  return GM_OK;
+}
+int gm_idx_free(uint64_t handle) {
+  GM_CTX();
+  std::unique_ptr<IdxVec> I;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->indices.find(handle);
+    GM_CHECK(it != C->indices.end(), GM_EHANDLE, "idx_free: unknown handle %llu", (unsigned long long)handle);
+    I = std::move(it->second);
+    C->indices.erase(it);
+  }
+  if (I->d) (void)hipFree(I->d);
+  return GM_OK;
+}
+#define GM_IDX(var, h, who)                                                                             \
+  IdxVec* var;                                                                                          \
+  {                                                                                                     \
+    std::lock_guard<std::mutex> lk(C->mu);                                                              \
+    auto it = C->indices.find(h);                                                                       \
+    GM_CHECK(it != C->indices.end(), GM_EHANDLE, who ": unknown index handle %llu", (unsigned long long)(h)); \
+    var = it->second.get();                                                                             \
+  }
+int gm_fr_gather(uint64_t src, uint64_t index, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vs, src, "fr_gather");
+  GM_VEC(vo, out, "fr_gather");
+  GM_IDX(ix, index, "fr_gather");
+  return fr_gather(C, vs, ix, vo);
+}
+int gm_fr_alg_hash(uint64_t v, uint64_t index, const uint64_t zeta_mont[4], uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_alg_hash");
+  GM_VEC(vo, out, "fr_alg_hash");
+  if (index == 0) return fr_alg_hash(C, vv, nullptr, zeta_mont, vo);
+  GM_IDX(ix, index, "fr_alg_hash");
+  return fr_alg_hash(C, vv, ix, zeta_mont, vo);
+}
+int gm_fr_plookup_set(uint64_t v, const uint64_t y_mont[4], const uint64_t z_mont[4], uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_plookup_set");
+  GM_VEC(vo, out, "fr_plookup_set");
+  return fr_plookup_set(C, vv, y_mont, z_mont, vo);
+}
+int gm_fr_add_scalar(uint64_t v, const uint64_t y_mont[4], uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_add_scalar");
+  GM_VEC(vo, out, "fr_add_scalar");
+  return fr_add_scalar(C, vv, y_mont, vo);
+}
+int gm_fr_shift_monic(uint64_t v, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_shift_monic");
+  GM_VEC(vo, out, "fr_shift_monic");
+  return fr_shift_monic(C, vv, vo);
+}
+int gm_fr_acc_product(uint64_t v, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_acc_product");
+  GM_VEC(vo, out, "fr_acc_product");
+  return fr_acc_product(C, vv, vo);
 }
 
 // ---- sparse matrices (R1CS) -------------------------------------------------------------------

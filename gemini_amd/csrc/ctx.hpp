@@ -70,6 +70,13 @@ struct SparseMatrix {
   size_t nrows = 0, ncols = 0, nnz = 0;
 };
 
+// index vector resident in HBM (`&[usize]` arguments of plookup / lookup: row_index, col_index, ...)
+struct IdxVec {
+  uint32_t* d = nullptr;
+  size_t n = 0;
+  size_t max_plus_1 = 0;  // 1 + the largest index (0 for an empty vector)
+};
+
 struct Sumcheck {
   // ping-pong state of TimeProver (src/subprotocols/sumcheck/time_prover.rs:42-52)
   uint8_t* f[2] = {nullptr, nullptr};
@@ -162,6 +169,7 @@ struct Context {
   std::unordered_map<uint64_t, std::unique_ptr<SparseMatrix>> matrices;
   std::unordered_map<uint64_t, std::unique_ptr<SpaceProver>> space_provers;
   std::unordered_map<uint64_t, std::unique_ptr<HerringG1>> herring_g1;
+  std::unordered_map<uint64_t, std::unique_ptr<IdxVec>> indices;
   MsmWorkspace msm;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results

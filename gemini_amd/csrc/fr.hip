@@ -387,6 +387,102 @@ __global__ __launch_bounds__(256) void k_div_phase3(const uint8_t* __restrict__ 
   }
 }
 
+
+// ---- entry-product / plookup vector builders (psnark) ------------------------------------------
+// out[j] = src[index[j]]: `lookup` (plookup/time_prover.rs:5-8) and `sorted` (:67-74, with the
+// extended-frequency index)
+__global__ __launch_bounds__(256) void k_gather(const uint8_t* __restrict__ src, const uint32_t* __restrict__ index, size_t n,
+                                                uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + i * FR_BYTES, fp_load<FrParams>(src + (size_t)index[i] * FR_BYTES));
+}
+// out[i] = v[i] + F::from(index[i]) * zeta (index == nullptr: the range 0..n)   plookup/time_prover.rs:11-21
+// zeta2 = zeta * R^2 so that the Montgomery product with the plain integer is (index * zeta) * R
+__global__ __launch_bounds__(256) void k_alg_hash(const uint8_t* __restrict__ v, const uint32_t* __restrict__ index, size_t n,
+                                                  const uint32_t* __restrict__ zeta2_8, uint8_t* __restrict__ out) {
+  Fr z2 = fp_load<FrParams>(zeta2_8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t k = index ? (uint64_t)index[i] : (uint64_t)i;
+    Fr kk = Fr::zero();
+    kk.l[0] = (uint32_t)k;
+    kk.l[1] = (uint32_t)(k >> 32);
+    fp_store<FrParams>(out + i * FR_BYTES, fr_add(fp_load<FrParams>(v + i * FR_BYTES), fr_mul(kk, z2)));
+  }
+}
+// plookup_set (plookup/time_prover.rs:23-35): out has n + 1 entries,
+// out[i] = (1 + z) y + [i >= 1] v[i-1] + [i < n] z v[i]
+__global__ __launch_bounds__(256) void k_plookup_set(const uint8_t* __restrict__ v, size_t n, const uint32_t* __restrict__ yz8,
+                                                     uint8_t* __restrict__ out) {
+  Fr y1z = fp_load<FrParams>(yz8), z = fp_load<FrParams>(yz8 + 8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = y1z;
+    if (i >= 1) acc = fr_add(acc, fp_load<FrParams>(v + (i - 1) * FR_BYTES));
+    if (i < n) acc = fr_add(acc, fr_mul(z, fp_load<FrParams>(v + i * FR_BYTES)));
+    fp_store<FrParams>(out + i * FR_BYTES, acc);
+  }
+}
+// out[i] = v[i] + y: plookup_subset (:62-64)
+__global__ __launch_bounds__(256) void k_add_scalar(const uint8_t* __restrict__ v, size_t n, const uint32_t* __restrict__ y8,
+                                                    uint8_t* __restrict__ out) {
+  Fr y = fp_load<FrParams>(y8);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + i * FR_BYTES, fr_add(fp_load<FrParams>(v + i * FR_BYTES), y));
+}
+// right_rotation(monic(v)) = [1, v_0, ..., v_{n-1}]            entryproduct/time_prover.rs:14-23,47-51
+__global__ __launch_bounds__(256) void k_shift_monic(const uint8_t* __restrict__ v, size_t n, uint8_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + i * FR_BYTES, i == 0 ? Fr::one() : fp_load<FrParams>(v + (i - 1) * FR_BYTES));
+}
+
+// accumulated_product(monic(v)) (entryproduct/time_prover.rs:25-45): out[i] = prod_{j >= i} v[j], out[n] = 1.
+// The same three-phase blocked scan as the division above with the monoid (Fr, *):
+//   phase 1: p_c = product of chunk c (ACC_K elements per thread)
+//   phase 2: suffix products of p over segments of `seg` chunks (one thread each, in place) + the
+//            segment products; the few segment carries are combined on the host
+//   phase 3: rerun each chunk from its incoming suffix
+constexpr int ACC_K = 64;
+__global__ __launch_bounds__(256) void k_accp_phase1(const uint8_t* __restrict__ v, size_t n, uint8_t* __restrict__ chunk_prod) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nch = (n + ACC_K - 1) / ACC_K;
+  if (c >= nch) return;
+  const size_t lo = c * ACC_K, hi = min(lo + (size_t)ACC_K, n);
+  Fr acc = fp_load<FrParams>(v + (hi - 1) * FR_BYTES);
+  for (size_t j = hi - 1; j-- > lo;) acc = fr_mul(acc, fp_load<FrParams>(v + j * FR_BYTES));
+  fp_store<FrParams>(chunk_prod + c * FR_BYTES, acc);
+}
+__global__ __launch_bounds__(256) void k_accp_phase2a(uint8_t* __restrict__ prods, size_t nch, size_t seg, uint8_t* __restrict__ seg_prods) {
+  const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nseg = (nch + seg - 1) / seg;
+  if (s >= nseg) return;
+  const size_t lo = s * seg, hi = min(lo + seg, nch);
+  Fr acc = fp_load<FrParams>(prods + (hi - 1) * FR_BYTES);
+  for (size_t c = hi - 1; c-- > lo;) {
+    acc = fr_mul(acc, fp_load<FrParams>(prods + c * FR_BYTES));
+    fp_store<FrParams>(prods + c * FR_BYTES, acc);  // suffix product within the segment
+  }
+  fp_store<FrParams>(seg_prods + s * FR_BYTES, acc);
+}
+__global__ __launch_bounds__(256) void k_accp_phase3(const uint8_t* __restrict__ v, size_t n, const uint8_t* __restrict__ prods,
+                                                     const uint8_t* __restrict__ carry, size_t seg, uint8_t* __restrict__ out) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nch = (n + ACC_K - 1) / ACC_K;
+  if (c >= nch) return;
+  // product of everything above chunk c
+  Fr state;
+  if (c + 1 < nch) {
+    const size_t c1 = c + 1, s1 = c1 / seg;
+    state = fr_mul(fp_load<FrParams>(prods + c1 * FR_BYTES), fp_load<FrParams>(carry + s1 * FR_BYTES));
+  } else {
+    state = Fr::one();
+    fp_store<FrParams>(out + n * FR_BYTES, state);  // the monic entry
+  }
+  const size_t lo = c * ACC_K, hi = min(lo + (size_t)ACC_K, n);
+  for (size_t j = hi; j-- > lo;) {
+    state = fr_mul(state, fp_load<FrParams>(v + j * FR_BYTES));
+    fp_store<FrParams>(out + j * FR_BYTES, state);
+  }
+}
+
 // y[i] = sum_k vals[k] * x[cols[k]] over row i of a CSR matrix       src/misc.rs:100-110
 // (product_matrix_vector; the reference skips the multiplication when the coefficient is one,
 // which cannot change the value)
@@ -1028,6 +1124,117 @@ int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y) {
   return GM_OK;
 }
 
+// ---- entry-product / plookup builders ---------------------------------------------------------
+int fr_gather(Context* C, FrVec* src, const IdxVec* index, FrVec* out) {
+  GM_CHECK(out->cap >= index->n, GM_EINVAL, "gather: output capacity %zu < %zu", out->cap, index->n);
+  GM_CHECK(out != src, GM_EINVAL, "gather: output must not alias the input");
+  GM_CHECK(index->max_plus_1 <= src->len, GM_EINVAL, "gather: index %zu outside the source vector (%zu)", index->max_plus_1 - 1, src->len);
+  if (index->n) hipLaunchKernelGGL(k_gather, dim3(grid_for(index->n)), dim3(256), 0, C->stream, src->d, index->d, index->n, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = index->n;
+  return GM_OK;
+}
+
+int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4], FrVec* out) {
+  // zip semantics of the reference: the shorter of (v, index) decides the length
+  const size_t n = index ? std::min(v->len, index->n) : v->len;
+  GM_CHECK(out->cap >= n, GM_EINVAL, "alg_hash: output capacity %zu < %zu", out->cap, n);
+  gmh::Fr z2 = gmh::Fr::from_limbs(zeta) * gmh::Fr::from_limbs(gmh::FrP::R2);
+  uint8_t* dz;
+  int rc = upload_small(C, z2.l, 32, &dz);
+  if (rc) return rc;
+  if (n) hipLaunchKernelGGL(k_alg_hash, dim3(grid_for(n)), dim3(256), 0, C->stream, v->d, index ? index->d : nullptr, n, (const uint32_t*)dz, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = n;
+  return GM_OK;
+}
+
+int fr_plookup_set(Context* C, FrVec* v, const uint64_t y[4], const uint64_t z[4], FrVec* out) {
+  GM_CHECK(out != v, GM_EINVAL, "plookup_set: output must not alias the input");
+  if (v->len == 0) {
+    out->len = 0;
+    return GM_OK;
+  }
+  GM_CHECK(out->cap >= v->len + 1, GM_EINVAL, "plookup_set: output capacity %zu < %zu", out->cap, v->len + 1);
+  gmh::Fr zz = gmh::Fr::from_limbs(z);
+  gmh::Fr y1z = (gmh::Fr::one() + zz) * gmh::Fr::from_limbs(y);
+  uint64_t small[8];
+  memcpy(small, y1z.l, 32);
+  memcpy(small + 4, zz.l, 32);
+  uint8_t* d;
+  int rc = upload_small(C, small, 64, &d);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_plookup_set, dim3(grid_for(v->len + 1)), dim3(256), 0, C->stream, v->d, v->len, (const uint32_t*)d, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = v->len + 1;
+  return GM_OK;
+}
+
+int fr_add_scalar(Context* C, FrVec* v, const uint64_t y[4], FrVec* out) {
+  GM_CHECK(out->cap >= v->len, GM_EINVAL, "add_scalar: output capacity %zu < %zu", out->cap, v->len);
+  uint8_t* d;
+  int rc = upload_small(C, y, 32, &d);
+  if (rc) return rc;
+  if (v->len) hipLaunchKernelGGL(k_add_scalar, dim3(grid_for(v->len)), dim3(256), 0, C->stream, v->d, v->len, (const uint32_t*)d, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = v->len;
+  return GM_OK;
+}
+
+int fr_shift_monic(Context* C, FrVec* v, FrVec* out) {
+  GM_CHECK(out->cap >= v->len + 1, GM_EINVAL, "shift_monic: output capacity %zu < %zu", out->cap, v->len + 1);
+  GM_CHECK(out != v, GM_EINVAL, "shift_monic: output must not alias the input");
+  hipLaunchKernelGGL(k_shift_monic, dim3(grid_for(v->len + 1)), dim3(256), 0, C->stream, v->d, v->len, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = v->len + 1;
+  return GM_OK;
+}
+
+int fr_acc_product(Context* C, FrVec* v, FrVec* out) {
+  const size_t n = v->len;
+  GM_CHECK(out->cap >= n + 1, GM_EINVAL, "acc_product: output capacity %zu < %zu", out->cap, n + 1);
+  GM_CHECK(out != v, GM_EINVAL, "acc_product: output must not alias the input");
+  out->len = n + 1;
+  if (n == 0) {
+    uint64_t one[4];
+    gmh::Fr::one().to_limbs(one);
+    GM_HIP(hipMemcpyAsync(out->d, one, 32, hipMemcpyHostToDevice, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+    return GM_OK;
+  }
+  const size_t nch = (n + ACC_K - 1) / ACC_K, seg = 64, nseg = (nch + seg - 1) / seg;
+  int rc = C->fr_scratch.ensure((1 << 20) + (nch + 2 * nseg + 8) * FR_BYTES);
+  if (rc) return rc;
+  uint8_t* prods = C->fr_scratch.as<uint8_t>() + (1 << 20);
+  uint8_t* seg_prods = prods + nch * FR_BYTES;
+  uint8_t* carry = seg_prods + nseg * FR_BYTES;
+  hipLaunchKernelGGL(k_accp_phase1, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, v->d, n, prods);
+  hipLaunchKernelGGL(k_accp_phase2a, dim3(grid_for(nseg, 1u << 22)), dim3(256), 0, C->stream, prods, nch, seg, seg_prods);
+  GM_HIP(hipGetLastError());
+  {
+    // carry[s] = product of the segments above s: nseg <= n / 4096 sequential host multiplications
+    std::vector<uint64_t> hs(nseg * 4), hc(nseg * 4);
+    GM_HIP(hipMemcpyAsync(hs.data(), seg_prods, nseg * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+    gmh::Fr acc = gmh::Fr::one();
+    for (size_t s = nseg; s-- > 0;) {
+      acc.to_limbs(hc.data() + 4 * s);
+      acc = acc * gmh::Fr::from_limbs(hs.data() + 4 * s);
+    }
+    GM_HIP(hipMemcpyAsync(carry, hc.data(), nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+  }
+  hipLaunchKernelGGL(k_accp_phase3, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, v->d, n, prods, carry, seg, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
+
 int fr_reverse(Context* C, FrVec* in, FrVec* out) {
   GM_CHECK(out->cap >= in->len, GM_EINVAL, "reverse: output capacity %zu < %zu", out->cap, in->len);
   GM_CHECK(out != in, GM_EINVAL, "reverse: output must not alias the input");
@@ -1086,8 +1293,8 @@ int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k
     memcpy(small + 4, m.l, 32);
     GM_HIP(hipMemcpyAsync(base, small, 64, hipMemcpyHostToDevice, C->stream));
     const size_t nch = (n + DIV_K - 1) / DIV_K, nseg = (nch + seg - 1) / seg;
-    hipLaunchKernelGGL(k_div_phase1, dim3(grid_for(nch)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums);
-    hipLaunchKernelGGL(k_div_phase2a, dim3(grid_for(nseg)), dim3(256), 0, C->stream, sums, nch, seg, (const uint32_t*)(base + 32), seg_sums);
+    hipLaunchKernelGGL(k_div_phase1, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums);
+    hipLaunchKernelGGL(k_div_phase2a, dim3(grid_for(nseg, 1u << 22)), dim3(256), 0, C->stream, sums, nch, seg, (const uint32_t*)(base + 32), seg_sums);
     {
       // phase 2b on the host: nseg (<= n/4096) sequential steps of a first-order recurrence cost
       // microseconds on a CPU core and milliseconds on a single GPU lane
@@ -1113,7 +1320,7 @@ int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k
       GM_HIP(hipMemcpyAsync(carry, hc.data(), nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
       GM_HIP(hipStreamSynchronize(C->stream));  // hc goes out of scope
     }
-    hipLaunchKernelGGL(k_div_phase3, dim3(grid_for(nch)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums, carry, seg, mt, dst,
+    hipLaunchKernelGGL(k_div_phase3, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums, carry, seg, mt, dst,
                        base + 128 + j * 32);
     GM_HIP(hipGetLastError());
     GM_HIP(hipStreamSynchronize(C->stream));  // `small` staging reused next pass

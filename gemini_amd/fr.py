@@ -211,3 +211,109 @@ def div_vanishing(f, points_mont):
         if tmp:
             fv.free()
     return q, rem
+
+
+# ---- index vectors + entry-product / plookup builders (psnark) ------------------------------------
+class IdxVec:
+    """`&[usize]` resident in HBM (row_index, col_index, extended frequencies)"""
+
+    def __init__(self, handle: int, n: int):
+        self.handle, self.n = handle, n
+
+    @classmethod
+    def from_host(cls, index) -> "IdxVec":
+        capi.ensure_init()
+        ix = np.ascontiguousarray(index, dtype=np.uint32)
+        h = C.c_uint64()
+        capi.check(capi.load().gm_idx_register(capi.ptr(ix), C.c_size_t(len(ix)), C.byref(h)))
+        return cls(h.value, len(ix))
+
+    def __len__(self) -> int:
+        return self.n
+
+    def free(self):
+        if self.handle:
+            capi.check(capi.load().gm_idx_free(C.c_uint64(self.handle)))
+            self.handle = 0
+
+
+def lookup(v, index: IdxVec) -> FrVec:
+    """src/subprotocols/plookup/time_prover.rs:5-8: [v[i] for i in index]"""
+    vv, tmp = _as_vec(v)
+    out = FrVec.alloc(len(index))
+    try:
+        capi.check(capi.load().gm_fr_gather(C.c_uint64(vv.handle), C.c_uint64(index.handle), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
+def alg_hash(v, index, chal_mont) -> FrVec:
+    """plookup/time_prover.rs:11-21; index None = the range 0..len(v)"""
+    vv, tmp = _as_vec(v)
+    n = len(vv) if index is None else min(len(vv), len(index))
+    out = FrVec.alloc(n)
+    try:
+        capi.check(capi.load().gm_fr_alg_hash(C.c_uint64(vv.handle), C.c_uint64(0 if index is None else index.handle),
+                                              capi.ptr(capi.u64(chal_mont).reshape(4)), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
+def plookup_set(v, y_mont, z_mont) -> FrVec:
+    """plookup/time_prover.rs:23-35"""
+    vv, tmp = _as_vec(v)
+    out = FrVec.alloc(len(vv) + 1 if len(vv) else 0)
+    try:
+        capi.check(capi.load().gm_fr_plookup_set(C.c_uint64(vv.handle), capi.ptr(capi.u64(y_mont).reshape(4)),
+                                                 capi.ptr(capi.u64(z_mont).reshape(4)), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
+def plookup_subset(v, y_mont) -> FrVec:
+    """plookup/time_prover.rs:62-64"""
+    vv, tmp = _as_vec(v)
+    out = FrVec.alloc(len(vv))
+    try:
+        capi.check(capi.load().gm_fr_add_scalar(C.c_uint64(vv.handle), capi.ptr(capi.u64(y_mont).reshape(4)), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
+def shift_monic(v) -> FrVec:
+    """right_rotation(monic(v)) = [1, v...] (src/subprotocols/entryproduct/time_prover.rs:14-23,47-51)"""
+    vv, tmp = _as_vec(v)
+    out = FrVec.alloc(len(vv) + 1)
+    try:
+        capi.check(capi.load().gm_fr_shift_monic(C.c_uint64(vv.handle), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
+def accumulated_product_monic(v) -> FrVec:
+    """accumulated_product(monic(v)) (entryproduct/time_prover.rs:25-51): out[i] = prod_{j>=i} v[j], out[len] = 1"""
+    vv, tmp = _as_vec(v)
+    out = FrVec.alloc(len(vv) + 1)
+    try:
+        capi.check(capi.load().gm_fr_acc_product(C.c_uint64(vv.handle), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
+def element(v: FrVec, i: int) -> np.ndarray:
+    """v[i] as a (4,) Montgomery array"""
+    out = np.empty((1, 4), dtype=np.uint64)
+    capi.check(capi.load().gm_fr_vec_download(C.c_uint64(v.handle), C.c_size_t(i), capi.ptr(out), C.c_size_t(1)))
+    return out[0]

@@ -24,16 +24,28 @@ class CommitterKey:
     """src/kzg/time.rs:24-27.  powers_of_g lives on the GPU; powers_of_g2 is only used by the
     verifier (out of scope) so just its length (max_eval_points + 1) is kept."""
 
-    def __init__(self, powers_of_g: G1Bases, max_eval_points: int):
+    def __init__(self, powers_of_g: G1Bases, max_eval_points: int, powers_of_g2=None):
         self.powers_of_g = powers_of_g
         self._max_eval_points = max_eval_points
+        self.powers_of_g2 = powers_of_g2  # affine G2 points (gemini_amd.g2), only absorbed into transcripts
 
     @classmethod
     def new(cls, max_degree: int, max_eval_points: int, tau_canonical: np.ndarray, g_affine: np.ndarray | None = None) -> "CommitterKey":
-        """src/kzg/time.rs:49-72 with the trapdoor passed in (the reference draws tau and g from rng;
-        ark_std::test_rng() is not reproducible without Rust)."""
+        """src/kzg/time.rs:49-72 with the trapdoor passed in (the reference draws tau, g and g2 from rng;
+        ark_std::test_rng() is not reproducible without Rust): g, g2 = the standard generators."""
+        from . import g2 as G2
+
         g = g1_generator_mont() if g_affine is None else g_affine
-        return cls(G1Bases.srs(g, tau_canonical, max_degree + 1), max_eval_points)
+        tau = sum(int(v) << (64 * i) for i, v in enumerate(np.asarray(tau_canonical, dtype=np.uint64).reshape(4)))
+        powers_of_g2 = [G2.mul(G2.generator(), pow(tau, i, R_MOD)) for i in range(max_eval_points + 1)]  # :60-67
+        return cls(G1Bases.srs(g, tau_canonical, max_degree + 1), max_eval_points, powers_of_g2)
+
+    def powers_of_g2_bytes(self) -> bytes:
+        """serialize_uncompressed(&self.powers_of_g2), what `append_serializable(b"ck", ..)` absorbs"""
+        from . import g2 as G2
+
+        assert self.powers_of_g2 is not None, "this key was built without its G2 half"
+        return G2.serialize_vec_uncompressed(self.powers_of_g2)
 
     def max_eval_points(self) -> int:  # :75-78
         return self._max_eval_points

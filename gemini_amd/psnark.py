@@ -1,0 +1,406 @@
+"""Host mirror of the preprocessing SNARK time prover (src/psnark/time_prover.rs:49-384), the
+entry-product argument (src/subprotocols/entryproduct/time_prover.rs:53-114) and the plookup vector
+builders (src/subprotocols/plookup/time_prover.rs:89-112): orchestration only -- every O(n) step is a
+device call (MSM, batched sumcheck, gather / hash / scan / vector passes)."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .circuit import R1cs
+from .fr import (FrVec, IdxVec, R_MOD, accumulated_product_monic, alg_hash, element, evaluate_le, fr_from_int, fr_to_int, hadamard, ip,
+                 linear_combination, lookup, plookup_set, plookup_subset, powers, shift_monic, tensor)
+from .kzg import CommitterKey
+from .sumcheck import Sumcheck, TimeProver
+from .tensorcheck import TensorcheckProof
+from .transcript import PROTOCOL_NAME, Transcript
+
+_ONE = fr_from_int(1)
+
+
+# ---- src/misc.rs:269-366 on the host CSR arrays -------------------------------------------------------
+def joint_matrices(a, b, c, num_constraints: int, num_variables: int):
+    """sum_matrices + joint_matrices: the union of the supports of A, B, C walked column-major
+    (column ascending, row ascending inside a column -- BTreeSet order), with the three value
+    vectors (zero where a matrix has no entry; the last duplicate wins like BTreeMap::collect).
+    Returns (row_index, col_index, val_a, val_b, val_c) as numpy arrays (values Montgomery (nnz, 4))."""
+    keys, vals = [], []
+    for m in (a, b, c):
+        rowptr, cols, v = m.csr
+        rows = np.repeat(np.arange(m.nrows, dtype=np.uint64), np.diff(rowptr.astype(np.int64)))
+        assert cols.size == 0 or int(cols.max()) < num_variables, "column index outside num_variables"
+        keys.append(cols.astype(np.uint64) * np.uint64(num_constraints) + rows)
+        vals.append(np.asarray(v, dtype=np.uint64).reshape(-1, 4))
+    union = np.unique(np.concatenate(keys))
+    row_index = (union % np.uint64(num_constraints)).astype(np.uint32)
+    col_index = (union // np.uint64(num_constraints)).astype(np.uint32)
+    out_vals = []
+    for k, v in zip(keys, vals):
+        dense = np.zeros((len(union), 4), dtype=np.uint64)
+        order = np.argsort(k, kind="stable")
+        ks = k[order]
+        last = np.ones(len(ks), dtype=bool)
+        last[:-1] = ks[1:] != ks[:-1]  # the last occurrence of every key
+        dense[np.searchsorted(union, ks[last])] = v[order][last]
+        out_vals.append(dense)
+    return row_index, col_index, out_vals[0], out_vals[1], out_vals[2]
+
+
+def _field_of_index(index: IdxVec) -> FrVec:
+    """[F::from(i) for i in index] (the `row` / `col` vectors, src/misc.rs:343-349)"""
+    zeros = FrVec.alloc(len(index))
+    zeros.fill(fr_from_int(0))
+    out = alg_hash(zeros, index, _ONE)
+    zeros.free()
+    return out
+
+
+# ---- src/subprotocols/plookup/time_prover.rs ------------------------------------------------------------
+def compute_frequency(set_len: int, index: np.ndarray) -> np.ndarray:
+    """:66-70"""
+    return 1 + np.bincount(index, minlength=set_len).astype(np.int64)
+
+
+def extend_frequency(frequency: np.ndarray) -> np.ndarray:
+    """:72-79"""
+    return np.repeat(np.arange(len(frequency), dtype=np.uint32), frequency)
+
+
+def plookup(subset: FrVec, set_: FrVec, index: IdxVec, ext_fre: IdxVec, y, z, zeta):
+    """:89-112 -> [lookup_set, lookup_subset, lookup_sorted]; ext_fre = extend_frequency(compute_frequency(..))
+    so that sorted(set, frequency) = [set[i] for i in ext_fre]"""
+    tmp = []
+    if fr_to_int(zeta) != 0:
+        set_h = alg_hash(set_, None, zeta)
+        subset_h = alg_hash(subset, index, zeta)
+        tmp += [set_h, subset_h]
+    else:
+        set_h, subset_h = set_, subset
+    lookup_set = plookup_set(set_h, y, z)
+    lookup_subset = plookup_subset(subset_h, y)
+    srt = lookup(set_h, ext_fre)
+    lookup_sorted = plookup_set(srt, y, z)
+    for v in tmp + [srt]:
+        v.free()
+    return [lookup_set, lookup_subset, lookup_sorted]
+
+
+# ---- src/subprotocols/entryproduct -----------------------------------------------------------------------
+class EntryProductMsgs:
+    """entryproduct/mod.rs:21-25"""
+
+    def __init__(self, acc_v_commitments, claimed_sumchecks):
+        self.acc_v_commitments = acc_v_commitments
+        self.claimed_sumchecks = claimed_sumchecks
+
+
+class EntryProduct:
+    """entryproduct/mod.rs:27-31"""
+
+    def __init__(self, msgs, chal, provers):
+        self.msgs, self.chal, self.provers = msgs, chal, provers
+
+    @staticmethod
+    def new_time_batch(transcript, ck, vs, claimed_products, acc_vs=None) -> "EntryProduct":
+        """entryproduct/time_prover.rs:53-114.  acc_vs: accumulated_product(monic(v)) when the caller has
+        them already (the psnark prover does)."""
+        assert len(vs) == len(claimed_products)
+        own = acc_vs is None
+        if own:
+            acc_vs = [accumulated_product_monic(v) for v in vs]
+        rrot_vs = [shift_monic(v) for v in vs]
+        acc_v_commitments = ck.batch_commit(acc_vs)
+        for c in acc_v_commitments:
+            transcript.append_g1(b"acc_v", c)
+        chal = transcript.get_challenge(b"ep-chal")
+        ci = fr_to_int(chal)
+        provers = [TimeProver(acc_v, rrot_v, chal) for rrot_v, acc_v in zip(rrot_vs, acc_vs)]
+        claimed_sumchecks = []
+        for cp, acc_v in zip(claimed_products, acc_vs):
+            acc_v_chal = fr_to_int(evaluate_le(acc_v, chal.reshape(1, 4))[0])
+            chal_n = pow(ci, len(acc_v), R_MOD)
+            claimed_sumchecks.append(fr_from_int((acc_v_chal * ci + fr_to_int(cp) - chal_n) % R_MOD))
+        for v in rrot_vs + (acc_vs if own else []):
+            v.free()
+        return EntryProduct(EntryProductMsgs(acc_v_commitments, claimed_sumchecks), chal, provers)
+
+    @staticmethod
+    def new_time(transcript, ck, v, claimed_product) -> "EntryProduct":
+        """entryproduct/time_prover.rs:116-147"""
+        return EntryProduct.new_time_batch(transcript, ck, [v], [claimed_product])
+
+
+class Proof:
+    """src/psnark/mod.rs:29-51"""
+
+    FIELDS = ("witness_commitment", "zc_alpha", "first_sumcheck_msgs", "r_star_commitments", "z_star_commitment", "second_sumcheck_msgs",
+              "set_r_ep", "subset_r_ep", "sorted_r_commitment", "set_alpha_ep", "subset_alpha_ep", "sorted_alpha_commitment", "set_z_ep",
+              "subset_z_ep", "sorted_z_commitment", "ep_msgs", "ralpha_star_acc_mu_evals", "ralpha_star_acc_mu_proof", "rstars_vals",
+              "third_sumcheck_msgs", "tensorcheck_proof")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw[f])
+        self.spans = {}
+
+    @staticmethod
+    def index(ck: CommitterKey, r1cs: R1cs) -> list:
+        """src/psnark/time_prover.rs:49-64"""
+        num_constraints, num_variables = r1cs.a.nrows, len(r1cs.z)
+        row_index, col_index, val_a, val_b, val_c = joint_matrices(r1cs.a, r1cs.b, r1cs.c, num_constraints, num_variables)
+        ri, cidx = IdxVec.from_host(row_index), IdxVec.from_host(col_index)
+        row, col = _field_of_index(ri), _field_of_index(cidx)
+        out = ck.batch_commit([row, col, val_a, val_b, val_c])
+        for v in (row, col, ri, cidx):
+            v.free()
+        return out
+
+    @staticmethod
+    def new_time(ck: CommitterKey, r1cs: R1cs, index: list) -> "Proof":
+        """src/psnark/time_prover.rs:69-384"""
+        spans = {}
+        keep = []  # device vectors freed at the end
+
+        def K(v):
+            keep.append(v)
+            return v
+
+        t_all = time.perf_counter()
+        z_a = K(r1cs.a.mul(r1cs.z))  # :74-76
+        z_b = K(r1cs.b.mul(r1cs.z))
+        z_c = K(r1cs.c.mul(r1cs.z))
+        transcript = Transcript(PROTOCOL_NAME)
+        t0 = time.perf_counter()
+        witness_commitment = ck.commit(r1cs.w)  # :79
+        spans["Commitment to w"] = time.perf_counter() - t0
+
+        transcript.append_g1(b"witness", witness_commitment)  # :82-86
+        transcript.append_message(b"ck", ck.powers_of_g2_bytes())
+        transcript.append_g1(b"instance", np.stack(index), with_len=True)
+        alpha = transcript.get_challenge(b"alpha")
+
+        zc_alpha = evaluate_le(z_c, alpha.reshape(1, 4))[0]  # :88-89
+        transcript.append_fr(b"zc(alpha)", zc_alpha)
+
+        t0 = time.perf_counter()
+        first_proof = Sumcheck.new_time(transcript, z_a, z_b, alpha)  # :92
+        spans["First sumcheck"] = time.perf_counter() - t0
+
+        t0 = time.perf_counter()
+        b_challenges = K(tensor(np.stack(first_proof.challenges)))  # :95-97
+        c_challenges = K(powers(alpha, len(b_challenges)))
+        a_challenges = K(hadamard(b_challenges, c_challenges))
+
+        num_constraints, num_variables = r1cs.a.nrows, len(r1cs.z)  # :99-110
+        row_index_h, col_index_h, val_a_h, val_b_h, val_c_h = joint_matrices(r1cs.a, r1cs.b, r1cs.c, num_constraints, num_variables)
+        row_index, col_index = K(IdxVec.from_host(row_index_h)), K(IdxVec.from_host(col_index_h))
+        row, col = K(_field_of_index(row_index)), K(_field_of_index(col_index))
+        val_a, val_b, val_c = K(FrVec.from_host(val_a_h)), K(FrVec.from_host(val_b_h)), K(FrVec.from_host(val_c_h))
+        num_non_zero = len(row_index)
+        spans["joint matrices"] = time.perf_counter() - t0
+
+        ralpha_star = K(lookup(a_challenges, row_index))  # :114-117
+        r_star = K(lookup(b_challenges, row_index))
+        alpha_star = K(lookup(c_challenges, row_index))
+        z_star = K(lookup(r1cs.z, col_index))
+
+        # :119-127.  ck.index_by(row_index).commit(a_challenges) = sum_j a_challenges[row_index[j]] * g_j, the
+        # commitment to the looked-up vector under ck itself (the reference's commented-out line :126): one
+        # MSM over the resident key instead of building an indexed key.  The index_by zip needs as many
+        # powers as indices.
+        assert len(ck.powers_of_g) >= num_non_zero, "committer key shorter than the number of non-zero entries"
+        t0 = time.perf_counter()
+        z_r_commitments = ck.batch_commit([ralpha_star, r_star, alpha_star]) + [ck.commit(z_star)]
+        spans["Commitments to z* and r*"] = time.perf_counter() - t0
+
+        transcript.append_g1(b"ra*", z_r_commitments[0])  # :129-132
+        transcript.append_g1(b"rb*", z_r_commitments[1])
+        transcript.append_g1(b"rc*", z_r_commitments[2])
+        transcript.append_g1(b"z*", z_r_commitments[3])
+
+        eta = transcript.get_challenge(b"chal")  # :134-135
+        eta_i = fr_to_int(eta)
+        challenges = np.stack([_ONE, eta, fr_from_int(eta_i * eta_i % R_MOD)])
+
+        h_a, h_b, h_c = hadamard(ralpha_star, val_a), hadamard(r_star, val_b), hadamard(alpha_star, val_c)
+        r_star_val = K(linear_combination([h_a, h_b, h_c], challenges))  # :137-144
+        for v in (h_a, h_b, h_c):
+            v.free()
+
+        t0 = time.perf_counter()
+        second_proof = Sumcheck.new_time(transcript, z_star, r_star_val, _ONE)  # :147-152
+        second_challenges = K(tensor(np.stack(second_proof.challenges)))
+        assert len(second_challenges) >= num_non_zero
+        second_challenges_head = second_challenges
+        second_challenges_head.set_len(num_non_zero)  # &second_challenges[..num_non_zero]
+        spans["Second sumcheck"] = time.perf_counter() - t0
+
+        zeta = transcript.get_challenge(b"zeta")  # :157
+
+        t0 = time.perf_counter()
+        alg_hash_poly = [K(alg_hash(b_challenges, None, zeta)), K(alg_hash(c_challenges, None, zeta)), K(alg_hash(r1cs.z, None, zeta))]  # :160-164
+        frequency = [compute_frequency(len(alg_hash_poly[0]), row_index_h), compute_frequency(len(alg_hash_poly[2]), col_index_h)]  # :165-168
+        ext_fre = [K(IdxVec.from_host(extend_frequency(frequency[0]))), K(IdxVec.from_host(extend_frequency(frequency[1])))]  # :175-178
+        sorted_polynomials = [K(lookup(alg_hash_poly[0], ext_fre[0])), K(lookup(alg_hash_poly[1], ext_fre[0])),
+                              K(lookup(alg_hash_poly[2], ext_fre[1]))]  # :169-173
+        # :179-183: ck.index_by(ext_fre).commit(alg_hash_poly) = commitment to the sorted vector under ck (:183)
+        assert len(ck.powers_of_g) >= max(len(ext_fre[0]), len(ext_fre[1])), "committer key shorter than the sorted vectors"
+        sorted_commitments = ck.batch_commit(sorted_polynomials)
+        spans["Commitments to sorted vectors"] = time.perf_counter() - t0
+
+        transcript.append_g1(b"sorted_alpha_commitment", sorted_commitments[1])  # :186-188
+        transcript.append_g1(b"sorted_r_commitment", sorted_commitments[0])
+        transcript.append_g1(b"sorted_z_commitment", sorted_commitments[2])
+
+        gamma = transcript.get_challenge(b"gamma")  # :190-191
+        chi = transcript.get_challenge(b"chi")
+
+        t0 = time.perf_counter()
+        r_lookup_vec = [K(v) for v in plookup(r_star, b_challenges, row_index, ext_fre[0], gamma, chi, zeta)]  # :194-204
+        alpha_lookup_vec = [K(v) for v in plookup(alpha_star, c_challenges, row_index, ext_fre[0], gamma, chi, zeta)]
+        z_lookup_vec = [K(v) for v in plookup(z_star, r1cs.z, col_index, ext_fre[1], gamma, chi, zeta)]
+        lookup_vec = r_lookup_vec + alpha_lookup_vec + z_lookup_vec  # :206-209
+        accumulated_vec = [K(accumulated_product_monic(v)) for v in lookup_vec]  # accproduct3, :211-214
+        prod = [element(acc, 0) for acc in accumulated_vec]  # product3: the full product is the first accumulated entry
+        r_prod_vec, alpha_prod_vec, z_prod_vec = prod[0:3], prod[3:6], prod[6:9]
+        spans["plookup vectors + accumulated products"] = time.perf_counter() - t0
+
+        transcript.append_fr(b"set_r_ep", alpha_prod_vec[0])  # :216-221 (labels as in the reference)
+        transcript.append_fr(b"subset_r_ep", alpha_prod_vec[1])
+        transcript.append_fr(b"set_r_ep", r_prod_vec[0])
+        transcript.append_fr(b"subset_r_ep", r_prod_vec[1])
+        transcript.append_fr(b"set_z_ep", z_prod_vec[0])
+        transcript.append_fr(b"subset_z_ep", z_prod_vec[1])
+
+        t0 = time.perf_counter()
+        entry_products = EntryProduct.new_time_batch(transcript, ck, lookup_vec, prod, acc_vs=accumulated_vec)  # :223-239
+        spans["Entry products"] = time.perf_counter() - t0
+
+        psi = entry_products.chal  # :241-242
+        open_chal = transcript.get_challenge(b"open-chal")
+
+        t0 = time.perf_counter()
+        polynomials = [ralpha_star] + accumulated_vec  # :244-251
+        ralpha_star_acc_mu_proof = ck.batch_open_multi_points(polynomials, psi.reshape(1, 4), open_chal)
+        ralpha_star_acc_mu_evals = [evaluate_le(p, psi.reshape(1, 4))[0] for p in polynomials]
+        spans["Opening at psi"] = time.perf_counter() - t0
+
+        h_a, h_b = hadamard(ralpha_star, val_a), hadamard(r_star, val_b)  # :253-254
+        s_0_prime, s_1_prime = ip(h_a, second_challenges_head), ip(h_b, second_challenges_head)
+        h_a.free()
+        h_b.free()
+        for e in ralpha_star_acc_mu_evals:  # :258-261
+            transcript.append_fr(b"ralpha_star_acc_mu", e)
+        transcript.append_g1(b"ralpha_star_mu_proof", ralpha_star_acc_mu_proof)
+
+        provers = list(entry_products.provers)  # :263-290
+        for lhs, rhs in ((ralpha_star, val_a), (r_star, val_b), (alpha_star, val_c)):
+            h = hadamard(lhs, second_challenges_head)
+            provers.append(TimeProver(h, rhs, _ONE))
+            h.free()
+        provers.append(TimeProver(r_star, alpha_star, psi))
+
+        t0 = time.perf_counter()
+        third_proof = Sumcheck.prove_batch(transcript, provers)  # :293
+        for p in provers:
+            p.free()
+        spans["Third sumcheck"] = time.perf_counter() - t0
+
+        tc_base_polynomials = [r1cs.w, ralpha_star, r_star, alpha_star, z_star, row, col, val_a, val_b, val_c] + sorted_polynomials + accumulated_vec  # :296-319
+
+        third_ch = [fr_to_int(c) for c in third_proof.challenges]
+        second_ch = [fr_to_int(c) for c in second_proof.challenges]
+        twist_powers2 = [pow(fr_to_int(psi), 1 << j, R_MOD) for j in range(len(third_ch))]  # :321
+
+        shift_monic_lookup_vec = [K(shift_monic(v)) for v in lookup_vec]  # :323-326
+        third_proof_vec = shift_monic_lookup_vec + [val_a, val_b, val_c, alpha_star]  # :329-330
+        body_polynomials_0 = accumulated_vec + [r_star]  # :334-345
+        head = third_ch[: len(second_ch)]  # :346
+        F = lambda ints: [fr_from_int(v) for v in ints]
+        tc_body_polynomials = [  # :347-359
+            (body_polynomials_0, F([a * b % R_MOD for a, b in zip(third_ch, twist_powers2)])),
+            (third_proof_vec, F(third_ch)),
+            ([z_star], F(second_ch)),
+            ([ralpha_star, r_star, alpha_star], F([a * b % R_MOD for a, b in zip(second_ch, head)])),
+        ]
+
+        t0 = time.perf_counter()
+        tensorcheck_proof = TensorcheckProof.new_time(transcript, ck, tc_base_polynomials, tc_body_polynomials)  # :362-367
+        spans["Tensorcheck"] = time.perf_counter() - t0
+
+        for v in keep:
+            v.free()
+        transcript.free()
+        spans["ark_gemini::psnark::time_prover"] = time.perf_counter() - t_all
+        proof = Proof(
+            witness_commitment=witness_commitment, zc_alpha=zc_alpha,
+            first_sumcheck_msgs=(first_proof.messages, first_proof.final_foldings),
+            r_star_commitments=z_r_commitments[:3], z_star_commitment=z_r_commitments[3],
+            second_sumcheck_msgs=(second_proof.messages, second_proof.final_foldings),
+            set_r_ep=r_prod_vec[0], subset_r_ep=r_prod_vec[1], sorted_r_commitment=sorted_commitments[0],
+            set_alpha_ep=alpha_prod_vec[0], subset_alpha_ep=alpha_prod_vec[1], sorted_alpha_commitment=sorted_commitments[1],
+            set_z_ep=z_prod_vec[0], subset_z_ep=z_prod_vec[1], sorted_z_commitment=sorted_commitments[2],
+            ep_msgs=entry_products.msgs, ralpha_star_acc_mu_evals=ralpha_star_acc_mu_evals,
+            ralpha_star_acc_mu_proof=ralpha_star_acc_mu_proof, rstars_vals=[s_0_prime, s_1_prime],
+            third_sumcheck_msgs=(third_proof.messages, third_proof.final_foldings), tensorcheck_proof=tensorcheck_proof)
+        proof.spans = spans
+        return proof
+
+    def serialize_compressed(self) -> bytes:
+        """derive(CanonicalSerialize) order of src/psnark/mod.rs:29-51 (Vec = u64 length + items, arrays = items)"""
+        from .snark import _fr_bytes, _g1_compressed
+
+        u64 = lambda n: int(n).to_bytes(8, "little")
+        out = bytearray()
+
+        def sumcheck_msgs(m):
+            msgs, finals = m
+            out.extend(u64(len(msgs)))
+            for a, b in msgs:
+                out.extend(_fr_bytes(a) + _fr_bytes(b))
+            out.extend(u64(len(finals)))
+            for f0, g0 in finals:
+                out.extend(_fr_bytes(f0) + _fr_bytes(g0))
+
+        out += _g1_compressed(self.witness_commitment)
+        out += _fr_bytes(self.zc_alpha)
+        sumcheck_msgs(self.first_sumcheck_msgs)
+        for c in self.r_star_commitments:
+            out += _g1_compressed(c)
+        out += _g1_compressed(self.z_star_commitment)
+        sumcheck_msgs(self.second_sumcheck_msgs)
+        for ep0, ep1, cm in ((self.set_r_ep, self.subset_r_ep, self.sorted_r_commitment),
+                             (self.set_alpha_ep, self.subset_alpha_ep, self.sorted_alpha_commitment),
+                             (self.set_z_ep, self.subset_z_ep, self.sorted_z_commitment)):
+            out += _fr_bytes(ep0) + _fr_bytes(ep1) + _g1_compressed(cm)
+        out += u64(len(self.ep_msgs.acc_v_commitments))
+        for c in self.ep_msgs.acc_v_commitments:
+            out += _g1_compressed(c)
+        out += u64(len(self.ep_msgs.claimed_sumchecks))
+        for e in self.ep_msgs.claimed_sumchecks:
+            out += _fr_bytes(e)
+        out += u64(len(self.ralpha_star_acc_mu_evals))
+        for e in self.ralpha_star_acc_mu_evals:
+            out += _fr_bytes(e)
+        out += _g1_compressed(self.ralpha_star_acc_mu_proof)
+        for e in self.rstars_vals:
+            out += _fr_bytes(e)
+        sumcheck_msgs(self.third_sumcheck_msgs)
+        tc = self.tensorcheck_proof
+        out += u64(len(tc.folded_polynomials_commitments))
+        for c in tc.folded_polynomials_commitments:
+            out += _g1_compressed(c)
+        out += u64(len(tc.folded_polynomials_evaluations))
+        for e2 in tc.folded_polynomials_evaluations:
+            for e in e2:
+                out += _fr_bytes(e)
+        out += _g1_compressed(tc.evaluation_proof)
+        out += u64(len(tc.base_polynomials_evaluations))
+        for e3 in tc.base_polynomials_evaluations:
+            for e in e3:
+                out += _fr_bytes(e)
+        return bytes(out)
+
+    def compressed_size(self) -> int:
+        return len(self.serialize_compressed())

@@ -160,6 +160,24 @@ int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, 
  * Replaces DensePolynomial::div in open_multi_points           src/kzg/time.rs:134-145 */
 int gm_fr_div_vanishing(uint64_t f, const uint64_t* points_mont, size_t k, uint64_t quotient, uint64_t* rem_mont);
 
+/* ---- index vectors and the entry-product / plookup vector builders (preprocessing SNARK) ---------- */
+/* `&[usize]` arguments (row_index, col_index, extended frequencies) copied to HBM once. */
+int gm_idx_register(const uint32_t* index, size_t n, uint64_t* handle);
+int gm_idx_free(uint64_t handle);
+/* out[j] = src[index[j]]: `lookup` and `sorted`        src/subprotocols/plookup/time_prover.rs:5-8,67-74 */
+int gm_fr_gather(uint64_t src, uint64_t index, uint64_t out);
+/* out[i] = v[i] + F::from(index[i]) * zeta; index = 0 means the range 0..len   plookup/time_prover.rs:11-21 */
+int gm_fr_alg_hash(uint64_t v, uint64_t index, const uint64_t zeta_mont[4], uint64_t out);
+/* plookup_set: len + 1 entries (1+z)y + v[i-1] + z v[i]                         plookup/time_prover.rs:23-35 */
+int gm_fr_plookup_set(uint64_t v, const uint64_t y_mont[4], const uint64_t z_mont[4], uint64_t out);
+/* plookup_subset: out[i] = v[i] + y                                             plookup/time_prover.rs:62-64 */
+int gm_fr_add_scalar(uint64_t v, const uint64_t y_mont[4], uint64_t out);
+/* right_rotation(monic(v)) = [1, v...]                         src/subprotocols/entryproduct/time_prover.rs:14-23,47-51 */
+int gm_fr_shift_monic(uint64_t v, uint64_t out);
+/* accumulated_product(monic(v)): out[i] = prod_{j>=i} v[j], out[len] = 1 (reverse prefix-product scan)
+ *                                                              src/subprotocols/entryproduct/time_prover.rs:25-45 */
+int gm_fr_acc_product(uint64_t v, uint64_t out);
+
 /* ---- sparse R1CS matrices ------------------------------------------------------------------------ */
 /* `Matrix<F> = Vec<Vec<(F, usize)>>` (src/circuit.rs:43) as CSR, copied to HBM once.  gm_spm_mul is
  * product_matrix_vector (src/misc.rs:100-110): y = M x.  Registering the TRANSPOSE turns the

@@ -1,0 +1,170 @@
+"""GPU parity for SURVEY.md section 8f rank 4: the preprocessing SNARK time prover
+(src/psnark/time_prover.rs) with its entry-product / plookup builders, through the device path vs the
+CPU restatement (oracle/psnark_ref.py), transcript included."""
+import numpy as np
+import pytest
+
+from tests.util import jac_to_affine_ints
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gm():
+    import gemini_amd
+
+    gemini_amd.capi.init()
+    return gemini_amd
+
+
+def _M(orc, ints):
+    return orc.fr_to_mont(orc.ints_to_limbs(ints, 4)) if len(ints) else np.empty((0, 4), dtype=np.uint64)
+
+
+def test_plookup_entryproduct_builders(gm, oracle, pyref):
+    """lookup / alg_hash / plookup_set / plookup_subset / sorted / accumulated_product / right_rotation
+    (plookup/time_prover.rs, entryproduct/time_prover.rs) incl. the reference's own relation tests
+    (plookup/time_prover.rs:114-148 test_plookup_relation, :37-60 test_plookup_set_correct)."""
+    from gemini_amd import fr as F
+    from gemini_amd import psnark as ps
+    from oracle import psnark_ref as pr
+
+    R = pyref.R_MOD
+    I = lambda v: oracle.limbs_to_ints(oracle.fr_from_mont(v.to_host() if hasattr(v, "to_host") else np.asarray(v).reshape(-1, 4)))
+    for n, m, seed in ((6, 4, 1), (1, 1, 2), (64, 200, 3), (5000, 9000, 4), (300000, 100000, 5)):
+        rng = np.random.default_rng(seed)
+        set_ = oracle.limbs_to_ints(oracle.random_fr(10 * seed, n))
+        index = rng.integers(0, n, size=m).astype(np.uint32)
+        y, z, zeta = oracle.limbs_to_ints(oracle.random_fr(10 * seed + 1, 3))
+        dset = F.FrVec.from_host(_M(oracle, set_))
+        didx = F.IdxVec.from_host(index)
+        sub = F.lookup(dset, didx)
+        subset = pr.lookup(set_, index.tolist())
+        assert I(sub) == subset
+        assert I(F.alg_hash(dset, None, _M(oracle, [zeta])[0])) == pr.alg_hash(set_, range(n), zeta)
+        assert I(F.alg_hash(sub, didx, _M(oracle, [zeta])[0])) == pr.alg_hash(subset, index.tolist(), zeta)
+        assert I(F.plookup_set(dset, _M(oracle, [y])[0], _M(oracle, [z])[0])) == pr.plookup_set(set_, y, z)
+        assert I(F.plookup_subset(dset, _M(oracle, [y])[0])) == pr.plookup_subset(set_, y)
+        assert I(F.shift_monic(dset)) == pr.right_rotation(pr.monic(set_))
+        acc = F.accumulated_product_monic(dset)
+        assert I(acc) == pr.accumulated_product(pr.monic(set_))
+        freq = ps.compute_frequency(n, index)
+        assert freq.tolist() == pr.compute_frequency(n, index.tolist())
+        ext = ps.extend_frequency(freq)
+        assert ext.tolist() == pr.extend_frequency(freq.tolist())
+        dext = F.IdxVec.from_host(ext)
+        assert I(F.lookup(dset, dext)) == pr.sorted_(set_, freq.tolist())
+        for zt in (zeta, 0):
+            got = ps.plookup(sub, dset, didx, dext, _M(oracle, [y])[0], _M(oracle, [z])[0], _M(oracle, [zt])[0])
+            want = pr.plookup(subset, set_, index.tolist(), y, z, zt)
+            assert [I(v) for v in got] == want
+            # the plookup relation: prod(sorted) = prod(set) prod(subset) (1+z)^|subset|
+            prods = [I(F.accumulated_product_monic(v))[0] for v in got]
+            assert prods[2] == prods[0] * prods[1] % R * pow(1 + z, m, R) % R
+    # empty inputs
+    e = F.FrVec.alloc(0)
+    assert len(F.plookup_set(e, _M(oracle, [1])[0], _M(oracle, [2])[0])) == 0
+    assert I(F.accumulated_product_monic(e)) == [1] and I(F.shift_monic(e)) == [1]
+
+
+def _random_instance(pyref, sr, n, seed):
+    rng = pyref.SplitMix64(seed)
+    R = pyref.R_MOD
+    z = [rng.fr() for _ in range(n)]
+    mk = lambda: [[(rng.fr(), int(rng.next() % n)) for _ in range(1 + int(rng.next() % 3))] for _ in range(n)]
+    a, b = mk(), mk()
+    za, zb = sr.matvec(a, z), sr.matvec(b, z)
+    c = [[(za[i] * zb[i] % R * pow(z[i], -1, R) % R, i)] for i in range(n)]
+    return {"a": a, "b": b, "c": c, "z": z, "w": z[1:], "x": z[:1]}, rng.fr()
+
+
+def _device_instance(gm, oracle, inst, n):
+    from gemini_amd.circuit import R1cs, SparseMatrix
+
+    M = lambda v: gm.fr.fr_from_int(v)
+    dev = lambda rows: [[(M(v), col) for v, col in row] for row in rows]
+    mats = [SparseMatrix.from_rows(dev(inst[k]), n) for k in "abc"] + [SparseMatrix.from_rows(dev(inst[k]), n, transpose=True) for k in "abc"]
+    return R1cs(*mats, gm.FrVec.from_host(_M(oracle, inst["z"])), gm.FrVec.from_host(_M(oracle, inst["w"])), gm.FrVec.from_host(_M(oracle, inst["x"])))
+
+
+def _check_proof(gm, oracle, proof, exp):
+    I = gm.fr.fr_to_int
+    A = lambda j: jac_to_affine_ints(oracle, j)
+    assert A(proof.witness_commitment) == exp["witness_commitment"]
+    assert I(proof.zc_alpha) == exp["zc_alpha"]
+    for name in ("first_sumcheck_msgs", "second_sumcheck_msgs", "third_sumcheck_msgs"):
+        msgs, finals = getattr(proof, name)
+        assert [(I(x), I(y)) for x, y in msgs] == exp[name][0], name
+        want = exp[name][1]
+        want = [tuple(want)] if isinstance(want[0], int) else [tuple(f) for f in want]  # sumcheck_prove returns one pair
+        assert [(I(x), I(y)) for x, y in finals] == want, name
+    assert [A(c) for c in proof.r_star_commitments] == exp["r_star_commitments"]
+    assert A(proof.z_star_commitment) == exp["z_star_commitment"]
+    for k in ("set_r_ep", "subset_r_ep", "set_alpha_ep", "subset_alpha_ep", "set_z_ep", "subset_z_ep"):
+        assert I(getattr(proof, k)) == exp[k], k
+    for k in ("sorted_r_commitment", "sorted_alpha_commitment", "sorted_z_commitment", "ralpha_star_acc_mu_proof"):
+        assert A(getattr(proof, k)) == exp[k], k
+    assert [A(c) for c in proof.ep_msgs.acc_v_commitments] == exp["ep_msgs"]["acc_v_commitments"]
+    assert [I(e) for e in proof.ep_msgs.claimed_sumchecks] == exp["ep_msgs"]["claimed_sumchecks"]
+    assert [I(e) for e in proof.ralpha_star_acc_mu_evals] == exp["ralpha_star_acc_mu_evals"]
+    assert [I(e) for e in proof.rstars_vals] == exp["rstars_vals"]
+    tc, etc = proof.tensorcheck_proof, exp["tensorcheck_proof"]
+    assert [A(c) for c in tc.folded_polynomials_commitments] == etc["folded_polynomials_commitments"]
+    assert [[I(e) for e in e2] for e2 in tc.folded_polynomials_evaluations] == etc["folded_polynomials_evaluations"]
+    assert [[I(e) for e in e3] for e3 in tc.base_polynomials_evaluations] == etc["base_polynomials_evaluations"]
+    assert A(tc.evaluation_proof) == etc["evaluation_proof"]
+
+
+@pytest.mark.parametrize("n,seed", [(8, 78), (16, 79)])
+def test_psnark_time_prover_random_r1cs(gm, oracle, pyref, n, seed):
+    """src/psnark/tests.rs shape (random circuit, ck of num_constraints * 100 + num_variables powers):
+    every field of the proof against the restatement."""
+    from gemini_amd import g2
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.psnark import Proof
+    from oracle import psnark_ref as pr
+    from oracle import snark_ref as sr
+
+    inst, tau = _random_instance(pyref, sr, n, seed)
+    srs = sr.srs(tau, 12 * n + 1)
+    g2p = pr.powers_of_g2(tau, 3)
+    exp_index = pr.index(srs, inst)
+    exp = pr.psnark_new_time(srs, g2p, inst, exp_index)
+
+    r1cs = _device_instance(gm, oracle, inst, n)
+    ck = CommitterKey.new(12 * n, 3, oracle.ints_to_limbs([tau], 4)[0])
+    assert ck.powers_of_g2 == g2p  # two independent G2 implementations
+    assert ck.powers_of_g2_bytes() == len(g2p).to_bytes(8, "little") + b"".join(pr.g2_serialize_uncompressed(p) for p in g2p)
+    index = Proof.index(ck, r1cs)
+    assert [jac_to_affine_ints(oracle, c) for c in index] == exp_index
+    proof = Proof.new_time(ck, r1cs, index)
+    _check_proof(gm, oracle, proof, exp)
+    # serialized size: fixed-size fields + the vectors (src/psnark/mod.rs:29-51)
+    blob = proof.serialize_compressed()
+    n_msgs = sum(len(getattr(proof, k)[0]) for k in ("first_sumcheck_msgs", "second_sumcheck_msgs", "third_sumcheck_msgs"))
+    assert len(blob) == proof.compressed_size() and len(blob) > 48 * 10 + 64 * n_msgs
+    r1cs.free()
+
+
+def test_psnark_time_prover_dummy_r1cs(gm, oracle, pyref):
+    """examples/psnark.rs:70-81 recipe at a small size: dummy_r1cs, ck of num_constraints + num_variables"""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.psnark import Proof
+    from oracle import psnark_ref as pr
+    from oracle import snark_ref as sr
+
+    n = 16
+    e = 987654321987654321
+    tau = 1234567890123456789012345
+    srs = sr.srs(tau, 2 * n + 1)
+    inst = sr.dummy_r1cs(e, n)
+    g2p = pr.powers_of_g2(tau, 5)
+    exp_index = pr.index(srs, inst)
+    exp = pr.psnark_new_time(srs, g2p, inst, exp_index)
+    r1cs = dummy_r1cs(e, n)
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    index = Proof.index(ck, r1cs)
+    proof = Proof.new_time(ck, r1cs, index)
+    _check_proof(gm, oracle, proof, exp)
+    r1cs.free()
