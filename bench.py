@@ -196,6 +196,30 @@ def main():
         tables = {"value": round(n * args.steps / t_tab / 1e6, 3), "unit": "Mscalar/s", "ms_per_step": round(t_tab / args.steps * 1e3, 4),
                   "window_bits": 20, "table_bytes": 13 * n * 96, "precompute_s": round(t_pre, 3),
                   "note": "gm_g1_bases_precompute: 2^(20w)*P_i resident in HBM, one shared bucket set; results identical to the plain path"}
+    # extra (not the headline): CommitterKey::batch_commit shape -- 8 MSMs per call through gm_g1_msm_v_batch,
+    # which overlaps the host tail (bit-plane Horner) of MSM j with the kernels of MSM j+1
+    batch = None
+    if world == 1:
+        from gemini_amd.fr import FrVec
+
+        lib.gm_set_msm_table_min(C.c_size_t(1 << 62))  # plain path even if tables were just built
+        vecs = [FrVec.from_host(s) for s in host_scalars]  # the same limbs read as Montgomery residues
+        seq = [bases.msm_vec(v) for v in vecs]
+        kb = 8
+        got = bases.msm_vec_batch([vecs[j & 1] for j in range(kb)], [n] * kb)
+        assert all((got[j] == seq[j & 1]).all() for j in range(kb)), "batched MSM differs from the one-call MSM"
+        reps = max(1, args.steps // kb)
+        barrier()
+        tb0 = time.perf_counter()
+        for _ in range(reps):
+            bases.msm_vec_batch([vecs[j & 1] for j in range(kb)], [n] * kb)
+        barrier()
+        t_b = time.perf_counter() - tb0
+        batch = {"value": round(n * kb * reps / t_b / 1e6, 3), "unit": "Mscalar/s", "ms_per_msm": round(t_b / (kb * reps) * 1e3, 4),
+                 "msms_per_call": kb, "calls": reps, "note": "gm_g1_msm_v_batch, no fixed-base tables; results identical to one-call MSMs"}
+        for v in vecs:
+            v.free()
+        lib.gm_set_msm_table_min(C.c_size_t(1 << 17))
     stage_names = ["digits_hist", "scan", "scatter", "acc0", "merge", "reduce", "sc_round"]
     stages = {k: (ms[i] / cnt[i] if cnt[i] else None) for i, k in enumerate(stage_names)}
 
@@ -268,6 +292,8 @@ def main():
             }
         if tables:
             out["with_fixed_base_tables"] = tables
+        if batch:
+            out["batch_commit_pipelined"] = batch
         if world == 1 and args.snark_logn > 0:
             out["time_prover"] = snark_time_prover(gm, args.snark_logn)
         print(json.dumps(out))

@@ -250,7 +250,12 @@ void gm_shutdown(void) {
   for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.tmp_entries, &w.sortmeta, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
                     &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc})
     b->release();
-  if (w.host_planes) (void)hipHostFree(w.host_planes);
+  for (int k = 0; k < 2; k++)
+    if (w.host_planes[k]) (void)hipHostFree(w.host_planes[k]);
+  if (w.have_done_ev) {
+    (void)hipEventDestroy(w.done_ev[0]);
+    (void)hipEventDestroy(w.done_ev[1]);
+  }
   C->fr_scratch.release();
   if (C->host_small) (void)hipHostFree(C->host_small);
   (void)hipStreamDestroy(C->stream);
@@ -379,6 +384,22 @@ int gm_g1_msm_v(uint64_t bases_handle, size_t offset, int reversed, uint64_t vec
   GM_CHECK(v != nullptr, GM_EHANDLE, "msm_v: unknown vector handle %llu", (unsigned long long)vec_handle);
   GM_CHECK(voffset + n <= v->len, GM_EINVAL, "msm_v: range [%zu, %zu) outside vector of length %zu", voffset, voffset + n, v->len);
   return msm_run(C, b, (int64_t)offset, reversed ? -1 : 1, v->d + voffset * 32, 1, n, true, out_jac);
+}
+
+int gm_g1_msm_v_batch(uint64_t bases_handle, size_t offset, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
+                      uint64_t* out_jac) {
+  GM_CTX();
+  Bases* b = find_bases(bases_handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "msm_v_batch: unknown bases handle %llu", (unsigned long long)bases_handle);
+  GM_CHECK(k == 0 || (vec_handles && ns && out_jac), GM_EINVAL, "msm_v_batch: null pointer");
+  std::vector<const void*> ptrs(k);
+  for (size_t j = 0; j < k; j++) {
+    FrVec* v = find_vec(vec_handles[j]);
+    GM_CHECK(v != nullptr, GM_EHANDLE, "msm_v_batch: unknown vector handle %llu", (unsigned long long)vec_handles[j]);
+    GM_CHECK(ns[j] <= v->len, GM_EINVAL, "msm_v_batch: %zu pairs from a vector of length %zu", ns[j], v->len);
+    ptrs[j] = v->d;
+  }
+  return msm_run_batch(C, b, (int64_t)offset, reversed ? -1 : 1, ptrs.data(), 1, ns, k, true, out_jac);
 }
 
 int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,

@@ -125,8 +125,10 @@ struct HerringG1 {
 
 struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
-  uint64_t* host_planes = nullptr;  // pinned staging for the D2H of window bit-planes
-  size_t host_planes_cap = 0;
+  uint64_t* host_planes[2] = {nullptr, nullptr};  // pinned staging for the D2H of window bit-planes (two calls in flight)
+  size_t host_planes_cap[2] = {0, 0};
+  hipEvent_t done_ev[2];
+  bool have_done_ev = false;
 };
 
 // per-stage kernel timing with HIP events on the library's own stream (bench.py's roofline leg)
@@ -194,5 +196,7 @@ uint64_t put_prover(std::unique_ptr<Sumcheck> p);
 // MSM engine (msm.hip)
 int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
             bool normalize, uint64_t out_jac[18]);
+int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, const void* const* d_scalars, int mont, const size_t* ns,
+                  size_t k, bool normalize, uint64_t* out_jac);
 
 }  // namespace gm

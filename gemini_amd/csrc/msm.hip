@@ -786,6 +786,20 @@ static int choose_window(size_t n) {
 static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
                        bool normalize, uint64_t out_jac[18]);
 
+// One MSM is an enqueue (every kernel + the async copy of the window bit-planes to pinned memory, no host
+// wait) and a finish (wait for the copy, Horner over the bit positions on the host).  Splitting them lets
+// a batch of MSMs overlap the host tail of call i with the kernels of call i+1 (msm_run_batch).
+struct MsmPending {
+  int slot = 0;
+  bool empty = true;
+  int Wb = 0, c = 0, m = 0;
+  uint32_t nbits = 0, wf[3] = {0, 0, 0};
+  size_t plane_off[3] = {0, 0, 0};
+};
+static int msm_enqueue(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n, int slot,
+                       MsmPending* P);
+static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18]);
+
 // Calls larger than 2^26 pairs are split into 2^26-pair MSMs whose results are added on the host --
 // the same composition ChunkedPippenger / msm_chunks use (src/kzg/space.rs:41-53), with the chunk
 // sized for the device (entry indices are 26 + 5 bits; n * windows must stay below 2^32).
@@ -808,12 +822,47 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
 
 static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
                        bool normalize, uint64_t out_jac[18]) {
-  const size_t nbases = bases->n;
-  gmh::G1 result = gmh::G1::identity();
-  if (n == 0) {
-    result.to_limbs(out_jac);
+  std::lock_guard<std::mutex> lk(C->msm_mu);
+  MsmPending P;
+  int rc = msm_enqueue(C, bases, first, step, d_scalars, mont, n, 0, &P);
+  if (rc) return rc;
+  return msm_finish(C, P, normalize, out_jac);
+}
+
+// k MSMs against the same registered bases, pipelined two deep: the kernels of call j are enqueued
+// before the host finishes call j-1.  Results are identical to k msm_run calls.
+int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, const void* const* d_scalars, int mont, const size_t* ns,
+                  size_t k, bool normalize, uint64_t* out_jac) {
+  const size_t CH = (size_t)1 << 26;
+  bool pipelined = !C->prof.on;
+  for (size_t j = 0; j < k; j++) pipelined = pipelined && ns[j] <= CH;
+  if (!pipelined) {
+    for (size_t j = 0; j < k; j++) {
+      int rc = msm_run(C, bases, first, step, d_scalars[j], mont, ns[j], normalize, out_jac + 18 * j);
+      if (rc) return rc;
+    }
     return GM_OK;
   }
+  std::lock_guard<std::mutex> lk(C->msm_mu);
+  MsmPending P[2];
+  for (size_t j = 0; j < k; j++) {
+    int rc = msm_enqueue(C, bases, first, step, d_scalars[j], mont, ns[j], (int)(j & 1), &P[j & 1]);
+    if (rc) {
+      (void)hipStreamSynchronize(C->stream);
+      return rc;
+    }
+    if (j > 0 && (rc = msm_finish(C, P[(j - 1) & 1], normalize, out_jac + 18 * (j - 1)))) return rc;
+  }
+  if (k) return msm_finish(C, P[(k - 1) & 1], normalize, out_jac + 18 * (k - 1));
+  return GM_OK;
+}
+
+static int msm_enqueue(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n, int slot,
+                       MsmPending* P) {
+  const size_t nbases = bases->n;
+  P->slot = slot;
+  P->empty = n == 0;
+  if (n == 0) return GM_OK;
   GM_CHECK(n < (1ull << 31), GM_EINVAL, "msm: n = %zu exceeds 2^31 - 1 pairs per call; chunk the stream", n);
   {
     int64_t last = first + step * (int64_t)(n - 1);
@@ -821,7 +870,6 @@ static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t st
              "msm: base range [%lld .. %lld] outside registered bases (len %zu)", (long long)first, (long long)last,
              nbases);
   }
-  std::lock_guard<std::mutex> lk(C->msm_mu);
   MsmWorkspace& ws = C->msm;
   hipStream_t st = C->stream;
 
@@ -1033,35 +1081,60 @@ static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t st
   pf.end(PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
   const size_t plane_bytes = plane_count * XYZZ_BYTES;
-  if (ws.host_planes_cap < plane_bytes) {
-    if (ws.host_planes) (void)hipHostFree(ws.host_planes);
-    ws.host_planes = nullptr;
-    GM_HIP(hipHostMalloc((void**)&ws.host_planes, plane_bytes, hipHostMallocDefault));
-    ws.host_planes_cap = plane_bytes;
+  if (ws.host_planes_cap[slot] < plane_bytes) {
+    if (ws.host_planes[slot]) (void)hipHostFree(ws.host_planes[slot]);
+    ws.host_planes[slot] = nullptr;
+    ws.host_planes_cap[slot] = 0;
+    GM_HIP(hipHostMalloc((void**)&ws.host_planes[slot], plane_bytes, hipHostMallocDefault));
+    ws.host_planes_cap[slot] = plane_bytes;
   }
-  GM_HIP(hipMemcpyAsync(ws.host_planes, planes, plane_bytes, hipMemcpyDeviceToHost, st));
-  GM_HIP(hipStreamSynchronize(st));
-  pf.collect();
+  if (!ws.have_done_ev) {
+    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[0], hipEventDisableTiming));
+    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[1], hipEventDisableTiming));
+    ws.have_done_ev = true;
+  }
+  GM_HIP(hipMemcpyAsync(ws.host_planes[slot], planes, plane_bytes, hipMemcpyDeviceToHost, st));
+  GM_HIP(hipEventRecord(ws.done_ev[slot], st));
+  P->Wb = Wb;
+  P->c = c;
+  P->m = m;
+  P->nbits = nbits;
+  for (int k = 0; k < 3; k++) {
+    P->wf[k] = wf[k];
+    P->plane_off[k] = k < m ? plane_off[k] : 0;
+  }
+  return GM_OK;
+}
+
+static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18]) {
+  gmh::G1 result = gmh::G1::identity();
+  if (P.empty) {
+    result.to_limbs(out_jac);
+    return GM_OK;
+  }
+  MsmWorkspace& ws = C->msm;
+  GM_HIP(hipEventSynchronize(ws.done_ev[P.slot]));
+  C->prof.collect();
 
   // Horner over bit positions, bucket sets high -> low (variable_base.rs:168-175 with the weighted
   // bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)
-  const uint64_t* hp = ws.host_planes;
+  const uint64_t* hp = ws.host_planes[P.slot];
   auto plane_at = [&](int w, int field, uint32_t j) {
-    return gmh::xyzz_to_jac_dev(hp + (plane_off[field] + (size_t)w * (wf[field] + 1) + j) * 24);
+    return gmh::xyzz_to_jac_dev(hp + (P.plane_off[field] + (size_t)w * (P.wf[field] + 1) + j) * 24);
   };
-  for (int w = Wb - 1; w >= 0; w--) {
-    for (int j = c - 1; j >= 0; j--) {
+  for (int w = P.Wb - 1; w >= 0; w--) {
+    for (int j = P.c - 1; j >= 0; j--) {
       result = result.dbl();
-      if ((uint32_t)j < nbits) {
+      if ((uint32_t)j < P.nbits) {
         int field = 0;
         uint32_t jj = (uint32_t)j;
-        while (jj >= wf[field]) {
-          jj -= wf[field];
+        while (jj >= P.wf[field]) {
+          jj -= P.wf[field];
           field++;
         }
         result = result.add(plane_at(w, field, jj));
       }
-      if (j == 0) result = result.add(plane_at(w, 0, wf[0]));  // Tot_w
+      if (j == 0) result = result.add(plane_at(w, 0, P.wf[0]));  // Tot_w
     }
   }
   if (normalize) result = result.normalized();

@@ -61,8 +61,16 @@ class CommitterKey:
                 v.free()
 
     def batch_commit(self, polynomials) -> list:
-        """:98-107 (sequential loop of MSMs, like the reference)"""
-        return [self.commit(p) for p in polynomials]
+        """:98-107: one MSM per polynomial, issued as one pipelined batch (gm_g1_msm_v_batch)"""
+        vecs = [_as_vec(p) for p in polynomials]
+        try:
+            nb = len(self.powers_of_g)
+            out = self.powers_of_g.msm_vec_batch([v for v, _ in vecs], [min(len(v), nb) for v, _ in vecs])
+            return [out[j] for j in range(len(vecs))]
+        finally:
+            for v, tmp in vecs:
+                if tmp:
+                    v.free()
 
     def open(self, polynomial, evaluation_point_mont):
         """:112-131 -> (evaluation, proof).  The Horner quotient is the device linear-factor division."""

@@ -25,26 +25,38 @@ def joint_matrices(a, b, c, num_constraints: int, num_variables: int):
     (column ascending, row ascending inside a column -- BTreeSet order), with the three value
     vectors (zero where a matrix has no entry; the last duplicate wins like BTreeMap::collect).
     Returns (row_index, col_index, val_a, val_b, val_c) as numpy arrays (values Montgomery (nnz, 4))."""
-    keys, vals = [], []
+    keys, vals = {}, {}
     for m in (a, b, c):
+        if id(m) in keys:  # the same matrix object used twice (dummy_r1cs: A = B = C)
+            continue
         rowptr, cols, v = m.csr
         rows = np.repeat(np.arange(m.nrows, dtype=np.uint64), np.diff(rowptr.astype(np.int64)))
         assert cols.size == 0 or int(cols.max()) < num_variables, "column index outside num_variables"
-        keys.append(cols.astype(np.uint64) * np.uint64(num_constraints) + rows)
-        vals.append(np.asarray(v, dtype=np.uint64).reshape(-1, 4))
-    union = np.unique(np.concatenate(keys))
+        keys[id(m)] = cols.astype(np.uint64) * np.uint64(num_constraints) + rows
+        vals[id(m)] = np.asarray(v, dtype=np.uint64).reshape(-1, 4)
+    union = np.unique(np.concatenate(list(keys.values())))
     row_index = (union % np.uint64(num_constraints)).astype(np.uint32)
     col_index = (union // np.uint64(num_constraints)).astype(np.uint32)
-    out_vals = []
-    for k, v in zip(keys, vals):
-        dense = np.zeros((len(union), 4), dtype=np.uint64)
+    dense = {}
+    for mid, k in keys.items():
+        d = np.zeros((len(union), 4), dtype=np.uint64)
         order = np.argsort(k, kind="stable")
         ks = k[order]
         last = np.ones(len(ks), dtype=bool)
         last[:-1] = ks[1:] != ks[:-1]  # the last occurrence of every key
-        dense[np.searchsorted(union, ks[last])] = v[order][last]
-        out_vals.append(dense)
-    return row_index, col_index, out_vals[0], out_vals[1], out_vals[2]
+        d[np.searchsorted(union, ks[last])] = vals[mid][order][last]
+        dense[mid] = d
+    return row_index, col_index, dense[id(a)], dense[id(b)], dense[id(c)]
+
+
+def _joint(r1cs: R1cs):
+    """joint_matrices of an instance, computed once per R1cs object: they depend on the matrices only
+    (the reference recomputes them in `index` and in `new_time`, src/psnark/time_prover.rs:53-61,102-110)."""
+    j = getattr(r1cs, "_joint_matrices", None)
+    if j is None:
+        j = joint_matrices(r1cs.a, r1cs.b, r1cs.c, r1cs.a.nrows, len(r1cs.z))
+        r1cs._joint_matrices = j
+    return j
 
 
 def _field_of_index(index: IdxVec) -> FrVec:
@@ -147,8 +159,7 @@ class Proof:
     @staticmethod
     def index(ck: CommitterKey, r1cs: R1cs) -> list:
         """src/psnark/time_prover.rs:49-64"""
-        num_constraints, num_variables = r1cs.a.nrows, len(r1cs.z)
-        row_index, col_index, val_a, val_b, val_c = joint_matrices(r1cs.a, r1cs.b, r1cs.c, num_constraints, num_variables)
+        row_index, col_index, val_a, val_b, val_c = _joint(r1cs)
         ri, cidx = IdxVec.from_host(row_index), IdxVec.from_host(col_index)
         row, col = _field_of_index(ri), _field_of_index(cidx)
         out = ck.batch_commit([row, col, val_a, val_b, val_c])
@@ -192,8 +203,7 @@ class Proof:
         c_challenges = K(powers(alpha, len(b_challenges)))
         a_challenges = K(hadamard(b_challenges, c_challenges))
 
-        num_constraints, num_variables = r1cs.a.nrows, len(r1cs.z)  # :99-110
-        row_index_h, col_index_h, val_a_h, val_b_h, val_c_h = joint_matrices(r1cs.a, r1cs.b, r1cs.c, num_constraints, num_variables)
+        row_index_h, col_index_h, val_a_h, val_b_h, val_c_h = _joint(r1cs)  # :99-110
         row_index, col_index = K(IdxVec.from_host(row_index_h)), K(IdxVec.from_host(col_index_h))
         row, col = K(_field_of_index(row_index)), K(_field_of_index(col_index))
         val_a, val_b, val_c = K(FrVec.from_host(val_a_h)), K(FrVec.from_host(val_b_h)), K(FrVec.from_host(val_c_h))

@@ -86,6 +86,12 @@ int gm_g1_msm_h(uint64_t handle, size_t offset, int reversed, const uint64_t* sc
 int gm_g1_msm_v(uint64_t bases_handle, size_t offset, int reversed, uint64_t vec_handle, size_t voffset, size_t n,
                 uint64_t out_jac[18]);
 
+/* k MSMs against the same bases (CommitterKey::batch_commit, src/kzg/time.rs:98-107): MSM j pairs
+ * elements [0, ns[j]) of vector j with bases[offset ...].  Same results as k gm_g1_msm_v calls; the
+ * host tail of call j overlaps the kernels of call j+1.  out_jac: k x 18 limbs. */
+int gm_g1_msm_v_batch(uint64_t bases_handle, size_t offset, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
+                      uint64_t* out_jac);
+
 /* Same, raw device pointer to n x 32-byte scalars already in HBM (mont != 0: Montgomery form).
  * This is the entry bench.py times: inputs resident, result = 144 bytes. */
 int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,

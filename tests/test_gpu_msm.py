@@ -280,3 +280,25 @@ def test_msm_2_24_properties(gm, oracle, pyref):
         assert_same_point(oracle, se, oracle.g1_mul(oracle.g1_to_affine(s1), e))
     finally:
         reg.free()
+
+
+def test_batch_msm_equals_single_calls(gm, oracle):
+    """gm_g1_msm_v_batch (pipelined enqueue/finish) returns exactly what k gm_g1_msm_v calls return,
+    for mixed sizes including empty, and matches the oracle on one of them."""
+    from gemini_amd.fr import FrVec
+
+    n = 5000
+    bases_h = oracle.g1_fixed_base_mul(oracle.g1_generator(), oracle.random_fr(31, n))
+    b = gm.G1Bases.register(bases_h)
+    sizes = [5000, 0, 1, 777, 4096, 5000, 33, 2]
+    vecs = [FrVec.from_host(oracle.fr_to_mont(oracle.random_fr(40 + j, max(m, 1)))) for j, m in enumerate(sizes)]
+    single = [b.msm_vec(v, n=m) for v, m in zip(vecs, sizes)]
+    for _ in range(3):
+        got = b.msm_vec_batch(vecs, sizes)
+        assert all((got[j] == single[j]).all() for j in range(len(sizes)))
+    exp = oracle.msm_pippenger(bases_h[:777], oracle.random_fr(43, 777))
+    assert oracle.g1_jac_eq(got[3], exp)
+    assert b.msm_vec_batch([], []).shape == (0, 18)
+    for v in vecs:
+        v.free()
+    b.free()

@@ -290,3 +290,31 @@ def test_sharded_committer_key_single_process(gm, oracle, pyref):
         assert a == b
     finally:
         dist.destroy_process_group()
+
+
+def test_division_property_at_full_size(gm, oracle, pyref):
+    """open_multi_points' quotient at n = 2^26 + 5 (more than 2^25 elements, i.e. > 2^19 blocked-scan chunks):
+    f(beta) = q(beta) * prod (beta - p_j) + r(beta) with r the Newton-form remainder, at a random beta."""
+    from gemini_amd.fr import FrVec, div_vanishing, evaluate_le, fr_from_int, fr_to_int, powers
+
+    R = pyref.R_MOD
+    n = (1 << 26) + 5
+    x = oracle.limbs_to_ints(oracle.random_fr(4242, 5))
+    f = powers(fr_from_int(x[0]), n)  # f_i = x0^i: a dense vector without a host upload
+    pts = [x[1], x[1] * x[1] % R, (-x[1]) % R]
+    q, rem = div_vanishing(f, np.stack([fr_from_int(p) for p in pts]))
+    assert len(q) == n - 3
+    beta = x[2]
+    fb = fr_to_int(evaluate_le(f, fr_from_int(beta).reshape(1, 4))[0])
+    assert fb == (pow(x[0] * beta % R, n, R) - 1) * pow(x[0] * beta - 1, -1, R) % R  # geometric sum: checks evaluate_le too
+    qb = fr_to_int(evaluate_le(q, fr_from_int(beta).reshape(1, 4))[0])
+    van, rb, basis = 1, 0, 1
+    for p, r_j in zip(pts, rem):  # remainder in Newton form: sum_j r_j prod_{t<j} (x - p_t)
+        rb = (rb + fr_to_int(r_j) * basis) % R
+        basis = basis * (beta - p) % R
+        van = van * (beta - p) % R
+    assert fb == (qb * van + rb) % R
+    # and the first remainder is f(p_0)
+    assert fr_to_int(rem[0]) == (pow(x[0] * pts[0] % R, n, R) - 1) * pow(x[0] * pts[0] - 1, -1, R) % R
+    f.free()
+    q.free()
