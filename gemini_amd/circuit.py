@@ -101,6 +101,7 @@ class R1csStream:
     def __init__(self, r1cs: R1cs):
         from .fr import reverse
 
+        self.r1cs = r1cs  # the matrices (the preprocessing SNARK walks their joint support)
         self.at, self.bt, self.ct = r1cs.at, r1cs.bt, r1cs.ct
         z_a, z_b, z_c = r1cs.a.mul(r1cs.z), r1cs.b.mul(r1cs.z), r1cs.c.mul(r1cs.z)
         self.z = reverse(r1cs.z)

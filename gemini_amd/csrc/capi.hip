@@ -871,6 +871,13 @@ int gm_sp_new(const uint64_t* f_stream_mont, size_t nf, const uint64_t* g_stream
   GM_CHECK(f_stream_mont && g_stream_mont && twist_mont && handle, GM_EINVAL, "sp_new: null pointer");
   return sp_create(C, f_stream_mont, nf, g_stream_mont, ng, false, twist_mont, handle);
 }
+int gm_sp_new_v(uint64_t f_stream_vec, uint64_t g_stream_vec, const uint64_t twist_mont[4], uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(twist_mont && handle, GM_EINVAL, "sp_new_v: null pointer");
+  GM_VEC(vf, f_stream_vec, "sp_new_v");
+  GM_VEC(vg, g_stream_vec, "sp_new_v");
+  return sp_create(C, vf->d, vf->len, vg->d, vg->len, true, twist_mont, handle);
+}
 int gm_sp_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg) {
   GM_CTX();
   GM_SP(S, handle, "sp_round");

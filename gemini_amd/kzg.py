@@ -148,13 +148,20 @@ class CommitterKeyStream:
     (:287-296); in HBM the SRS stays in time order and the stream view is the `reversed` addressing
     of gm_g1_msm_*.  Polynomials are big-endian coefficient streams (numpy arrays or FrVec)."""
 
-    def __init__(self, powers_of_g: G1Bases, max_eval_points: int):
+    def __init__(self, powers_of_g: G1Bases, max_eval_points: int, powers_of_g2=None):
         self.powers_of_g = powers_of_g
         self._max_eval_points = max_eval_points
+        self.powers_of_g2 = powers_of_g2
 
     @classmethod
     def from_committer_key(cls, ck: "CommitterKey") -> "CommitterKeyStream":
-        return cls(ck.powers_of_g, ck.max_eval_points())
+        return cls(ck.powers_of_g, ck.max_eval_points(), ck.powers_of_g2)
+
+    def powers_of_g2_bytes(self) -> bytes:
+        from . import g2 as G2
+
+        assert self.powers_of_g2 is not None, "this key was built without its G2 half"
+        return G2.serialize_vec_uncompressed(self.powers_of_g2)
 
     def as_committer_key(self, max_degree: int) -> "CommitterKey":
         """:77-92 (keeps the first max_degree powers; shares the resident SRS)"""

@@ -357,6 +357,220 @@ class Proof:
         proof.spans = spans
         return proof
 
+    @staticmethod
+    def new_elastic(ck, r1cs_stream, index: list, max_msm_buffer: int) -> "Proof":
+        """src/psnark/elastic_prover.rs:60-634 over device-resident streams: `ck` is a CommitterKeyStream,
+        every polynomial a big-endian stream (reversed device vector); commitments are chunked stream MSMs,
+        sumchecks run on the space / elastic provers, the tensor check on FoldedPolynomialTrees.  The
+        reference's test asserts this proof equals new_time's (src/psnark/tests.rs:56-124)."""
+        from .fr import fold_polynomial, reverse
+        from .kzg import FoldedPolynomialTree
+        from .msm import g1_sum
+        from .snark import _evaluate_be
+        from .sumcheck import ElasticProver
+
+        spans = {}
+        keep = []
+
+        def K(v):
+            keep.append(v)
+            return v
+
+        S = lambda v: K(reverse(v))  # little-endian vector -> big-endian stream
+        t_all = time.perf_counter()
+        r1cs = r1cs_stream.r1cs
+        transcript = Transcript(PROTOCOL_NAME)
+        witness_commitment = ck.commit(r1cs_stream.witness)  # :82
+        transcript.append_g1(b"witness", witness_commitment)  # :86-89
+        transcript.append_message(b"ck", ck.powers_of_g2_bytes())
+        transcript.append_g1(b"instance", np.stack(index), with_len=True)
+        alpha = transcript.get_challenge(b"alpha")
+        zc_alpha = _evaluate_be(r1cs_stream.z_c, alpha.reshape(1, 4))[0]  # :92-93
+        transcript.append_fr(b"zc(alpha)", zc_alpha)
+        t0 = time.perf_counter()
+        sumcheck1 = Sumcheck.new_space(transcript, r1cs_stream.z_a, r1cs_stream.z_b, alpha)  # :97
+        spans["sumcheck1"] = time.perf_counter() - t0
+
+        # the Joint{Row,Col,Val} streams (:100-146) walk the joint support; here its index / value vectors
+        row_index_h, col_index_h, val_a_h, val_b_h, val_c_h = _joint(r1cs)
+        row_index, col_index = K(IdxVec.from_host(row_index_h)), K(IdxVec.from_host(col_index_h))
+        row, col = K(_field_of_index(row_index)), K(_field_of_index(col_index))
+        val_a, val_b, val_c = K(FrVec.from_host(val_a_h)), K(FrVec.from_host(val_b_h)), K(FrVec.from_host(val_c_h))
+        num_non_zero = len(row_index)
+        z_le = K(reverse(r1cs_stream.z))
+        w_le = K(reverse(r1cs_stream.witness))
+        z_star = K(lookup(z_le, col_index))  # :148
+        rs = K(tensor(np.stack(sumcheck1.challenges)))  # Tensor(r_short)                         :150-157
+        alphas = K(powers(alpha, len(rs)))  # Tensor(powers2(alpha)) = powers of alpha
+        ralphas = K(hadamard(rs, alphas))
+        ralpha_star, r_star, alpha_star = K(lookup(ralphas, row_index)), K(lookup(rs, row_index)), K(lookup(alphas, row_index))  # :159-161
+
+        t0 = time.perf_counter()
+        r_star_commitments = [ck.commit(S(ralpha_star)), ck.commit(S(r_star)), ck.commit(S(alpha_star))]  # :164-172
+        z_star_commitment = ck.commit(S(z_star))
+        spans["Commitments to z* and r*"] = time.perf_counter() - t0
+        transcript.append_g1(b"ra*", r_star_commitments[0])
+        transcript.append_g1(b"rb*", r_star_commitments[1])
+        transcript.append_g1(b"rc*", r_star_commitments[2])
+        transcript.append_g1(b"z*", z_star_commitment)
+
+        challenge = transcript.get_challenge(b"chal")  # :181-192
+        ci = fr_to_int(challenge)
+        h_a, h_b, h_c = hadamard(ralpha_star, val_a), hadamard(r_star, val_b), hadamard(alpha_star, val_c)
+        rhs = K(linear_combination([h_a, h_b, h_c], np.stack([_ONE, challenge, fr_from_int(ci * ci % R_MOD)])))
+        for v in (h_a, h_b, h_c):
+            v.free()
+        t0 = time.perf_counter()
+        sumcheck2 = Sumcheck.new_elastic(transcript, S(z_star), S(rhs), _ONE)  # :195
+        spans["sumcheck2"] = time.perf_counter() - t0
+
+        zeta = transcript.get_challenge(b"zeta")  # :199
+        hashed_r, hashed_alpha, hashed_z = K(alg_hash(rs, None, zeta)), K(alg_hash(alphas, None, zeta)), K(alg_hash(z_le, None, zeta))  # :205-210
+        frequency = [compute_frequency(len(rs), row_index_h), compute_frequency(len(z_le), col_index_h)]
+        ext_fre = [K(IdxVec.from_host(extend_frequency(frequency[0]))), K(IdxVec.from_host(extend_frequency(frequency[1])))]
+        sorted_r, sorted_alpha, sorted_z = K(lookup(hashed_r, ext_fre[0])), K(lookup(hashed_alpha, ext_fre[0])), K(lookup(hashed_z, ext_fre[1]))  # :212-214
+        t0 = time.perf_counter()
+        sorted_r_commitment, sorted_alpha_commitment, sorted_z_commitment = ck.commit(S(sorted_r)), ck.commit(S(sorted_alpha)), ck.commit(S(sorted_z))
+        spans["Commitments to sorted vectors"] = time.perf_counter() - t0
+        transcript.append_g1(b"sorted_alpha_commitment", sorted_alpha_commitment)  # :220-222
+        transcript.append_g1(b"sorted_r_commitment", sorted_r_commitment)
+        transcript.append_g1(b"sorted_z_commitment", sorted_z_commitment)
+        gamma = transcript.get_challenge(b"gamma")
+        chi = transcript.get_challenge(b"chi")
+
+        pl_r = [K(v) for v in plookup(r_star, rs, row_index, ext_fre[0], gamma, chi, zeta)]  # plookup_streams, :227-232
+        pl_alpha = [K(v) for v in plookup(alpha_star, alphas, row_index, ext_fre[0], gamma, chi, zeta)]
+        pl_z = [K(v) for v in plookup(z_star, z_le, col_index, ext_fre[1], gamma, chi, zeta)]
+        pls = pl_r + pl_alpha + pl_z
+        accs = [K(accumulated_product_monic(v)) for v in pls]  # ProductStream
+        shifts = [K(shift_monic(v)) for v in pls]  # RightRotationStreamer
+        prod = [element(a, 0) for a in accs]  # :235-243
+        transcript.append_fr(b"set_r_ep", prod[3])  # :245-250
+        transcript.append_fr(b"subset_r_ep", prod[4])
+        transcript.append_fr(b"set_r_ep", prod[0])
+        transcript.append_fr(b"subset_r_ep", prod[1])
+        transcript.append_fr(b"set_z_ep", prod[6])
+        transcript.append_fr(b"subset_z_ep", prod[7])
+
+        assert len(K(tensor(np.stack(sumcheck2.challenges)))) >= num_non_zero
+        ep_r = keep[-1]  # Tensor(&sumcheck2.challenges), cut to the looked-up length             :254-257
+        ep_r.set_len(num_non_zero)
+
+        # EntryProduct::new_elastic_batch (entryproduct/elastic_prover.rs:66-127)
+        t0 = time.perf_counter()
+        acc_streams = [S(a) for a in accs]
+        acc_v_commitments = []
+        for a in acc_streams:
+            cm = ck.commit(a)
+            transcript.append_g1(b"acc_v", cm)
+            acc_v_commitments.append(cm)
+        psi = transcript.get_challenge(b"ep-chal")
+        pi = fr_to_int(psi)
+        claimed_sumchecks, provers = [], []
+        for cp, a, a_s, sh in zip(prod, accs, acc_streams, shifts):
+            acc_v_chal = fr_to_int(_evaluate_be(a_s, psi.reshape(1, 4))[0])
+            claimed_sumchecks.append(fr_from_int((acc_v_chal * pi + fr_to_int(cp) - pow(pi, len(a), R_MOD)) % R_MOD))
+            provers.append(ElasticProver(a_s, S(sh), psi))
+        msgs = EntryProductMsgs(acc_v_commitments, claimed_sumchecks)
+        spans["Entry products"] = time.perf_counter() - t0
+
+        open_chal = transcript.get_challenge(b"open-chal")  # :313-330
+        oc10 = powers(open_chal, 10)
+        polynomial = K(linear_combination([ralpha_star] + accs, oc10.to_host()))
+        oc10.free()
+        ralpha_star_acc_mu_proof = ck.open(S(polynomial), psi, max_msm_buffer)[1]
+        ralpha_star_acc_mu_evals = [evaluate_le(p, psi.reshape(1, 4))[0] for p in [ralpha_star] + accs]  # :332-343
+        lhs = [K(hadamard(v, ep_r)) for v in (ralpha_star, r_star, alpha_star)]
+        r_val_chal_a, r_val_chal_b = ip(lhs[0], val_a), ip(lhs[1], val_b)  # :348-349
+        for e in ralpha_star_acc_mu_evals:
+            transcript.append_fr(b"ralpha_star_acc_mu", e)
+        transcript.append_g1(b"ralpha_star_mu_proof", ralpha_star_acc_mu_proof)
+        for l, v in zip(lhs, (val_a, val_b, val_c)):  # :358-377
+            provers.append(ElasticProver(S(l), S(v), _ONE))
+        provers.append(ElasticProver(S(r_star), S(alpha_star), psi))
+        t0 = time.perf_counter()
+        sumcheck3 = Sumcheck.prove_batch_generic(transcript, provers)  # :380
+        for p in provers:
+            p.free()
+        spans["sumcheck3"] = time.perf_counter() - t0
+
+        # tensorcheck (:384-600)
+        t0 = time.perf_counter()
+        tc_chal = transcript.get_challenge(b"batch_challenge")
+        tcc_v = powers(tc_chal, 13)
+        tcc = tcc_v.to_host()
+        tcc_v.free()
+        bodies = [K(linear_combination(accs + [r_star], tcc)), K(linear_combination(shifts + [val_a, val_b, val_c, alpha_star], tcc)), z_star,
+                  K(linear_combination([ralpha_star, r_star, alpha_star], tcc))]
+        ch2 = [fr_to_int(c) for c in sumcheck2.challenges]
+        ch3 = [fr_to_int(c) for c in sumcheck3.challenges]
+        psi_squares = [pow(pi, 1 << j, R_MOD) for j in range(len(ch3))]
+        F = lambda ints: [fr_from_int(v) for v in ints]
+        tc_challenges = [F([a * b % R_MOD for a, b in zip(ch3, psi_squares)][:-1]), F(ch3[:-1]), F(ch2[:-1]),
+                         F([a * b % R_MOD for a, b in zip(ch2, ch3[: len(ch2)])][:-1])]
+        trees = [FoldedPolynomialTree(S(b), c) for b, c in zip(bodies, tc_challenges)]
+        folded_polynomials_commitments = []
+        for t in trees:
+            folded_polynomials_commitments.extend(ck.commit_folding(t, max_msm_buffer))
+        for c in folded_polynomials_commitments:
+            transcript.append_g1(b"commitment", c)
+        eval_chal = transcript.get_challenge(b"evaluation-chal")
+        ec = fr_to_int(eval_chal)
+        pts = np.stack([fr_from_int(ec * ec % R_MOD), eval_chal, fr_from_int((-ec) % R_MOD)])
+        folded_polynomials_evaluations = []  # evaluate_folding at +-eval_chal, tree by tree
+        for b, chs in zip(bodies, tc_challenges):
+            cur = b
+            for ch in chs:
+                nxt = fold_polynomial(cur, ch)
+                if cur is not b:
+                    cur.free()
+                cur = nxt
+                folded_polynomials_evaluations.append(evaluate_le(cur, pts[1:]))
+            if cur is not b:
+                cur.free()
+        base = [w_le, ralpha_star, r_star, alpha_star, z_star, row, col, val_a, val_b, val_c, sorted_r, sorted_alpha, sorted_z] + accs
+        base_polynomials_evaluations = []
+        for p in base:  # evaluate_base_polynomial appends as it goes (:36-57)
+            e3 = evaluate_le(p, pts)
+            for e in e3:
+                transcript.append_fr(b"eval", e)
+            base_polynomials_evaluations.append(e3)
+        for e2 in folded_polynomials_evaluations:
+            for e in e2:
+                transcript.append_fr(b"eval", e)
+        open_chal = transcript.get_challenge(b"open-chal")
+        open_chal_len = len(folded_polynomials_evaluations) * trees[2].depth() + 3 * len(base)
+        ocv = powers(open_chal, max(open_chal_len, len(base) + len(folded_polynomials_evaluations)))
+        oc = ocv.to_host()
+        ocv.free()
+        partial_eval = K(linear_combination(base, oc[: len(base)]))
+        parts = [ck.open_multi_points(S(partial_eval), pts, max_msm_buffer)[1]]
+        off = len(base)
+        for t in trees:
+            parts.append(ck.open_folding(t, pts, oc[off: off + t.depth()], max_msm_buffer)[1])
+            off += t.depth()
+        evaluation_proof = g1_sum(np.stack(parts))
+        tensorcheck_proof = TensorcheckProof(folded_polynomials_commitments, folded_polynomials_evaluations, evaluation_proof, base_polynomials_evaluations)
+        spans["tensorcheck"] = time.perf_counter() - t0
+
+        for v in keep:
+            v.free()
+        transcript.free()
+        spans["ark_gemini::psnark::elastic_prover"] = time.perf_counter() - t_all
+        proof = Proof(
+            witness_commitment=witness_commitment, zc_alpha=zc_alpha,
+            first_sumcheck_msgs=(sumcheck1.messages, sumcheck1.final_foldings),
+            r_star_commitments=r_star_commitments, z_star_commitment=z_star_commitment,
+            second_sumcheck_msgs=(sumcheck2.messages, sumcheck2.final_foldings),
+            set_r_ep=prod[0], subset_r_ep=prod[1], sorted_r_commitment=sorted_r_commitment,
+            set_alpha_ep=prod[3], subset_alpha_ep=prod[4], sorted_alpha_commitment=sorted_alpha_commitment,
+            set_z_ep=prod[6], subset_z_ep=prod[7], sorted_z_commitment=sorted_z_commitment,
+            ep_msgs=msgs, ralpha_star_acc_mu_evals=ralpha_star_acc_mu_evals, ralpha_star_acc_mu_proof=ralpha_star_acc_mu_proof,
+            rstars_vals=[r_val_chal_a, r_val_chal_b], third_sumcheck_msgs=(sumcheck3.messages, sumcheck3.final_foldings),
+            tensorcheck_proof=tensorcheck_proof)
+        proof.spans = spans
+        return proof
+
     def serialize_compressed(self) -> bytes:
         """derive(CanonicalSerialize) order of src/psnark/mod.rs:29-51 (Vec = u64 length + items, arrays = items)"""
         from .snark import _fr_bytes, _g1_compressed

@@ -81,11 +81,14 @@ class SpaceProver:
 
     def __init__(self, f_stream, g_stream, twist_mont):
         capi.ensure_init()
-        fm = capi.u64(f_stream).reshape(-1, 4)
-        gm_ = capi.u64(g_stream).reshape(-1, 4)
         h = C.c_uint64()
-        capi.check(capi.load().gm_sp_new(capi.ptr(fm), C.c_size_t(len(fm)), capi.ptr(gm_), C.c_size_t(len(gm_)),
-                                         capi.ptr(capi.u64(twist_mont).reshape(4)), C.byref(h)))
+        tw = capi.u64(twist_mont).reshape(4)
+        if isinstance(f_stream, FrVec) and isinstance(g_stream, FrVec):
+            capi.check(capi.load().gm_sp_new_v(C.c_uint64(f_stream.handle), C.c_uint64(g_stream.handle), capi.ptr(tw), C.byref(h)))
+        else:
+            fm = capi.u64(f_stream).reshape(-1, 4)
+            gm_ = capi.u64(g_stream).reshape(-1, 4)
+            capi.check(capi.load().gm_sp_new(capi.ptr(fm), C.c_size_t(len(fm)), capi.ptr(gm_), C.c_size_t(len(gm_)), capi.ptr(tw), C.byref(h)))
         self.handle = h.value
 
     def next_message(self, verifier_message=None):
@@ -252,6 +255,39 @@ class Sumcheck:
         n = r.value
         return Sumcheck([(msgs[i, :4].copy(), msgs[i, 4:].copy()) for i in range(n)], [chs[i].copy() for i in range(n)], n,
                         [(ff[j, :4].copy(), ff[j, 4:].copy()) for j in range(k)])
+
+    @staticmethod
+    def prove_batch_generic(transcript, provers) -> "Sumcheck":
+        """proof.rs:69-122 over any `Prover` objects (space / elastic / time), round loop on the host"""
+        from .fr import R_MOD, fr_from_int, fr_to_int
+
+        rounds = max(p.rounds() for p in provers) + 1
+        coefficients = [fr_to_int(transcript.get_challenge(b"batch-sumcheck")) for _ in provers]
+        messages, challenges = [], []
+        vm = None
+        for _ in range(rounds):
+            a = b = 0
+            for p, c in zip(provers, coefficients):
+                m = p.next_message(vm)
+                if m is None:
+                    ff = p.final_foldings()
+                    ma, mb = fr_to_int(ff[0]) * fr_to_int(ff[1]) % R_MOD, 0
+                else:
+                    ma, mb = fr_to_int(m[0]), fr_to_int(m[1])
+                a = (a + ma * c) % R_MOD
+                b = (b + mb * c) % R_MOD
+            msg = (fr_from_int(a), fr_from_int(b))
+            transcript.append_round_msg(b"evaluations", msg[0], msg[1])
+            vm = transcript.get_challenge(b"challenge")
+            messages.append(msg)
+            challenges.append(vm)
+        finals = []
+        for p in provers:
+            ff = p.final_foldings()
+            transcript.append_fr(b"final-folding-lhs", ff[0])
+            transcript.append_fr(b"final-folding-rhs", ff[1])
+            finals.append(ff)
+        return Sumcheck(messages, challenges, rounds, finals)
 
     @staticmethod
     def new_time(transcript, f, g, twist_mont, native: bool = True) -> "Sumcheck":

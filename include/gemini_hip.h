@@ -228,6 +228,8 @@ int gm_sc_download(uint64_t handle, uint64_t* f_mont, uint64_t* g_mont);
  * when rounds - round < SPACE_TIME_THRESHOLD = 22 (elastic_prover.rs:44-57, src/lib.rs:76). */
 int gm_sp_new(const uint64_t* f_stream_mont, size_t nf, const uint64_t* g_stream_mont, size_t ng, const uint64_t twist_mont[4],
               uint64_t* handle);
+/* same, the streams taken from device-resident vectors (copied, like gm_sc_new_v) */
+int gm_sp_new_v(uint64_t f_stream_vec, uint64_t g_stream_vec, const uint64_t twist_mont[4], uint64_t* handle);
 int gm_sp_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg);
 int gm_sp_fold(uint64_t handle, const uint64_t challenge_mont[4]);
 int gm_sp_rounds(uint64_t handle, size_t* tot_rounds, size_t* round);

@@ -168,3 +168,36 @@ def test_psnark_time_prover_dummy_r1cs(gm, oracle, pyref):
     proof = Proof.new_time(ck, r1cs, index)
     _check_proof(gm, oracle, proof, exp)
     r1cs.free()
+
+
+@pytest.mark.parametrize("kind", ["random", "dummy"])
+def test_psnark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
+    """src/psnark/tests.rs:14-125 test_consistency: `assert!(elastic_proof == time_proof)`"""
+    from gemini_amd.circuit import R1csStream, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from gemini_amd.psnark import Proof
+    from oracle import snark_ref as sr
+
+    n = 32
+    if kind == "random":
+        inst, tau = _random_instance(pyref, sr, n, 91)
+        r1cs = _device_instance(gm, oracle, inst, n)
+    else:
+        r1cs, tau = dummy_r1cs(424242, n), 31337
+    ck = CommitterKey.new(n * 100 + n, 3, oracle.ints_to_limbs([tau], 4)[0])
+    ck_stream = CommitterKeyStream.from_committer_key(ck)
+    index = Proof.index(ck, r1cs)
+    time_proof = Proof.new_time(ck, r1cs, index)
+    stream = R1csStream(r1cs)
+    elastic_proof = Proof.new_elastic(ck_stream, stream, index, 1 << 20)
+    a, b = time_proof.serialize_compressed(), elastic_proof.serialize_compressed()
+    for f in ("witness_commitment", "z_star_commitment", "sorted_r_commitment", "ralpha_star_acc_mu_proof"):
+        assert (getattr(time_proof, f) == getattr(elastic_proof, f)).all(), f
+    I = gm.fr.fr_to_int
+    assert [(I(x), I(y)) for x, y in time_proof.third_sumcheck_msgs[0]] == [(I(x), I(y)) for x, y in elastic_proof.third_sumcheck_msgs[0]]
+    assert (time_proof.tensorcheck_proof.evaluation_proof == elastic_proof.tensorcheck_proof.evaluation_proof).all()
+    assert a == b
+    # a small MSM buffer changes the chunking only
+    assert Proof.new_elastic(ck_stream, stream, index, 1 << 6).serialize_compressed() == a
+    stream.free()
+    r1cs.free()
