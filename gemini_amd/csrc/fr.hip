@@ -516,13 +516,15 @@ struct SpArgs {
   const uint8_t* wg_lo;  // tensor(challenges)
   const uint8_t* wg_hi;
   uint32_t k, klo;
+  uint32_t le;  // inputs are little-endian partially folded vectors (sp_reduce), not the big-endian streams
   uint32_t tau[8];
   PowTable tau2;
   uint32_t log_threads;
   size_t npairs;
 };
 
-GM_DEV Fr sp_folded(const uint8_t* stream, size_t n, const uint8_t* lo, const uint8_t* hi, uint32_t k, uint32_t klo, size_t m) {
+GM_DEV Fr sp_folded(const uint8_t* stream, size_t n, const uint8_t* lo, const uint8_t* hi, uint32_t k, uint32_t klo, size_t m,
+                    bool le = false) {
   // F[m] over the little-endian view; elements past the end are zero
   const size_t span = (size_t)1 << k;
   const size_t first = m << k;
@@ -532,7 +534,7 @@ GM_DEV Fr sp_folded(const uint8_t* stream, size_t n, const uint8_t* lo, const ui
   const size_t lomask = ((size_t)1 << klo) - 1;
   for (size_t i = first; i < last; i++) {
     const size_t u = i - first;
-    Fr v = fp_load<FrParams>(stream + (n - 1 - i) * FR_BYTES);
+    Fr v = fp_load<FrParams>(stream + (le ? i : n - 1 - i) * FR_BYTES);
     if (k > 0) {
       v = fr_mul(v, fp_load<FrParams>(lo + (u & lomask) * FR_BYTES));
       if (k > klo) v = fr_mul(v, fp_load<FrParams>(hi + (u >> klo) * FR_BYTES));
@@ -555,10 +557,10 @@ __global__ __launch_bounds__(256) void k_sp_message(SpArgs A, uint8_t* __restric
   Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
   if (t < A.npairs) tw = pow_from_table(A.tau2, t);
   for (size_t j = t; j < A.npairs; j += T) {
-    Fr fe = sp_folded(A.f, A.nf, A.wf_lo, A.wf_hi, A.k, A.klo, 2 * j);
-    Fr fo = sp_folded(A.f, A.nf, A.wf_lo, A.wf_hi, A.k, A.klo, 2 * j + 1);
-    Fr ge = sp_folded(A.g, A.ng, A.wg_lo, A.wg_hi, A.k, A.klo, 2 * j);
-    Fr go = sp_folded(A.g, A.ng, A.wg_lo, A.wg_hi, A.k, A.klo, 2 * j + 1);
+    Fr fe = sp_folded(A.f, A.nf, A.wf_lo, A.wf_hi, A.k, A.klo, 2 * j, A.le);
+    Fr fo = sp_folded(A.f, A.nf, A.wf_lo, A.wf_hi, A.k, A.klo, 2 * j + 1, A.le);
+    Fr ge = sp_folded(A.g, A.ng, A.wg_lo, A.wg_hi, A.k, A.klo, 2 * j, A.le);
+    Fr go = sp_folded(A.g, A.ng, A.wg_lo, A.wg_hi, A.k, A.klo, 2 * j + 1, A.le);
     Fr u = fr_mul(fe, tw), w = fr_mul(fo, tw);
     acc[0] = fr_add(acc[0], fr_mul(u, ge));
     acc[1] = fr_add(acc[1], fr_mul(u, go));
@@ -577,9 +579,9 @@ __global__ __launch_bounds__(256) void k_sp_message(SpArgs A, uint8_t* __restric
 // space_prover.rs:269-307) in little-endian order
 __global__ __launch_bounds__(256) void k_sp_materialize(const uint8_t* __restrict__ stream, size_t n, const uint8_t* __restrict__ lo,
                                                         const uint8_t* __restrict__ hi, uint32_t k, uint32_t klo, size_t nout,
-                                                        uint8_t* __restrict__ out) {
+                                                        uint8_t* __restrict__ out, bool le) {
   for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < nout; m += (size_t)gridDim.x * blockDim.x)
-    fp_store<FrParams>(out + m * FR_BYTES, sp_folded(stream, n, lo, hi, k, klo, m));
+    fp_store<FrParams>(out + m * FR_BYTES, sp_folded(stream, n, lo, hi, k, klo, m, le));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -764,30 +766,72 @@ int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has) 
 }
 
 // ---- space prover -------------------------------------------------------------------------------
-static int sp_tables(Context* C, SpaceProver* S, uint32_t* klo_out) {
-  // tensor half tables for the challenges so far: [twisted lo | twisted hi | plain lo | plain hi]
+// The tensor weights factor level by level: with SP_LV challenges per level,
+//   F_k[m] = sum_t W_hi(t) * ( sum_v x[(m 2^(k-SP_LV) + t) 2^SP_LV + v] W_lo(v) ),
+// so a round first folds the streams by groups of SP_LV challenges into short little-endian vectors
+// (one thread per output, 2^SP_LV terms each -- every level has >= n / 2^SP_LV outputs to spread over
+// the GPU) and hands the last <= SP_LV challenges to the message / materialise kernel.  Nothing is kept
+// between rounds: the space prover's state stays the streams and the challenges.
+constexpr uint32_t SP_LV = 8;
+struct SpReduced {
+  const uint8_t *f, *g;  // inputs of the final kernel
+  size_t nf, ng;
+  bool le;
+  uint32_t krem;          // challenges left for the final kernel (tables wf_lo / wg_lo of 2^krem entries)
+};
+static size_t ceil_shift(size_t n, uint32_t k);
+static int sp_reduce(Context* C, SpaceProver* S, SpReduced* R) {
   const uint32_t k = (uint32_t)S->challenges.size() / 4;
-  const uint32_t klo = k < 10 ? k : 10, khi = k - klo;
-  *klo_out = klo;
+  const uint32_t levels = k > SP_LV ? (k - 1) / SP_LV : 0;
+  const uint32_t krem = k - levels * SP_LV;
+  R->f = S->f;
+  R->g = S->g;
+  R->nf = S->nf;
+  R->ng = S->ng;
+  R->le = false;
+  R->krem = krem;
   if (k == 0) return GM_OK;
-  GM_CHECK(khi <= 20, GM_EINVAL, "space prover: %u folds exceed the supported 30 (switch to the time prover, elastic_prover.rs:44-57)", k);
-  const size_t nlo = (size_t)1 << klo, nhi = (size_t)1 << khi;
-  int rc = S->tables.ensure((2 * k * 4 * 8) + 2 * (nlo + nhi) * FR_BYTES + 256);
+  const size_t ntab = (size_t)1 << SP_LV;
+  // layout: [k twisted challenges][k plain challenges][per level: twisted table, plain table][final: twisted, plain]
+  //         [f ping][f pong][g ping][g pong]
+  const size_t f0 = ceil_shift(S->nf, SP_LV), f1 = ceil_shift(S->nf, 2 * SP_LV), g0 = ceil_shift(S->ng, SP_LV), g1 = ceil_shift(S->ng, 2 * SP_LV);
+  const size_t tab_bytes = (size_t)2 * k * 32 + ((size_t)levels + 1) * 2 * ntab * FR_BYTES;
+  int rc = S->tables.ensure(tab_bytes + (f0 + f1 + g0 + g1 + 4) * FR_BYTES + 256);
   if (rc) return rc;
   uint8_t* base = S->tables.as<uint8_t>();
-  uint8_t* ch_t = base;                     // k twisted challenges
-  uint8_t* ch_p = base + (size_t)k * 32;    // k plain challenges
+  uint8_t* ch_t = base;
+  uint8_t* ch_p = base + (size_t)k * 32;
   uint8_t* tabs = base + (size_t)2 * k * 32;
+  uint8_t* bufs = base + tab_bytes;
+  uint8_t* fbuf[2] = {bufs, bufs + f0 * FR_BYTES};
+  uint8_t* gbuf[2] = {bufs + (f0 + f1) * FR_BYTES, bufs + (f0 + f1 + g0) * FR_BYTES};
   GM_HIP(hipMemcpyAsync(ch_t, S->twisted.data(), (size_t)k * 32, hipMemcpyHostToDevice, C->stream));
   GM_HIP(hipMemcpyAsync(ch_p, S->challenges.data(), (size_t)k * 32, hipMemcpyHostToDevice, C->stream));
-  S->wf_lo = tabs;
-  S->wf_hi = tabs + nlo * FR_BYTES;
-  S->wg_lo = tabs + (nlo + nhi) * FR_BYTES;
-  S->wg_hi = tabs + (2 * nlo + nhi) * FR_BYTES;
-  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nlo)), dim3(256), 0, C->stream, (const uint32_t*)ch_t, klo, S->wf_lo);
-  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nhi)), dim3(256), 0, C->stream, (const uint32_t*)(ch_t + (size_t)klo * 32), khi, S->wf_hi);
-  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nlo)), dim3(256), 0, C->stream, (const uint32_t*)ch_p, klo, S->wg_lo);
-  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for(nhi)), dim3(256), 0, C->stream, (const uint32_t*)(ch_p + (size_t)klo * 32), khi, S->wg_hi);
+  for (uint32_t l = 0; l <= levels; l++) {
+    const uint32_t cnt = l < levels ? SP_LV : krem;
+    uint8_t* tt = tabs + (size_t)l * 2 * ntab * FR_BYTES;
+    hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << cnt)), dim3(256), 0, C->stream,
+                       (const uint32_t*)(ch_t + (size_t)l * SP_LV * 32), cnt, tt);
+    hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << cnt)), dim3(256), 0, C->stream,
+                       (const uint32_t*)(ch_p + (size_t)l * SP_LV * 32), cnt, tt + ntab * FR_BYTES);
+  }
+  for (uint32_t l = 0; l < levels; l++) {
+    const uint8_t* tt = tabs + (size_t)l * 2 * ntab * FR_BYTES;
+    const size_t nfo = ceil_shift(R->nf, SP_LV), ngo = ceil_shift(R->ng, SP_LV);
+    hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(nfo, 1u << 20)), dim3(256), 0, C->stream, R->f, R->nf, tt, (const uint8_t*)nullptr, SP_LV,
+                       SP_LV, nfo, fbuf[l & 1], R->le);
+    hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(ngo, 1u << 20)), dim3(256), 0, C->stream, R->g, R->ng, tt + ntab * FR_BYTES,
+                       (const uint8_t*)nullptr, SP_LV, SP_LV, ngo, gbuf[l & 1], R->le);
+    R->f = fbuf[l & 1];
+    R->g = gbuf[l & 1];
+    R->nf = nfo;
+    R->ng = ngo;
+    R->le = true;
+  }
+  const uint8_t* tf = tabs + (size_t)levels * 2 * ntab * FR_BYTES;
+  S->wf_lo = const_cast<uint8_t*>(tf);
+  S->wg_lo = const_cast<uint8_t*>(tf + ntab * FR_BYTES);
+  S->wf_hi = S->wg_hi = nullptr;
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
@@ -851,25 +895,26 @@ int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a_o
     *has_msg = 0;
     return GM_OK;
   }
-  uint32_t klo = 0;
-  int rc = sp_tables(C, S, &klo);
+  SpReduced R;
+  int rc = sp_reduce(C, S, &R);
   if (rc) return rc;
   SpArgs A;
   memset(&A, 0, sizeof A);
-  A.f = S->f;
-  A.g = S->g;
-  A.nf = S->nf;
-  A.ng = S->ng;
+  A.f = R.f;
+  A.g = R.g;
+  A.nf = R.nf;
+  A.ng = R.ng;
+  A.le = R.le ? 1u : 0u;
   A.wf_lo = S->wf_lo;
-  A.wf_hi = S->wf_hi;
+  A.wf_hi = nullptr;
   A.wg_lo = S->wg_lo;
-  A.wg_hi = S->wg_hi;
-  A.k = (uint32_t)S->challenges.size() / 4;
-  A.klo = klo;
+  A.wg_hi = nullptr;
+  A.k = R.krem;
+  A.klo = R.krem;
   gmh::Fr tau = gmh::Fr::from_limbs(S->twist);
   memcpy(A.tau, tau.l, 32);
   make_pow_table(tau.sqr(), A.tau2);
-  const size_t nfk = ceil_shift(S->nf, A.k), ngk = ceil_shift(S->ng, A.k);
+  const size_t nfk = ceil_shift(R.nf, A.k), ngk = ceil_shift(R.ng, A.k);
   const size_t pf = (nfk + 1) / 2, pg = (ngk + 1) / 2;
   A.npairs = pf < pg ? pf : pg;  // the streams are aligned at the low end (space_prover.rs:141-153)
   uint32_t lt = 8;
@@ -895,16 +940,17 @@ int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a_o
 // folded vectors of the current round, little-endian, into fresh pooled buffers
 static int sp_materialize(Context* C, SpaceProver* S, uint8_t** f_out, size_t* nf_out, size_t* fcap, uint8_t** g_out, size_t* ng_out,
                           size_t* gcap) {
-  uint32_t klo = 0;
-  int rc = sp_tables(C, S, &klo);
+  SpReduced R;
+  int rc = sp_reduce(C, S, &R);
   if (rc) return rc;
-  const uint32_t k = (uint32_t)S->challenges.size() / 4;
-  *nf_out = ceil_shift(S->nf, k);
-  *ng_out = ceil_shift(S->ng, k);
+  *nf_out = ceil_shift(R.nf, R.krem);
+  *ng_out = ceil_shift(R.ng, R.krem);
   if ((rc = C->pool.alloc(*nf_out * FR_BYTES, (void**)f_out, fcap))) return rc;
   if ((rc = C->pool.alloc(*ng_out * FR_BYTES, (void**)g_out, gcap))) return rc;
-  hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(*nf_out)), dim3(256), 0, C->stream, S->f, S->nf, S->wf_lo, S->wf_hi, k, klo, *nf_out, *f_out);
-  hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(*ng_out)), dim3(256), 0, C->stream, S->g, S->ng, S->wg_lo, S->wg_hi, k, klo, *ng_out, *g_out);
+  hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(*nf_out, 1u << 20)), dim3(256), 0, C->stream, R.f, R.nf, S->wf_lo, (const uint8_t*)nullptr, R.krem,
+                     R.krem, *nf_out, *f_out, R.le);
+  hipLaunchKernelGGL(k_sp_materialize, dim3(grid_for(*ng_out, 1u << 20)), dim3(256), 0, C->stream, R.g, R.ng, S->wg_lo, (const uint8_t*)nullptr, R.krem,
+                     R.krem, *ng_out, *g_out, R.le);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;

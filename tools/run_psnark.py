@@ -32,7 +32,8 @@ def main():
     r1cs = dummy_r1cs(rnd(), n)
     t0 = time.perf_counter()
     tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
-    ck = CommitterKey.new(2 * n, 5, tau)
+    # examples/psnark.rs: time main num_constraints + num_variables powers (:76), elastic main 3 * instance_size + 1 (:62)
+    ck = CommitterKey.new(3 * n if args.elastic else 2 * n, 5, tau)
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
     index = Proof.index(ck, r1cs)
