@@ -220,6 +220,33 @@ def main():
         for v in vecs:
             v.free()
         lib.gm_set_msm_table_min(C.c_size_t(1 << 17))
+    # extra (never `value`): the same MSM when the boundary hands over HOST buffers -- scalars only (SRS resident,
+    # gm_g1_msm_h: 32 MiB over PCIe per call) and the one-shot gm_g1_msm (bases 96 MiB + scalars 32 MiB per call)
+    pcie = None
+    if world == 1:
+        from gemini_amd.msm import VariableBaseMSM
+
+        hb_full = bases.download()
+        r_h = bases.msm_bigint(host_scalars[0])
+        assert (r_h == results[0]).all()
+        barrier()
+        tp0 = time.perf_counter()
+        for i in range(5):
+            bases.msm_bigint(host_scalars[i & 1])
+        barrier()
+        t_h = (time.perf_counter() - tp0) / 5
+        r_o = VariableBaseMSM.msm_bigint(hb_full, host_scalars[0])
+        assert (r_o == results[0]).all()
+        barrier()
+        tp0 = time.perf_counter()
+        for i in range(3):
+            VariableBaseMSM.msm_bigint(hb_full, host_scalars[i & 1])
+        barrier()
+        t_o = (time.perf_counter() - tp0) / 3
+        pcie = {"scalars_from_host_Mscalar_per_s": round(n / t_h / 1e6, 2), "scalars_from_host_ms": round(t_h * 1e3, 3),
+                "bases_and_scalars_from_host_Mscalar_per_s": round(n / t_o / 1e6, 2), "bases_and_scalars_from_host_ms": round(t_o * 1e3, 3),
+                "note": "pageable numpy buffers; PCIe-inclusive, reported for DESIGN.md only"}
+        del hb_full
     stage_names = ["digits_hist", "scan", "scatter", "acc0", "merge", "reduce", "sc_round"]
     stages = {k: (ms[i] / cnt[i] if cnt[i] else None) for i, k in enumerate(stage_names)}
 
@@ -294,6 +321,8 @@ def main():
             out["with_fixed_base_tables"] = tables
         if batch:
             out["batch_commit_pipelined"] = batch
+        if pcie:
+            out["pcie_inclusive"] = pcie
         if world == 1 and args.snark_logn > 0:
             out["time_prover"] = snark_time_prover(gm, args.snark_logn)
         print(json.dumps(out))
