@@ -248,7 +248,8 @@ void gm_shutdown(void) {
   }
   MsmWorkspace& w = C->msm;
   for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.tmp_entries, &w.sortmeta, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
-                    &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc})
+                    &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc, &w.lvl_cnt, &w.lvl_pos, &w.lvl_pts[0], &w.lvl_pts[1], &w.lvl_keys[0],
+                    &w.lvl_keys[1], &w.lvl_prefix, &w.lvl_lane, &w.lvl_entries, &w.lvl_n})
     b->release();
   for (int k = 0; k < 2; k++)
     if (w.host_planes[k]) (void)hipHostFree(w.host_planes[k]);
@@ -293,6 +294,13 @@ int gm_set_msm_window(int c) {
   GM_CTX();
   GM_CHECK(c == 0 || (c >= 2 && c <= 22), GM_EINVAL, "gm_set_msm_window: c = %d not in {0} u [2, 22]", c);
   C->msm_c_override = c;
+  return GM_OK;
+}
+
+int gm_set_msm_affine_levels(int levels) {
+  GM_CTX();
+  GM_CHECK(levels >= -1 && levels <= 8, GM_EINVAL, "gm_set_msm_affine_levels: %d not in [-1, 8]", levels);
+  C->msm_affine_levels = levels;
   return GM_OK;
 }
 

@@ -125,6 +125,7 @@ struct HerringG1 {
 
 struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
+  DevBuf lvl_cnt, lvl_pos, lvl_pts[2], lvl_keys[2], lvl_prefix, lvl_lane, lvl_entries, lvl_n;  // affine tree levels
   uint64_t* host_planes[2] = {nullptr, nullptr};  // pinned staging for the D2H of window bit-planes (two calls in flight)
   size_t host_planes_cap[2] = {0, 0};
   hipEvent_t done_ev[2];
@@ -176,6 +177,7 @@ struct Context {
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
   int msm_c_override = 0;
+  int msm_affine_levels = 0;  // affine tree levels in front of the XYZZ accumulation; -1 = automatic
   size_t msm_table_min = (size_t)1 << 17;  // smallest MSM that uses fixed-base tables when present
   int cu_count = 256;
 };

@@ -416,6 +416,235 @@ __global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entri
 }
 
 // ------------------------------------------------------------------------------------------
+// Affine tree levels (optional, gm_set_msm_affine_levels): before the XYZZ accumulation, neighbours
+// of the sorted list that fall into the same bucket are added pairwise in AFFINE coordinates, level
+// by level, with ONE field inversion per level shared by all pairs (Montgomery's trick): an affine
+// addition is then 1 product (running prefix) + 2 (inverse hand-back) + 3 (lambda, x3, y3) = 6
+// products instead of the 10 of an XYZZ mixed addition.  Pair u of a level is (in[2u], in[2u+1]); if
+// the keys differ (a bucket boundary) both elements are copied through, so the list stays sorted and
+// every level roughly halves deep buckets.  After a few levels k_acc0 / k_merge finish on short lists.
+//   count   out-slots per pair (1 merged / 2 copied) + the exclusive scan -> output positions
+//   pass A  lane-strided over the pairs: denominator x2 - x1 (only the x coordinates are read), the
+//           lane's running product stored per pair, lane totals
+//   pass B  prefix / suffix products of the lane totals (two block levels); the grand total is
+//           inverted on the host (one Fq inversion ~ 30 us on a CPU core; ~1 ms on a lone GPU lane)
+//   pass C  lanes walk their pairs backwards handing out 1/d, do the affine additions, write the next
+//           level (points + keys; on the last level the entry list k_acc0 consumes)
+// Exceptional pairs (an identity operand, P + P, P - P) are rare and take a slow path: P + P uses the
+// denominator 2y (y != 0: the curve has no 2-torsion), the others need no inverse.
+// ------------------------------------------------------------------------------------------
+struct LvlArgs {
+  const uint32_t* n_in;     // device: number of input elements (level 1: the entry count)
+  const uint64_t* entries;  // first level: sorted entries + bases
+  const uint8_t* bases;
+  long long first, step, tab_stride;
+  const uint8_t* pin;       // later levels: affine points + keys of the previous level
+  const uint32_t* kin;
+  uint32_t npairs_bound;    // host-side bound on ceil(n_in / 2)
+  uint32_t T;               // lanes in the grid
+  const uint32_t* outpos;   // exclusive scan of the per-pair output counts (npairs_bound + 1 entries)
+  uint8_t* pout;
+  uint32_t* kout;
+  uint64_t* entries_out;    // last level: key << 32 | slot
+  uint8_t* prefix;          // 48 B per pair: the lane's running product after the pair
+  uint8_t* lane_tot;        // pass A out
+  const uint8_t* lane_inv;  // pass C in
+};
+constexpr int FQ_BYTES = 48;
+
+template <bool FIRST>
+GM_DEV uint32_t lvl_key(const LvlArgs& A, uint32_t i) {
+  return FIRST ? (uint32_t)(A.entries[i] >> 32) : A.kin[i];
+}
+template <bool FIRST>
+GM_DEV const uint8_t* lvl_ptr(const LvlArgs& A, uint32_t i, bool* negate) {
+  if (FIRST) {
+    const uint64_t e = A.entries[i];
+    long long idx;
+    if (A.tab_stride) {
+      const uint32_t lo = (uint32_t)e & 0x7fffffffu;
+      idx = (long long)(lo >> ENTRY_W_SHIFT) * A.tab_stride + A.first + A.step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
+    } else {
+      idx = A.first + A.step * (long long)(e & 0x7fffffffull);
+    }
+    *negate = ((e >> 31) & 1ull) != 0;
+    return A.bases + (size_t)idx * AFF_BYTES;
+  }
+  *negate = false;
+  return A.pin + (size_t)i * AFF_BYTES;
+}
+GM_DEV G1Affine lvl_point(const uint8_t* ptr, bool negate) {
+  G1Affine p = g1_load_affine(ptr);
+  if (negate) p.y = fq_neg_canonical(p.y);
+  return p;
+}
+// 0: result = p, 1: result = q, 2: result = identity, 3: chord (d = x1 - x0), 4: tangent (d = 2 y0).
+// The common case (distinct non-zero x) is decided from the x coordinates alone; only equal or zero x
+// coordinates load the y's.  Passes A and C call this with the same inputs, so they agree.
+GM_DEV int lvl_mode(const FqE& x0, const FqE& x1, const uint8_t* p0, bool n0, const uint8_t* p1, bool n1, FqE& d) {
+  d = fq_sub<1>(x1, x0);
+  const bool dz = fq_is_zero_mod(d);
+  if (!dz && !fq_is_exact_zero(x0) && !fq_is_exact_zero(x1)) return 3;
+  const G1Affine p = lvl_point(p0, n0), q = lvl_point(p1, n1);
+  if (q.is_identity()) return 0;
+  if (p.is_identity()) return 1;
+  if (!dz) return 3;  // x = 0 on a real point
+  const FqE sy = fq_add(p.y, q.y);
+  if (fq_is_zero_mod(sy)) return 2;
+  d = sy;
+  return 4;
+}
+
+// out-slots per pair: 1 if the two elements share a bucket (or the list ends on a single), else 2
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_lvl_count(LvlArgs A, uint32_t* __restrict__ cnt) {
+  const uint32_t n = *A.n_in;
+  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= A.npairs_bound; u += gridDim.x * blockDim.x) {
+    const uint32_t i0 = 2u * u;
+    uint32_t c = 0;
+    if (u < A.npairs_bound && i0 < n) c = (i0 + 1u < n && lvl_key<FIRST>(A, i0) != lvl_key<FIRST>(A, i0 + 1u)) ? 2u : 1u;
+    cnt[u] = c;
+  }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_lvl_a(LvlArgs A) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = *A.n_in;
+  const uint32_t npairs = (n + 1u) >> 1;
+  FqE run = fqe_one();
+  for (uint64_t u64 = lane; u64 < npairs; u64 += A.T) {
+    const uint32_t u = (uint32_t)u64, i0 = 2u * u;
+    if (i0 + 1u < n && lvl_key<FIRST>(A, i0) == lvl_key<FIRST>(A, i0 + 1u)) {
+      bool n0, n1;
+      const uint8_t* p0 = lvl_ptr<FIRST>(A, i0, &n0);
+      const uint8_t* p1 = lvl_ptr<FIRST>(A, i0 + 1u, &n1);
+      const FqE x0 = fqe_load(p0), x1 = fqe_load(p1);
+      FqE d;
+      if (lvl_mode(x0, x1, p0, n0, p1, n1, d) >= 3) run = fq_mul(run, d);
+    }
+    fqe_store(A.prefix + (size_t)u * FQ_BYTES, run);
+  }
+  fqe_store(A.lane_tot + (size_t)lane * FQ_BYTES, run);
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_lvl_c(LvlArgs A) {
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = *A.n_in;
+  const uint32_t npairs = (n + 1u) >> 1;
+  if (lane >= npairs) return;
+  FqE inv_run = fqe_load(A.lane_inv + (size_t)lane * FQ_BYTES);
+  uint32_t u = lane + ((npairs - 1u - lane) / A.T) * A.T;  // the lane's last pair
+  for (;;) {
+    const uint32_t i0 = 2u * u, o = A.outpos[u];
+    const uint32_t k0 = lvl_key<FIRST>(A, i0);
+    bool n0, n1 = false;
+    const uint8_t* p0 = lvl_ptr<FIRST>(A, i0, &n0);
+    const bool second = i0 + 1u < n;
+    const uint32_t k1 = second ? lvl_key<FIRST>(A, i0 + 1u) : KEY_INV;
+    const uint8_t* p1 = second ? lvl_ptr<FIRST>(A, i0 + 1u, &n1) : p0;
+    if (second && k1 == k0) {
+      const FqE x0 = fqe_load(p0), x1 = fqe_load(p1);
+      FqE d;
+      const int mode = lvl_mode(x0, x1, p0, n0, p1, n1, d);
+      G1Affine r;
+      if (mode >= 3) {
+        FqE inv_d = inv_run;
+        if (u != lane) inv_d = fq_mul(inv_run, fqe_load(A.prefix + (size_t)(u - A.T) * FQ_BYTES));
+        inv_run = fq_mul(inv_run, d);
+        FqE y0 = fqe_load(p0 + 48);
+        if (n0) y0 = fq_neg_canonical(y0);
+        FqE num;
+        if (mode == 3) {
+          FqE y1 = fqe_load(p1 + 48);
+          if (n1) y1 = fq_neg_canonical(y1);
+          num = fq_sub<1>(y1, y0);
+        } else {
+          const FqE xx = fq_sqr(x0);
+          num = fq_add(fq_dbl(xx), xx);
+        }
+        const FqE lam = fq_mul(num, inv_d);
+        r.x = fq_sub<1>(fq_sub<1>(fq_sqr(lam), x0), x1);
+        r.y = fq_sub<1>(fq_mul(lam, fq_sub<1>(x0, r.x)), y0);
+      } else if (mode == 0) {
+        r = lvl_point(p0, n0);
+      } else if (mode == 1) {
+        r = lvl_point(p1, n1);
+      } else {
+        r.x = fqe_zero();
+        r.y = fqe_zero();
+      }
+      g1_store_affine(A.pout + (size_t)o * AFF_BYTES, r);
+      if (A.entries_out) A.entries_out[o] = ((uint64_t)k0 << 32) | (uint64_t)o;
+      else A.kout[o] = k0;
+    } else {
+      g1_store_affine(A.pout + (size_t)o * AFF_BYTES, lvl_point(p0, n0));
+      if (A.entries_out) A.entries_out[o] = ((uint64_t)k0 << 32) | (uint64_t)o;
+      else A.kout[o] = k0;
+      if (second) {
+        g1_store_affine(A.pout + (size_t)(o + 1u) * AFF_BYTES, lvl_point(p1, n1));
+        if (A.entries_out) A.entries_out[o + 1u] = ((uint64_t)k1 << 32) | (uint64_t)(o + 1u);
+        else A.kout[o + 1u] = k1;
+      }
+    }
+    if (u == lane) break;
+    u -= A.T;
+  }
+}
+
+// pass B: exclusive prefix and suffix products of n values inside blocks of 512, plus the block products
+__global__ __launch_bounds__(512) void k_lvl_b(const uint8_t* __restrict__ vals, uint32_t n, uint8_t* __restrict__ pre_excl,
+                                               uint8_t* __restrict__ suf_excl, uint8_t* __restrict__ blk_tot) {
+  __shared__ __attribute__((aligned(16))) uint8_t sh[512 * FQ_BYTES];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * 512u + tid;
+  const FqE v0 = i < n ? fqe_load(vals + (size_t)i * FQ_BYTES) : fqe_one();
+  // inclusive prefix
+  FqE v = v0;
+  for (uint32_t dlt = 1; dlt < 512; dlt <<= 1) {
+    fqe_store(sh + tid * FQ_BYTES, v);
+    __syncthreads();
+    const FqE o = tid >= dlt ? fqe_load(sh + (tid - dlt) * FQ_BYTES) : fqe_one();
+    __syncthreads();
+    v = fq_mul(v, o);
+  }
+  fqe_store(sh + tid * FQ_BYTES, v);
+  __syncthreads();
+  const FqE pe = tid ? fqe_load(sh + (tid - 1) * FQ_BYTES) : fqe_one();
+  if (tid == 511) fqe_store(blk_tot + (size_t)blockIdx.x * FQ_BYTES, v);
+  __syncthreads();
+  // inclusive suffix
+  v = v0;
+  for (uint32_t dlt = 1; dlt < 512; dlt <<= 1) {
+    fqe_store(sh + tid * FQ_BYTES, v);
+    __syncthreads();
+    const FqE o = tid + dlt < 512 ? fqe_load(sh + (tid + dlt) * FQ_BYTES) : fqe_one();
+    __syncthreads();
+    v = fq_mul(v, o);
+  }
+  fqe_store(sh + tid * FQ_BYTES, v);
+  __syncthreads();
+  const FqE se = tid + 1 < 512 ? fqe_load(sh + (tid + 1) * FQ_BYTES) : fqe_one();
+  if (i < n) {
+    fqe_store(pre_excl + (size_t)i * FQ_BYTES, pe);
+    fqe_store(suf_excl + (size_t)i * FQ_BYTES, se);
+  }
+}
+// 1 / T_l = (1 / prod of all) * (everything before l) * (everything after l)
+__global__ __launch_bounds__(256) void k_lvl_b3(uint32_t n, const uint8_t* __restrict__ inv_total, const uint8_t* __restrict__ pre_loc,
+                                                const uint8_t* __restrict__ suf_loc, const uint8_t* __restrict__ pre_blk,
+                                                const uint8_t* __restrict__ suf_blk, uint8_t* __restrict__ lane_inv) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t blk = i >> 9;
+  FqE r = fq_mul(fqe_load(inv_total), fqe_load(pre_loc + (size_t)i * FQ_BYTES));
+  r = fq_mul(r, fqe_load(suf_loc + (size_t)i * FQ_BYTES));
+  r = fq_mul(r, fqe_load(pre_blk + (size_t)blk * FQ_BYTES));
+  r = fq_mul(r, fqe_load(suf_blk + (size_t)blk * FQ_BYTES));
+  fqe_store(lane_inv + (size_t)i * FQ_BYTES, r);
+}
+
+// ------------------------------------------------------------------------------------------
 // merge levels: one wave reduces 128 keyed slots (sorted by key, holes allowed) to <= 2
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_in, const uint8_t* __restrict__ pts_in,
@@ -888,11 +1117,23 @@ static int msm_enqueue(Context* C, const Bases* bases, int64_t first, int64_t st
   const uint64_t N = (uint64_t)n * (uint64_t)W;
   GM_CHECK(N < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)N);
 
+  // affine tree levels in front of the XYZZ accumulation (see k_lvl_*): automatic = as many as leave ~4
+  // entries per bucket, none for small calls where the per-level round trip to the host costs more
+  int levels = C->msm_affine_levels;
+  if (levels < 0) {
+    levels = 0;
+    if (N >= ((uint64_t)1 << 22))
+      for (uint64_t avg = N / nbuckets; avg >= 8 && levels < 6; avg >>= 1) levels++;
+  }
+  GM_CHECK(levels <= 8, GM_EINVAL, "msm: %d affine levels (max 8)", levels);
+  uint64_t Nacc = N;  // upper bound on the entries k_acc0 sees: every level maps m -> ceil(m / 2) per bucket
+  for (int l = 0; l < levels; l++) Nacc = Nacc / 2 + 2 * nbuckets + 2;
+
   // level-0 chunk length: keep >= 2 waves per SIMD when the problem is large enough
   static const int L_env = getenv("GM_MSM_L") ? atoi(getenv("GM_MSM_L")) : 0;  // tuning override
-  uint32_t L = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(4, (N + 131071) / 131072));
+  uint32_t L = (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(4, (Nacc + 131071) / 131072));
   if (L_env > 0) L = (uint32_t)L_env;
-  const uint64_t T0 = (N + L - 1) / L;
+  const uint64_t T0 = (Nacc + L - 1) / L;
   const uint64_t T0pad = (T0 + 255) / 256 * 256;
   const uint64_t E1 = 2 * T0pad;
 
@@ -968,10 +1209,104 @@ static int msm_enqueue(Context* C, const Bases* bases, int64_t first, int64_t st
                        ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
     pf.end(PROF_SCATTER, st);
   }
+  const uint64_t* acc_entries = ws.entries.as<uint64_t>();
+  const uint32_t* acc_total = ws.offsets.as<uint32_t>() + nbuckets;
+  const uint8_t* acc_bases = d_bases;
+  long long acc_first = (long long)first, acc_step = (long long)step, acc_tab = tab_stride;
+  if (levels > 0) {
+    pf.begin(PROF_SCAN, st);
+    const uint32_t T = 1u << 18;  // lanes of passes A / C; pass B handles T / 512 <= 512 block products
+    // bounds per level: a level maps a bucket of m elements to at most m / 2 + 1.5 elements
+    uint64_t bnd[10];
+    bnd[0] = N;
+    for (int l = 0; l < levels; l++) bnd[l + 1] = bnd[l] / 2 + 2 * nbuckets + 2;
+    if ((rc = ws.lvl_pts[0].ensure(bnd[1] * AFF_BYTES))) return rc;
+    if (levels > 1 && (rc = ws.lvl_pts[1].ensure(bnd[2] * AFF_BYTES))) return rc;
+    if ((rc = ws.lvl_keys[0].ensure(bnd[1] * 4))) return rc;
+    if (levels > 1 && (rc = ws.lvl_keys[1].ensure(bnd[2] * 4))) return rc;
+    const uint64_t np0 = (bnd[0] + 1) / 2;
+    if ((rc = ws.lvl_prefix.ensure(np0 * FQ_BYTES))) return rc;
+    if ((rc = ws.lvl_cnt.ensure((np0 + 1) * 4))) return rc;
+    if ((rc = ws.lvl_pos.ensure((np0 + 2) * 4))) return rc;
+    if ((rc = ws.lvl_entries.ensure(bnd[levels] * 8))) return rc;
+    if ((rc = ws.lvl_lane.ensure(((size_t)4 * T + 3 * 512 + 8) * FQ_BYTES))) return rc;
+    if ((rc = ws.lvl_n.ensure(64))) return rc;
+    if ((rc = ws.misc.ensure((np0 / SCAN_PER_BLOCK + 4) * 4))) return rc;
+    uint8_t* lane_tot = ws.lvl_lane.as<uint8_t>();
+    uint8_t* lane_pre = lane_tot + (size_t)T * FQ_BYTES;
+    uint8_t* lane_suf = lane_pre + (size_t)T * FQ_BYTES;
+    uint8_t* lane_inv = lane_suf + (size_t)T * FQ_BYTES;
+    uint8_t* blk_tot = lane_inv + (size_t)T * FQ_BYTES;
+    uint8_t* blk_pre = blk_tot + 512 * FQ_BYTES;
+    uint8_t* blk_suf = blk_pre + 512 * FQ_BYTES;
+    uint8_t* grand = blk_suf + 512 * FQ_BYTES;  // the inverse of the product of everything
+    uint8_t* grand_tot = grand + FQ_BYTES;       // that product
+    const uint32_t* n_in = ws.offsets.as<uint32_t>() + nbuckets;  // the entry count left by the sort's scan
+    const uint8_t* pin = nullptr;
+    const uint32_t* kin = nullptr;
+    for (int l = 0; l < levels; l++) {
+      const uint32_t npb = (uint32_t)((bnd[l] + 1) / 2);
+      uint32_t* cnt = ws.lvl_cnt.as<uint32_t>();
+      uint32_t* pos = ws.lvl_pos.as<uint32_t>();
+      LvlArgs A{};
+      A.n_in = n_in;
+      A.entries = ws.entries.as<uint64_t>();
+      A.bases = d_bases;
+      A.first = (long long)first;
+      A.step = (long long)step;
+      A.tab_stride = tab_stride;
+      A.pin = pin;
+      A.kin = kin;
+      A.npairs_bound = npb;
+      A.T = T;
+      A.outpos = pos;
+      A.pout = ws.lvl_pts[l & 1].as<uint8_t>();
+      A.kout = ws.lvl_keys[l & 1].as<uint32_t>();
+      A.entries_out = l == levels - 1 ? ws.lvl_entries.as<uint64_t>() : nullptr;
+      A.prefix = ws.lvl_prefix.as<uint8_t>();
+      A.lane_tot = lane_tot;
+      A.lane_inv = lane_inv;
+      const uint32_t cb = (uint32_t)std::min<uint64_t>(2048, (npb + 256) / 256);
+      const uint32_t sb = (npb + 1 + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+      if (l == 0) hipLaunchKernelGGL(k_lvl_count<true>, dim3(cb), dim3(256), 0, st, A, cnt);
+      else hipLaunchKernelGGL(k_lvl_count<false>, dim3(cb), dim3(256), 0, st, A, cnt);
+      // exclusive scan of cnt[0 .. npb] (cnt[npb] = 0) -> pos; pos[npb] = the level's output count
+      hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, st, cnt, npb + 1, ws.misc.as<uint32_t>());
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, ws.misc.as<uint32_t>(), sb, pos + npb + 1);
+      hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, st, cnt, npb + 1, ws.misc.as<uint32_t>(), pos, pos);
+      if (l == 0) hipLaunchKernelGGL(k_lvl_a<true>, dim3(T / 256), dim3(256), 0, st, A);
+      else hipLaunchKernelGGL(k_lvl_a<false>, dim3(T / 256), dim3(256), 0, st, A);
+      hipLaunchKernelGGL(k_lvl_b, dim3(T / 512), dim3(512), 0, st, lane_tot, T, lane_pre, lane_suf, blk_tot);
+      hipLaunchKernelGGL(k_lvl_b, dim3(1), dim3(512), 0, st, blk_tot, T / 512, blk_pre, blk_suf, grand_tot);
+      GM_HIP(hipGetLastError());
+      uint64_t* hs = C->host_small;
+      GM_HIP(hipMemcpyAsync(hs, grand_tot, FQ_BYTES, hipMemcpyDeviceToHost, st));
+      GM_HIP(hipStreamSynchronize(st));
+      gmh::Fq tot = gmh::Fq::from_limbs(hs);
+      GM_CHECK(!tot.is_zero(), GM_ESTATE, "msm: zero denominator product in an affine level");
+      tot.inv().to_limbs(hs + 8);
+      GM_HIP(hipMemcpyAsync(grand, hs + 8, FQ_BYTES, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_lvl_b3, dim3(T / 256), dim3(256), 0, st, T, grand, lane_pre, lane_suf, blk_pre, blk_suf, lane_inv);
+      if (l == 0) hipLaunchKernelGGL(k_lvl_c<true>, dim3(T / 256), dim3(256), 0, st, A);
+      else hipLaunchKernelGGL(k_lvl_c<false>, dim3(T / 256), dim3(256), 0, st, A);
+      // the next level's element count lives behind the scan output; copy it next to nothing else that
+      // the next scan overwrites
+      GM_HIP(hipMemcpyAsync(ws.lvl_n.as<uint32_t>() + (l & 1), pos + npb, 4, hipMemcpyDeviceToDevice, st));
+      n_in = ws.lvl_n.as<uint32_t>() + (l & 1);
+      pin = A.pout;
+      kin = A.kout;
+    }
+    acc_entries = ws.lvl_entries.as<uint64_t>();
+    acc_total = n_in;
+    acc_bases = pin;
+    acc_first = 0;
+    acc_step = 1;
+    acc_tab = 0;
+    pf.end(PROF_SCAN, st);
+  }
   pf.begin(PROF_ACC0, st);
-  hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, ws.entries.as<uint64_t>(),
-                     ws.offsets.as<uint32_t>() + nbuckets, d_bases, (long long)first, (long long)step, tab_stride, L,
-                     ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
+  hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+                     acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
   pf.end(PROF_ACC0, st);
   pf.begin(PROF_MERGE, st);
   {

@@ -120,6 +120,10 @@ int gm_set_msm_window(int c);
 /* Smallest pair count for which an MSM uses the fixed-base tables of its handle (default 2^17:
  * below that the MSM is latency-bound and few buckets win).  Tuning/test knob. */
 int gm_set_msm_table_min(size_t n);
+/* Affine tree levels in front of the XYZZ bucket accumulation (0 = none, -1 = automatic, <= 8): every
+ * level adds the sorted entries of each bucket pairwise in affine coordinates with one shared field
+ * inversion (6 instead of 10 field products per addition).  The result does not depend on it. */
+int gm_set_msm_affine_levels(int levels);
 
 /* Per-stage device timing (HIP events on the library's stream).  Stages, in order:
  * 0 digits+histogram, 1 scan, 2 scatter, 3 bucket accumulate (k_acc0), 4 partial merge,

@@ -302,3 +302,76 @@ def test_batch_msm_equals_single_calls(gm, oracle):
     for v in vecs:
         v.free()
     b.free()
+
+
+def _set_levels(gm, k):
+    import ctypes as C
+
+    gm.capi.check(gm.capi.load().gm_set_msm_affine_levels(C.c_int(k)))
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 5])
+def test_affine_levels_same_results(gm, oracle, levels):
+    """gm_set_msm_affine_levels: pairwise affine additions with one shared inversion per level in front of
+    the XYZZ accumulation -- the result cannot depend on it.  Inputs hit every exceptional pair: repeated
+    bases (P + P), P and -P in one bucket, identity bases, all-equal scalars (one bucket per window), zero
+    scalars, and sizes around the lane count."""
+    rng = np.random.default_rng(levels)
+    cases = []
+    n = 3000
+    bases = rand_bases(oracle, 51, n)
+    sc = oracle.random_fr(52, n)
+    cases.append((bases, sc))
+    b2 = bases.copy()
+    b2[100:200] = bases[7]  # the same point many times
+    b2[300] = 0  # identity
+    b2[301] = 0
+    s2 = sc.copy()
+    s2[100:200] = sc[100]  # same scalar on the same point: P + P at every level
+    s2[400:500] = 0
+    neg = oracle.limbs_to_ints(sc[600:601])[0]
+    s2[601] = oracle.ints_to_limbs([(0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001 - neg)], 4)[0]
+    b2[601] = b2[600]  # k*P + (r-k)*P: digits cancel bucket-wise in places
+    cases.append((b2, s2))
+    s3 = np.tile(sc[5], (n, 1))  # the reference's benchmark instance: every pair in the same buckets
+    cases.append((bases, s3))
+    b4 = np.tile(bases[9], (n, 1))
+    cases.append((b4, s3))  # one point, one scalar: only doublings
+    cases.append((bases[:1], sc[:1]))
+    cases.append((bases[:2], s3[:2]))
+    try:
+        for c in (0, 5):
+            _set_window(gm, c)
+            for bs, ss in cases:
+                _set_levels(gm, 0)
+                want = gm.VariableBaseMSM.msm_bigint(bs, ss)
+                _set_levels(gm, levels)
+                got = gm.VariableBaseMSM.msm_bigint(bs, ss)
+                assert (got == want).all()
+        _set_window(gm, 0)
+        exp = oracle.msm_pippenger(cases[1][0], cases[1][1])
+        assert_same_point(oracle, gm.VariableBaseMSM.msm_bigint(cases[1][0], cases[1][1]), exp)
+    finally:
+        _set_levels(gm, 0)
+        _set_window(gm, 0)
+
+
+def test_affine_levels_large(gm, oracle):
+    """2^18 pairs, automatic and fixed level counts against the plain path, also with fixed-base tables"""
+    n = 1 << 18
+    ks = oracle.random_fr(61, n)
+    b = gm.G1Bases.fixed_base(oracle.g1_generator(), ks)
+    sc = oracle.random_fr(62, n)
+    try:
+        _set_levels(gm, 0)
+        want = b.msm_bigint(sc)
+        for lv in (1, 3, 4):
+            _set_levels(gm, lv)
+            assert (b.msm_bigint(sc) == want).all(), lv
+        b.precompute(0)
+        for lv in (0, 2):
+            _set_levels(gm, lv)
+            assert (b.msm_bigint(sc) == want).all(), ("tables", lv)
+    finally:
+        _set_levels(gm, 0)
+        b.free()
