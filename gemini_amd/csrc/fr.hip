@@ -348,19 +348,7 @@ __global__ __launch_bounds__(256) void k_div_phase2a(uint8_t* __restrict__ sums,
   }
   fp_store<FrParams>(seg_sums + s * FR_BYTES, acc);
 }
-// sequential over segments (one thread): carry[s] = value flowing INTO segment s from above
-__global__ void k_div_phase2b(const uint8_t* __restrict__ seg_sums, size_t nseg, size_t seg, size_t nch, PowTable mt,
-                              uint8_t* __restrict__ carry) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Fr acc = Fr::zero();
-  Fr mseg = pow_from_table(mt, seg);
-  for (size_t s = nseg; s-- > 0;) {
-    fp_store<FrParams>(carry + s * FR_BYTES, acc);
-    const size_t len = min(seg, nch - s * seg);
-    Fr mm = len == seg ? mseg : pow_from_table(mt, len);
-    acc = fr_add(fr_mul(acc, mm), fp_load<FrParams>(seg_sums + s * FR_BYTES));
-  }
-}
+// (the sequential combine over the few segment sums runs on the host, see fr_div_linear_factors)
 // phase 3: q_i for i in chunk c.  S_{c+1} = local suffix of chunk c+1 within its segment
 // + m^(chunks remaining in that segment) * carry[segment]
 __global__ __launch_bounds__(256) void k_div_phase3(const uint8_t* __restrict__ f, size_t n, const uint32_t* __restrict__ alpha8,
