@@ -219,6 +219,7 @@ int gm_init(int device) {
   GM_HIP(hipGetDeviceProperties(&prop, device));
   C->cu_count = prop.multiProcessorCount;
   GM_HIP(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
+  for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithFlags(&C->small_stream[k], hipStreamNonBlocking));
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
   g_ctx = C;
   return GM_OK;
@@ -246,18 +247,23 @@ void gm_shutdown(void) {
     if (kv.second->cols) (void)hipFree(kv.second->cols);
     if (kv.second->vals) (void)hipFree(kv.second->vals);
   }
-  MsmWorkspace& w = C->msm;
-  for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.tmp_entries, &w.sortmeta, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
-                    &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc, &w.lvl_cnt, &w.lvl_pos, &w.lvl_pts[0], &w.lvl_pts[1], &w.lvl_keys[0],
-                    &w.lvl_keys[1], &w.lvl_prefix, &w.lvl_lane, &w.lvl_entries, &w.lvl_n})
-    b->release();
-  for (int k = 0; k < 2; k++)
-    if (w.host_planes[k]) (void)hipHostFree(w.host_planes[k]);
-  if (w.have_done_ev) {
-    (void)hipEventDestroy(w.done_ev[0]);
-    (void)hipEventDestroy(w.done_ev[1]);
+  auto release_ws = [](MsmWorkspace& w) {
+    for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.tmp_entries, &w.sortmeta, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
+                      &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc, &w.lvl_cnt, &w.lvl_pos, &w.lvl_pts[0], &w.lvl_pts[1], &w.lvl_keys[0],
+                      &w.lvl_keys[1], &w.lvl_prefix, &w.lvl_lane, &w.lvl_entries, &w.lvl_n})
+      b->release();
+    for (int k = 0; k < 2; k++)
+      if (w.host_planes[k]) (void)hipHostFree(w.host_planes[k]);
+    if (w.have_done_ev) {
+      (void)hipEventDestroy(w.done_ev[0]);
+      (void)hipEventDestroy(w.done_ev[1]);
+    }
+  };
+  release_ws(C->msm);
+  for (int k = 0; k < MSM_SMALL_LANES; k++) {
+    release_ws(C->msm_small[k]);
+    if (C->small_stream[k]) (void)hipStreamDestroy(C->small_stream[k]);
   }
-  C->fr_scratch.release();
   if (C->host_small) (void)hipHostFree(C->host_small);
   (void)hipStreamDestroy(C->stream);
   delete C;

@@ -123,6 +123,7 @@ struct HerringG1 {
   std::mutex mu;
 };
 
+constexpr int MSM_SMALL_LANES = 4;
 struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
   DevBuf lvl_cnt, lvl_pos, lvl_pts[2], lvl_keys[2], lvl_prefix, lvl_lane, lvl_entries, lvl_n;  // affine tree levels
@@ -174,6 +175,9 @@ struct Context {
   std::unordered_map<uint64_t, std::unique_ptr<HerringG1>> herring_g1;
   std::unordered_map<uint64_t, std::unique_ptr<IdxVec>> indices;
   MsmWorkspace msm;
+  // extra workspaces + streams for the small calls of a batch (msm_run_batch)
+  MsmWorkspace msm_small[MSM_SMALL_LANES];
+  hipStream_t small_stream[MSM_SMALL_LANES] = {};
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
   int msm_c_override = 0;

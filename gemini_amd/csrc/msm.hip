@@ -1019,14 +1019,15 @@ static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t st
 // wait) and a finish (wait for the copy, Horner over the bit positions on the host).  Splitting them lets
 // a batch of MSMs overlap the host tail of call i with the kernels of call i+1 (msm_run_batch).
 struct MsmPending {
+  MsmWorkspace* ws = nullptr;  // the workspace (and stream) the call was enqueued on
   int slot = 0;
   bool empty = true;
   int Wb = 0, c = 0, m = 0;
   uint32_t nbits = 0, wf[3] = {0, 0, 0};
   size_t plane_off[3] = {0, 0, 0};
 };
-static int msm_enqueue(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n, int slot,
-                       MsmPending* P);
+static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
+                       int mont, size_t n, int slot, MsmPending* P);
 static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18]);
 
 // Calls larger than 2^26 pairs are split into 2^26-pair MSMs whose results are added on the host --
@@ -1053,13 +1054,18 @@ static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t st
                        bool normalize, uint64_t out_jac[18]) {
   std::lock_guard<std::mutex> lk(C->msm_mu);
   MsmPending P;
-  int rc = msm_enqueue(C, bases, first, step, d_scalars, mont, n, 0, &P);
+  int rc = msm_enqueue(C, C->msm, C->stream, bases, first, step, d_scalars, mont, n, 0, &P);
   if (rc) return rc;
   return msm_finish(C, P, normalize, out_jac);
 }
 
-// k MSMs against the same registered bases, pipelined two deep: the kernels of call j are enqueued
-// before the host finishes call j-1.  Results are identical to k msm_run calls.
+// k MSMs against the same registered bases.  Results are identical to k msm_run calls; what changes is
+// the schedule: (i) the kernels of a call are enqueued before the host finishes the previous one (two
+// pinned result buffers on the main workspace), so the host Horner runs under the next call's kernels;
+// (ii) small calls (<= MSM_SMALL_N pairs) are latency-bound chains of a dozen tiny launches, so they go
+// round-robin to MSM_SMALL_LANES extra workspaces with their own streams and run side by side -- the
+// folding commitments of the tensor check are ~20 MSMs of sizes n/2, n/4, ..., 1.
+constexpr size_t MSM_SMALL_N = (size_t)1 << 17;
 int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, const void* const* d_scalars, int mont, const size_t* ns,
                   size_t k, bool normalize, uint64_t* out_jac) {
   const size_t CH = (size_t)1 << 26;
@@ -1073,22 +1079,57 @@ int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, c
     return GM_OK;
   }
   std::lock_guard<std::mutex> lk(C->msm_mu);
-  MsmPending P[2];
+  struct Inflight {
+    size_t j;
+    int lane;  // 0 = main workspace, 1.. = small workspaces
+    MsmPending P;
+  };
+  std::vector<Inflight> q;  // FIFO, at most 2 + MSM_SMALL_LANES long
+  size_t head = 0;
+  auto drain_one = [&]() {
+    Inflight& e = q[head++];
+    return msm_finish(C, e.P, normalize, out_jac + 18 * e.j);
+  };
+  auto fail = [&](int rc) {
+    (void)hipStreamSynchronize(C->stream);
+    for (int s = 0; s < MSM_SMALL_LANES; s++)
+      if (C->small_stream[s]) (void)hipStreamSynchronize(C->small_stream[s]);
+    return rc;
+  };
+  int main_parity = 0, small_rr = 0;
   for (size_t j = 0; j < k; j++) {
-    int rc = msm_enqueue(C, bases, first, step, d_scalars[j], mont, ns[j], (int)(j & 1), &P[j & 1]);
-    if (rc) {
-      (void)hipStreamSynchronize(C->stream);
-      return rc;
+    const bool small = ns[j] <= MSM_SMALL_N && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0;
+    const int lane = small ? 1 + (small_rr++ % MSM_SMALL_LANES) : 0;
+    const int hslot = small ? 0 : main_parity;
+    if (!small) main_parity ^= 1;
+    // a (workspace, result buffer) pair is free again once its previous call has been finished
+    for (;;) {
+      bool busy = false;
+      for (size_t t = head; t < q.size(); t++) busy = busy || (q[t].lane == lane && q[t].P.slot == hslot);
+      if (!busy) break;
+      int rc = drain_one();
+      if (rc) return fail(rc);
     }
-    if (j > 0 && (rc = msm_finish(C, P[(j - 1) & 1], normalize, out_jac + 18 * (j - 1)))) return rc;
+    Inflight e;
+    e.j = j;
+    e.lane = lane;
+    MsmWorkspace& ws = lane ? C->msm_small[lane - 1] : C->msm;
+    hipStream_t st = lane ? C->small_stream[lane - 1] : C->stream;
+    int rc = msm_enqueue(C, ws, st, bases, first, step, d_scalars[j], mont, ns[j], hslot, &e.P);
+    if (rc) return fail(rc);
+    q.push_back(e);
   }
-  if (k) return msm_finish(C, P[(k - 1) & 1], normalize, out_jac + 18 * (k - 1));
+  while (head < q.size()) {
+    int rc = drain_one();
+    if (rc) return fail(rc);
+  }
   return GM_OK;
 }
 
-static int msm_enqueue(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n, int slot,
-                       MsmPending* P) {
+static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
+                       int mont, size_t n, int slot, MsmPending* P) {
   const size_t nbases = bases->n;
+  P->ws = &ws;
   P->slot = slot;
   P->empty = n == 0;
   if (n == 0) return GM_OK;
@@ -1099,9 +1140,6 @@ static int msm_enqueue(Context* C, const Bases* bases, int64_t first, int64_t st
              "msm: base range [%lld .. %lld] outside registered bases (len %zu)", (long long)first, (long long)last,
              nbases);
   }
-  MsmWorkspace& ws = C->msm;
-  hipStream_t st = C->stream;
-
   // fixed-base tables (gm_g1_bases_precompute) serve large MSMs; small ones are latency-bound and
   // cheaper with few buckets
   const size_t tab_min = C->msm_table_min;
@@ -1450,7 +1488,7 @@ static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t 
     result.to_limbs(out_jac);
     return GM_OK;
   }
-  MsmWorkspace& ws = C->msm;
+  MsmWorkspace& ws = *P.ws;
   GM_HIP(hipEventSynchronize(ws.done_ev[P.slot]));
   C->prof.collect();
 
