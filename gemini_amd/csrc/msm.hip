@@ -1004,11 +1004,15 @@ static int ceil_log2_sz(size_t n) {
 }
 
 // window width: balances n*W mixed additions against W*2^(c-1) bucket work; tuned on MI355X
+// (sweep of 2^10 .. 2^19 pairs, c = 8 .. 16: with c = 16 there are exactly 16 windows and sparse buckets,
+// so chunk boundaries rarely split a bucket and k_merge has little to do -- from 2^15 pairs on that beats
+// the smaller bucket count of a narrower window, e.g. 3.52 vs 3.96 ms at 2^19, 1.61 vs 1.84 ms at 2^16)
 static int choose_window(size_t n) {
   int lg = ceil_log2_sz(n);
+  if (lg >= 15) return 16;
+  if (lg >= 13) return 13;
   int c = lg - 4;
   if (c < 4) c = 4;
-  if (c > 16) c = 16;
   return c;
 }
 
