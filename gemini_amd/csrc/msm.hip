@@ -1009,6 +1009,7 @@ static int ceil_log2_sz(size_t n) {
 // the smaller bucket count of a narrower window, e.g. 3.52 vs 3.96 ms at 2^19, 1.61 vs 1.84 ms at 2^16)
 static int choose_window(size_t n) {
   int lg = ceil_log2_sz(n);
+  if (lg >= 23) return 19;  // 14 windows: -2.5 % at 2^23, -7 % at 2^24, -11 % at 2^26 against c = 16 (the 3.7 M buckets cost 2.7 ms to reduce)
   if (lg >= 15) return 16;
   if (lg >= 13) return 13;
   int c = lg - 4;
