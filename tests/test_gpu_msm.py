@@ -81,7 +81,7 @@ def test_msm_all_equal_bases(gm, oracle, pyref, n):
     assert jac_to_affine_ints(oracle, got) == pyref.g1_mul(pyref.G1_GEN, oracle.limbs_to_ints(e)[0] * n % pyref.R_MOD)
 
 
-@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16, 17, 19])
 def test_msm_window_independence(gm, oracle, c):
     """the result is a group element: it cannot depend on the window width"""
     n = 700
@@ -192,6 +192,22 @@ def test_msm_2_16_vs_oracle(gm, oracle):
     bases = rand_bases(oracle, 71, n)
     sc = oracle.random_fr(72, n)
     assert_same_point(oracle, gm.VariableBaseMSM.msm_bigint(bases, sc), oracle.msm_pippenger(bases, sc))
+
+
+def test_msm_2_23_vs_oracle(gm, oracle):
+    """the wide-window configuration (c = 19, 14 windows, 3.7 M buckets) at a size where it is the default,
+    against the CPU Pippenger on the same inputs (about 10 s of CPU on the GPU box)"""
+    import bench
+
+    n = (1 << 23) - 3
+    rng = np.random.default_rng(2323)
+    reg = gm.G1Bases.fixed_base(oracle.g1_generator(), bench.uniform_fr(rng, n))
+    try:
+        sc = bench.uniform_fr(rng, n)
+        got = reg.msm_bigint(sc)
+        assert_same_point(oracle, got, oracle.msm_pippenger(reg.download(), sc))
+    finally:
+        reg.free()
 
 
 def test_msm_2_20_properties(gm, oracle, pyref):
