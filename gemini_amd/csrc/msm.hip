@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__
 constexpr uint32_t SORT_TS = 1024;     // scalars per block in pass 1
 constexpr uint32_t SORT_CH = 16384;    // entries per block in pass 2
 constexpr uint32_t SORT_GMAX = 4096;   // coarse bins
-constexpr uint32_t SORT_FMAX = 1024;   // fine bins
+constexpr uint32_t SORT_FMAX = 4096;   // fine bins (10 key bits by default, up to 12 for the widest windows)
 
 struct SortGeom {
   int c, W;
@@ -1009,6 +1009,7 @@ static int ceil_log2_sz(size_t n) {
 // the smaller bucket count of a narrower window, e.g. 3.52 vs 3.96 ms at 2^19, 1.61 vs 1.84 ms at 2^16)
 static int choose_window(size_t n) {
   int lg = ceil_log2_sz(n);
+  if (lg >= 25) return 20;  // 13 windows: another -4 % at 2^25 and 2^26
   if (lg >= 23) return 19;  // 14 windows: -2.5 % at 2^23, -7 % at 2^24, -11 % at 2^26 against c = 16 (the 3.7 M buckets cost 2.7 ms to reduce)
   if (lg >= 15) return 16;
   if (lg >= 13) return 13;
@@ -1231,6 +1232,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     sg.B = B;
     sg.shared = use_table ? 1 : 0;
     sg.FB = std::min<uint32_t>((uint32_t)(c - 1), 10u);
+    while ((nbuckets >> sg.FB) > SORT_GMAX && (1u << sg.FB) < SORT_FMAX) sg.FB++;
     sg.G = (uint32_t)(nbuckets >> sg.FB);
     GM_CHECK(sg.G <= SORT_GMAX, GM_EINVAL, "msm: %u coarse sort bins exceed %u (window %d too wide for this sort)", sg.G, SORT_GMAX, c);
     if ((rc = ws.tmp_entries.ensure(N * 8))) return rc;
