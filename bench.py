@@ -294,6 +294,11 @@ def main():
                 "kernel_ms": round(acc0_ms, 4) if acc0_ms else None,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
                 "note": "integer-ALU bound (~300 v_mad_u64_u32 per Fq product); HBM fraction reported as the contract asks",
+                # the truthful utilisation figure: Fq products per second of the kernel against the
+                # multiplier's own measured peak on this chip (tools/ubench_isa.hip, profiles/r1_ubench_isa.txt)
+                "fq_mul_per_s": round(10 * 16 * n / (acc0_ms * 1e-3)) if acc0_ms and args.logn == LOG_N else None,
+                "fq_mul_peak_measured": 50.4e9,
+                "alu_frac": round(10 * 16 * n / (acc0_ms * 1e-3) / 50.4e9, 4) if acc0_ms and args.logn == LOG_N else None,
             },
             "stage_ms": {k: (round(v, 4) if v is not None else None) for k, v in stages.items()},
         }

@@ -168,11 +168,18 @@ class CommitterKeyStream:
         assert max_degree <= len(self.powers_of_g)
         return CommitterKey(self.powers_of_g, self._max_eval_points)
 
+    # The reference flushes its Pippenger buffers every max_msm_buffer (/ depth) pairs to bound HOST memory
+    # (src/kzg/space.rs:105,139,205); the sum does not depend on where it is cut.  Scalars and SRS are already
+    # resident in HBM here, so cuts shorter than this many pairs are merged into one device MSM (2^20 / 26
+    # = 40 k-pair flushes would cost a latency-bound launch chain each).  Set to 1 to cut literally.
+    min_device_chunk = 1 << 22
+
     def _msm_stream(self, scalars_stream: FrVec, first_stream_pos: int, chunk: int) -> np.ndarray:
         """sum over stream positions: pair k = (base_stream[first_stream_pos + k], scalars_stream[k]),
         flushed every `chunk` pairs like ChunkedPippenger / msm_chunks"""
         n = len(self.powers_of_g)
         total = len(scalars_stream)
+        chunk = max(chunk, self.min_device_chunk)
         result = g1_zero()
         for off in range(0, total, chunk):
             m = min(chunk, total - off)

@@ -208,7 +208,7 @@ def new_elastic(r1cs_stream, ck_stream, max_msm_buffer: int) -> Proof:
     zc_alpha = _evaluate_be(r1cs_stream.z_c, alpha.reshape(1, 4))[0]  # :216
     transcript.append_fr(b"zc(alpha)", zc_alpha)
     t0 = time.perf_counter()
-    first_proof = Sumcheck.new_elastic(transcript, r1cs_stream.z_a.to_host(), r1cs_stream.z_b.to_host(), alpha)  # :222
+    first_proof = Sumcheck.new_elastic(transcript, r1cs_stream.z_a, r1cs_stream.z_b, alpha)  # :222
     spans["First sumcheck"] = time.perf_counter() - t0
     eta = transcript.get_challenge(b"eta")
     eta_i = fr_to_int(eta)
@@ -223,7 +223,7 @@ def new_elastic(r1cs_stream, ck_stream, max_msm_buffer: int) -> Proof:
     for v in (ta, tb, tc, a_challenges, b_challenges, c_challenges):
         v.free()
     t0 = time.perf_counter()
-    second_proof = Sumcheck.new_elastic(transcript, lhs.to_host(), r1cs_stream.z.to_host(), fr_from_int(1))  # :241
+    second_proof = Sumcheck.new_elastic(transcript, lhs, r1cs_stream.z, fr_from_int(1))  # :241
     spans["Second sumcheck"] = time.perf_counter() - t0
     batch_challenge = transcript.get_challenge(b"batch_challenge")
     t0 = time.perf_counter()

@@ -198,6 +198,7 @@ def test_psnark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
     assert (time_proof.tensorcheck_proof.evaluation_proof == elastic_proof.tensorcheck_proof.evaluation_proof).all()
     assert a == b
     # a small MSM buffer changes the chunking only
+    ck_stream.min_device_chunk = 1
     assert Proof.new_elastic(ck_stream, stream, index, 1 << 6).serialize_compressed() == a
     stream.free()
     r1cs.free()

@@ -146,7 +146,9 @@ def test_committer_key_stream_consistency(gm, oracle, pyref):
         te, tp = time_ck.open(poly, alpha)
         se, sp = space_ck.open(stream, alpha, 1 << 20)
         assert (te == se).all() and (tp == sp).all()
+        space_ck.min_device_chunk = 1  # cut literally (the default merges short flushes into one device MSM)
         se2, sp2 = space_ck.open(stream, alpha, 7)  # tiny buffer: many ChunkedPippenger flushes
+        del space_ck.min_device_chunk
         assert (te == se2).all() and (tp == sp2).all()
     # space.rs test_open_multi_points
     f_be = [80, 80, 88, 3, 73, 7, 24]
@@ -227,7 +229,10 @@ def test_snark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
     old = S.SPACE_TIME_THRESHOLD
     S.SPACE_TIME_THRESHOLD = 3  # make the elastic provers spend rounds in the space prover at this size
     try:
-        space_proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 20)
+        ck_stream = CommitterKeyStream.from_committer_key(ck)
+        ck_stream.min_device_chunk = 1  # cut the streams literally every 20 / depth pairs
+        space_proof = Proof.new_elastic(stream, ck_stream, 20)
+        assert Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 20).serialize_compressed() == space_proof.serialize_compressed()
     finally:
         S.SPACE_TIME_THRESHOLD = old
     eq = lambda x, y: bool((np.asarray(x) == np.asarray(y)).all())

@@ -17,6 +17,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-i", "--instance-logsize", type=int, default=20)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--dummy-srs", action="store_true", help="powers_of_g = copies of the generator, the DummyStreamer key of "
+                    "examples/snark.rs:59-63 (elastic main) instead of tau^i * g")
+    ap.add_argument("--max-msm-buffer-log", type=int, default=20, help="max_msm_buffer of the elastic prover (examples/snark.rs:57: 2^20)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/snark.rs elastic_snark_main) instead of --time-prover")
     args = ap.parse_args()
@@ -57,7 +60,15 @@ def main():
 
         ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
     else:
-        ck = CommitterKey.new(2 * n, 5, tau)
+        if args.dummy_srs:
+            from gemini_amd.kzg import g1_generator_mont
+            from gemini_amd.msm import G1Bases
+
+            ones = np.zeros((2 * n + 1, 4), dtype=np.uint64)
+            ones[:, 0] = 1
+            ck = CommitterKey(G1Bases.fixed_base(g1_generator_mont(), ones), 5)
+        else:
+            ck = CommitterKey.new(2 * n, 5, tau)
     t_srs = time.perf_counter() - t0
     out = {"n_gpus": world, "logn": args.instance_logsize, "instance_s": round(t_inst, 3), "srs_s": round(t_srs, 3), "runs": []}
     for _ in range(args.repeat):
@@ -68,7 +79,7 @@ def main():
             from gemini_amd.kzg import CommitterKeyStream
 
             stream = R1csStream(r1cs)
-            proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << 20)
+            proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << args.max_msm_buffer_log)
             stream.free()
         else:
             proof = Proof.new_time(r1cs, ck)
