@@ -212,3 +212,42 @@ class ShardedCommitterKey:
         from .kzg import CommitterKey
 
         return CommitterKey.batch_open_multi_points(self, polynomials, eval_points_mont, eval_chal_mont)
+
+
+def _stream_key_base():
+    from .kzg import CommitterKeyStream
+
+    return CommitterKeyStream
+
+
+class ShardedCommitterKeyStream(_stream_key_base()):
+    """`CommitterKeyStream` (src/kzg/space.rs:59-69) with powers_of_g[lo, hi) (time order) resident on this
+    rank -- "MSM chunks sharded across the GPUs" for the elastic prover (BASELINE config 4).  Every stream MSM
+    (commit, open, open_multi_points, commit_folding, open_folding all funnel into `_msm_stream`) is the local
+    part over the rank's powers + one all-gather of 144-byte partials + EC add; the streams are replicated."""
+
+    def __init__(self, local_powers, lo: int, n_global: int, max_eval_points: int, powers_of_g2=None):
+        super().__init__(local_powers, max_eval_points, powers_of_g2)
+        self.lo, self.hi, self.n_global = lo, lo + len(local_powers), n_global
+
+    @classmethod
+    def from_sharded_key(cls, key: "ShardedCommitterKey") -> "ShardedCommitterKeyStream":
+        return cls(key.powers_of_g, key.lo, key.n_global, key.max_eval_points(), getattr(key, "powers_of_g2", None))
+
+    def _n(self) -> int:
+        return self.n_global
+
+    def _msm_stream(self, scalars_stream, first_stream_pos: int, chunk: int) -> np.ndarray:
+        from .msm import g1_zero
+
+        n, total = self.n_global, len(scalars_stream)
+        chunk = max(chunk, self.min_device_chunk)
+        # stream position p <-> power n - 1 - p; this rank holds powers [lo, hi)
+        k_lo = max(0, n - first_stream_pos - self.hi)
+        k_hi = min(total, n - first_stream_pos - self.lo)
+        part = g1_zero()
+        for off in range(k_lo, max(k_lo, k_hi), chunk):
+            m = min(chunk, k_hi - off)
+            p = self.powers_of_g.msm_vec(scalars_stream, n=m, voffset=off, offset=n - 1 - (first_stream_pos + off) - self.lo, reversed_=True)
+            part = g1_sum(np.stack([part, p]))
+        return g1_sum(all_gather_u64(part))

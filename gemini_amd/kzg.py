@@ -163,9 +163,13 @@ class CommitterKeyStream:
         assert self.powers_of_g2 is not None, "this key was built without its G2 half"
         return G2.serialize_vec_uncompressed(self.powers_of_g2)
 
+    def _n(self) -> int:
+        """number of powers of the (whole) key"""
+        return len(self.powers_of_g)
+
     def as_committer_key(self, max_degree: int) -> "CommitterKey":
         """:77-92 (keeps the first max_degree powers; shares the resident SRS)"""
-        assert max_degree <= len(self.powers_of_g)
+        assert max_degree <= self._n()
         return CommitterKey(self.powers_of_g, self._max_eval_points)
 
     # The reference flushes its Pippenger buffers every max_msm_buffer (/ depth) pairs to bound HOST memory
@@ -177,7 +181,7 @@ class CommitterKeyStream:
     def _msm_stream(self, scalars_stream: FrVec, first_stream_pos: int, chunk: int) -> np.ndarray:
         """sum over stream positions: pair k = (base_stream[first_stream_pos + k], scalars_stream[k]),
         flushed every `chunk` pairs like ChunkedPippenger / msm_chunks"""
-        n = len(self.powers_of_g)
+        n = self._n()
         total = len(scalars_stream)
         chunk = max(chunk, self.min_device_chunk)
         result = g1_zero()
@@ -191,8 +195,8 @@ class CommitterKeyStream:
         """:169-177 -> msm_chunks (:22-55): skip len(powers) - len(poly) bases, 2^20-pair MSMs, summed"""
         v, tmp = _as_vec(polynomial_stream)
         try:
-            assert len(self.powers_of_g) >= len(v)
-            return self._msm_stream(v, len(self.powers_of_g) - len(v), 1 << 20)
+            assert self._n() >= len(v)
+            return self._msm_stream(v, self._n() - len(v), 1 << 20)
         finally:
             if tmp:
                 v.free()
@@ -213,7 +217,7 @@ class CommitterKeyStream:
                 host = qr.to_host()
                 capi.check(capi.load().gm_fr_vec_upload(C.c_uint64(qs.handle), C.c_size_t(1), capi.ptr(host), C.c_size_t(len(host))))
                 qr.free()
-            proof = self._msm_stream(qs, len(self.powers_of_g) - len(v), max_msm_buffer)
+            proof = self._msm_stream(qs, self._n() - len(v), max_msm_buffer)
             q.free()
             qs.free()
             return rem[0], proof
@@ -231,7 +235,7 @@ class CommitterKeyStream:
             q, rem = div_vanishing(le, pts)
             remainder = _newton_to_monomial_be(rem, [fr_to_int(p) for p in pts])
             qs = reverse(q)
-            proof = self._msm_stream(qs, len(self.powers_of_g) - len(v) + len(pts), max_msm_buffer)
+            proof = self._msm_stream(qs, self._n() - len(v) + len(pts), max_msm_buffer)
             q.free()
             qs.free()
             return remainder, proof
@@ -260,7 +264,7 @@ class CommitterKeyStream:
         out = []
         for lvl in levels:
             s = reverse(lvl)
-            out.append(self._msm_stream(s, len(self.powers_of_g) - len(s), max(1, max_msm_buffer // n)))
+            out.append(self._msm_stream(s, self._n() - len(s), max(1, max_msm_buffer // n)))
             s.free()
             lvl.free()
         return out
@@ -293,7 +297,7 @@ class CommitterKeyStream:
             return remainders, g1_zero()
         s = reverse(batched)
         # bases: tau^j for coefficient j -> stream position n - len(batched)
-        proof = self._msm_stream(s, len(self.powers_of_g) - len(s), max_msm_buffer)
+        proof = self._msm_stream(s, self._n() - len(s), max_msm_buffer)
         s.free()
         batched.free()
         return remainders, proof

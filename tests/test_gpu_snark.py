@@ -323,3 +323,54 @@ def test_division_property_at_full_size(gm, oracle, pyref):
     assert fr_to_int(rem[0]) == (pow(x[0] * pts[0] % R, n, R) - 1) * pow(x[0] * pts[0] - 1, -1, R) % R
     f.free()
     q.free()
+
+
+def test_sharded_stream_key_single_process(gm, oracle, pyref):
+    """ShardedCommitterKeyStream on a world of one (gloo): the elastic proof over the sharded stream key equals
+    the proof over the plain stream key; with three shards on the one GPU the per-rank stream partials
+    (commit, open, open_multi_points) add up to the unsharded results."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from gemini_amd import dist as gd
+    from gemini_amd.circuit import R1csStream, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from gemini_amd.msm import g1_sum
+    from gemini_amd.snark import Proof
+
+    tau_l = oracle.random_fr(78, 1)[0]
+    n = 1 << 9
+    ck = CommitterKey.new(2 * n, 5, tau_l)
+    plain = CommitterKeyStream.from_committer_key(ck)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        # three shards in one process: replace the collective by "this rank only" and add the partials by hand
+        shards = [gd.ShardedCommitterKeyStream.from_sharded_key(gd.ShardedCommitterKey.new(2 * n, 5, tau_l, r, 3)) for r in range(3)]
+        poly = gm.FrVec.from_host(oracle.fr_to_mont(oracle.random_fr(79, 700)))
+        alpha = oracle.fr_to_mont(oracle.random_fr(80, 1))[0]
+        for sk in shards:
+            sk.min_device_chunk = 64
+        want_commit = plain.commit(poly)
+        want_open = plain.open(poly, alpha, 1 << 10)
+        # with world 1 the all-gather returns the rank's own partial: sum the three partials
+        assert (g1_sum(np.stack([sk.commit(poly) for sk in shards])) == want_commit).all()
+        got = [sk.open(poly, alpha, 100) for sk in shards]
+        assert all((g[0] == want_open[0]).all() for g in got)
+        assert (g1_sum(np.stack([g[1] for g in got])) == want_open[1]).all()
+        one = gd.ShardedCommitterKeyStream.from_sharded_key(gd.ShardedCommitterKey.new(2 * n, 5, tau_l, 0, 1))
+        r1cs = dummy_r1cs(4321, n)
+        stream = R1csStream(r1cs)
+        a = Proof.new_elastic(stream, plain, 1 << 20).serialize_compressed()
+        b = Proof.new_elastic(stream, one, 1 << 20).serialize_compressed()
+        assert a == b == Proof.new_time(r1cs, ck).serialize_compressed()
+        stream.free()
+        poly.free()
+    finally:
+        dist.destroy_process_group()

@@ -79,7 +79,13 @@ def main():
             from gemini_amd.kzg import CommitterKeyStream
 
             stream = R1csStream(r1cs)
-            proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << args.max_msm_buffer_log)
+            if world > 1:
+                from gemini_amd.dist import ShardedCommitterKeyStream
+
+                cks = ShardedCommitterKeyStream.from_sharded_key(ck)
+            else:
+                cks = CommitterKeyStream.from_committer_key(ck)
+            proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log)
             stream.free()
         else:
             proof = Proof.new_time(r1cs, ck)
