@@ -147,12 +147,13 @@ class ShardedCommitterKey:
     local_msm(polynomial, a, b) -> (18,) Jacobian of sum_{a <= i < b} polynomial[i] * powers_of_g[i];
     by default the HIP MSM over the resident slice (gemini_amd.msm.G1Bases)."""
 
-    def __init__(self, local_powers, lo: int, n_global: int, max_eval_points: int, local_msm=None):
+    def __init__(self, local_powers, lo: int, n_global: int, max_eval_points: int, local_msm=None, powers_of_g2=None):
         self.powers_of_g = local_powers
         self.lo, self.hi = lo, lo + len(local_powers)
         self.n_global = n_global
         self._max_eval_points = max_eval_points
         self._local_msm = local_msm or self._hip_msm
+        self.powers_of_g2 = powers_of_g2  # replicated: max_eval_points + 1 G2 points
 
     @classmethod
     def new(cls, max_degree: int, max_eval_points: int, tau_canonical, rank: int, world: int, g_affine=None) -> "ShardedCommitterKey":
@@ -167,10 +168,21 @@ class ShardedCommitterKey:
         first = G1Bases.fixed_base(g, np.array([_to_limbs(pow(tau, lo, R_MOD))], dtype=np.uint64))
         base = first.download()[0]
         first.free()
-        return cls(G1Bases.srs(base, tau_canonical, hi - lo), lo, n, max_eval_points)
+        from . import g2 as G2
+
+        powers_of_g2 = [G2.mul(G2.generator(), pow(tau, i, R_MOD)) for i in range(max_eval_points + 1)]
+        return cls(G1Bases.srs(base, tau_canonical, hi - lo), lo, n, max_eval_points, powers_of_g2=powers_of_g2)
 
     def max_eval_points(self) -> int:
         return self._max_eval_points
+
+    def num_powers(self) -> int:
+        return self.n_global
+
+    def powers_of_g2_bytes(self) -> bytes:
+        from .kzg import CommitterKey
+
+        return CommitterKey.powers_of_g2_bytes(self)
 
     def _hip_msm(self, polynomial, a: int, b: int) -> np.ndarray:
         from .fr import _as_vec

@@ -50,6 +50,10 @@ class CommitterKey:
     def max_eval_points(self) -> int:  # :75-78
         return self._max_eval_points
 
+    def num_powers(self) -> int:
+        """len(powers_of_g) of the whole key (a sharded key holds only a slice of it)"""
+        return len(self.powers_of_g)
+
     def commit(self, polynomial) -> np.ndarray:
         """:81-83  msm_unchecked(&powers_of_g, polynomial): truncates to the shorter side."""
         v, tmp = _as_vec(polynomial)

@@ -219,7 +219,7 @@ class Proof:
         # commitment to the looked-up vector under ck itself (the reference's commented-out line :126): one
         # MSM over the resident key instead of building an indexed key.  The index_by zip needs as many
         # powers as indices.
-        assert len(ck.powers_of_g) >= num_non_zero, "committer key shorter than the number of non-zero entries"
+        assert ck.num_powers() >= num_non_zero, "committer key shorter than the number of non-zero entries"
         t0 = time.perf_counter()
         z_r_commitments = ck.batch_commit([ralpha_star, r_star, alpha_star]) + [ck.commit(z_star)]
         spans["Commitments to z* and r*"] = time.perf_counter() - t0
@@ -255,7 +255,7 @@ class Proof:
         sorted_polynomials = [K(lookup(alg_hash_poly[0], ext_fre[0])), K(lookup(alg_hash_poly[1], ext_fre[0])),
                               K(lookup(alg_hash_poly[2], ext_fre[1]))]  # :169-173
         # :179-183: ck.index_by(ext_fre).commit(alg_hash_poly) = commitment to the sorted vector under ck (:183)
-        assert len(ck.powers_of_g) >= max(len(ext_fre[0]), len(ext_fre[1])), "committer key shorter than the sorted vectors"
+        assert ck.num_powers() >= max(len(ext_fre[0]), len(ext_fre[1])), "committer key shorter than the sorted vectors"
         sorted_commitments = ck.batch_commit(sorted_polynomials)
         spans["Commitments to sorted vectors"] = time.perf_counter() - t0
 

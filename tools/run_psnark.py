@@ -25,7 +25,22 @@ def main():
     from gemini_amd.kzg import CommitterKey
     from gemini_amd.psnark import Proof
 
-    gm.capi.init()
+    # N > 1 (torch.distributed.run): KZG key sharded by powers (gemini_amd.dist.ShardedCommitterKey), the
+    # field arithmetic replicated; GM_BENCH_BACKEND / GM_BENCH_SINGLE_DEVICE as in bench.py
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if os.environ.get("GM_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        backend = os.environ.get("GM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    gm.capi.init(local_rank)
     n = 1 << args.instance_logsize
     rng = np.random.default_rng(2022420)
     rnd = lambda: int.from_bytes(rng.bytes(40), "little") % gm.fr.R_MOD
@@ -33,7 +48,13 @@ def main():
     t0 = time.perf_counter()
     tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
     # examples/psnark.rs: time main num_constraints + num_variables powers (:76), elastic main 3 * instance_size + 1 (:62)
-    ck = CommitterKey.new(3 * n if args.elastic else 2 * n, 5, tau)
+    if world > 1:
+        from gemini_amd.dist import ShardedCommitterKey
+
+        assert not args.elastic, "the sharded preprocessing prover runs the time prover"
+        ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
+    else:
+        ck = CommitterKey.new(3 * n if args.elastic else 2 * n, 5, tau)
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
     index = Proof.index(ck, r1cs)
@@ -53,7 +74,18 @@ def main():
         out["proof_size_B"] = proof.compressed_size()
     key = "ark_gemini::psnark::elastic_prover" if args.elastic else "ark_gemini::psnark::time_prover"
     out["elastic_prover_s" if args.elastic else "time_prover_s"] = min(r[key] for r in out["runs"])
-    print(json.dumps(out))
+    import hashlib
+
+    out["n_gpus"] = world
+    out["proof_sha256"] = hashlib.sha256(proof.serialize_compressed()).hexdigest()
+    if world > 1:
+        allt = [None] * world
+        dist.all_gather_object(allt, (out.get("time_prover_s"), out["proof_sha256"]))
+        assert len({d for _, d in allt}) == 1, "ranks produced different proofs"
+        out["time_prover_s"] = max(t for t, _ in allt)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":
