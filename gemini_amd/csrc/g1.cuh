@@ -42,7 +42,13 @@ GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fq30_add(a, b); }
 GM_DEV FqE fq_dbl(const FqE& a) { return fq30_add(a, a); }
 template <int K>
 GM_DEV FqE fq_sub(const FqE& a, const FqE& b) { return fq30_sub<K>(a, b); }
-GM_DEV FqE fq_neg_canonical(const FqE& y) { return fq30_sub<1>(FqE::zero(), y); }  // y < q (as loaded)
+GM_DEV FqE fq_neg_canonical(const FqE& y) {  // y < q (as loaded); -0 stays the exact zero of the identity record
+  FqE r = fq30_sub<1>(FqE::zero(), y);
+  const bool z = y.is_exact_zero();
+#pragma unroll
+  for (int i = 0; i < 13; i++) r.l[i] = z ? 0u : r.l[i];
+  return r;
+}
 GM_DEV bool fq_is_zero_mod(const FqE& a) { return fq30_is_zero_modq(a); }
 GM_DEV bool fq_is_exact_zero(const FqE& a) { return a.is_exact_zero(); }
 GM_DEV FqE fqe_zero() { return FqE::zero(); }
@@ -60,9 +66,22 @@ GM_DEV Fq fqe_export(const FqE& dev) {
 }
 #else
 using FqE = Fq;
-__device__ __noinline__ Fq fq_mul_fn(const Fq a, const Fq b) { return fp_mul<FqParams>(a, b); }
-GM_DEV FqE fq_mul(const FqE& a, const FqE& b) { return fq_mul_fn(a, b); }
-GM_DEV FqE fq_sqr(const FqE& a) { return fq_mul_fn(a, a); }
+// The out-of-line multiplier takes its operands as 24 scalar arguments: hipcc passes a second by-value
+// struct through the scratch stack (a 48-byte store + load and a vmcnt drain per call), scalars travel
+// in v0..v23.
+__device__ __noinline__ Fq fq_mul_fn(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+                                     uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
+                                     uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
+  Fq a, b;
+  a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7; a.l[8] = a8; a.l[9] = a9; a.l[10] = a10; a.l[11] = a11;
+  b.l[0] = b0; b.l[1] = b1; b.l[2] = b2; b.l[3] = b3; b.l[4] = b4; b.l[5] = b5; b.l[6] = b6; b.l[7] = b7; b.l[8] = b8; b.l[9] = b9; b.l[10] = b10; b.l[11] = b11;
+  return fp_mul<FqParams>(a, b);
+}
+GM_DEV FqE fq_mul(const FqE& a, const FqE& b) {
+  return fq_mul_fn(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1], b.l[2], b.l[3],
+                   b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
+}
+GM_DEV FqE fq_sqr(const FqE& a) { return fq_mul(a, a); }
 GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fp_add<FqParams>(a, b); }
 GM_DEV FqE fq_dbl(const FqE& a) { return fp_add<FqParams>(a, a); }
 template <int K>

@@ -416,6 +416,152 @@ __global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entri
 }
 
 // ------------------------------------------------------------------------------------------
+// k_acc0 with the bucket accumulator in LDS.  The XYZZ accumulator (4 x FQE_LIMBS dwords per lane) is the
+// largest long-lived value of the kernel; parked in LDS (limb-major, conflict-free: word [c][i][lane]) it
+// is fetched coordinate by coordinate where the addition law needs it and written back as soon as a
+// coordinate is final, so at most four field elements are live across a multiplier call.  That is what
+// lets the 13-limb representation (GM_FQ30) run without scratch spills; LDS traffic is ~1 KiB per lane
+// per addition against ~26 k cycles of multiplier time.
+// ------------------------------------------------------------------------------------------
+struct AccLds {
+  uint32_t (*w)[FQE_LIMBS][256];  // [coordinate][limb][lane]
+  uint32_t lane;
+  GM_DEV FqE get(int c) const {
+    FqE r;
+#pragma unroll
+    for (int i = 0; i < FQE_LIMBS; i++) r.l[i] = w[c][i][lane];
+    return r;
+  }
+  GM_DEV void put(int c, const FqE& v) const {
+#pragma unroll
+    for (int i = 0; i < FQE_LIMBS; i++) w[c][i][lane] = v.l[i];
+  }
+  GM_DEV G1Xyzz all() const {
+    G1Xyzz a;
+    a.x = get(0);
+    a.y = get(1);
+    a.zz = get(2);
+    a.zzz = get(3);
+    return a;
+  }
+  GM_DEV void put_all(const G1Xyzz& a) const {
+    put(0, a.x);
+    put(1, a.y);
+    put(2, a.zz);
+    put(3, a.zzz);
+  }
+};
+// the exceptional additions, out of line so that their registers do not count against the hot loop:
+// equal x with equal y doubles the affine operand, equal x with opposite y gives the identity.
+// Returns the new identity flag.
+__device__ __noinline__ bool madd_lds_rare(uint32_t (*w)[FQE_LIMBS][256], uint32_t lane, const G1Affine q, bool same_y) {
+  if (!same_y) return true;
+  AccLds A;
+  A.w = w;
+  A.lane = lane;
+  const G1Xyzz d = xyzz_dbl_affine(q);
+  A.put_all(d);
+  return d.is_identity();
+}
+// run result -> memory (canonicalises), out of line for the same reason
+__device__ __noinline__ void acc_lds_flush(uint32_t (*w)[FQE_LIMBS][256], uint32_t lane, bool ident, uint8_t* dst) {
+  AccLds A;
+  A.w = w;
+  A.lane = lane;
+  if (ident) {
+    const Fq z = Fq::zero();
+    for (int c = 0; c < 4; c++) fp_store<FqParams>(dst + 48 * c, z);
+    return;
+  }
+#pragma unroll 1
+  for (int c = 0; c < 4; c++) fqe_store(dst + 48 * c, A.get(c));  // one coordinate live at a time
+}
+// acc += q with the same formulas, bounds and exceptional cases as xyzz_madd (g1.cuh); `ident` is the
+// accumulator's identity flag (kept in a register instead of testing zz)
+GM_DEV void madd_lds(const AccLds& A, bool& ident, const G1Affine& q) {
+  if (q.is_identity()) return;
+  if (ident) {
+    A.put(0, q.x);
+    A.put(1, q.y);
+    A.put(2, fqe_one());
+    A.put(3, fqe_one());
+    ident = false;
+    return;
+  }
+  const FqE p = fq_sub<8>(fq_mul(q.x, A.get(2)), A.get(0));
+  const FqE r = fq_sub<4>(fq_mul(q.y, A.get(3)), A.get(1));
+  if (fq_is_zero_mod(p)) {
+    ident = madd_lds_rare(A.w, A.lane, q, fq_is_zero_mod(r));
+    return;
+  }
+  const FqE pp = fq_sqr(p);
+  A.put(2, fq_mul(A.get(2), pp));
+  const FqE ppp = fq_mul(p, pp);
+  A.put(3, fq_mul(A.get(3), ppp));
+  const FqE qq = fq_mul(A.get(0), pp);
+  const FqE x3 = fq_sub<4>(fq_sub<2>(fq_sqr(r), ppp), fq_dbl(qq));
+  A.put(0, x3);
+  A.put(1, fq_sub<2>(fq_mul(r, fq_sub<8>(qq, x3)), fq_mul(A.get(1), ppp)));
+}
+
+__global__ __launch_bounds__(256) void k_acc0_lds(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
+                                                  const uint8_t* __restrict__ bases, long long first, long long step,
+                                                  long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
+                                                  uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets) {
+  __shared__ uint32_t accw[4][FQE_LIMBS][256];
+  AccLds A;
+  A.w = accw;
+  A.lane = threadIdx.x;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = *total_ptr;
+  const uint64_t start = (uint64_t)t * L;
+  uint32_t head_key = KEY_INV, tail_key = KEY_INV;
+  if (start < total) {
+    const uint64_t end = min(start + (uint64_t)L, total);
+    bool ident = true;
+    uint32_t cur = KEY_INV;
+    bool first_run = true;
+    auto flush = [&](uint8_t* dst) { acc_lds_flush(accw, threadIdx.x, ident, dst); };
+    for (uint64_t i = start; i < end; i++) {
+      const uint64_t e = entries[i];
+      long long idx;
+      if (tab_stride) {
+        const uint32_t lo = (uint32_t)e & 0x7fffffffu;
+        idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
+      } else {
+        idx = first + step * (long long)(e & 0x7fffffffull);
+      }
+      G1Affine p = g1_load_affine(bases + (size_t)idx * AFF_BYTES);
+      const uint32_t key = (uint32_t)(e >> 32);
+      if (key != cur) {
+        if (cur != KEY_INV) {
+          if (first_run) {
+            head_key = cur;
+            flush(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES);
+            first_run = false;
+          } else {
+            flush(buckets + (size_t)cur * XYZZ_BYTES);
+          }
+        }
+        cur = key;
+        ident = true;
+      }
+      if ((e >> 31) & 1ull) p.y = fq_neg_canonical(p.y);
+      madd_lds(A, ident, p);
+    }
+    if (first_run) {
+      head_key = cur;
+      flush(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES);
+    } else {
+      tail_key = cur;
+      flush(pp + (size_t)(2 * (size_t)t + 1) * XYZZ_BYTES);
+    }
+  }
+  pk[2 * (size_t)t] = head_key;
+  pk[2 * (size_t)t + 1] = tail_key;
+}
+
+// ------------------------------------------------------------------------------------------
 // Affine tree levels (optional, gm_set_msm_affine_levels): before the XYZZ accumulation, neighbours
 // of the sorted list that fall into the same bucket are added pairwise in AFFINE coordinates, level
 // by level, with ONE field inversion per level shared by all pairs (Montgomery's trick): an affine
@@ -1353,8 +1499,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     pf.end(PROF_SCAN, st);
   }
   pf.begin(PROF_ACC0, st);
-  hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
-                     acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
+  static const bool acc0_lds = getenv("GM_ACC0") ? !strcmp(getenv("GM_ACC0"), "lds") : (GM_FQ30 != 0);
+  if (acc0_lds)
+    hipLaunchKernelGGL(k_acc0_lds, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
+  else
+    hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
   pf.end(PROF_ACC0, st);
   pf.begin(PROF_MERGE, st);
   {
