@@ -13,12 +13,14 @@
 // (in-tree statement: src/kzg/msm/variable_base.rs:125-175).
 //
 // Coordinate arithmetic goes through the `FqE` element layer below.  GM_FQ30 = 0 (default, what ships)
-// is the 12 x 32-bit canonical representation of field.cuh.  GM_FQ30 = 1 is the EXPERIMENTAL
-// 13 x 30-bit lazy-carry representation of field30.cuh (one v_mad_u64_u32 per partial product,
-// Montgomery factor 2^390, loose values): its multiplier is 22 % faster in isolation, but inside
-// k_acc0 the 13-limb elements push the kernel to the 256-VGPR cap (AGPR traffic) and it measured
-// 30 % SLOWER end to end, with a parity mismatch still open -- it is not built by default.
-// With GM_FQ30 = 1 every device-resident coordinate (bases, buckets, partials, tables) is stored as
+// is the 12 x 32-bit canonical representation of field.cuh.  Two EXPERIMENTAL alternatives are kept,
+// parity-green (tools/fq30_check.hip, tests/test_gpu_msm.py) but slower inside the kernels:
+//   GM_FQ30 = 1: 13 x 30-bit lazy-carry elements (field30.cuh: one v_mad_u64_u32 per partial product,
+//                Montgomery factor 2^390, loose values).  The multiplier is 22 % faster in isolation,
+//                but 13-limb XYZZ operands spill (k_acc0 864 B scratch per lane): 4.25 ms vs 3.48 ms.
+//   GM_FQ30 = 2: hybrid -- canonical 12 x 32-bit elements, only the product unpacks to 13 x 30 bits.
+//                No spills, but the unpack / conditional subtraction / repack cancel the gain: 3.56 ms.
+// With GM_FQ30 != 0 every device-resident coordinate (bases, buckets, partials, tables) is stored as
 // a * 2^390 mod q in the same 12 x u32 packed, fully reduced record; conversion from / to ark-ff's
 // a * 2^384 happens once at the boundary (k_pack_bases, k_export_bases, host plane conversion).
 #pragma once
@@ -31,11 +33,22 @@
 
 namespace gm {
 
-#if GM_FQ30
+#if GM_FQ30 == 1
 // ---- element layer: 13 x 30-bit, loose.  Bounds (multiples of q) are tracked in the comments of the
 // group law: products are < 2q whenever bound(a) * bound(b) <= 512, fqe_sub<K> needs b < K q.
 using FqE = Fq30;
-__device__ __noinline__ Fq30 fq30_mul_fn(const Fq30 a, const Fq30 b) { return fq30_mul(a, b); }
+// 26 scalar arguments: a second by-value struct would travel through the scratch stack (see fq_mul_fn below)
+__device__ __noinline__ Fq30 fq30_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12,
+                                           uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11, uint32_t b12) {
+  Fq30 a, b;
+  a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7; a.l[8] = a8; a.l[9] = a9; a.l[10] = a10; a.l[11] = a11; a.l[12] = a12;
+  b.l[0] = b0; b.l[1] = b1; b.l[2] = b2; b.l[3] = b3; b.l[4] = b4; b.l[5] = b5; b.l[6] = b6; b.l[7] = b7; b.l[8] = b8; b.l[9] = b9; b.l[10] = b10; b.l[11] = b11; b.l[12] = b12;
+  return fq30_mul(a, b);
+}
+GM_DEV Fq30 fq30_mul_fn(const Fq30& a, const Fq30& b) {
+  return fq30_mul_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12],
+                       b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12]);
+}
 GM_DEV FqE fq_mul(const FqE& a, const FqE& b) { return fq30_mul_fn(a, b); }
 GM_DEV FqE fq_sqr(const FqE& a) { return fq30_mul_fn(a, a); }
 GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fq30_add(a, b); }
@@ -64,6 +77,42 @@ GM_DEV Fq fqe_export(const FqE& dev) {
   FqE t = fq30_mul_fn(dev, fq30_const(Fq30Consts::COUT));
   return fq30_pack(fq30_canonical_tail(fq30_mul_fn(t, fq30_const(Fq30Consts::ONE))));
 }
+#elif GM_FQ30 == 2
+// ---- hybrid: elements are the canonical 12 x 32-bit records of field.cuh (additions, subtractions,
+// comparisons, memory all as in mode 0), only the PRODUCT runs in radix 2^30: unpack both operands to
+// 13 x 30-bit limbs, lazy-carry Montgomery product with R' = 2^390 (one v_mad_u64_u32 per partial
+// product, no carry instruction), one conditional subtraction (canonical inputs give < 1.002 q), repack.
+// Values are therefore a * 2^390 mod q at rest, with the same boundary conversions as mode 1.
+using FqE = Fq;
+template <int K>
+GM_DEV FqE fq_sub(const FqE& a, const FqE& b);
+__device__ __noinline__ Fq fq_mul_fn(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
+                                     uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
+                                     uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
+  Fq a, b;
+  a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7; a.l[8] = a8; a.l[9] = a9; a.l[10] = a10; a.l[11] = a11;
+  b.l[0] = b0; b.l[1] = b1; b.l[2] = b2; b.l[3] = b3; b.l[4] = b4; b.l[5] = b5; b.l[6] = b6; b.l[7] = b7; b.l[8] = b8; b.l[9] = b9; b.l[10] = b10; b.l[11] = b11;
+  return fq30_pack(fq30_canonical_tail(fq30_mul(fq30_unpack(a), fq30_unpack(b))));
+}
+GM_DEV FqE fq_mul(const FqE& a, const FqE& b) {
+  return fq_mul_fn(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1], b.l[2], b.l[3],
+                   b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
+}
+GM_DEV FqE fq_sqr(const FqE& a) { return fq_mul(a, a); }
+GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fp_add<FqParams>(a, b); }
+GM_DEV FqE fq_dbl(const FqE& a) { return fp_add<FqParams>(a, a); }
+template <int K>
+GM_DEV FqE fq_sub(const FqE& a, const FqE& b) { return fp_sub<FqParams>(a, b); }
+GM_DEV FqE fq_neg_canonical(const FqE& y) { return fp_neg<FqParams>(y); }
+GM_DEV bool fq_is_zero_mod(const FqE& a) { return a.is_zero(); }
+GM_DEV bool fq_is_exact_zero(const FqE& a) { return a.is_zero(); }
+GM_DEV FqE fqe_zero() { return Fq::zero(); }
+GM_DEV FqE fqe_one() { return fq30_pack(fq30_const(Fq30Consts::ONE)); }
+GM_DEV FqE fqe_load(const void* p) { return fp_load<FqParams>(p); }
+GM_DEV void fqe_store(void* p, const FqE& a) { fp_store<FqParams>(p, a); }
+constexpr int FQE_LIMBS = 12;
+GM_DEV FqE fqe_import(const Fq& ark) { return fq_mul(ark, fq30_pack(fq30_const(Fq30Consts::CIN))); }
+GM_DEV Fq fqe_export(const FqE& dev) { return fq_mul(dev, fq30_pack(fq30_const(Fq30Consts::COUT))); }
 #else
 using FqE = Fq;
 // The out-of-line multiplier takes its operands as 24 scalar arguments: hipcc passes a second by-value
@@ -246,7 +295,7 @@ GM_DEV G1Xyzz g1_load_xyzz(const void* p) {
   r.zzz = fqe_load(c + 144);
   return r;
 }
-#if GM_FQ30
+#if GM_FQ30 == 1
 __device__ __noinline__  // canonicalisation makes the store path long: keep one out-of-line copy
 #else
 GM_DEV

@@ -1499,7 +1499,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     pf.end(PROF_SCAN, st);
   }
   pf.begin(PROF_ACC0, st);
-  static const bool acc0_lds = getenv("GM_ACC0") ? !strcmp(getenv("GM_ACC0"), "lds") : (GM_FQ30 != 0);
+  static const bool acc0_lds = getenv("GM_ACC0") ? !strcmp(getenv("GM_ACC0"), "lds") : (GM_FQ30 == 1);
   if (acc0_lds)
     hipLaunchKernelGGL(k_acc0_lds, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
