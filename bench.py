@@ -294,11 +294,12 @@ def main():
                 "kernel_ms": round(acc0_ms, 4) if acc0_ms else None,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
                 "note": "integer-ALU bound (~300 v_mad_u64_u32 per Fq product); HBM fraction reported as the contract asks",
-                # the truthful utilisation figure: Fq products per second of the kernel against the
-                # multiplier's own measured peak on this chip (tools/ubench_isa.hip, profiles/r1_ubench_isa.txt)
+                # the truthful utilisation figure: Fq products per second of the kernel (10 per mixed
+                # addition, 16 windows) against the multiplier's instruction-issue bound -- 288 v_mad_u64_u32 + 288 v_addc_co_u32,
+                # both 4.5 cycles per wave (tools/ubench_isa.hip, profiles/r1_ubench_isa.txt), 1024 SIMDs x 64 lanes at 2.4 GHz
                 "fq_mul_per_s": round(10 * 16 * n / (acc0_ms * 1e-3)) if acc0_ms and args.logn == LOG_N else None,
-                "fq_mul_peak_measured": 50.4e9,
-                "alu_frac": round(10 * 16 * n / (acc0_ms * 1e-3) / 50.4e9, 4) if acc0_ms and args.logn == LOG_N else None,
+                "fq_mul_issue_bound": 60.7e9,
+                "alu_frac": round(10 * 16 * n / (acc0_ms * 1e-3) / 60.7e9, 4) if acc0_ms and args.logn == LOG_N else None,
             },
             "stage_ms": {k: (round(v, 4) if v is not None else None) for k, v in stages.items()},
         }
