@@ -374,3 +374,40 @@ def test_sharded_stream_key_single_process(gm, oracle, pyref):
         poly.free()
     finally:
         dist.destroy_process_group()
+
+
+def test_snark_time_prover_full_size_closed_forms(gm, oracle, pyref):
+    """BASELINE config 3 (`snark --time-prover -i 24`) at FULL size, through what the dummy instance fixes in
+    closed form (src/circuit.rs:349-365: z = [e; n], w = [e; n-1], A = B = C = diag(1/e), so z_a = z_b = z_c =
+    [1; n]):  commitment(w) = e (tau^(n-1) - 1)/(tau - 1) g;  zc(alpha) = (alpha^n - 1)/(alpha - 1) with alpha
+    re-derived by the oracle's Merlin from that commitment;  the first message of the first sumcheck,
+    a = sum_i alpha^(2i) = (alpha^n - 1)/(alpha^2 - 1), b = sum_i (1 + alpha) alpha^(2i) (time_prover.rs:105-118 on
+    all-ones vectors).  Ties the 2^24-pair MSM, the transcript and the 2^24-element passes together."""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+
+    R = pyref.R_MOD
+    logn = 24
+    n = 1 << logn
+    e = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % R
+    tau = 0xFEDCBA9876543210FEDCBA9876543210FEDCBA98765432 % R
+    r1cs = dummy_r1cs(e, n)
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    proof = Proof.new_time(r1cs, ck)
+    inv = lambda v: pow(v % R, -1, R)
+    k = e * (pow(tau, n - 1, R) - 1) % R * inv(tau - 1) % R
+    want_cm = pyref.g1_mul(pyref.G1_GEN, k)
+    assert jac_to_affine_ints(oracle, proof.witness_commitment) == want_cm
+    tr = pyref.GeminiTranscript(pyref.PROTOCOL_NAME)
+    tr.append_message(b"witness", pyref.g1_serialize_uncompressed(want_cm))
+    alpha = tr.get_challenge(b"alpha")
+    I = gm.fr.fr_to_int
+    assert I(proof.zc_alpha) == (pow(alpha, n, R) - 1) * inv(alpha - 1) % R
+    a0 = (pow(alpha, n, R) - 1) * inv(alpha * alpha - 1) % R
+    msgs = proof.first_sumcheck_msgs[0]
+    assert len(msgs) == logn
+    assert I(msgs[0][0]) == a0 and I(msgs[0][1]) == a0 * (1 + alpha) % R
+    assert len(proof.tensorcheck_proof.folded_polynomials_commitments) == logn - 1
+    assert proof.compressed_size() == 6056  # the size DESIGN.md derives for logN 24
+    r1cs.free()
