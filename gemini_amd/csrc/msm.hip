@@ -277,6 +277,96 @@ __global__ __launch_bounds__(256) void k_sort2(const uint64_t* __restrict__ tmp,
   }
 }
 
+// Scatter half of pass 2 with the block's chunk staged in LDS.  k_sort2<true> writes each 8-byte entry
+// straight to entries[base[f] + rank]: neighbouring lanes hold random fine bins, so a wave's store is 64
+// separate 8-byte writes (a 64-byte sector each): 1.9 GB of entries cost 4.2 ms at 2^24 pairs, 0.9 TB/s.
+// Here the block (1024 threads, the whole 160 KiB of LDS) first counting-sorts its 16 Ki entries by fine
+// bin INSIDE LDS and then streams the LDS image out: lane i writes the i-th locally sorted entry, so
+// neighbouring lanes write neighbouring addresses of the same bin (runs of chunk / bins = 8-16 entries).
+constexpr uint32_t SORT_STAGE_FMAX = 2048;
+__global__ __launch_bounds__(1024) void k_sort2_staged(const uint64_t* __restrict__ tmp, const uint32_t* __restrict__ goff,
+                                                       const uint32_t* __restrict__ blkoff, SortGeom sg, uint32_t* __restrict__ cursor,
+                                                       uint64_t* __restrict__ entries) {
+  __shared__ uint64_t buf[SORT_CH];
+  __shared__ uint32_t cnt[SORT_STAGE_FMAX], base[SORT_STAGE_FMAX], lst[SORT_STAGE_FMAX];
+  __shared__ uint32_t scan[1024];
+  __shared__ uint32_t s_g;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nf = 1u << sg.FB;
+  if (blockIdx.x >= blkoff[sg.G]) return;
+  if (tid == 0) {
+    uint32_t lo = 0, hi = sg.G;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (blkoff[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    s_g = lo;
+  }
+  for (uint32_t f = tid; f < nf; f += 1024) cnt[f] = 0;
+  __syncthreads();
+  const uint32_t g = s_g;
+  const uint32_t chunk = blockIdx.x - blkoff[g];
+  const uint32_t lo = goff[g] + chunk * SORT_CH;
+  const uint32_t hi = min(lo + SORT_CH, goff[g + 1]);
+  const uint32_t m = hi - lo;
+  const uint32_t mask = nf - 1u;
+  constexpr uint32_t PER = SORT_CH / 1024;
+  uint64_t e[PER];
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t i = tid + k * 1024;
+    if (i < m) {
+      e[k] = tmp[lo + i];
+      atomicAdd(&cnt[(uint32_t)(e[k] >> 32) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  // global ranges of this block's entries per bin + exclusive scan of the local counts
+  const uint32_t per = nf > 1024 ? nf / 1024 : 1;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t f = tid * per + k;
+    if (f < nf) {
+      const uint32_t c = cnt[f];
+      base[f] = c ? atomicAdd(cursor + ((size_t)g << sg.FB) + f, c) : 0u;
+      s += c;
+    }
+  }
+  scan[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint32_t x = tid >= d ? scan[tid - d] : 0;
+    __syncthreads();
+    scan[tid] += x;
+    __syncthreads();
+  }
+  uint32_t run = scan[tid] - s;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t f = tid * per + k;
+    if (f < nf) {
+      lst[f] = run;
+      run += cnt[f];
+    }
+  }
+  __syncthreads();
+  for (uint32_t f = tid; f < nf; f += 1024) cnt[f] = 0;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    const uint32_t i = tid + k * 1024;
+    if (i < m) {
+      const uint32_t f = (uint32_t)(e[k] >> 32) & mask;
+      buf[lst[f] + atomicAdd(&cnt[f], 1u)] = e[k];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < m; i += 1024) {
+    const uint64_t v = buf[i];
+    const uint32_t f = (uint32_t)(v >> 32) & mask;
+    entries[base[f] + (i - lst[f])] = v;
+  }
+}
+
 // exclusive scan of m counters in three launches: per-block sums (4096 counters per block),
 // a single-block scan of the block sums, then the local scans with the block offsets applied
 constexpr uint32_t SCAN_PER_THREAD = 16;
@@ -1399,8 +1489,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     hipLaunchKernelGGL(k_sort2<false>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
                        ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
     run_scan();
-    hipLaunchKernelGGL(k_sort2<true>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
-                       ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
+    static const bool sort_staged = !(getenv("GM_MSM_SORT2") && !strcmp(getenv("GM_MSM_SORT2"), "direct"));
+    if (sort_staged && (1u << sg.FB) <= SORT_STAGE_FMAX)
+      hipLaunchKernelGGL(k_sort2_staged, dim3(b2), dim3(1024), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
+                         ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
+    else
+      hipLaunchKernelGGL(k_sort2<true>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
+                         ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
     pf.end(PROF_SCATTER, st);
   }
   const uint64_t* acc_entries = ws.entries.as<uint64_t>();
