@@ -190,6 +190,90 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
   }
 }
 
+// Scatter half of pass 1, staged in LDS like k_sort2_staged: one thread per scalar (1024 per block) keeps
+// its <= 16 entries in registers, the block counting-sorts them by coarse bin inside LDS and streams the
+// image out, so a wave writes runs of neighbouring addresses instead of 64 scattered 8-byte words.
+// Dynamic LDS: SORT_TS * W entries + 3 G counters + the scan array (<= 160 KiB for c >= 16).
+constexpr int SORT1_STAGE_WMAX = 16;
+__global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg,
+                                                       uint32_t* __restrict__ gcursor, uint64_t* __restrict__ tmp) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + (size_t)SORT_TS * sg.W);
+  uint32_t* base = cnt + sg.G;
+  uint32_t* lst = base + sg.G;
+  uint32_t* scan = lst + sg.G;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t g = tid; g < sg.G; g += 1024) cnt[g] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * SORT_TS + tid;
+  const bool active = i < n;
+  uint64_t e[SORT1_STAGE_WMAX];
+  {
+    DigitIter it;
+    it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
+#pragma unroll
+    for (int w = 0; w < SORT1_STAGE_WMAX; w++) {
+      e[w] = ~0ull;
+      if (w < sg.W) {
+        int32_t d = it.next(sg.c);
+        if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
+        if (active && d != 0) {
+          const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+          const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
+          const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : i;
+          e[w] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
+          atomicAdd(&cnt[key >> sg.FB], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t per = (sg.G + 1023u) / 1024u;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t g = tid * per + k;
+    if (g < sg.G) {
+      const uint32_t c = cnt[g];
+      base[g] = c ? atomicAdd(gcursor + g, c) : 0u;
+      s += c;
+    }
+  }
+  scan[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint32_t x = tid >= d ? scan[tid - d] : 0;
+    __syncthreads();
+    scan[tid] += x;
+    __syncthreads();
+  }
+  const uint32_t m = scan[1023];
+  uint32_t run = scan[tid] - s;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t g = tid * per + k;
+    if (g < sg.G) {
+      lst[g] = run;
+      run += cnt[g];
+    }
+  }
+  __syncthreads();
+  for (uint32_t g = tid; g < sg.G; g += 1024) cnt[g] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < SORT1_STAGE_WMAX; w++) {
+    if (e[w] != ~0ull) {
+      const uint32_t g = (uint32_t)(e[w] >> 32) >> sg.FB;
+      buf[lst[g] + atomicAdd(&cnt[g], 1u)] = e[w];
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = tid; j < m; j += 1024) {
+    const uint64_t v = buf[j];
+    const uint32_t g = (uint32_t)(v >> 32) >> sg.FB;
+    tmp[base[g] + (j - lst[g])] = v;
+  }
+}
+
 // exclusive scan of the G coarse counters + prefix of the pass-2 block counts (one block)
 __global__ __launch_bounds__(1024) void k_sort1_scan(const uint32_t* __restrict__ gcount, uint32_t G,
                                                      uint32_t* __restrict__ goff, uint32_t* __restrict__ gcursor,
@@ -1483,7 +1567,18 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     pf.begin(PROF_DIGITS, st);
     hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcount, (uint64_t*)nullptr);
     hipLaunchKernelGGL(k_sort1_scan, dim3(1), dim3(1024), 0, st, gcount, sg.G, goff, gcursor, blkoff);
-    hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>());
+    const size_t stage1_lds = (size_t)SORT_TS * W * 8 + (size_t)3 * sg.G * 4 + 1024 * 4;
+    static const bool sort1_staged_env = !(getenv("GM_MSM_SORT1") && !strcmp(getenv("GM_MSM_SORT1"), "direct"));
+    if (sort1_staged_env && W <= SORT1_STAGE_WMAX && stage1_lds <= 160 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort1_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_sort1_staged, dim3(b1), dim3(1024), stage1_lds, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>());
+    } else {
+      hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>());
+    }
     pf.end(PROF_DIGITS, st);
     pf.begin(PROF_SCATTER, st);
     hipLaunchKernelGGL(k_sort2<false>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
