@@ -1734,9 +1734,15 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   }
   // lanes per output: enough lanes to put ~2^17 threads in flight (2 waves per SIMD), never more than
   // the element count; few lanes keep the work near the minimum (the shuffle tree runs on every lane)
-  auto lpo_for = [](uint32_t len, uint32_t n_out) {
+  static const int lpo_env = getenv("GM_MSM_LPO_LOG") ? atoi(getenv("GM_MSM_LPO_LOG")) : 0;  // tuning override
+  // (measured: 2^17 threads per launch for the 0.5 M buckets of c = 16 -- 0.57 vs 0.67 ms --, 2^18 for the
+  // millions of buckets of the wide windows)
+  const int lpo_target_log = lpo_env ? lpo_env : (nbuckets >= ((size_t)1 << 21) ? 18 : 17);
+  // the jobs of one launch share the GPU: aim the launch as a whole at ~2^17 threads
+  uint32_t lpo_jobs = 1;
+  auto lpo_for = [&](uint32_t len, uint32_t n_out) {
     uint32_t s = 0;
-    while (s < 5 && (1u << s) < len && ((uint64_t)n_out << s) < (1u << 17)) s++;
+    while (s < 5 && (1u << s) < len && ((uint64_t)n_out << s) * lpo_jobs < (1ull << lpo_target_log)) s++;
     return s;
   };
   auto strided = [&](const uint8_t* in, uint8_t* out, uint32_t win_in, uint32_t n_hi, uint32_t n_lo, uint32_t s_hi, uint32_t s_lo,
@@ -1778,12 +1784,14 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   const uint8_t* X = ws.buckets.as<uint8_t>();
   const uint32_t n0 = 1u << wf[0], n1 = 1u << wf[1], n2 = 1u << wf[2];
   if (m == 1) {
+    lpo_jobs = 1;
     launch({plane(X, planes, wf[0])});
   } else if (m == 2) {
     // Y1[d1] = sum_{d0} X (rows), Y0[d0] = sum_{d1} X (columns)
     if ((rc = ws.rows.ensure((size_t)Wb * (n0 + n1) * XYZZ_BYTES))) return rc;
     uint8_t* Y0 = ws.rows.as<uint8_t>();
     uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ_BYTES;
+    lpo_jobs = 2;
     launch({strided(X, Y1, B, 1, n1, 0, n0, 1, n0), strided(X, Y0, B, 1, n0, 0, 1, n0, n1)});
     launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1])});
   } else {
@@ -1795,8 +1803,10 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     uint8_t* Y0 = ws.cols.as<uint8_t>();
     uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ_BYTES;
     uint8_t* Y2 = Y1 + (size_t)Wb * n1 * XYZZ_BYTES;
+    lpo_jobs = 2;
     launch({strided(X, A, B, n2, n1, n1 * n0, n0, 1, n0), strided(X, Bm, B, n2, n0, n1 * n0, 1, n0, n1)});
     // level 2: Y2[d2] = sum_{d1} A, Y1[d1] = sum_{d2} A, Y0[d0] = sum_{d2} Bm
+    lpo_jobs = 3;
     launch({strided(A, Y2, n2 * n1, 1, n2, 0, n1, 1, n1), strided(A, Y1, n2 * n1, 1, n1, 0, 1, n1, n2),
             strided(Bm, Y0, n2 * n0, 1, n0, 0, 1, n0, n2)});
     launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1]),
