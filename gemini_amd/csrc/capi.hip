@@ -220,6 +220,7 @@ int gm_init(int device) {
   C->cu_count = prop.multiProcessorCount;
   GM_HIP(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
   for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithFlags(&C->small_stream[k], hipStreamNonBlocking));
+  GM_HIP(hipStreamCreateWithFlags(&C->stream_b, hipStreamNonBlocking));
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
   g_ctx = C;
   return GM_OK;
@@ -260,6 +261,8 @@ void gm_shutdown(void) {
     }
   };
   release_ws(C->msm);
+  release_ws(C->msm_b);
+  if (C->stream_b) (void)hipStreamDestroy(C->stream_b);
   for (int k = 0; k < MSM_SMALL_LANES; k++) {
     release_ws(C->msm_small[k]);
     if (C->small_stream[k]) (void)hipStreamDestroy(C->small_stream[k]);

@@ -178,6 +178,10 @@ struct Context {
   // extra workspaces + streams for the small calls of a batch (msm_run_batch)
   MsmWorkspace msm_small[MSM_SMALL_LANES];
   hipStream_t small_stream[MSM_SMALL_LANES] = {};
+  // second full-size workspace + stream: the big calls of a batch alternate between the two so that the
+  // sort / merge / reduce of one overlap the (ALU-bound) accumulation of the other
+  MsmWorkspace msm_b;
+  hipStream_t stream_b = nullptr;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
   int msm_c_override = 0;

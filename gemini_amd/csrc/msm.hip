@@ -1420,14 +1420,23 @@ int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, c
     (void)hipStreamSynchronize(C->stream);
     for (int s = 0; s < MSM_SMALL_LANES; s++)
       if (C->small_stream[s]) (void)hipStreamSynchronize(C->small_stream[s]);
+    if (C->stream_b) (void)hipStreamSynchronize(C->stream_b);
     return rc;
   };
-  int main_parity = 0, small_rr = 0;
+  int big_rr = 0, small_rr = 0;
   for (size_t j = 0; j < k; j++) {
     const bool small = ns[j] <= MSM_SMALL_N && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0;
-    const int lane = small ? 1 + (small_rr++ % MSM_SMALL_LANES) : 0;
-    const int hslot = small ? 0 : main_parity;
-    if (!small) main_parity ^= 1;
+    // big calls alternate between the two full-size lanes (0 and -1), each with two result buffers
+    static const bool two_big = !(getenv("GM_MSM_BIG_LANES") && !strcmp(getenv("GM_MSM_BIG_LANES"), "1"));
+    int lane, hslot;
+    if (small) {
+      lane = 1 + (small_rr++ % MSM_SMALL_LANES);
+      hslot = 0;
+    } else {
+      lane = (two_big && C->stream_b && (big_rr & 1)) ? -1 : 0;
+      hslot = (big_rr >> 1) & 1;
+      big_rr++;
+    }
     // a (workspace, result buffer) pair is free again once its previous call has been finished
     for (;;) {
       bool busy = false;
@@ -1439,8 +1448,8 @@ int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, c
     Inflight e;
     e.j = j;
     e.lane = lane;
-    MsmWorkspace& ws = lane ? C->msm_small[lane - 1] : C->msm;
-    hipStream_t st = lane ? C->small_stream[lane - 1] : C->stream;
+    MsmWorkspace& ws = lane > 0 ? C->msm_small[lane - 1] : (lane < 0 ? C->msm_b : C->msm);
+    hipStream_t st = lane > 0 ? C->small_stream[lane - 1] : (lane < 0 ? C->stream_b : C->stream);
     int rc = msm_enqueue(C, ws, st, bases, first, step, d_scalars[j], mont, ns[j], hslot, &e.P);
     if (rc) return fail(rc);
     q.push_back(e);
