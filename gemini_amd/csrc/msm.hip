@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     for (int w = 0; w < sg.W; w++) {
       int32_t d = it.next(sg.c);
       if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
-      if (active && d != 0) {
-        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        atomicAdd(&cnt[((sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u)) >> sg.FB], 1u);
-      }
+      // (wave_atomic_inc: one LDS atomic per wave when all lanes hit the same bin -- the all-equal-scalars
+      // instance of the reference's benchmark would otherwise serialise 64 same-address atomics)
+      const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+      wave_atomic_inc(cnt, (active && d != 0) ? (((sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
     }
   }
   __syncthreads();
@@ -178,11 +178,12 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     for (int w = 0; w < sg.W; w++) {
       int32_t d = it.next(sg.c);
       if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
-      if (active && d != 0) {
-        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
-        const uint32_t g = key >> sg.FB;
-        const uint32_t r = atomicAdd(&cnt[g], 1u);
+      const bool live = active && d != 0;
+      const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+      const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
+      const uint32_t g = key >> sg.FB;
+      const uint32_t r = wave_atomic_inc(cnt, live ? g : KEY_INV);
+      if (live) {
         const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : i;
         tmp[(SCATTER ? base[g] : 0u) + r] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
       }
@@ -223,9 +224,9 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
           const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
           const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : i;
           e[w] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
-          atomicAdd(&cnt[key >> sg.FB], 1u);
         }
       }
+      wave_atomic_inc(cnt, e[w] != ~0ull ? ((uint32_t)(e[w] >> 32) >> sg.FB) : KEY_INV);
     }
   }
   __syncthreads();
@@ -261,10 +262,10 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
   __syncthreads();
 #pragma unroll
   for (int w = 0; w < SORT1_STAGE_WMAX; w++) {
-    if (e[w] != ~0ull) {
-      const uint32_t g = (uint32_t)(e[w] >> 32) >> sg.FB;
-      buf[lst[g] + atomicAdd(&cnt[g], 1u)] = e[w];
-    }
+    const bool live = e[w] != ~0ull;
+    const uint32_t g = (uint32_t)(e[w] >> 32) >> sg.FB;
+    const uint32_t r = wave_atomic_inc(cnt, live ? g : KEY_INV);
+    if (live) buf[lst[g] + r] = e[w];
   }
   __syncthreads();
   for (uint32_t j = tid; j < m; j += 1024) {
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(256) void k_sort2(const uint64_t* __restrict__ tmp,
   const uint32_t lo = goff[g] + chunk * SORT_CH;
   const uint32_t hi = min(lo + SORT_CH, goff[g + 1]);
   const uint32_t mask = nf - 1u;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&cnt[(uint32_t)(tmp[i] >> 32) & mask], 1u);
+  for (uint32_t i0 = lo; i0 < hi; i0 += 256) {  // whole waves enter wave_atomic_inc together
+    const uint32_t i = i0 + threadIdx.x;
+    wave_atomic_inc(cnt, i < hi ? ((uint32_t)(tmp[i] >> 32) & mask) : KEY_INV);
+  }
   __syncthreads();
   if (!SCATTER) {
     for (uint32_t f = threadIdx.x; f < nf; f += 256)
@@ -353,11 +357,13 @@ __global__ __launch_bounds__(256) void k_sort2(const uint64_t* __restrict__ tmp,
     cnt[f] = 0;
   }
   __syncthreads();
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-    const uint64_t e = tmp[i];
+  for (uint32_t i0 = lo; i0 < hi; i0 += 256) {
+    const uint32_t i = i0 + threadIdx.x;
+    const bool live = i < hi;
+    const uint64_t e = live ? tmp[i] : 0;
     const uint32_t f = (uint32_t)(e >> 32) & mask;
-    const uint32_t r = atomicAdd(&cnt[f], 1u);
-    entries[(SCATTER ? base[f] : 0u) + r] = e;
+    const uint32_t r = wave_atomic_inc(cnt, live ? f : KEY_INV);
+    if (live) entries[(SCATTER ? base[f] : 0u) + r] = e;
   }
 }
 
@@ -399,10 +405,8 @@ __global__ __launch_bounds__(1024) void k_sort2_staged(const uint64_t* __restric
 #pragma unroll
   for (uint32_t k = 0; k < PER; k++) {
     const uint32_t i = tid + k * 1024;
-    if (i < m) {
-      e[k] = tmp[lo + i];
-      atomicAdd(&cnt[(uint32_t)(e[k] >> 32) & mask], 1u);
-    }
+    e[k] = i < m ? tmp[lo + i] : 0;
+    wave_atomic_inc(cnt, i < m ? ((uint32_t)(e[k] >> 32) & mask) : KEY_INV);
   }
   __syncthreads();
   // global ranges of this block's entries per bin + exclusive scan of the local counts
@@ -438,10 +442,9 @@ __global__ __launch_bounds__(1024) void k_sort2_staged(const uint64_t* __restric
 #pragma unroll
   for (uint32_t k = 0; k < PER; k++) {
     const uint32_t i = tid + k * 1024;
-    if (i < m) {
-      const uint32_t f = (uint32_t)(e[k] >> 32) & mask;
-      buf[lst[f] + atomicAdd(&cnt[f], 1u)] = e[k];
-    }
+    const uint32_t f = (uint32_t)(e[k] >> 32) & mask;
+    const uint32_t r = wave_atomic_inc(cnt, i < m ? f : KEY_INV);
+    if (i < m) buf[lst[f] + r] = e[k];
   }
   __syncthreads();
   for (uint32_t i = tid; i < m; i += 1024) {
