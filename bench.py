@@ -93,9 +93,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--logn", type=int, default=LOG_N, help="pairs per GPU per step = 2^logn (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline loop (what the rocprofv3 summary under profiles/ is taken "
+                    "from: the extra legs overlap kernels on several streams, which stretches their durations)")
     ap.add_argument("--no-tables", action="store_true", help="skip the extra fixed-base-table measurement")
     ap.add_argument("--snark-logn", type=int, default=24, help="also time snark::Proof::new_time on dummy_r1cs(2^k) (N=1 only; 0 = skip)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = True
+        args.no_tables = True
+        args.snark_logn = 0
 
     import torch
     import torch.distributed as dist
@@ -199,7 +205,7 @@ def main():
     # extra (not the headline): CommitterKey::batch_commit shape -- 8 MSMs per call through gm_g1_msm_v_batch,
     # which overlaps the host tail (bit-plane Horner) of MSM j with the kernels of MSM j+1
     batch = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         from gemini_amd.fr import FrVec
 
         lib.gm_set_msm_table_min(C.c_size_t(1 << 62))  # plain path even if tables were just built
@@ -223,7 +229,7 @@ def main():
     # extra (never `value`): the same MSM when the boundary hands over HOST buffers -- scalars only (SRS resident,
     # gm_g1_msm_h: 32 MiB over PCIe per call) and the one-shot gm_g1_msm (bases 96 MiB + scalars 32 MiB per call)
     pcie = None
-    if world == 1:
+    if world == 1 and not args.headline_only:
         from gemini_amd.msm import VariableBaseMSM
 
         hb_full = bases.download()

@@ -12,8 +12,8 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
 rows = list(csv.DictReader(open(os.path.join(G, "prof_final", "msm20_kernel_stats.csv"))))
-out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --snark-logn 0 --no-tables (MI355X, round 1 final library)", "",
-       "The headline loop is the 12 one-call MSMs (2 warm-up + 10 timed); the remaining `k_acc0` calls belong to the batch_commit (8 MSMs per call) and PCIe-inclusive legs of the same command.", "",
+out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --headline-only (MI355X, round 1 final library)", "",
+       "23 one-call 2^20-pair MSMs (3 warm-up + 20 timed), nothing else in the command.", "",
        "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
 for r in rows:
     out.append("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
