@@ -391,3 +391,30 @@ def test_affine_levels_large(gm, oracle):
     finally:
         _set_levels(gm, 0)
         b.free()
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "two_values", "few_values", "runs"])
+def test_msm_skewed_digit_distributions_multi_block(gm, oracle, kind):
+    """2^17 + 3 pairs (c = 16, a hundred sort blocks per pass) with scalars drawn from very few values, so whole
+    waves hit the same sort bin (wave-aggregated LDS atomics), a bin's entries straddle many blocks of the
+    staged scatter passes, and single buckets hold tens of thousands of entries -- against the CPU Pippenger."""
+    n = (1 << 17) + 3
+    rng = np.random.default_rng({"all_equal": 1, "two_values": 2, "few_values": 3, "runs": 4}[kind])
+    ks = oracle.random_fr(91, n)
+    reg = gm.G1Bases.fixed_base(oracle.g1_generator(), ks)
+    vals = oracle.random_fr(92, 37)
+    if kind == "all_equal":
+        idx = np.zeros(n, dtype=np.int64)
+    elif kind == "two_values":
+        idx = rng.integers(0, 2, size=n)
+    elif kind == "few_values":
+        idx = rng.integers(0, 37, size=n)
+    else:  # long runs of one value, then another: waves are uniform, blocks are not
+        idx = (np.arange(n) // 3000) % 5
+    sc = vals[idx]
+    sc[::977] = 0  # holes
+    try:
+        got = reg.msm_bigint(sc)
+        assert_same_point(oracle, got, oracle.msm_pippenger(reg.download(), sc))
+    finally:
+        reg.free()
