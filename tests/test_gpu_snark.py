@@ -411,3 +411,38 @@ def test_snark_time_prover_full_size_closed_forms(gm, oracle, pyref):
     assert len(proof.tensorcheck_proof.folded_polynomials_commitments) == logn - 1
     assert proof.compressed_size() == 6056  # the size DESIGN.md derives for logN 24
     r1cs.free()
+
+
+def test_matrix_tensor_known_answers(gm, oracle, pyref):
+    """src/snark/streams.rs:104-222 (test_matrix_tensor_stream, test_matrix_tensor): the MatrixTensor stream
+    M^T tensor(challenges) is a product with the transposed CSR matrix on the device.  Identities that hold for
+    any r: diag(r) with the all-ones tensor gives [r; n]; with a random tensor the (big-endian) stream is
+    [r t0 t1, r t1, r t0, r]; the 4x4 example gives [r^3 + r^2 + r + 1, r, r^2, 0]; the identity matrix
+    returns tensor(challenges) itself."""
+    from gemini_amd.circuit import SparseMatrix
+    from gemini_amd.fr import FrVec, fr_from_int, fr_to_int, tensor
+
+    R = pyref.R_MOD
+    rng = pyref.SplitMix64(222)
+    r, t0, t1 = rng.fr(), rng.fr(), rng.fr()
+    M = lambda v: fr_from_int(v % R)
+    ints = lambda vec: [fr_to_int(x) for x in vec.to_host()]
+    diag = SparseMatrix.from_rows([[(M(r), i)] for i in range(4)], 4, transpose=True)
+    ones = tensor(np.stack([M(1), M(1)]))
+    assert ints(diag.mul(ones)) == [r] * 4
+    tt = tensor(np.stack([M(t0), M(t1)]))
+    assert ints(diag.mul(tt))[::-1] == [r * t0 * t1 % R, r * t1 % R, r * t0 % R, r]  # stream order = reversed vector
+    # column-major example of test_matrix_tensor: column 0 holds rows 0..3, column 1 row 1, column 2 row 2, column 3 nothing
+    rows = [[(M(1), 0)], [(M(1), 0), (M(1), 1)], [(M(1), 0), (M(1), 2)], [(M(1), 0)]]
+    mt = SparseMatrix.from_rows(rows, 4, transpose=True)
+    T = tensor(np.stack([M(r), M(r * r)]))
+    assert ints(T) == [1, r, r * r % R, pow(r, 3, R)]
+    assert ints(mt.mul(T)) == [(pow(r, 3, R) + r * r + r + 1) % R, r, r * r % R, 0]
+    ch = [rng.fr() for _ in range(4)]
+    ident = SparseMatrix.from_rows([[(M(1), i)] for i in range(16)], 16, transpose=True)
+    Tc = tensor(np.stack([M(c) for c in ch]))
+    assert ints(ident.mul(Tc)) == pyref.tensor(ch)
+    for m in (diag, mt, ident):
+        m.free()
+    for v in (ones, tt, T, Tc):
+        v.free()
