@@ -142,6 +142,26 @@ class EntryProduct:
         """entryproduct/time_prover.rs:116-147"""
         return EntryProduct.new_time_batch(transcript, ck, [v], [claimed_product])
 
+    @staticmethod
+    def new_elastic(transcript, ck_stream, v_stream, claimed_product) -> "EntryProduct":
+        """entryproduct/elastic_prover.rs:32-63 over a big-endian device stream: ProductStream /
+        RightRotationStreamer are the reversed accumulated-product / shifted vectors"""
+        from .fr import reverse
+        from .snark import _evaluate_be
+        from .sumcheck import ElasticProver
+
+        v = reverse(v_stream)
+        acc_s, rrot_s = reverse(accumulated_product_monic(v)), reverse(shift_monic(v))
+        cm = ck_stream.commit(acc_s)
+        transcript.append_g1(b"acc_v", cm)
+        chal = transcript.get_challenge(b"ep-chal")
+        ci = fr_to_int(chal)
+        claimed = fr_from_int((ci * fr_to_int(_evaluate_be(acc_s, chal.reshape(1, 4))[0]) + fr_to_int(claimed_product) - pow(ci, len(acc_s), R_MOD)) % R_MOD)
+        provers = [ElasticProver(acc_s, rrot_s, chal)]
+        for x in (v, acc_s, rrot_s):
+            x.free()
+        return EntryProduct(EntryProductMsgs([cm], [claimed]), chal, provers)
+
 
 class Proof:
     """src/psnark/mod.rs:29-51"""

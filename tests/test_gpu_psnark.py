@@ -202,3 +202,72 @@ def test_psnark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
     assert Proof.new_elastic(ck_stream, stream, index, 1 << 6).serialize_compressed() == a
     stream.free()
     r1cs.free()
+
+
+@pytest.mark.parametrize("n", [1000, (1 << 20) + 5])
+def test_entry_product_relation(gm, oracle, pyref, n):
+    """src/subprotocols/entryproduct/tests.rs:14-36: for any v, with g = accumulated_product(monic(v)) and psi,
+    <(right_rotation(monic(v)) - psi) o powers(psi), g> = prod(v) - psi^(n+1).  Runs the reverse prefix-product
+    scan, the shift, hadamard / powers / ip at n = 1000 (the reference's size) and beyond 2^20."""
+    from gemini_amd import fr as F
+
+    R = pyref.R_MOD
+    rng = np.random.default_rng(n)
+    host = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    host[:, 3] &= np.uint64((1 << 62) - 1)
+    v = F.FrVec.from_host(host)  # arbitrary Montgomery residues
+    chal = oracle.limbs_to_ints(oracle.random_fr(n % 97, 1))[0]
+    acc = F.accumulated_product_monic(v)
+    rrot = F.shift_monic(v)
+    shifted = F.plookup_subset(rrot, F.fr_from_int((-chal) % R))  # every entry minus psi
+    twist = F.powers(F.fr_from_int(chal), n + 1)
+    had = F.hadamard(shifted, twist)
+    lhs = F.fr_to_int(F.ip(had, acc))
+    product = F.fr_to_int(F.element(acc, 0))
+    assert lhs == (product - pow(chal, n + 1, R)) % R
+    if n <= 1000:  # the product itself against Python integers
+        want = 1
+        for x in oracle.limbs_to_ints(oracle.fr_from_mont(host)):
+            want = want * x % R
+        assert product == want
+    for x in (v, acc, rrot, shifted, twist, had):
+        x.free()
+
+
+def test_entry_product_consistency(gm, oracle, pyref):
+    """entryproduct/tests.rs:38-54: EntryProduct::new_time and new_elastic produce the same messages (and,
+    here, the same sumcheck transcripts) on v = [r; 1000]."""
+    from gemini_amd import fr as F
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from gemini_amd.psnark import EntryProduct
+    from gemini_amd.sumcheck import Sumcheck
+    from gemini_amd.transcript import Transcript
+
+    R = pyref.R_MOD
+    n = 1000
+    r = oracle.limbs_to_ints(oracle.random_fr(55, 1))[0]
+    v = F.FrVec.alloc(n)
+    v.fill(F.fr_from_int(r))
+    product = F.fr_from_int(pow(r, n, R))
+    ck = CommitterKey.new(n + 1, 1, oracle.random_fr(56, 1)[0])
+    t1, t2 = Transcript(b"test"), Transcript(b"test")
+    ep_time = EntryProduct.new_time(t1, ck, v, product)
+    v_stream = F.reverse(v)
+    ep_space = EntryProduct.new_elastic(t2, CommitterKeyStream.from_committer_key(ck), v_stream, product)
+    assert (ep_time.msgs.acc_v_commitments[0] == ep_space.msgs.acc_v_commitments[0]).all()
+    assert (ep_time.msgs.claimed_sumchecks[0] == ep_space.msgs.claimed_sumchecks[0]).all()
+    assert (ep_time.chal == ep_space.chal).all()
+    a = Sumcheck.prove(t1, ep_time.provers[0])
+    b = Sumcheck.prove(t2, ep_space.provers[0])
+    I = F.fr_to_int
+    assert [(I(x), I(y)) for x, y in a.messages] == [(I(x), I(y)) for x, y in b.messages]
+    # the claimed sumcheck is the first message's a + b? no: it is the inner product <acc o twist, rrot>: check it
+    acc = F.accumulated_product_monic(v)
+    rrot = F.shift_monic(v)
+    tw = F.powers(ep_time.chal, len(acc))
+    had = F.hadamard(acc, tw)
+    assert I(F.ip(had, rrot)) == I(ep_time.msgs.claimed_sumchecks[0])
+    for p in ep_time.provers + ep_space.provers:
+        p.free()
+    for x in (v, v_stream, acc, rrot, tw, had):
+        x.free()
