@@ -271,3 +271,25 @@ def test_entry_product_consistency(gm, oracle, pyref):
         p.free()
     for x in (v, v_stream, acc, rrot, tw, had):
         x.free()
+
+
+@pytest.mark.parametrize("n", [147, 1 << 21])
+def test_evaluate_index_poly(gm, oracle, pyref, n):
+    """src/misc.rs:424-437 (test_evaluate_index_poly): the `row` / `col` style vector [F::from(i)] evaluated on
+    the device equals the closed form x (1 - x^(n-1)) / (1 - x)^2 - (n - 1) x^(n-1) x / (1 - x) (:394-399)."""
+    from gemini_amd import fr as F
+    from gemini_amd.psnark import _field_of_index
+
+    R = pyref.R_MOD
+    x = oracle.limbs_to_ints(oracle.random_fr(n % 89, 1))[0]
+    idx = F.IdxVec.from_host(np.arange(n, dtype=np.uint32))
+    vec = _field_of_index(idx)
+    got = F.fr_to_int(F.evaluate_le(vec, F.fr_from_int(x).reshape(1, 4))[0])
+    inv = lambda v: pow(v % R, -1, R)
+    x1 = (1 - x) % R
+    xn = pow(x, n - 1, R)
+    want = (x * (1 - xn) % R * inv(x1 * x1) - (n - 1) * xn % R * x % R * inv(x1)) % R
+    assert got == want
+    assert F.fr_to_int(F.element(vec, n - 1)) == n - 1
+    idx.free()
+    vec.free()
