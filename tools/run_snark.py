@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--dummy-srs", action="store_true", help="powers_of_g = copies of the generator, the DummyStreamer key of "
                     "examples/snark.rs:59-63 (elastic main) instead of tau^i * g")
     ap.add_argument("--max-msm-buffer-log", type=int, default=20, help="max_msm_buffer of the elastic prover (examples/snark.rs:57: 2^20)")
+    ap.add_argument("--tables", action="store_true", help="gm_g1_bases_precompute on the committer key before proving (13 x the key in HBM)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/snark.rs elastic_snark_main) instead of --time-prover")
     args = ap.parse_args()
@@ -70,7 +71,12 @@ def main():
         else:
             ck = CommitterKey.new(2 * n, 5, tau)
     t_srs = time.perf_counter() - t0
-    out = {"n_gpus": world, "logn": args.instance_logsize, "instance_s": round(t_inst, 3), "srs_s": round(t_srs, 3), "runs": []}
+    t_tab = None
+    if args.tables:
+        t0 = time.perf_counter()
+        ck.powers_of_g.precompute(0)
+        t_tab = time.perf_counter() - t0
+    out = {"n_gpus": world, "logn": args.instance_logsize, "instance_s": round(t_inst, 3), "srs_s": round(t_srs, 3), "tables_s": None if t_tab is None else round(t_tab, 3), "runs": []}
     for _ in range(args.repeat):
         if world > 1:
             dist.barrier()
