@@ -50,6 +50,17 @@ def test_no_silent_fallback_without_gpu(lib):
     h = C.c_uint64()
     assert lib.gm_fr_vec_alloc(C.c_size_t(4), C.byref(h)) == -2
     assert lib.gm_sc_round(C.c_uint64(1), None, capi.ptr(out), capi.ptr(out), C.byref(C.c_int())) == -2
+    # the entry points added for the preprocessing SNARK and the batched MSM
+    idx = np.zeros(4, dtype=np.uint32)
+    assert lib.gm_idx_register(capi.ptr(idx), C.c_size_t(4), C.byref(h)) == -2
+    assert lib.gm_fr_acc_product(C.c_uint64(1), C.c_uint64(2)) == -2
+    assert lib.gm_fr_gather(C.c_uint64(1), C.c_uint64(2), C.c_uint64(3)) == -2
+    hs = np.zeros(2, dtype=np.uint64)
+    ns = np.zeros(2, dtype=np.uintp)
+    assert lib.gm_g1_msm_v_batch(C.c_uint64(1), C.c_size_t(0), C.c_int(0), capi.ptr(hs), ns.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(2),
+                                 capi.ptr(np.zeros(36, dtype=np.uint64))) == -2
+    assert lib.gm_set_msm_affine_levels(C.c_int(0)) == -2
+    assert lib.gm_sp_new_v(C.c_uint64(1), C.c_uint64(2), capi.ptr(out), C.byref(h)) == -2
 
 
 def test_g1_sum_host(lib, oracle, pyref):
