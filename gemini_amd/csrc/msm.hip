@@ -1235,9 +1235,45 @@ __global__ __launch_bounds__(256) void k_xyzz_to_affine(const uint8_t* __restric
   g1_store_affine(out + i * AFF_BYTES, a);
 }
 
+// Batched normalisation: one Fermat inversion (~570 products) per NORM_K points instead of per point
+// (Montgomery's trick inside a thread: prefix products of t_k = zz_k * zzz_k, one inversion, back-substitution).
+// Identity records (zz = 0) are skipped in the products and written as the all-zero affine record.
+constexpr int NORM_K = 8;
+__global__ __launch_bounds__(256) void k_xyzz_to_affine_batch(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i0 = t * NORM_K;
+  if (i0 >= n) return;
+  const int m = (int)min((size_t)NORM_K, n - i0);
+  FqE pre[NORM_K];
+  FqE run = fqe_one();
+  for (int k = 0; k < m; k++) {
+    const uint8_t* rec = in + (i0 + k) * XYZZ_BYTES;
+    const FqE zz = fqe_load(rec + 96);
+    if (!fq_is_exact_zero(zz)) run = fq_mul(run, fq_mul(zz, fqe_load(rec + 144)));
+    pre[k] = run;
+  }
+  FqE inv = fq_inv(run);
+  for (int k = m - 1; k >= 0; k--) {
+    const uint8_t* rec = in + (i0 + k) * XYZZ_BYTES;
+    const FqE zz = fqe_load(rec + 96);
+    G1Affine a;
+    if (fq_is_exact_zero(zz)) {
+      a.x = fqe_zero();
+      a.y = fqe_zero();
+    } else {
+      const FqE zzz = fqe_load(rec + 144);
+      const FqE ti = k ? fq_mul(inv, pre[k - 1]) : inv;  // 1 / (zz * zzz)
+      inv = fq_mul(inv, fq_mul(zz, zzz));
+      a.x = fq_mul(fqe_load(rec), fq_mul(ti, zzz));
+      a.y = fq_mul(fqe_load(rec + 48), fq_mul(ti, zz));
+    }
+    g1_store_affine(out + (i0 + k) * AFF_BYTES, a);
+  }
+}
+
 // scalars canonical (mont = 0) or Montgomery; table in XYZZ; output affine
 __global__ __launch_bounds__(256) void k_fixed_base_mul(const uint32_t* __restrict__ scalars, int mont, size_t n,
-                                                        const uint8_t* __restrict__ table_aff, uint8_t* __restrict__ out) {
+                                                        const uint8_t* __restrict__ table_aff, uint8_t* __restrict__ out_xyzz) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr s = fp_load<FrParams>(scalars + 8 * i);
@@ -1250,17 +1286,7 @@ __global__ __launch_bounds__(256) void k_fixed_base_mul(const uint32_t* __restri
       xyzz_madd(acc, p);
     }
   }
-  G1Affine a;
-  if (acc.is_identity()) {
-    a.x = fqe_zero();
-    a.y = fqe_zero();
-  } else {
-    FqE t = fq_mul(acc.zz, acc.zzz);
-    FqE ti = fq_inv(t);
-    a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
-    a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
-  }
-  g1_store_affine(out + i * AFF_BYTES, a);
+  g1_store_xyzz(out_xyzz + i * XYZZ_BYTES, acc);  // normalised in batches by k_xyzz_to_affine_batch
 }
 
 // herring split_fold over G1 (src/herring/time_prover.rs:72-76): out[i] = P[2i] + s * P[2i+1], affine out.
@@ -1294,23 +1320,13 @@ __global__ __launch_bounds__(256) void k_g1_split_fold(const uint8_t* __restrict
 }
 
 // table[(w + 1) * n + i] = 2^c * table[w * n + i]: c doublings and one normalisation per point
-__global__ __launch_bounds__(256) void k_table_next(const uint8_t* __restrict__ prev, uint8_t* __restrict__ next, size_t n, int c) {
+__global__ __launch_bounds__(256) void k_table_next(const uint8_t* __restrict__ prev, uint8_t* __restrict__ next_xyzz, size_t n, int c) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1Affine p = g1_load_affine(prev + i * AFF_BYTES);
   G1Xyzz acc = G1Xyzz::from_affine(p);
   for (int k = 0; k < c; k++) acc = xyzz_dbl(acc);
-  G1Affine a;
-  if (acc.is_identity()) {
-    a.x = fqe_zero();
-    a.y = fqe_zero();
-  } else {
-    FqE t = fq_mul(acc.zz, acc.zzz);
-    FqE ti = fq_inv(t);
-    a.x = fq_mul(acc.x, fq_mul(ti, acc.zzz));
-    a.y = fq_mul(acc.y, fq_mul(ti, acc.zz));
-  }
-  g1_store_affine(next + i * AFF_BYTES, a);
+  g1_store_xyzz(next_xyzz + i * XYZZ_BYTES, acc);  // normalised in batches by k_xyzz_to_affine_batch
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2087,11 +2103,21 @@ int bases_precompute(Context* C, Bases* b, int c) {
   uint8_t* t = nullptr;
   GM_HIP(hipMalloc((void**)&t, (size_t)W * b->n * AFF_BYTES));
   GM_HIP(hipMemcpyAsync(t, b->d, b->n * AFF_BYTES, hipMemcpyDeviceToDevice, C->stream));
+  // one slab of XYZZ results at a time (192 B per point), normalised NORM_K points per inversion
+  const size_t slab = std::min<size_t>(b->n, (size_t)1 << 22);
+  uint8_t* xy = nullptr;
+  GM_HIP(hipMalloc((void**)&xy, slab * XYZZ_BYTES));
   for (int w = 0; w + 1 < W; w++)
-    hipLaunchKernelGGL(k_table_next, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, C->stream,
-                       t + (size_t)w * b->n * AFF_BYTES, t + (size_t)(w + 1) * b->n * AFF_BYTES, b->n, c);
+    for (size_t off = 0; off < b->n; off += slab) {
+      const size_t m = std::min(slab, b->n - off);
+      hipLaunchKernelGGL(k_table_next, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, C->stream,
+                         t + ((size_t)w * b->n + off) * AFF_BYTES, xy, m, c);
+      hipLaunchKernelGGL(k_xyzz_to_affine_batch, dim3((unsigned)(((m + NORM_K - 1) / NORM_K + 255) / 256)), dim3(256), 0, C->stream, xy, m,
+                         t + ((size_t)(w + 1) * b->n + off) * AFF_BYTES);
+    }
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
+  GM_HIP(hipFree(xy));
   b->table = t;
   b->tab_c = c;
   b->tab_W = W;
@@ -2107,9 +2133,19 @@ int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* 
     int rc = build_fixed_table(C, base_affine, &table);
     if (rc) return rc;
     GM_HIP(hipMalloc((void**)&b->d, n * AFF_BYTES));
-    hipLaunchKernelGGL(k_fixed_base_mul, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C->stream,
-                       reinterpret_cast<const uint32_t*>(d_scalars), mont, n, table, b->d);
+    const size_t slab = std::min<size_t>(n, (size_t)1 << 22);
+    uint8_t* xy = nullptr;
+    GM_HIP(hipMalloc((void**)&xy, slab * XYZZ_BYTES));
+    for (size_t off = 0; off < n; off += slab) {
+      const size_t m = std::min(slab, n - off);
+      hipLaunchKernelGGL(k_fixed_base_mul, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, C->stream,
+                         reinterpret_cast<const uint32_t*>(d_scalars) + 8 * off, mont, m, table, xy);
+      hipLaunchKernelGGL(k_xyzz_to_affine_batch, dim3((unsigned)(((m + NORM_K - 1) / NORM_K + 255) / 256)), dim3(256), 0, C->stream, xy, m,
+                         b->d + off * AFF_BYTES);
+    }
+    GM_HIP(hipGetLastError());
     GM_HIP(hipStreamSynchronize(C->stream));
+    GM_HIP(hipFree(xy));
     GM_HIP(hipFree(table));
   }
   out = std::move(b);
