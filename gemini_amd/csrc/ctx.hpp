@@ -53,6 +53,7 @@ struct Bases {
   // (table row 0 is a copy of d so one pointer serves every window)
   uint8_t* table = nullptr;
   int tab_c = 0, tab_W = 0;
+  size_t tab_min = 0;  // smallest call the tables pay off for (depends on their window width)
 };
 
 struct FrVec {

@@ -1508,7 +1508,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   }
   // fixed-base tables (gm_g1_bases_precompute) serve large MSMs; small ones are latency-bound and
   // cheaper with few buckets
-  const size_t tab_min = C->msm_table_min;
+  const size_t tab_min = std::max(C->msm_table_min, bases->tab_min);
   const bool use_table = bases->table != nullptr && !C->msm_c_override && n >= tab_min && n < ((size_t)1 << ENTRY_W_SHIFT);
   const int c = use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
@@ -2091,7 +2091,11 @@ int hg1_final(Context* C, HerringG1* H, uint64_t f0_jac[18], uint64_t g0[4], int
 
 // gm_g1_bases_precompute
 int bases_precompute(Context* C, Bases* b, int c) {
-  if (c == 0) c = 20;
+  // automatic width (measured): c = 20 (13 windows, 2^19 shared buckets) wins from 2^17 pairs on -- 4.14 vs 4.76 ms at
+  // 2^20 --; a key of >= 2^23 points mostly serves big calls, where c = 22 (12 windows, 2^21 buckets) gives
+  // 43.8 vs 47.8 (c = 20) vs 51.5 ms (no tables) at 2^24 but loses below 2^22 pairs to its bucket reduction
+  const bool auto_c = c == 0;
+  if (auto_c) c = b->n >= ((size_t)1 << 23) ? 22 : 20;
   GM_CHECK(c >= 8 && c <= 22, GM_EINVAL, "bases_precompute: window %d outside [8, 22]", c);
   GM_CHECK(b->n >= 1 && b->n < ((size_t)1 << ENTRY_W_SHIFT), GM_EINVAL, "bases_precompute: %zu bases (need 1 .. 2^26 - 1)", b->n);
   const int W = (256 + c - 1) / c;
@@ -2121,6 +2125,7 @@ int bases_precompute(Context* C, Bases* b, int c) {
   b->table = t;
   b->tab_c = c;
   b->tab_W = W;
+  b->tab_min = c >= 22 ? ((size_t)1 << 22) : (c >= 21 ? ((size_t)1 << 21) : 0);
   return GM_OK;
 }
 

@@ -22,6 +22,6 @@ def run(tag):
     names = ["sort1", "scan", "sort2", "acc0", "merge", "reduce"]
     print(tag, round(dt*1e3,3), {k: round(ms[i]/max(cnt[i],1),3) for i,k in enumerate(names)}, flush=True)
 run("plain c=16")
-for c in (16, 18, 20, 21):
+for c in ([int(x) for x in sys.argv[2:]] or [16, 18, 20, 21]):
     t0=time.perf_counter(); bases.precompute(c); tp=time.perf_counter()-t0
     run(f"tables c={c} (pre {tp:.2f}s)")
