@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgemini_hip.so")
+# GM_LIB_PATH: development hook (tools/ A/B runs of differently built libraries); the product path is the in-tree .so
+LIB_PATH = os.environ.get("GM_LIB_PATH") or os.path.join(_HERE, "libgemini_hip.so")
 
 GM_OK = 0
 ERRORS = {-1: "GM_EINVAL", -2: "GM_ENOTINIT", -3: "GM_EHANDLE", -4: "GM_EHIP", -5: "GM_ENOMEM", -6: "GM_ESTATE"}

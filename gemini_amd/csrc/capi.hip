@@ -365,11 +365,9 @@ int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96) 
 static int msm_host_scalars(Context* C, Bases* b, size_t offset, int reversed, const uint64_t* scalars, size_t n,
                             uint64_t out_jac[18]) {
   int rc;
-  {
-    std::lock_guard<std::mutex> lk(C->msm_mu);
-    if ((rc = C->msm.scalars.ensure(n * 32 + 32))) return rc;
-    if (n) GM_HIP(hipMemcpyAsync(C->msm.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
-  }
+  GM_MSM_LOCK(C);  // held across the upload AND the MSM: another thread must not restage C->msm.scalars in between
+  if ((rc = C->msm.scalars.ensure(n * 32 + 32))) return rc;
+  if (n) GM_HIP(hipMemcpyAsync(C->msm.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
   return msm_run(C, b, (int64_t)offset, reversed ? -1 : 1, C->msm.scalars.p, 0, n, true, out_jac);
 }
 

@@ -166,7 +166,12 @@ struct Context {
   Profiler prof;
   hipStream_t stream = nullptr;
   std::mutex mu;       // guards handle tables
-  std::mutex msm_mu;   // MSM workspace is single-flight (the reference's MSM calls are sequential)
+  // The MSM workspaces are single-flight (the reference's MSM calls are sequential): msm_mu is held from the
+  // staging of host scalars to the end of the call (recursive: msm_host_scalars -> msm_run).
+  std::recursive_mutex msm_mu;
+  // Vector entry points (gm_fr_*) stage per-call parameters and partial results in fr_scratch / host_small and
+  // share one stream: fr_mu serialises them, so calls from different threads are safe (and ordered).
+  std::recursive_mutex fr_mu;
   uint64_t next_handle = 1;
   std::unordered_map<uint64_t, std::unique_ptr<Bases>> bases;
   std::unordered_map<uint64_t, std::unique_ptr<FrVec>> vecs;
@@ -199,6 +204,9 @@ Sumcheck* find_prover(uint64_t h);
 uint64_t put_bases(std::unique_ptr<Bases> b);
 uint64_t put_vec(std::unique_ptr<FrVec> v);
 uint64_t put_prover(std::unique_ptr<Sumcheck> p);
+
+#define GM_FR_LOCK(C) std::lock_guard<std::recursive_mutex> gm_fr_lock_((C)->fr_mu)
+#define GM_MSM_LOCK(C) std::lock_guard<std::recursive_mutex> gm_msm_lock_((C)->msm_mu)
 
 #define GM_CTX()                                            \
   ::gm::Context* C = ::gm::context();                       \

@@ -982,11 +982,13 @@ int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle) {
 
 static int upload_small(Context* C, const void* src, size_t bytes, uint8_t** dptr);
 int fr_stride_raw(Context* C, const uint8_t* in, size_t start, size_t stride, size_t count, uint8_t* out) {
+  GM_FR_LOCK(C);
   if (count) hipLaunchKernelGGL(k_fr_stride, dim3(grid_for(count)), dim3(256), 0, C->stream, in, start, stride, count, out);
   GM_HIP(hipGetLastError());
   return GM_OK;
 }
 int fr_fold_raw(Context* C, const uint8_t* f, size_t n, const uint64_t r[4], uint8_t* out) {
+  GM_FR_LOCK(C);
   uint8_t* dr;
   int rc = upload_small(C, r, 32, &dr);
   if (rc) return rc;
@@ -1007,6 +1009,7 @@ static int upload_small(Context* C, const void* src, size_t bytes, uint8_t** dpt
 }
 
 int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out) {
+  GM_FR_LOCK(C);
   const size_t m = (f->len + 1) / 2;
   GM_CHECK(out->cap >= m, GM_EINVAL, "fold: output capacity %zu < %zu", out->cap, m);
   GM_CHECK(out != f, GM_EINVAL, "fold: output must not alias the input");
@@ -1021,6 +1024,7 @@ int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out) {
 }
 
 int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(out->cap >= n, GM_EINVAL, "powers: output capacity %zu < %zu", out->cap, n);
   PowTable t;
   make_pow_table(gmh::Fr::from_limbs(x), t);
@@ -1032,6 +1036,7 @@ int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out) {
 }
 
 int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(k >= 1 && k <= 32, GM_EINVAL, "tensor: need 1 <= k <= 32 elements (got %zu)", k);
   const size_t n = (size_t)1 << k;
   GM_CHECK(out->cap >= n, GM_EINVAL, "tensor: output capacity %zu < %zu", out->cap, n);
@@ -1053,6 +1058,7 @@ int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out) {
 }
 
 int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(a->len == b->len, GM_EINVAL, "hadamard: lengths differ (%zu vs %zu)", a->len, b->len);
   GM_CHECK(out->cap >= a->len, GM_EINVAL, "hadamard: output capacity %zu < %zu", out->cap, a->len);
   if (a->len) hipLaunchKernelGGL(k_hadamard, dim3(grid_for(a->len)), dim3(256), 0, C->stream, a->d, b->d, a->len, out->d);
@@ -1063,6 +1069,7 @@ int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out) {
 }
 
 int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]) {
+  GM_FR_LOCK(C);
   GM_CHECK(a->len == b->len, GM_EINVAL, "ip: lengths differ (%zu vs %zu)", a->len, b->len);
   const unsigned blocks = grid_for(a->len, 512);
   int rc = C->fr_scratch.ensure(1 << 20);
@@ -1078,6 +1085,7 @@ int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]) {
 }
 
 int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results) {
+  GM_FR_LOCK(C);
   GM_CHECK(npoints >= 1 && npoints <= 3, GM_EINVAL, "eval_le: 1..3 points per pass (got %zu)", npoints);
   EvalArgs A;
   memset(&A, 0, sizeof A);
@@ -1102,6 +1110,7 @@ int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_
 }
 
 int fr_trim(Context* C, FrVec* v) {
+  GM_FR_LOCK(C);
   // DensePolynomial::from_coefficients_vec strips high zero coefficients
   if (v->len == 0) return GM_OK;
   int rc = C->fr_scratch.ensure(1 << 20);
@@ -1117,6 +1126,7 @@ int fr_trim(Context* C, FrVec* v) {
 }
 
 int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out) {
+  GM_FR_LOCK(C);
   size_t n = 0;
   for (size_t j = 0; j < k; j++) n = polys[j]->len > n ? polys[j]->len : n;
   GM_CHECK(out->cap >= n, GM_EINVAL, "lincomb: output capacity %zu < %zu", out->cap, n);
@@ -1148,6 +1158,7 @@ int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVe
 }
 
 int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y) {
+  GM_FR_LOCK(C);
   GM_CHECK(y->cap >= M->nrows, GM_EINVAL, "spm_mul: output capacity %zu < %zu rows", y->cap, M->nrows);
   GM_CHECK(y != x, GM_EINVAL, "spm_mul: output must not alias the input");
   if (M->nrows)
@@ -1160,6 +1171,7 @@ int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y) {
 
 // ---- entry-product / plookup builders ---------------------------------------------------------
 int fr_gather(Context* C, FrVec* src, const IdxVec* index, FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(out->cap >= index->n, GM_EINVAL, "gather: output capacity %zu < %zu", out->cap, index->n);
   GM_CHECK(out != src, GM_EINVAL, "gather: output must not alias the input");
   GM_CHECK(index->max_plus_1 <= src->len, GM_EINVAL, "gather: index %zu outside the source vector (%zu)", index->max_plus_1 - 1, src->len);
@@ -1171,6 +1183,7 @@ int fr_gather(Context* C, FrVec* src, const IdxVec* index, FrVec* out) {
 }
 
 int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4], FrVec* out) {
+  GM_FR_LOCK(C);
   // zip semantics of the reference: the shorter of (v, index) decides the length
   const size_t n = index ? std::min(v->len, index->n) : v->len;
   GM_CHECK(out->cap >= n, GM_EINVAL, "alg_hash: output capacity %zu < %zu", out->cap, n);
@@ -1186,6 +1199,7 @@ int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4
 }
 
 int fr_plookup_set(Context* C, FrVec* v, const uint64_t y[4], const uint64_t z[4], FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(out != v, GM_EINVAL, "plookup_set: output must not alias the input");
   if (v->len == 0) {
     out->len = 0;
@@ -1208,6 +1222,7 @@ int fr_plookup_set(Context* C, FrVec* v, const uint64_t y[4], const uint64_t z[4
 }
 
 int fr_add_scalar(Context* C, FrVec* v, const uint64_t y[4], FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(out->cap >= v->len, GM_EINVAL, "add_scalar: output capacity %zu < %zu", out->cap, v->len);
   uint8_t* d;
   int rc = upload_small(C, y, 32, &d);
@@ -1220,6 +1235,7 @@ int fr_add_scalar(Context* C, FrVec* v, const uint64_t y[4], FrVec* out) {
 }
 
 int fr_shift_monic(Context* C, FrVec* v, FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(out->cap >= v->len + 1, GM_EINVAL, "shift_monic: output capacity %zu < %zu", out->cap, v->len + 1);
   GM_CHECK(out != v, GM_EINVAL, "shift_monic: output must not alias the input");
   hipLaunchKernelGGL(k_shift_monic, dim3(grid_for(v->len + 1)), dim3(256), 0, C->stream, v->d, v->len, out->d);
@@ -1230,6 +1246,7 @@ int fr_shift_monic(Context* C, FrVec* v, FrVec* out) {
 }
 
 int fr_acc_product(Context* C, FrVec* v, FrVec* out) {
+  GM_FR_LOCK(C);
   const size_t n = v->len;
   GM_CHECK(out->cap >= n + 1, GM_EINVAL, "acc_product: output capacity %zu < %zu", out->cap, n + 1);
   GM_CHECK(out != v, GM_EINVAL, "acc_product: output must not alias the input");
@@ -1270,6 +1287,7 @@ int fr_acc_product(Context* C, FrVec* v, FrVec* out) {
 }
 
 int fr_reverse(Context* C, FrVec* in, FrVec* out) {
+  GM_FR_LOCK(C);
   GM_CHECK(out->cap >= in->len, GM_EINVAL, "reverse: output capacity %zu < %zu", out->cap, in->len);
   GM_CHECK(out != in, GM_EINVAL, "reverse: output must not alias the input");
   if (in->len) hipLaunchKernelGGL(k_reverse, dim3(grid_for(in->len)), dim3(256), 0, C->stream, in->d, in->len, out->d);
@@ -1280,6 +1298,7 @@ int fr_reverse(Context* C, FrVec* in, FrVec* out) {
 }
 
 int fr_fill(Context* C, FrVec* v, const uint64_t val[4]) {
+  GM_FR_LOCK(C);
   uint8_t* dv;
   int rc = upload_small(C, val, 32, &dv);
   if (rc) return rc;
@@ -1292,6 +1311,7 @@ int fr_fill(Context* C, FrVec* v, const uint64_t val[4]) {
 // quotient of f by prod_j (x - points[j]): k successive divisions by linear factors.
 // rem_out[j] = value of the j-th intermediate polynomial at points[j] (= f(points[0]) for j = 0).
 int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k, FrVec* q, uint64_t* rem_out) {
+  GM_FR_LOCK(C);
   GM_CHECK(k >= 1 && k <= 8, GM_EINVAL, "div_vanishing: 1..8 points (got %zu)", k);
   GM_CHECK(q != f, GM_EINVAL, "div_vanishing: quotient must not alias the dividend");
   if (f->len <= k) {

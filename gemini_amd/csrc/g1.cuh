@@ -28,7 +28,7 @@
 #include "field30.cuh"
 
 #ifndef GM_FQ30
-#define GM_FQ30 0
+#define GM_FQ30 2
 #endif
 
 namespace gm {
@@ -37,20 +37,18 @@ namespace gm {
 // ---- element layer: 13 x 30-bit, loose.  Bounds (multiples of q) are tracked in the comments of the
 // group law: products are < 2q whenever bound(a) * bound(b) <= 512, fqe_sub<K> needs b < K q.
 using FqE = Fq30;
-// 26 scalar arguments: a second by-value struct would travel through the scratch stack (see fq_mul_fn below)
-__device__ __noinline__ Fq30 fq30_mul_regs(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7, uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t a12,
-                                           uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11, uint32_t b12) {
-  Fq30 a, b;
-  a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7; a.l[8] = a8; a.l[9] = a9; a.l[10] = a10; a.l[11] = a11; a.l[12] = a12;
-  b.l[0] = b0; b.l[1] = b1; b.l[2] = b2; b.l[3] = b3; b.l[4] = b4; b.l[5] = b5; b.l[6] = b6; b.l[7] = b7; b.l[8] = b8; b.l[9] = b9; b.l[10] = b10; b.l[11] = b11; b.l[12] = b12;
-  return fq30_mul(a, b);
-}
+// The product core is one asm statement on physical registers (gen_field_mul30.py --loose): operands in
+// v0..v12 / v13..v25 by the calling convention, result in v0..v12, every temporary a caller-saved register.
+#include "field_mul30l_gen.inc"
 GM_DEV Fq30 fq30_mul_fn(const Fq30& a, const Fq30& b) {
-  return fq30_mul_regs(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12],
-                       b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12]);
+  return fq30_mul_asm(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12],
+                      b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11], b.l[12]);
+}
+GM_DEV Fq30 fq30_sqr_fn(const Fq30& a) {
+  return fq30_sqr_asm(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], a.l[12]);
 }
 GM_DEV FqE fq_mul(const FqE& a, const FqE& b) { return fq30_mul_fn(a, b); }
-GM_DEV FqE fq_sqr(const FqE& a) { return fq30_mul_fn(a, a); }
+GM_DEV FqE fq_sqr(const FqE& a) { return fq30_sqr_fn(a); }
 GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fq30_add(a, b); }
 GM_DEV FqE fq_dbl(const FqE& a) { return fq30_add(a, a); }
 template <int K>
@@ -86,19 +84,15 @@ GM_DEV Fq fqe_export(const FqE& dev) {
 using FqE = Fq;
 template <int K>
 GM_DEV FqE fq_sub(const FqE& a, const FqE& b);
-__device__ __noinline__ Fq fq_mul_fn(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7,
-                                     uint32_t a8, uint32_t a9, uint32_t a10, uint32_t a11, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
-                                     uint32_t b4, uint32_t b5, uint32_t b6, uint32_t b7, uint32_t b8, uint32_t b9, uint32_t b10, uint32_t b11) {
-  Fq a, b;
-  a.l[0] = a0; a.l[1] = a1; a.l[2] = a2; a.l[3] = a3; a.l[4] = a4; a.l[5] = a5; a.l[6] = a6; a.l[7] = a7; a.l[8] = a8; a.l[9] = a9; a.l[10] = a10; a.l[11] = a11;
-  b.l[0] = b0; b.l[1] = b1; b.l[2] = b2; b.l[3] = b3; b.l[4] = b4; b.l[5] = b5; b.l[6] = b6; b.l[7] = b7; b.l[8] = b8; b.l[9] = b9; b.l[10] = b10; b.l[11] = b11;
-  return fq30_pack(fq30_canonical_tail(fq30_mul(fq30_unpack(a), fq30_unpack(b))));
-}
+// fq30h_mul_fn / fq30h_sqr_fn: one asm statement each on physical registers (gen_field_mul30.py)
+#include "field_mul30_gen.inc"
 GM_DEV FqE fq_mul(const FqE& a, const FqE& b) {
-  return fq_mul_fn(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1], b.l[2], b.l[3],
-                   b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
+  return fq30h_mul_fn(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11], b.l[0], b.l[1], b.l[2], b.l[3],
+                      b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9], b.l[10], b.l[11]);
 }
-GM_DEV FqE fq_sqr(const FqE& a) { return fq_mul(a, a); }
+GM_DEV FqE fq_sqr(const FqE& a) {
+  return fq30h_sqr_fn(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11]);
+}
 GM_DEV FqE fq_add(const FqE& a, const FqE& b) { return fp_add<FqParams>(a, b); }
 GM_DEV FqE fq_dbl(const FqE& a) { return fp_add<FqParams>(a, a); }
 template <int K>

@@ -247,7 +247,7 @@ struct G1 {
 // Device-resident Fq values are a * 2^390 mod q (g1.cuh, GM_FQ30); ark-ff's form is a * 2^384.
 // x_ark = x_dev * 2^-6: as a Montgomery (R = 2^384) operand that constant is 2^378.
 #ifndef GM_FQ30
-#define GM_FQ30 0
+#define GM_FQ30 2
 #endif
 static inline Fq fq_from_device(const u64* p) {
   Fq v = Fq::from_limbs(p);
@@ -256,6 +256,15 @@ static inline Fq fq_from_device(const u64* p) {
   return v * Fq::from_limbs(K);
 #else
   return v;
+#endif
+}
+// ark-ff form -> device form: x_dev = x_ark * 2^6, i.e. the Montgomery operand 2^390 mod q
+static inline void fq_to_device(const Fq& v, u64* out) {
+#if GM_FQ30
+  static const u64 K[6] = {0x4676000000d1ff2eULL, 0x84b803379b4800acULL, 0x0dd9a7e0e882431cULL, 0xc26c26d0b683dcf8ULL, 0x29f1457663c4a5eeULL, 0x015de9967f3e804bULL};
+  (v * Fq::from_limbs(K)).to_limbs(out);
+#else
+  v.to_limbs(out);
 #endif
 }
 // XYZZ record in device form -> Jacobian in ark-ff form

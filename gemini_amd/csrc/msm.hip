@@ -46,6 +46,7 @@ constexpr int AFF_BYTES = 96;
 struct DigitIter {
   uint32_t s[8];
   uint32_t carry;
+  bool bad;  // the scalar was not a canonical Fr image (>= 2^255): top digit clamped, call rejected
   GM_DEV void init(const uint32_t* p, bool active, int mont) {
     if (active) {
       Fr v = fp_load<FrParams>(p);
@@ -57,6 +58,19 @@ struct DigitIter {
       for (int i = 0; i < 8; i++) s[i] = 0;
     }
     carry = 0;
+    bad = false;
+  }
+  // top-window digit with the final carry folded back in (variable_base.rs:58: digits[last] += carry << w).
+  // For a canonical scalar (< r < 2^255) |d| <= 2^(c-1); a larger value would index past the bucket array
+  // (the reference panics there), so it is clamped and flagged instead.
+  GM_DEV int32_t last(int c) {
+    int32_t d = next(c) + (int32_t)(carry << c);
+    const int32_t B = 1 << (c - 1);
+    if (d > B) {
+      d = B;
+      bad = true;
+    }
+    return d;
   }
   // next signed digit in [-2^(c-1), 2^(c-1)]; semantics of variable_base.rs:21-61.  With
   // c * W >= 256 the top window's raw value is < 2^(c-1), so after the caller folds the final
@@ -102,8 +116,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__
   DigitIter it;
   it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
   for (int w = 0; w < W; w++) {
-    int32_t d = it.next(c);
-    if (w == W - 1) d += (int32_t)(it.carry << c);  // variable_base.rs:58: digits[last] += carry << w
+    int32_t d = w == W - 1 ? it.last(c) : it.next(c);
     uint32_t mag = (uint32_t)(d < 0 ? -d : d);
     uint32_t key = (active && d != 0) ? (uint32_t)w * B + (mag - 1u) : KEY_INV;
     uint32_t pos = wave_atomic_inc(counts_or_cursor, key);
@@ -150,8 +163,7 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     DigitIter it;
     it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
     for (int w = 0; w < sg.W; w++) {
-      int32_t d = it.next(sg.c);
-      if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
+      int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
       // (wave_atomic_inc: one LDS atomic per wave when all lanes hit the same bin -- the all-equal-scalars
       // instance of the reference's benchmark would otherwise serialise 64 same-address atomics)
       const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
@@ -176,8 +188,7 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     DigitIter it;
     it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
     for (int w = 0; w < sg.W; w++) {
-      int32_t d = it.next(sg.c);
-      if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
+      int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
       const bool live = active && d != 0;
       const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
       const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
@@ -217,8 +228,7 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
     for (int w = 0; w < SORT1_STAGE_WMAX; w++) {
       e[w] = ~0ull;
       if (w < sg.W) {
-        int32_t d = it.next(sg.c);
-        if (w == sg.W - 1) d += (int32_t)(it.carry << sg.c);
+        int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
         if (active && d != 0) {
           const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
           const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
@@ -1401,7 +1411,7 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
 
 static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
                        bool normalize, uint64_t out_jac[18]) {
-  std::lock_guard<std::mutex> lk(C->msm_mu);
+  GM_MSM_LOCK(C);
   MsmPending P;
   int rc = msm_enqueue(C, C->msm, C->stream, bases, first, step, d_scalars, mont, n, 0, &P);
   if (rc) return rc;
@@ -1435,7 +1445,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     }
     return GM_OK;
   }
-  std::lock_guard<std::mutex> lk(C->msm_mu);
+  GM_MSM_LOCK(C);
   struct Inflight {
     size_t j;
     int lane;  // 0 = main workspace, 1.. = small workspaces
@@ -1703,12 +1713,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
       hipLaunchKernelGGL(k_lvl_b, dim3(T / 512), dim3(512), 0, st, lane_tot, T, lane_pre, lane_suf, blk_tot);
       hipLaunchKernelGGL(k_lvl_b, dim3(1), dim3(512), 0, st, blk_tot, T / 512, blk_pre, blk_suf, grand_tot);
       GM_HIP(hipGetLastError());
+      GM_FR_LOCK(C);  // host_small is shared with the vector entry points
       uint64_t* hs = C->host_small;
       GM_HIP(hipMemcpyAsync(hs, grand_tot, FQ_BYTES, hipMemcpyDeviceToHost, st));
       GM_HIP(hipStreamSynchronize(st));
-      gmh::Fq tot = gmh::Fq::from_limbs(hs);
+      gmh::Fq tot = gmh::fq_from_device(hs);
       GM_CHECK(!tot.is_zero(), GM_ESTATE, "msm: zero denominator product in an affine level");
-      tot.inv().to_limbs(hs + 8);
+      gmh::fq_to_device(tot.inv(), hs + 8);
       GM_HIP(hipMemcpyAsync(grand, hs + 8, FQ_BYTES, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(k_lvl_b3, dim3(T / 256), dim3(256), 0, st, T, grand, lane_pre, lane_suf, blk_pre, blk_suf, lane_inv);
       if (l == 0) hipLaunchKernelGGL(k_lvl_c<true>, dim3(T / 256), dim3(256), 0, st, A);
@@ -2010,6 +2021,7 @@ void hg1_destroy(Context* C, HerringG1* H) {
 }
 
 static int hg1_fold_locked(Context* C, HerringG1* H, const uint64_t r[4]) {
+  GM_MSM_LOCK(C);  // the folding scalar is staged in the MSM workspace (C->msm.misc)
   gmh::Fr rr = gmh::Fr::from_limbs(r), tw = gmh::Fr::from_limbs(H->twist);
   gmh::Fr rt = rr * tw;
   uint64_t canon[4];
@@ -2099,7 +2111,7 @@ int bases_precompute(Context* C, Bases* b, int c) {
   GM_CHECK(c >= 8 && c <= 22, GM_EINVAL, "bases_precompute: window %d outside [8, 22]", c);
   GM_CHECK(b->n >= 1 && b->n < ((size_t)1 << ENTRY_W_SHIFT), GM_EINVAL, "bases_precompute: %zu bases (need 1 .. 2^26 - 1)", b->n);
   const int W = (256 + c - 1) / c;
-  std::lock_guard<std::mutex> lk(C->msm_mu);
+  GM_MSM_LOCK(C);
   if (b->table) {
     (void)hipFree(b->table);
     b->table = nullptr;

@@ -20,9 +20,19 @@
  *     gm_last_error() gives a message for the calling thread.
  *   - Ownership: the caller owns every host buffer for the duration of the call only; registered
  *     bases and vectors are copied to device memory owned by the library until *_free.
- *   - Threading: one process per GPU.  Calls on different handles may come from different
- *     threads (sumcheck::prove_batch calls next_message on distinct provers concurrently,
- *     src/subprotocols/sumcheck/proof.rs:85); calls on the same handle must be serialised.
+ *   - Threading: one process per GPU.  Every entry point may be called from any thread.  Calls on
+ *     different prover handles run concurrently (sumcheck::prove_batch calls next_message on distinct
+ *     provers from different rayon threads, src/subprotocols/sumcheck/proof.rs:85; `Prover: Send + Sync`,
+ *     prover.rs:30); calls on the SAME prover handle are serialised by a per-handle lock.  MSM calls
+ *     (gm_g1_msm*, herring G1 rounds) share the device workspaces and are serialised by one library
+ *     lock held from the staging of host scalars to the result (the reference's MSM calls are
+ *     sequential too, src/kzg/time.rs:103-106); the vector entry points (gm_fr_*) are serialised by a
+ *     second lock because they stage per-call parameters in one scratch buffer.  Results never depend
+ *     on the interleaving (tests/test_gpu_threads.py).  Freeing a handle another thread is still using
+ *     is the caller's error, as with any Rust `Drop`.
+ *   - Scalars passed as canonical integers (mont = 0) must be < r, as ark-ff's BigInt images of Fr
+ *     always are; the library rejects a call holding a scalar >= 2^255 with GM_EINVAL and does not
+ *     otherwise check (the reference panics on the out-of-range bucket index such a value produces).
  */
 #ifndef GEMINI_HIP_H
 #define GEMINI_HIP_H
