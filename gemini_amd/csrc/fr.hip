@@ -1315,6 +1315,31 @@ int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k
   GM_CHECK(k >= 1 && k <= 8, GM_EINVAL, "div_vanishing: 1..8 points (got %zu)", k);
   GM_CHECK(q != f, GM_EINVAL, "div_vanishing: quotient must not alias the dividend");
   if (f->len <= k) {
+    // polynomial no longer than the point set: the quotient is empty and the successive remainders are
+    // computed on the host (<= 8 coefficients).  CommitterKey::open([c], x) must return c
+    // (src/kzg/time.rs:112-131), open_multi_points the polynomial itself as remainder (:134-145).
+    std::vector<gmh::Fr> cur(f->len);
+    if (f->len) {
+      std::vector<uint64_t> h(4 * f->len);
+      GM_HIP(hipMemcpyAsync(h.data(), f->d, f->len * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+      GM_HIP(hipStreamSynchronize(C->stream));
+      for (size_t i = 0; i < f->len; i++) cur[i] = gmh::Fr::from_limbs(h.data() + 4 * i);
+    }
+    for (size_t j = 0; j < k; j++) {
+      gmh::Fr rem = gmh::Fr::zero();
+      if (!cur.empty()) {
+        const gmh::Fr alpha = gmh::Fr::from_limbs(points + 4 * j);
+        std::vector<gmh::Fr> qn(cur.size() - 1);
+        gmh::Fr carry = gmh::Fr::zero();  // synthetic division from the leading coefficient down
+        for (size_t i = cur.size(); i-- > 0;) {
+          carry = cur[i] + alpha * carry;
+          if (i > 0) qn[i - 1] = carry;
+        }
+        rem = carry;
+        cur.swap(qn);
+      }
+      if (rem_out) rem.to_limbs(rem_out + 4 * j);
+    }
     q->len = 0;
     return GM_OK;
   }

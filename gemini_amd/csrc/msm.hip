@@ -58,7 +58,7 @@ struct DigitIter {
       for (int i = 0; i < 8; i++) s[i] = 0;
     }
     carry = 0;
-    bad = false;
+    bad = (s[7] >> 31) != 0;  // >= 2^255: not the BigInt image of an Fr element (< r < 2^255)
   }
   // top-window digit with the final carry folded back in (variable_base.rs:58: digits[last] += carry << w).
   // For a canonical scalar (< r < 2^255) |d| <= 2^(c-1); a larger value would index past the bucket array
@@ -110,7 +110,7 @@ GM_DEV uint32_t wave_atomic_inc(uint32_t* arr, uint32_t key) {
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__ scalars, uint32_t n, int mont, int c,
                                                     int W, uint32_t B, uint32_t* __restrict__ counts_or_cursor,
-                                                    uint64_t* __restrict__ entries) {
+                                                    uint64_t* __restrict__ entries, uint32_t* __restrict__ err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool active = i < n;
   DigitIter it;
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint32_t* __restrict__
       entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)i;
     }
   }
+  if (!SCATTER && it.bad) atomicOr(err, 1u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -151,7 +152,7 @@ constexpr int ENTRY_W_SHIFT = 26;  // entry idx field: pair index in bits 0..25,
 
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg,
-                                               uint32_t* __restrict__ gcount_or_cursor, uint64_t* __restrict__ tmp) {
+                                               uint32_t* __restrict__ gcount_or_cursor, uint64_t* __restrict__ tmp, uint32_t* __restrict__ err) {
   __shared__ uint32_t cnt[SORT_GMAX];
   __shared__ uint32_t base[SCATTER ? SORT_GMAX : 1];
   for (uint32_t g = threadIdx.x; g < sg.G; g += 256) cnt[g] = 0;
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
       const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
       wave_atomic_inc(cnt, (active && d != 0) ? (((sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
     }
+    if (!SCATTER && it.bad) atomicOr(err, 1u);  // a scalar >= 2^255 (not an Fr image): the call fails with GM_EINVAL
   }
   __syncthreads();
   if (!SCATTER) {
@@ -1112,6 +1114,8 @@ struct GroupSumArgs {
 struct GroupSumJobs {
   GroupSumArgs j[3];
   uint32_t blk_end[3];  // cumulative block counts
+  const uint32_t* err_src;  // last launch of a call: forward the scalar-range flag behind the plane sums
+  uint32_t* err_dst;
 };
 
 GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
@@ -1129,6 +1133,7 @@ GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
 // up to three independent jobs per launch so that passes of the same level overlap instead of
 // serialising their (latency-bound) depth
 __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
+  if (J.err_dst && blockIdx.x == 0 && threadIdx.x == 0) *J.err_dst = *J.err_src;
   const int job = blockIdx.x < J.blk_end[0] ? 0 : (blockIdx.x < J.blk_end[1] ? 1 : 2);
   const GroupSumArgs& a = J.j[job];
   const uint32_t blk0 = job == 0 ? 0u : J.blk_end[job - 1];
@@ -1382,6 +1387,7 @@ struct MsmPending {
   int Wb = 0, c = 0, m = 0;
   uint32_t nbits = 0, wf[3] = {0, 0, 0};
   size_t plane_off[3] = {0, 0, 0};
+  size_t plane_count = 0;
 };
 static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
                        int mont, size_t n, int slot, MsmPending* P);
@@ -1555,7 +1561,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   const uint64_t E1 = 2 * T0pad;
 
   int rc;
-  if ((rc = ws.counts.ensure((nbuckets + 1) * 4))) return rc;
+  if ((rc = ws.counts.ensure((nbuckets + 2) * 4))) return rc;  // [nbuckets + 1] = scalar-range flag
   if ((rc = ws.offsets.ensure((nbuckets + 1) * 4))) return rc;
   if ((rc = ws.cursor.ensure((nbuckets + 1) * 4))) return rc;
   if ((rc = ws.misc.ensure((nbuckets / SCAN_PER_BLOCK + 2) * 4))) return rc;
@@ -1568,7 +1574,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   if ((rc = ws.pp[1].ensure(E2 * XYZZ_BYTES))) return rc;
 
   const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
-  GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 1) * 4, st));
+  GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 2) * 4, st));
+  uint32_t* d_err = ws.counts.as<uint32_t>() + nbuckets + 1;
   GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * XYZZ_BYTES, st));
   const uint32_t dblocks = (uint32_t)((n + 255) / 256);
   Profiler& pf = C->prof;
@@ -1586,14 +1593,14 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   if (sort_atomic) {
     pf.begin(PROF_DIGITS, st);
     hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
-                       ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
+                       ws.counts.as<uint32_t>(), (uint64_t*)nullptr, d_err);
     pf.end(PROF_DIGITS, st);
     pf.begin(PROF_SCAN, st);
     run_scan();
     pf.end(PROF_SCAN, st);
     pf.begin(PROF_SCATTER, st);
     hipLaunchKernelGGL(k_msm_digits<true>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
-                       ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
+                       ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>(), d_err);
     pf.end(PROF_SCATTER, st);
   } else {
     SortGeom sg;
@@ -1615,7 +1622,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     const uint32_t b1 = (uint32_t)((n + SORT_TS - 1) / SORT_TS);
     const uint32_t b2 = (uint32_t)(N / SORT_CH + sg.G + 1);
     pf.begin(PROF_DIGITS, st);
-    hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcount, (uint64_t*)nullptr);
+    hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcount, (uint64_t*)nullptr, d_err);
     hipLaunchKernelGGL(k_sort1_scan, dim3(1), dim3(1024), 0, st, gcount, sg.G, goff, gcursor, blkoff);
     const size_t stage1_lds = (size_t)SORT_TS * W * 8 + (size_t)3 * sg.G * 4 + 1024 * 4;
     static const bool sort1_staged_env = !(getenv("GM_MSM_SORT1") && !strcmp(getenv("GM_MSM_SORT1"), "direct"));
@@ -1627,7 +1634,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
       }
       hipLaunchKernelGGL(k_sort1_staged, dim3(b1), dim3(1024), stage1_lds, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>());
     } else {
-      hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>());
+      hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>(), d_err);
     }
     pf.end(PROF_DIGITS, st);
     pf.begin(PROF_SCATTER, st);
@@ -1811,8 +1818,14 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     g.lpo_shift = lpo_for(nb ? (1u << (nb - 1)) : 1u, g.n_out);
     return g;
   };
-  auto launch = [&](std::initializer_list<GroupSumArgs> jobs) {
+  uint8_t* planes = nullptr;
+  size_t plane_count = 0;
+  auto launch = [&](std::initializer_list<GroupSumArgs> jobs, bool last = false) {
     GroupSumJobs J{};
+    if (last) {
+      J.err_src = d_err;
+      J.err_dst = reinterpret_cast<uint32_t*>(planes + plane_count * XYZZ_BYTES);
+    }
     uint32_t tot = 0;
     int k = 0;
     for (const GroupSumArgs& g : jobs) {
@@ -1825,18 +1838,18 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     hipLaunchKernelGGL(k_group_sum, dim3(tot), dim3(256), 0, st, J);
   };
   // plane output layout: field k occupies Wb * (wf[k] + 1) records starting at plane_off[k]
-  size_t plane_off[3], plane_count = 0;
+  size_t plane_off[3];
   for (int k = 0; k < m; k++) {
     plane_off[k] = plane_count;
     plane_count += (size_t)Wb * (wf[k] + 1);
   }
-  if ((rc = ws.planes.ensure(plane_count * XYZZ_BYTES))) return rc;
-  uint8_t* planes = ws.planes.as<uint8_t>();
+  if ((rc = ws.planes.ensure(plane_count * XYZZ_BYTES + 64))) return rc;
+  planes = ws.planes.as<uint8_t>();
   const uint8_t* X = ws.buckets.as<uint8_t>();
   const uint32_t n0 = 1u << wf[0], n1 = 1u << wf[1], n2 = 1u << wf[2];
   if (m == 1) {
     lpo_jobs = 1;
-    launch({plane(X, planes, wf[0])});
+    launch({plane(X, planes, wf[0])}, true);
   } else if (m == 2) {
     // Y1[d1] = sum_{d0} X (rows), Y0[d0] = sum_{d1} X (columns)
     if ((rc = ws.rows.ensure((size_t)Wb * (n0 + n1) * XYZZ_BYTES))) return rc;
@@ -1844,7 +1857,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ_BYTES;
     lpo_jobs = 2;
     launch({strided(X, Y1, B, 1, n1, 0, n0, 1, n0), strided(X, Y0, B, 1, n0, 0, 1, n0, n1)});
-    launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1])});
+    launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1])}, true);
   } else {
     // level 1: A[d2][d1] = sum_{d0} X, Bm[d2][d0] = sum_{d1} X
     if ((rc = ws.rows.ensure((size_t)Wb * ((size_t)n2 * n1 + (size_t)n2 * n0) * XYZZ_BYTES))) return rc;
@@ -1861,11 +1874,11 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     launch({strided(A, Y2, n2 * n1, 1, n2, 0, n1, 1, n1), strided(A, Y1, n2 * n1, 1, n1, 0, 1, n1, n2),
             strided(Bm, Y0, n2 * n0, 1, n0, 0, 1, n0, n2)});
     launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1]),
-            plane(Y2, planes + plane_off[2] * XYZZ_BYTES, wf[2])});
+            plane(Y2, planes + plane_off[2] * XYZZ_BYTES, wf[2])}, true);
   }
   pf.end(PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
-  const size_t plane_bytes = plane_count * XYZZ_BYTES;
+  const size_t plane_bytes = plane_count * XYZZ_BYTES + 8;  // + the scalar-range flag
   if (ws.host_planes_cap[slot] < plane_bytes) {
     if (ws.host_planes[slot]) (void)hipHostFree(ws.host_planes[slot]);
     ws.host_planes[slot] = nullptr;
@@ -1881,6 +1894,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   GM_HIP(hipMemcpyAsync(ws.host_planes[slot], planes, plane_bytes, hipMemcpyDeviceToHost, st));
   GM_HIP(hipEventRecord(ws.done_ev[slot], st));
   P->Wb = Wb;
+  P->plane_count = plane_count;
   P->c = c;
   P->m = m;
   P->nbits = nbits;
@@ -1904,6 +1918,8 @@ static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t 
   // Horner over bit positions, bucket sets high -> low (variable_base.rs:168-175 with the weighted
   // bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)
   const uint64_t* hp = ws.host_planes[P.slot];
+  GM_CHECK((uint32_t)hp[P.plane_count * 24] == 0, GM_EINVAL,
+           "msm: a scalar passed as a canonical integer is >= 2^255 (not the BigInt image of an Fr element)");
   auto plane_at = [&](int w, int field, uint32_t j) {
     return gmh::xyzz_to_jac_dev(hp + (P.plane_off[field] + (size_t)w * (P.wf[field] + 1) + j) * 24);
   };

@@ -152,14 +152,23 @@ class CommitterKeyStream:
     (:287-296); in HBM the SRS stays in time order and the stream view is the `reversed` addressing
     of gm_g1_msm_*.  Polynomials are big-endian coefficient streams (numpy arrays or FrVec)."""
 
-    def __init__(self, powers_of_g: G1Bases, max_eval_points: int, powers_of_g2=None):
+    # The reference flushes its Pippenger buffers every max_msm_buffer (/ depth) pairs to bound HOST memory
+    # (src/kzg/space.rs:105,139,205); the sum does not depend on where it is cut.  Scalars and SRS are already
+    # resident in HBM here, so `max_msm_buffer` is ADVISORY on the device path: cuts shorter than
+    # `min_device_chunk` pairs are merged into one device MSM (2^20 / 26 = 40 k-pair flushes would each cost a
+    # latency-bound launch chain: snark -i 26 elastic 4.4 s instead of 1.46 s).  Pass min_device_chunk=1 to cut
+    # literally where the caller says (tests/test_gpu_snark.py does, at logn 22 with max_msm_buffer 2^20).
+    DEFAULT_MIN_DEVICE_CHUNK = 1 << 22
+
+    def __init__(self, powers_of_g: G1Bases, max_eval_points: int, powers_of_g2=None, min_device_chunk: int = None):
         self.powers_of_g = powers_of_g
         self._max_eval_points = max_eval_points
         self.powers_of_g2 = powers_of_g2
+        self.min_device_chunk = self.DEFAULT_MIN_DEVICE_CHUNK if min_device_chunk is None else int(min_device_chunk)
 
     @classmethod
-    def from_committer_key(cls, ck: "CommitterKey") -> "CommitterKeyStream":
-        return cls(ck.powers_of_g, ck.max_eval_points(), ck.powers_of_g2)
+    def from_committer_key(cls, ck: "CommitterKey", min_device_chunk: int = None) -> "CommitterKeyStream":
+        return cls(ck.powers_of_g, ck.max_eval_points(), ck.powers_of_g2, min_device_chunk=min_device_chunk)
 
     def powers_of_g2_bytes(self) -> bytes:
         from . import g2 as G2
@@ -175,12 +184,6 @@ class CommitterKeyStream:
         """:77-92 (keeps the first max_degree powers; shares the resident SRS)"""
         assert max_degree <= self._n()
         return CommitterKey(self.powers_of_g, self._max_eval_points)
-
-    # The reference flushes its Pippenger buffers every max_msm_buffer (/ depth) pairs to bound HOST memory
-    # (src/kzg/space.rs:105,139,205); the sum does not depend on where it is cut.  Scalars and SRS are already
-    # resident in HBM here, so cuts shorter than this many pairs are merged into one device MSM (2^20 / 26
-    # = 40 k-pair flushes would cost a latency-bound launch chain each).  Set to 1 to cut literally.
-    min_device_chunk = 1 << 22
 
     def _msm_stream(self, scalars_stream: FrVec, first_stream_pos: int, chunk: int) -> np.ndarray:
         """sum over stream positions: pair k = (base_stream[first_stream_pos + k], scalars_stream[k]),

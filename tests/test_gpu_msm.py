@@ -418,3 +418,22 @@ def test_msm_skewed_digit_distributions_multi_block(gm, oracle, kind):
         assert_same_point(oracle, got, oracle.msm_pippenger(reg.download(), sc))
     finally:
         reg.free()
+
+
+def test_msm_rejects_scalars_that_are_not_fr_images(gm, oracle):
+    """Canonical scalars (mont = 0) must be < r < 2^255 like every `BigInt` image of an Fr element.  With
+    c * W = 256 a value with bit 255 set gives a top-window digit beyond the bucket range: the reference
+    panics on the out-of-range bucket index (src/kzg/msm/variable_base.rs:133-146); the device clamps the
+    digit (no out-of-bounds write) and the call fails with GM_EINVAL.  The next call is unaffected."""
+    n = 300
+    bases = gm.G1Bases.register(rand_bases(oracle, 91, n))
+    sc = oracle.random_fr(92, n)
+    good = bases.msm_bigint(sc)
+    bad = sc.copy()
+    bad[n // 2, 3] |= np.uint64(1 << 63)
+    with pytest.raises(gm.capi.GeminiHipError) as ei:
+        bases.msm_bigint(bad)
+    assert ei.value.code == -1  # GM_EINVAL
+    assert (bases.msm_bigint(sc) == good).all()
+    assert_same_point(oracle, good, oracle.msm_pippenger(bases.download(), sc))
+    bases.free()

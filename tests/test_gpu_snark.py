@@ -148,7 +148,7 @@ def test_committer_key_stream_consistency(gm, oracle, pyref):
         assert (te == se).all() and (tp == sp).all()
         space_ck.min_device_chunk = 1  # cut literally (the default merges short flushes into one device MSM)
         se2, sp2 = space_ck.open(stream, alpha, 7)  # tiny buffer: many ChunkedPippenger flushes
-        del space_ck.min_device_chunk
+        space_ck.min_device_chunk = space_ck.DEFAULT_MIN_DEVICE_CHUNK
         assert (te == se2).all() and (tp == sp2).all()
     # space.rs test_open_multi_points
     f_be = [80, 80, 88, 3, 73, 7, 24]
@@ -446,3 +446,31 @@ def test_matrix_tensor_known_answers(gm, oracle, pyref):
         m.free()
     for v in (ones, tt, T, Tc):
         v.free()
+
+
+def test_open_polynomials_no_longer_than_the_point_set(gm, oracle, pyref):
+    """CommitterKey::open([c], x) returns c with the identity as proof (src/kzg/time.rs:112-131); the stream
+    key's open / open_multi_points return the polynomial itself as remainder when it is shorter than the
+    vanishing polynomial (src/kzg/space.rs:95-166).  The device division has no pass to run in that case and
+    used to leave the remainders unwritten."""
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+
+    I = gm.fr.fr_to_int
+    M = lambda v: oracle.fr_to_mont(oracle.ints_to_limbs(v, 4))
+    tau = oracle.limbs_to_ints(oracle.random_fr(171, 1))[0]
+    time_ck = CommitterKey.new(16, 3, oracle.ints_to_limbs([tau], 4)[0])
+    space_ck = CommitterKeyStream.from_committer_key(time_ck)
+    x = 11
+    ev, proof = time_ck.open(M([42]), M([x])[0])
+    assert I(ev) == 42 and not np.asarray(proof).reshape(3, 6)[2].any()  # evaluation c, quotient 0 -> identity
+    sev, sproof = space_ck.open(M([42]), M([x])[0], 1 << 20)
+    assert I(sev) == 42 and (np.asarray(sproof) == np.asarray(proof)).all()
+    # f(X) = 5 X^2 + 7 X + 9 (big-endian stream) against three points: remainder = f, quotient = 0
+    pts = [3, 10, pyref.R_MOD - 10]
+    rem, mp = space_ck.open_multi_points(M([5, 7, 9]), M(pts), 1 << 20)
+    assert [I(r) for r in rem] == [5, 7, 9] and not np.asarray(mp).reshape(3, 6)[2].any()
+    # ... and against two points: quotient 5, remainder f mod (X - 3)(X - 10) = (7 + 65) X + (9 - 150)
+    rem2, mp2 = space_ck.open_multi_points(M([5, 7, 9]), M(pts[:2]), 1 << 20)
+    assert [I(r) for r in rem2] == [72, (9 - 150) % pyref.R_MOD]
+    assert (np.asarray(mp2) == np.asarray(time_ck.commit(M([5])))).all()
+    assert (np.asarray(time_ck.open_multi_points(M([9, 7, 5]), M(pts[:2]))) == np.asarray(mp2)).all()
