@@ -272,7 +272,9 @@ def main():
                 "note": "pageable numpy buffers; PCIe-inclusive, reported for DESIGN.md only"}
         del hb_full
     stage_names = ["digits_hist", "scan", "scatter", "acc0", "merge", "reduce", "sc_round"]
-    stages = {k: (ms[i] / cnt[i] if cnt[i] else None) for i, k in enumerate(stage_names)}
+    # per CALL: a one-call MSM of >= 2^17 pairs runs as two window groups, so each stage is launched twice per step
+    stages = {k: (ms[i] / args.steps if cnt[i] else None) for i, k in enumerate(stage_names)}
+    launches = {k: (cnt[i] / args.steps if cnt[i] else None) for i, k in enumerate(stage_names)}
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
     # this same command; profiles/r1_pmc_msm20.json says how it was collected and corrected)
@@ -315,8 +317,13 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 6) if achieved else None,
                 "traffic": traffic,
+                # k_acc0 is launched `launches_per_step` times per step (one per window group, back to back on one
+                # stream); kernel_ms is their SUM, i.e. the time the kernel needs for the bytes of one whole MSM
                 "kernel_ms": round(acc0_ms, 4) if acc0_ms else None,
-                "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n,
+                "launches_per_step": launches["acc0"],
+                "kernel_ms_per_launch": round(acc0_ms / launches["acc0"], 4) if acc0_ms else None,
+                "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n / launches["acc0"] if acc0_ms else None,
+                "algorithmic_bytes_per_step": BYTES_PER_PAIR * n,
                 "note": "integer-ALU bound (~300 v_mad_u64_u32 per Fq product); HBM fraction reported as the contract asks",
                 # the truthful utilisation figure: Fq products per second of the kernel (10 per mixed
                 # addition, 16 windows) against the multiplier's instruction-issue bound -- 288 v_mad_u64_u32 + 288 v_addc_co_u32,

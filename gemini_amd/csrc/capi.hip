@@ -84,30 +84,32 @@ void DevPool::release_all() {
   pooled_bytes = 0;
 }
 
-void Profiler::begin(int stage, hipStream_t st) {
+void Profiler::begin(int part, int stage, hipStream_t st) {
   if (!on) return;
   if (!have_events) {
-    for (auto& e : ev) (void)hipEventCreate(&e);
+    for (auto& set : ev)
+      for (auto& e : set) (void)hipEventCreate(&e);
     have_events = true;
   }
-  (void)hipEventRecord(ev[2 * stage], st);
+  (void)hipEventRecord(ev[part][2 * stage], st);
 }
-void Profiler::end(int stage, hipStream_t st) {
+void Profiler::end(int part, int stage, hipStream_t st) {
   if (!on) return;
-  (void)hipEventRecord(ev[2 * stage + 1], st);
-  pending[stage] = true;
+  (void)hipEventRecord(ev[part][2 * stage + 1], st);
+  pending[part][stage] = true;
 }
 void Profiler::collect() {
   if (!on) return;
-  for (int s = 0; s < PROF_NSTAGES; s++) {
-    if (!pending[s]) continue;
-    float t = 0;
-    if (hipEventElapsedTime(&t, ev[2 * s], ev[2 * s + 1]) == hipSuccess) {
-      ms[s] += t;
-      count[s] += 1;
+  for (int p = 0; p < 2; p++)
+    for (int s = 0; s < PROF_NSTAGES; s++) {
+      if (!pending[p][s]) continue;
+      float t = 0;
+      if (hipEventElapsedTime(&t, ev[p][2 * s], ev[p][2 * s + 1]) == hipSuccess) {
+        ms[s] += t;
+        count[s] += 1;
+      }
+      pending[p][s] = false;
     }
-    pending[s] = false;
-  }
 }
 
 static Context* g_ctx = nullptr;
@@ -279,7 +281,7 @@ int gm_prof_enable(int on) {
   for (int s = 0; s < PROF_NSTAGES; s++) {
     C->prof.ms[s] = 0;
     C->prof.count[s] = 0;
-    C->prof.pending[s] = false;
+    C->prof.pending[0][s] = C->prof.pending[1][s] = false;
   }
   return GM_OK;
 }
@@ -303,6 +305,12 @@ int gm_set_msm_window(int c) {
   GM_CTX();
   GM_CHECK(c == 0 || (c >= 2 && c <= 22), GM_EINVAL, "gm_set_msm_window: c = %d not in {0} u [2, 22]", c);
   C->msm_c_override = c;
+  return GM_OK;
+}
+
+int gm_set_msm_split(int on) {
+  GM_CTX();
+  C->msm_split = on != 0;
   return GM_OK;
 }
 

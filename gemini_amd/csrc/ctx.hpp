@@ -131,6 +131,7 @@ struct MsmWorkspace {
   uint64_t* host_planes[2] = {nullptr, nullptr};  // pinned staging for the D2H of window bit-planes (two calls in flight)
   size_t host_planes_cap[2] = {0, 0};
   hipEvent_t done_ev[2];
+  hipEvent_t sort_ev, acc_ev;  // phase hand-over between the streams of a split call
   bool have_done_ev = false;
 };
 
@@ -138,14 +139,16 @@ struct MsmWorkspace {
 enum ProfStage { PROF_DIGITS = 0, PROF_SCAN, PROF_SCATTER, PROF_ACC0, PROF_MERGE, PROF_REDUCE, PROF_SC_ROUND, PROF_NSTAGES };
 struct Profiler {
   bool on = false;
-  hipEvent_t ev[2 * PROF_NSTAGES];
+  hipEvent_t ev[2][2 * PROF_NSTAGES];  // [window group of a split MSM call][stage begin / end]
   bool have_events = false;
-  bool pending[PROF_NSTAGES] = {};
-  double ms[PROF_NSTAGES] = {};
-  uint64_t count[PROF_NSTAGES] = {};
-  void begin(int stage, hipStream_t st);
-  void end(int stage, hipStream_t st);
-  void collect();  // after a stream sync
+  bool pending[2][PROF_NSTAGES] = {};
+  double ms[PROF_NSTAGES] = {};     // summed over calls AND over the window groups of a call
+  uint64_t count[PROF_NSTAGES] = {};  // launches of the stage (a split call counts two)
+  void begin(int part, int stage, hipStream_t st);
+  void end(int part, int stage, hipStream_t st);
+  void begin(int stage, hipStream_t st) { begin(0, stage, st); }
+  void end(int stage, hipStream_t st) { end(0, stage, st); }
+  void collect();  // after the streams of the call have been waited for
 };
 
 // Caching allocator for device vectors: the prover allocates and drops O(100) multi-hundred-MB
@@ -188,9 +191,12 @@ struct Context {
   // sort / merge / reduce of one overlap the (ALU-bound) accumulation of the other
   MsmWorkspace msm_b;
   hipStream_t stream_b = nullptr;
+  hipEvent_t start_ev;  // recorded on `stream` when an MSM call starts: its other streams wait for the producer of the scalars
+  bool have_start_ev = false;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
   int msm_c_override = 0;
+  int msm_split = 0;          // one-call MSMs as two window groups over three streams (gm_set_msm_split)
   int msm_affine_levels = 0;  // affine tree levels in front of the XYZZ accumulation; -1 = automatic
   size_t msm_table_min = (size_t)1 << 17;  // smallest MSM that uses fixed-base tables when present
   int cu_count = 256;

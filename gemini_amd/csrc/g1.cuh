@@ -225,15 +225,17 @@ GM_DEV void xyzz_madd(G1Xyzz& acc, const G1Affine& q) {
     }
     return;
   }
+  // Order chosen for register pressure (every product is an opaque call, so this is the order that runs): at most
+  // eight field elements are live at any call -- k_acc0 fits three waves per SIMD only below 168 VGPRs.
   FqE pp = fq_sqr(p);                                    // 100 <= 512 -> < 2q
-  FqE ppp = fq_mul(p, pp);                               // < 2q
-  FqE qq = fq_mul(acc.x, pp);                            // 8*2 -> < 2q
-  FqE x3 = fq_sub<4>(fq_sub<2>(fq_sqr(r), ppp), fq_dbl(qq));  // (r^2 - ppp) < 4q, 2qq < 4q -> < 8q
-  FqE y3 = fq_sub<2>(fq_mul(r, fq_sub<8>(qq, x3)), fq_mul(acc.y, ppp));  // (qq - x3) < 10q, 6*10; 4*2 -> < 4q
   acc.zz = fq_mul(acc.zz, pp);
+  FqE ppp = fq_mul(p, pp);                               // < 2q            (p dead)
   acc.zzz = fq_mul(acc.zzz, ppp);
+  FqE qq = fq_mul(acc.x, pp);                            // 8*2 -> < 2q     (x, pp dead)
+  FqE yp = fq_mul(acc.y, ppp);                           // 4*2             (y dead)
+  FqE x3 = fq_sub<4>(fq_sub<2>(fq_sqr(r), ppp), fq_dbl(qq));  // (r^2 - ppp) < 4q, 2qq < 4q -> < 8q   (ppp dead)
+  acc.y = fq_sub<2>(fq_mul(r, fq_sub<8>(qq, x3)), yp);   // (qq - x3) < 10q, 6*10 -> < 4q
   acc.x = x3;
-  acc.y = y3;
 }
 
 // acc += q (XYZZ), EFD add-2008-s with the exceptional cases resolved.

@@ -26,8 +26,13 @@
 //   7. host           Horner over <= 256 bit positions on the (W x c) plane sums
 //                     (src/kzg/msm/variable_base.rs:168-175 is the window Horner).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "ctx.hpp"
@@ -144,7 +149,8 @@ constexpr uint32_t SORT_GMAX = 4096;   // coarse bins
 constexpr uint32_t SORT_FMAX = 4096;   // fine bins (10 key bits by default, up to 12 for the widest windows)
 
 struct SortGeom {
-  int c, W;
+  int c, W;      // W: windows of the whole scalar (the signed-digit recurrence always runs from window 0)
+  int w_lo, Wg;  // this call sorts windows [w_lo, w_lo + Wg) only; keys are relative to w_lo
   uint32_t B, FB, G;
   int shared;  // 1: fixed-base tables in use -> one bucket set for all windows, window index rides in the entry
 };
@@ -163,12 +169,13 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     const bool active = i < n;
     DigitIter it;
     it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
-    for (int w = 0; w < sg.W; w++) {
+    for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
       int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
+      if (w < sg.w_lo) continue;  // wave-uniform
       // (wave_atomic_inc: one LDS atomic per wave when all lanes hit the same bin -- the all-equal-scalars
       // instance of the reference's benchmark would otherwise serialise 64 same-address atomics)
       const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-      wave_atomic_inc(cnt, (active && d != 0) ? (((sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
+      wave_atomic_inc(cnt, (active && d != 0) ? (((sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
     }
     if (!SCATTER && it.bad) atomicOr(err, 1u);  // a scalar >= 2^255 (not an Fr image): the call fails with GM_EINVAL
   }
@@ -189,11 +196,12 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     const bool active = i < n;
     DigitIter it;
     it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
-    for (int w = 0; w < sg.W; w++) {
+    for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
       int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
+      if (w < sg.w_lo) continue;
       const bool live = active && d != 0;
       const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-      const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
+      const uint32_t key = (sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u);
       const uint32_t g = key >> sg.FB;
       const uint32_t r = wave_atomic_inc(cnt, live ? g : KEY_INV);
       if (live) {
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
                                                        uint32_t* __restrict__ gcursor, uint64_t* __restrict__ tmp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + (size_t)SORT_TS * sg.W);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + (size_t)SORT_TS * sg.Wg);
   uint32_t* base = cnt + sg.G;
   uint32_t* lst = base + sg.G;
   uint32_t* scan = lst + sg.G;
@@ -226,19 +234,21 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
   {
     DigitIter it;
     it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
+    for (int w = 0; w < sg.w_lo; w++) it.next(sg.c);  // the recurrence starts at window 0
 #pragma unroll
-    for (int w = 0; w < SORT1_STAGE_WMAX; w++) {
-      e[w] = ~0ull;
-      if (w < sg.W) {
+    for (int j = 0; j < SORT1_STAGE_WMAX; j++) {
+      const int w = sg.w_lo + j;
+      e[j] = ~0ull;
+      if (j < sg.Wg) {
         int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
         if (active && d != 0) {
           const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-          const uint32_t key = (sg.shared ? 0u : (uint32_t)w * sg.B) + (mag - 1u);
+          const uint32_t key = (sg.shared ? 0u : (uint32_t)j * sg.B) + (mag - 1u);
           const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : i;
-          e[w] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
+          e[j] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
         }
       }
-      wave_atomic_inc(cnt, e[w] != ~0ull ? ((uint32_t)(e[w] >> 32) >> sg.FB) : KEY_INV);
+      wave_atomic_inc(cnt, e[j] != ~0ull ? ((uint32_t)(e[j] >> 32) >> sg.FB) : KEY_INV);
     }
   }
   __syncthreads();
@@ -548,7 +558,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // level 0: chunk-per-thread accumulation of sorted entries
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_acc0(const uint64_t* __restrict__ entries,
+#ifndef GM_ACC0_WAVES
+#define GM_ACC0_WAVES 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAVES, GM_ACC0_WAVES))) void k_acc0(const uint64_t* __restrict__ entries,
                                               const uint32_t* __restrict__ total_ptr,
                                               const uint8_t* __restrict__ bases, long long first, long long step,
                                               long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
@@ -1372,6 +1385,8 @@ static int choose_window(size_t n) {
   return c;
 }
 
+constexpr size_t MSM_SMALL_N = (size_t)1 << 17;
+constexpr size_t MSM_SPLIT_MIN_N = (size_t)1 << 17;  // smaller calls are launch-latency bound: one chain of launches beats two
 static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
                        bool normalize, uint64_t out_jac[18]);
 static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64_t step, const size_t* pair_offsets, const void* const* d_scalars,
@@ -1389,9 +1404,15 @@ struct MsmPending {
   size_t plane_off[3] = {0, 0, 0};
   size_t plane_count = 0;
 };
-static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
-                       int mont, size_t n, int slot, MsmPending* P);
-static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18]);
+// A call may be enqueued in `nparts` window groups (part p owns windows [p W / nparts, (p + 1) W / nparts)), each with
+// its own workspace; `sts` names the streams of its three phases -- sort, accumulate, merge + reduce + copy-out.
+struct MsmStreams {
+  hipStream_t sort, acc, tail;
+};
+static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
+                       int mont, size_t n, int slot, MsmPending* P, int part = 0, int nparts = 1);
+static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18]);
+static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18]) { return msm_finish_parts(C, &P, 1, normalize, out_jac); }
 
 // Calls larger than 2^26 pairs are split into 2^26-pair MSMs whose results are added on the host --
 // the same composition ChunkedPippenger / msm_chunks use (src/kzg/space.rs:41-53), with the chunk
@@ -1418,10 +1439,47 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
 static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
                        bool normalize, uint64_t out_jac[18]) {
   GM_MSM_LOCK(C);
-  MsmPending P;
-  int rc = msm_enqueue(C, C->msm, C->stream, bases, first, step, d_scalars, mont, n, 0, &P);
-  if (rc) return rc;
-  return msm_finish(C, P, normalize, out_jac);
+  // Optional (gm_set_msm_split, off by default): one large call as two window groups, high windows first, a
+  // software pipeline over three streams --
+  //   sort stream   sort(H)  sort(L)
+  //   main stream            acc0(H)            acc0(L)
+  //   tail streams                     merge + reduce + copy-out (H) | (L)
+  //   host                                                  Horner(H)      Horner(L)
+  // -- so that the sort and the merge / reduce of one group could run in the shadow of the accumulation of the
+  // other (the reduce work is per window: nothing is duplicated, unlike a split by pairs).  Measured on MI355X at
+  // 2^20 pairs: 4.18 ms against 4.05 ms unsplit.  k_acc0 fills every CU with two 196-register waves per SIMD for
+  // its whole duration, and k_merge / k_group_sum (216 registers) cannot become resident next to them, so the
+  // tail of the first group still runs after the second accumulation, twice as many latency-bound launches as
+  // before.  Results are identical (tests/test_gpu_msm.py::test_msm_window_group_split).
+  const bool tables = bases->table != nullptr && !C->msm_c_override && n >= std::max(C->msm_table_min, bases->tab_min) &&
+                      n < ((size_t)1 << ENTRY_W_SHIFT);
+  const bool split = C->msm_split && n >= MSM_SPLIT_MIN_N && !tables && C->msm_affine_levels == 0 && C->stream_b && C->small_stream[0];
+  if (!split) {
+    MsmPending P;
+    int rc = msm_enqueue(C, C->msm, MsmStreams{C->stream, C->stream, C->stream}, bases, first, step, d_scalars, mont, n, 0, &P);
+    if (rc) return rc;
+    return msm_finish(C, P, normalize, out_jac);
+  }
+  if (!C->have_start_ev) {
+    GM_HIP(hipEventCreateWithFlags(&C->start_ev, hipEventDisableTiming));
+    C->have_start_ev = true;
+  }
+  // the scalars may have been produced by earlier work on the main stream
+  GM_HIP(hipEventRecord(C->start_ev, C->stream));
+  GM_HIP(hipStreamWaitEvent(C->small_stream[0], C->start_ev, 0));
+  MsmPending P[2];
+  const MsmStreams sts{C->small_stream[0], C->stream, C->stream_b};
+  const MsmStreams sts_lo{C->small_stream[0], C->stream, C->small_stream[1]};  // the two tails end up side by side
+  int rc = msm_enqueue(C, C->msm, sts, bases, first, step, d_scalars, mont, n, 0, &P[1], 1, 2);  // high windows first
+  if (!rc) rc = msm_enqueue(C, C->msm_b, sts_lo, bases, first, step, d_scalars, mont, n, 0, &P[0], 0, 2);
+  if (rc) {
+    (void)hipStreamSynchronize(C->small_stream[0]);
+    (void)hipStreamSynchronize(C->stream);
+    (void)hipStreamSynchronize(C->stream_b);
+    (void)hipStreamSynchronize(C->small_stream[1]);
+    return rc;
+  }
+  return msm_finish_parts(C, P, 2, normalize, out_jac);
 }
 
 // k MSMs against the same registered bases.  Results are identical to k msm_run calls; what changes is
@@ -1430,7 +1488,6 @@ static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t st
 // (ii) small calls (<= MSM_SMALL_N pairs) are latency-bound chains of a dozen tiny launches, so they go
 // round-robin to MSM_SMALL_LANES extra workspaces with their own streams and run side by side -- the
 // folding commitments of the tensor check are ~20 MSMs of sizes n/2, n/4, ..., 1.
-constexpr size_t MSM_SMALL_N = (size_t)1 << 17;
 static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64_t step, const size_t* pair_offsets, const void* const* d_scalars,
                             int mont, const size_t* ns, size_t k, bool normalize, uint64_t* out_jac);
 int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, const void* const* d_scalars, int mont, const size_t* ns,
@@ -1452,6 +1509,11 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     return GM_OK;
   }
   GM_MSM_LOCK(C);
+  if (!C->have_start_ev) {
+    GM_HIP(hipEventCreateWithFlags(&C->start_ev, hipEventDisableTiming));
+    C->have_start_ev = true;
+  }
+  GM_HIP(hipEventRecord(C->start_ev, C->stream));
   struct Inflight {
     size_t j;
     int lane;  // 0 = main workspace, 1.. = small workspaces
@@ -1497,7 +1559,8 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     e.lane = lane;
     MsmWorkspace& ws = lane > 0 ? C->msm_small[lane - 1] : (lane < 0 ? C->msm_b : C->msm);
     hipStream_t st = lane > 0 ? C->small_stream[lane - 1] : (lane < 0 ? C->stream_b : C->stream);
-    int rc = msm_enqueue(C, ws, st, bases, first + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont, ns[j], hslot, &e.P);
+    if (st != C->stream) GM_HIP(hipStreamWaitEvent(st, C->start_ev, 0));  // scalars produced on the main stream
+    int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, first + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont, ns[j], hslot, &e.P);
     if (rc) return fail(rc);
     q.push_back(e);
   }
@@ -1508,8 +1571,9 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
   return GM_OK;
 }
 
-static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
-                       int mont, size_t n, int slot, MsmPending* P) {
+static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
+                       int mont, size_t n, int slot, MsmPending* P, int part, int nparts) {
+  hipStream_t st = sts.sort;  // memsets + sort; the accumulation runs on sts.acc, everything after it on sts.tail
   const size_t nbases = bases->n;
   P->ws = &ws;
   P->slot = slot;
@@ -1529,13 +1593,16 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   const int c = use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
   const int W = (256 + c - 1) / c;
+  GM_CHECK(nparts == 1 || !use_table, GM_EINVAL, "msm: the fixed-base table path is not split into window groups");
+  const int w_lo = part * W / nparts, Wg = (part + 1) * W / nparts - w_lo;  // this call's window group
   const uint32_t B = 1u << (c - 1);
-  const int Wb = use_table ? 1 : W;  // bucket sets
+  const int Wb = use_table ? 1 : Wg;  // bucket sets
   const size_t nbuckets = (size_t)Wb * B;
   const uint8_t* d_bases = use_table ? bases->table : bases->d;
   const long long tab_stride = use_table ? (long long)bases->n : 0;
-  const uint64_t N = (uint64_t)n * (uint64_t)W;
-  GM_CHECK(N < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)N);
+  const uint64_t Nall = (uint64_t)n * (uint64_t)W;
+  const uint64_t N = (uint64_t)n * (uint64_t)(use_table ? W : Wg);  // entries of this window group
+  GM_CHECK(Nall < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)Nall);
 
   // affine tree levels in front of the XYZZ accumulation (see k_lvl_*): automatic = as many as leave ~4
   // entries per bucket, none for small calls where the per-level round trip to the host costs more
@@ -1553,8 +1620,10 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   static const int L_env = getenv("GM_MSM_L") ? atoi(getenv("GM_MSM_L")) : 0;  // tuning override
   // (longer chunks for big calls: fewer keyed partials for k_merge -- 4.1 -> 2.4 ms at 2^24 pairs)
   // (from 2^24 entries on, two rounds of blocks overlap gather and arithmetic better than one: 4.18 -> 4.01 ms at 2^20 pairs)
-  const uint64_t lanes0 = Nacc >= ((uint64_t)1 << 24) ? 262144 : 131072;
-  uint32_t L = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(4, (Nacc + lanes0 - 1) / lanes0));
+  // (a window group of a split call uses the chunk length of the whole call: its two accumulations run back to back)
+  const uint64_t Nacc_all = nparts > 1 ? Nall : Nacc;
+  const uint64_t lanes0 = Nacc_all >= ((uint64_t)1 << 24) ? 262144 : 131072;
+  uint32_t L = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(4, (Nacc_all + lanes0 - 1) / lanes0));
   if (L_env > 0) L = (uint32_t)L_env;
   const uint64_t T0 = (Nacc + L - 1) / L;
   const uint64_t T0pad = (T0 + 255) / 256 * 256;
@@ -1589,23 +1658,25 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
                        ws.misc.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
   };
   static const bool sort_atomic_env = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
-  const bool sort_atomic = sort_atomic_env && !use_table;
+  const bool sort_atomic = sort_atomic_env && !use_table && nparts == 1;
   if (sort_atomic) {
-    pf.begin(PROF_DIGITS, st);
+    pf.begin(part, PROF_DIGITS, st);
     hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
                        ws.counts.as<uint32_t>(), (uint64_t*)nullptr, d_err);
-    pf.end(PROF_DIGITS, st);
-    pf.begin(PROF_SCAN, st);
+    pf.end(part, PROF_DIGITS, st);
+    pf.begin(part, PROF_SCAN, st);
     run_scan();
-    pf.end(PROF_SCAN, st);
-    pf.begin(PROF_SCATTER, st);
+    pf.end(part, PROF_SCAN, st);
+    pf.begin(part, PROF_SCATTER, st);
     hipLaunchKernelGGL(k_msm_digits<true>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
                        ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>(), d_err);
-    pf.end(PROF_SCATTER, st);
+    pf.end(part, PROF_SCATTER, st);
   } else {
     SortGeom sg;
     sg.c = c;
     sg.W = W;
+    sg.w_lo = use_table ? 0 : w_lo;
+    sg.Wg = use_table ? W : Wg;
     sg.B = B;
     sg.shared = use_table ? 1 : 0;
     sg.FB = std::min<uint32_t>((uint32_t)(c - 1), 10u);
@@ -1621,12 +1692,12 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     GM_HIP(hipMemsetAsync(gcount, 0, (sg.G + 1) * 4, st));
     const uint32_t b1 = (uint32_t)((n + SORT_TS - 1) / SORT_TS);
     const uint32_t b2 = (uint32_t)(N / SORT_CH + sg.G + 1);
-    pf.begin(PROF_DIGITS, st);
+    pf.begin(part, PROF_DIGITS, st);
     hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcount, (uint64_t*)nullptr, d_err);
     hipLaunchKernelGGL(k_sort1_scan, dim3(1), dim3(1024), 0, st, gcount, sg.G, goff, gcursor, blkoff);
-    const size_t stage1_lds = (size_t)SORT_TS * W * 8 + (size_t)3 * sg.G * 4 + 1024 * 4;
+    const size_t stage1_lds = (size_t)SORT_TS * sg.Wg * 8 + (size_t)3 * sg.G * 4 + 1024 * 4;
     static const bool sort1_staged_env = !(getenv("GM_MSM_SORT1") && !strcmp(getenv("GM_MSM_SORT1"), "direct"));
-    if (sort1_staged_env && W <= SORT1_STAGE_WMAX && stage1_lds <= 160 * 1024) {
+    if (sort1_staged_env && sg.Wg <= SORT1_STAGE_WMAX && stage1_lds <= 160 * 1024) {
       static bool attr_set = false;
       if (!attr_set) {
         GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort1_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1636,8 +1707,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     } else {
       hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>(), d_err);
     }
-    pf.end(PROF_DIGITS, st);
-    pf.begin(PROF_SCATTER, st);
+    pf.end(part, PROF_DIGITS, st);
+    pf.begin(part, PROF_SCATTER, st);
     hipLaunchKernelGGL(k_sort2<false>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
                        ws.counts.as<uint32_t>(), (uint64_t*)nullptr);
     run_scan();
@@ -1648,14 +1719,14 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     else
       hipLaunchKernelGGL(k_sort2<true>, dim3(b2), dim3(256), 0, st, ws.tmp_entries.as<uint64_t>(), goff, blkoff, sg,
                          ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>());
-    pf.end(PROF_SCATTER, st);
+    pf.end(part, PROF_SCATTER, st);
   }
   const uint64_t* acc_entries = ws.entries.as<uint64_t>();
   const uint32_t* acc_total = ws.offsets.as<uint32_t>() + nbuckets;
   const uint8_t* acc_bases = d_bases;
   long long acc_first = (long long)first, acc_step = (long long)step, acc_tab = tab_stride;
   if (levels > 0) {
-    pf.begin(PROF_SCAN, st);
+    pf.begin(part, PROF_SCAN, st);
     const uint32_t T = 1u << 18;  // lanes of passes A / C; pass B handles T / 512 <= 512 block products
     // bounds per level: a level maps a bucket of m elements to at most m / 2 + 1.5 elements
     uint64_t bnd[10];
@@ -1744,9 +1815,21 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     acc_first = 0;
     acc_step = 1;
     acc_tab = 0;
-    pf.end(PROF_SCAN, st);
+    pf.end(part, PROF_SCAN, st);
   }
-  pf.begin(PROF_ACC0, st);
+  if (!ws.have_done_ev) {
+    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[0], hipEventDisableTiming));
+    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[1], hipEventDisableTiming));
+    GM_HIP(hipEventCreateWithFlags(&ws.sort_ev, hipEventDisableTiming));
+    GM_HIP(hipEventCreateWithFlags(&ws.acc_ev, hipEventDisableTiming));
+    ws.have_done_ev = true;
+  }
+  if (sts.acc != st) {
+    GM_HIP(hipEventRecord(ws.sort_ev, st));
+    GM_HIP(hipStreamWaitEvent(sts.acc, ws.sort_ev, 0));
+  }
+  st = sts.acc;
+  pf.begin(part, PROF_ACC0, st);
   static const bool acc0_lds = getenv("GM_ACC0") ? !strcmp(getenv("GM_ACC0"), "lds") : (GM_FQ30 == 1);
   if (acc0_lds)
     hipLaunchKernelGGL(k_acc0_lds, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
@@ -1754,8 +1837,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   else
     hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
-  pf.end(PROF_ACC0, st);
-  pf.begin(PROF_MERGE, st);
+  pf.end(part, PROF_ACC0, st);
+  if (sts.tail != st) {
+    GM_HIP(hipEventRecord(ws.acc_ev, st));
+    GM_HIP(hipStreamWaitEvent(sts.tail, ws.acc_ev, 0));
+  }
+  st = sts.tail;
+  pf.begin(part, PROF_MERGE, st);
   {
     uint64_t E = E1;
     int src = 0;
@@ -1771,16 +1859,17 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     }
   }
 
-  pf.end(PROF_MERGE, st);
-  pf.begin(PROF_REDUCE, st);
+  pf.end(part, PROF_MERGE, st);
+  pf.begin(part, PROF_REDUCE, st);
   // bucket reduction (see k_group_sum): index bits split into m <= 3 fields w0 (low), w1, w2
   const uint32_t nbits = (uint32_t)(c - 1);
   uint32_t wf[3] = {0, 0, 0};
   int m;
+  static const int fields_env = getenv("GM_MSM_FIELDS") ? atoi(getenv("GM_MSM_FIELDS")) : 0;  // tuning override
   if (nbits <= 7) {
     m = 1;
     wf[0] = nbits;
-  } else if (nbits <= 14) {
+  } else if (nbits <= 14 || (fields_env == 2 && nbits <= 16)) {
     m = 2;
     wf[0] = nbits / 2;
     wf[1] = nbits - wf[0];
@@ -1876,7 +1965,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1]),
             plane(Y2, planes + plane_off[2] * XYZZ_BYTES, wf[2])}, true);
   }
-  pf.end(PROF_REDUCE, st);
+  pf.end(part, PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
   const size_t plane_bytes = plane_count * XYZZ_BYTES + 8;  // + the scalar-range flag
   if (ws.host_planes_cap[slot] < plane_bytes) {
@@ -1885,11 +1974,6 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
     ws.host_planes_cap[slot] = 0;
     GM_HIP(hipHostMalloc((void**)&ws.host_planes[slot], plane_bytes, hipHostMallocDefault));
     ws.host_planes_cap[slot] = plane_bytes;
-  }
-  if (!ws.have_done_ev) {
-    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[0], hipEventDisableTiming));
-    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[1], hipEventDisableTiming));
-    ws.have_done_ev = true;
   }
   GM_HIP(hipMemcpyAsync(ws.host_planes[slot], planes, plane_bytes, hipMemcpyDeviceToHost, st));
   GM_HIP(hipEventRecord(ws.done_ev[slot], st));
@@ -1905,39 +1989,157 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, hipStream_t st, const Bases
   return GM_OK;
 }
 
-static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18]) {
-  gmh::G1 result = gmh::G1::identity();
-  if (P.empty) {
-    result.to_limbs(out_jac);
-    return GM_OK;
+// ------------------------------------------------------------------------------------------
+// Host tail.  A lone GPU lane needs ~25 us per dependent group addition, a CPU core ~1 us, so the last
+// O(windows x bits) sequential additions run on the host -- and there they are the largest serial piece of a
+// call (~0.3 ms for the 256 doublings + 272 additions of 16 windows x 16 bit-planes).  The per-window sums
+// S_w = sum_j 2^j Z_{w,j} + Tot_w are independent, so a few persistent helper threads compute them side by
+// side; only the window Horner (c doublings + 1 addition per window) stays serial.
+// ------------------------------------------------------------------------------------------
+class HornerPool {
+ public:
+  static HornerPool& get() {
+    static HornerPool p;
+    return p;
   }
-  MsmWorkspace& ws = *P.ws;
-  GM_HIP(hipEventSynchronize(ws.done_ev[P.slot]));
-  C->prof.collect();
+  int threads() const { return (int)workers_.size() + 1; }
+  // called before the host blocks on the device: the helpers leave their condition variable now (a futex wake
+  // costs tens of microseconds) and poll for the job that follows
+  void prewake() {
+    if (workers_.empty()) return;
+    wake_.fetch_add(1, std::memory_order_release);
+    cv_.notify_all();
+  }
+  // fn(i) for i in [0, n), on the helpers and the calling thread; returns when all are done
+  void run(int n, const std::function<void(int)>& fn) {
+    if (workers_.empty() || n <= 1) {
+      for (int i = 0; i < n; i++) fn(i);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    fn_ = &fn;
+    n_ = n;
+    next_.store(0, std::memory_order_relaxed);
+    left_.store(n, std::memory_order_relaxed);
+    gen_.fetch_add(1, std::memory_order_release);
+    lk.unlock();
+    cv_.notify_all();
+    work();
+    while (left_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  }
+  ~HornerPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
 
-  // Horner over bit positions, bucket sets high -> low (variable_base.rs:168-175 with the weighted
-  // bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w)
-  const uint64_t* hp = ws.host_planes[P.slot];
-  GM_CHECK((uint32_t)hp[P.plane_count * 24] == 0, GM_EINVAL,
-           "msm: a scalar passed as a canonical integer is >= 2^255 (not the BigInt image of an Fr element)");
-  auto plane_at = [&](int w, int field, uint32_t j) {
-    return gmh::xyzz_to_jac_dev(hp + (P.plane_off[field] + (size_t)w * (P.wf[field] + 1) + j) * 24);
-  };
-  for (int w = P.Wb - 1; w >= 0; w--) {
-    for (int j = P.c - 1; j >= 0; j--) {
-      result = result.dbl();
-      if ((uint32_t)j < P.nbits) {
-        int field = 0;
-        uint32_t jj = (uint32_t)j;
-        while (jj >= P.wf[field]) {
-          jj -= P.wf[field];
-          field++;
-        }
-        result = result.add(plane_at(w, field, jj));
-      }
-      if (j == 0) result = result.add(plane_at(w, 0, P.wf[0]));  // Tot_w
+ private:
+  HornerPool() {
+    const char* e = getenv("GM_HOST_THREADS");
+    int want = e ? atoi(e) : 12;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && want > hw) want = hw;
+    for (int i = 1; i < want; i++) workers_.emplace_back([this] { loop(); });
+  }
+  void work() {
+    for (;;) {
+      const int i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n_) break;
+      (*fn_)(i);
+      left_.fetch_sub(1, std::memory_order_release);
     }
   }
+  void loop() {
+    uint64_t seen = 0, seen_wake = 0;
+    auto budget = std::chrono::microseconds(200);
+    for (;;) {
+      // spin for the next job -- briefly after a job (MSM calls come back to back inside a prover), for as long
+      // as a device call can take after prewake() -- then sleep
+      const auto t0 = std::chrono::steady_clock::now();
+      bool job = false;
+      while (!stop_) {
+        if (gen_.load(std::memory_order_acquire) != seen) {
+          job = true;
+          break;
+        }
+        if (std::chrono::steady_clock::now() - t0 > budget) {
+          std::unique_lock<std::mutex> lk(mu_);
+          cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || wake_.load(std::memory_order_acquire) != seen_wake || stop_; });
+          break;
+        }
+      }
+      if (stop_) return;
+      if (!job && gen_.load(std::memory_order_acquire) == seen) {  // woken ahead of a job: poll for it
+        seen_wake = wake_.load(std::memory_order_acquire);
+        budget = std::chrono::microseconds(20000);
+        continue;
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      seen_wake = wake_.load(std::memory_order_acquire);
+      budget = std::chrono::microseconds(200);
+      work();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::atomic<uint64_t> gen_{0}, wake_{0};
+  std::atomic<int> next_{0}, left_{0};
+  int n_ = 0;
+  const std::function<void(int)>* fn_ = nullptr;
+  bool stop_ = false;
+};
+
+static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18]) {
+  gmh::G1 result = gmh::G1::identity();
+  // Horner over bit positions, window groups and bucket sets high -> low (variable_base.rs:168-175 with the
+  // weighted bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w).
+  // The host starts on the high group as soon as its planes have landed; the device is still busy with the
+  // low one.
+  int rc = GM_OK;
+  for (int p = nparts - 1; p >= 0; p--) {
+    const MsmPending& P = parts[p];
+    if (P.empty) continue;
+    MsmWorkspace& ws = *P.ws;
+    if (P.Wb > 1) HornerPool::get().prewake();
+    GM_HIP(hipEventSynchronize(ws.done_ev[P.slot]));
+    const uint64_t* hp = ws.host_planes[P.slot];
+    if ((uint32_t)hp[P.plane_count * 24] != 0) {
+      set_error("msm: a scalar passed as a canonical integer is >= 2^255 (not the BigInt image of an Fr element)");
+      rc = GM_EINVAL;  // keep draining: every part's copy-out must have completed before the workspaces are reused
+      continue;
+    }
+    if (rc) continue;
+    auto plane_at = [&](int w, int field, uint32_t j) {
+      return gmh::xyzz_to_jac_dev(hp + (P.plane_off[field] + (size_t)w * (P.wf[field] + 1) + j) * 24);
+    };
+    // S_w = sum_j 2^j Z_{w,j} + Tot_w, one task per bucket set
+    std::vector<gmh::G1> S((size_t)P.Wb);
+    HornerPool::get().run(P.Wb, [&](int w) {
+      gmh::G1 s = gmh::G1::identity();
+      int field = P.m - 1;
+      uint32_t jj = P.wf[field];
+      for (int j = (int)P.nbits - 1; j >= 0; j--) {
+        while (jj == 0) {
+          field--;
+          jj = P.wf[field];
+        }
+        jj--;
+        s = s.dbl();
+        s = s.add(plane_at(w, field, jj));
+      }
+      S[(size_t)w] = s.add(plane_at(w, 0, P.wf[0]));  // Tot_w
+    });
+    for (int w = P.Wb - 1; w >= 0; w--) {
+      for (int j = 0; j < P.c; j++) result = result.dbl();
+      result = result.add(S[(size_t)w]);
+    }
+  }
+  C->prof.collect();
+  if (rc) return rc;
   if (normalize) result = result.normalized();
   result.to_limbs(out_jac);
   return GM_OK;

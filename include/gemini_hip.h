@@ -130,6 +130,9 @@ int gm_set_msm_window(int c);
 /* Smallest pair count for which an MSM uses the fixed-base tables of its handle (default 2^17:
  * below that the MSM is latency-bound and few buckets win).  Tuning/test knob. */
 int gm_set_msm_table_min(size_t n);
+/* Tuning knob (default 0): run one-call MSMs of >= 2^17 pairs as two window groups pipelined over three streams.
+ * Same results; slower on MI355X as measured (gemini_amd/csrc/msm.hip: msm_run_one). */
+int gm_set_msm_split(int on);
 /* Affine tree levels in front of the XYZZ bucket accumulation (0 = none, -1 = automatic, <= 8): every
  * level adds the sorted entries of each bucket pairwise in affine coordinates with one shared field
  * inversion (6 instead of 10 field products per addition).  The result does not depend on it. */

@@ -437,3 +437,22 @@ def test_msm_rejects_scalars_that_are_not_fr_images(gm, oracle):
     assert (bases.msm_bigint(sc) == good).all()
     assert_same_point(oracle, good, oracle.msm_pippenger(bases.download(), sc))
     bases.free()
+
+
+def test_msm_window_group_split(gm, oracle):
+    """gm_set_msm_split: a one-call MSM as two window groups on three streams gives the same group element
+    (2^17 + 3 pairs, the smallest size that splits, and the degenerate all-equal-scalars instance)."""
+    lib = gm.capi.load()
+    n = (1 << 17) + 3
+    bases = gm.G1Bases.fixed_base(oracle.g1_generator(), oracle.random_fr(95, n))
+    sc = oracle.random_fr(96, n)
+    eq = np.repeat(oracle.random_fr(97, 1), n, axis=0)
+    plain = [bases.msm_bigint(sc), bases.msm_bigint(eq)]
+    gm.capi.check(lib.gm_set_msm_split(C.c_int(1)))
+    try:
+        split = [bases.msm_bigint(sc), bases.msm_bigint(eq)]
+    finally:
+        gm.capi.check(lib.gm_set_msm_split(C.c_int(0)))
+    assert (split[0] == plain[0]).all() and (split[1] == plain[1]).all()
+    assert_same_point(oracle, plain[0], oracle.msm_pippenger(bases.download(), sc))
+    bases.free()
