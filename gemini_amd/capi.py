@@ -36,7 +36,7 @@ SYMBOLS = [
     "gm_sp_new", "gm_sp_new_v", "gm_sp_round", "gm_sp_fold", "gm_sp_rounds", "gm_sp_final", "gm_sp_to_time", "gm_sp_free",
     "gm_sc_set_herring", "gm_hg1_new", "gm_hg1_round", "gm_hg1_fold", "gm_hg1_rounds", "gm_hg1_final", "gm_hg1_free",
     "gm_transcript_new", "gm_transcript_free", "gm_transcript_append_message", "gm_transcript_challenge_bytes",
-    "gm_transcript_append_fr", "gm_transcript_append_g1", "gm_transcript_challenge_fr", "gm_sumcheck_prove", "gm_sumcheck_prove_batch",
+    "gm_transcript_append_fr", "gm_transcript_append_g1", "gm_transcript_set_g1_encoding", "gm_transcript_challenge_fr", "gm_sumcheck_prove", "gm_sumcheck_prove_batch",
 ]
 
 

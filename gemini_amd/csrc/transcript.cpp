@@ -130,6 +130,7 @@ struct Strobe128 {
 // merlin::Transcript
 struct Transcript {
   Strobe128 strobe;
+  int g1_encoding = 0;  // 0: ark-ec default short-Weierstrass framing; 1: ark-bls12-381's zcash framing
   explicit Transcript(const uint8_t* label, size_t len) : strobe((const uint8_t*)"Merlin v1.0", 11) {
     append_message((const uint8_t*)"dom-sep", 7, label, len);
   }
@@ -228,7 +229,22 @@ int gm_transcript_append_g1(uint64_t handle, const uint8_t* label, size_t llen, 
     uint8_t enc[96];
     memset(enc, 0, sizeof enc);
     gmh::G1 p = gmh::G1::from_limbs(jac + 18 * i).normalized();
-    if (p.is_identity()) {
+    if (t->g1_encoding == 1) {
+      // ark-bls12-381 `serialize_with_mode` override, Compress::No: x || y big-endian, bit 7 of byte 0 clear
+      // (uncompressed), bit 6 = infinity, no sort flag
+      if (p.is_identity()) {
+        enc[0] |= 1u << 6;
+      } else {
+        uint64_t x[6], y[6];
+        p.x.to_canonical(x);
+        p.y.to_canonical(y);
+        for (int k = 0; k < 6; k++)
+          for (int b = 0; b < 8; b++) {
+            enc[47 - (8 * k + b)] = (uint8_t)(x[k] >> (8 * b));
+            enc[95 - (8 * k + b)] = (uint8_t)(y[k] >> (8 * b));
+          }
+      }
+    } else if (p.is_identity()) {
       enc[95] |= 1u << 6;
     } else {
       uint64_t x[6], y[6], ny[6];
@@ -245,6 +261,16 @@ int gm_transcript_append_g1(uint64_t handle, const uint8_t* label, size_t llen, 
     buf.insert(buf.end(), enc, enc + 96);
   }
   t->append_message(label, llen, buf.data(), buf.size());
+  return GM_OK;
+}
+
+// Which ark-serialize framing `append_serializable` uses for G1: 0 = ark-ec's default (ark-test-curves, the
+// reference's examples and tests), 1 = the zcash framing ark-bls12-381 substitutes (the reference's benches).
+int gm_transcript_set_g1_encoding(uint64_t handle, int encoding) {
+  Transcript* t = find(handle);
+  T_CHECK(t, GM_EHANDLE, "transcript_set_g1_encoding: unknown handle %llu", (unsigned long long)handle);
+  T_CHECK(encoding == 0 || encoding == 1, GM_EINVAL, "transcript_set_g1_encoding: %d is not 0 (arkworks) or 1 (zcash)", encoding);
+  t->g1_encoding = encoding;
   return GM_OK;
 }
 

@@ -591,60 +591,31 @@ class Proof:
         proof.spans = spans
         return proof
 
-    def serialize_compressed(self) -> bytes:
-        """derive(CanonicalSerialize) order of src/psnark/mod.rs:29-51 (Vec = u64 length + items, arrays = items)"""
-        from .snark import _fr_bytes, _g1_compressed
+    def serialize(self, compress: bool = True, enc=0) -> bytes:
+        """derive(CanonicalSerialize) of src/psnark/mod.rs:29-51 (formats: gemini_amd/wire.py)"""
+        from . import wire
 
-        u64 = lambda n: int(n).to_bytes(8, "little")
-        out = bytearray()
+        return wire.serialize(wire.PSNARK_PROOF, self, compress, enc)
 
-        def sumcheck_msgs(m):
-            msgs, finals = m
-            out.extend(u64(len(msgs)))
-            for a, b in msgs:
-                out.extend(_fr_bytes(a) + _fr_bytes(b))
-            out.extend(u64(len(finals)))
-            for f0, g0 in finals:
-                out.extend(_fr_bytes(f0) + _fr_bytes(g0))
+    def serialize_compressed(self, enc=0) -> bytes:
+        return self.serialize(True, enc)
 
-        out += _g1_compressed(self.witness_commitment)
-        out += _fr_bytes(self.zc_alpha)
-        sumcheck_msgs(self.first_sumcheck_msgs)
-        for c in self.r_star_commitments:
-            out += _g1_compressed(c)
-        out += _g1_compressed(self.z_star_commitment)
-        sumcheck_msgs(self.second_sumcheck_msgs)
-        for ep0, ep1, cm in ((self.set_r_ep, self.subset_r_ep, self.sorted_r_commitment),
-                             (self.set_alpha_ep, self.subset_alpha_ep, self.sorted_alpha_commitment),
-                             (self.set_z_ep, self.subset_z_ep, self.sorted_z_commitment)):
-            out += _fr_bytes(ep0) + _fr_bytes(ep1) + _g1_compressed(cm)
-        out += u64(len(self.ep_msgs.acc_v_commitments))
-        for c in self.ep_msgs.acc_v_commitments:
-            out += _g1_compressed(c)
-        out += u64(len(self.ep_msgs.claimed_sumchecks))
-        for e in self.ep_msgs.claimed_sumchecks:
-            out += _fr_bytes(e)
-        out += u64(len(self.ralpha_star_acc_mu_evals))
-        for e in self.ralpha_star_acc_mu_evals:
-            out += _fr_bytes(e)
-        out += _g1_compressed(self.ralpha_star_acc_mu_proof)
-        for e in self.rstars_vals:
-            out += _fr_bytes(e)
-        sumcheck_msgs(self.third_sumcheck_msgs)
-        tc = self.tensorcheck_proof
-        out += u64(len(tc.folded_polynomials_commitments))
-        for c in tc.folded_polynomials_commitments:
-            out += _g1_compressed(c)
-        out += u64(len(tc.folded_polynomials_evaluations))
-        for e2 in tc.folded_polynomials_evaluations:
-            for e in e2:
-                out += _fr_bytes(e)
-        out += _g1_compressed(tc.evaluation_proof)
-        out += u64(len(tc.base_polynomials_evaluations))
-        for e3 in tc.base_polynomials_evaluations:
-            for e in e3:
-                out += _fr_bytes(e)
-        return bytes(out)
+    def serialize_uncompressed(self, enc=0) -> bytes:
+        return self.serialize(False, enc)
+
+    @staticmethod
+    def deserialize(data: bytes, compress: bool = True, enc=0, validate: bool = True) -> "Proof":
+        from . import wire
+
+        return wire.deserialize(wire.PSNARK_PROOF, data, compress, enc, validate)
+
+    def __eq__(self, other) -> bool:
+        """derive(PartialEq, Eq)"""
+        from . import wire
+
+        return isinstance(other, Proof) and wire.equal(wire.PSNARK_PROOF, self, other)
+
+    __hash__ = None
 
     def compressed_size(self) -> int:
         return len(self.serialize_compressed())

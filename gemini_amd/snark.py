@@ -86,63 +86,33 @@ class Proof:
         return proof
 
 
-# ---- CanonicalSerialize (compressed) of the proof: the byte string `examples/snark.rs:96` sizes ----------
-_Q = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
-_QRINV = pow(1 << 384, -1, _Q)
+# ---- CanonicalSerialize of the proof (src/snark/mod.rs:75-82): gemini_amd/wire.py holds the formats ------------
+def _proof_serialize(self, compress: bool = True, enc=0) -> bytes:
+    from . import wire
+
+    return wire.serialize(wire.SNARK_PROOF, self, compress, enc)
 
 
-def _fr_bytes(x) -> bytes:
-    return fr_to_int(x).to_bytes(32, "little")
+def _proof_deserialize(data: bytes, compress: bool = True, enc=0, validate: bool = True) -> "Proof":
+    from . import wire
+
+    return wire.deserialize(wire.SNARK_PROOF, data, compress, enc, validate)
 
 
-def _g1_compressed(jac) -> bytes:
-    """ark-serialize compressed short-Weierstrass point: x (48 B LE) with flags in the top bits of the last
-    byte (bit 7: y is the larger root, bit 6: infinity).  `jac` is a normalised Jacobian result."""
-    j = np.asarray(jac, dtype=np.uint64).reshape(3, 6)
-    if not j[2].any():
-        out = bytearray(48)
-        out[47] |= 1 << 6
-        return bytes(out)
-    x = sum(int(v) << (64 * i) for i, v in enumerate(j[0])) * _QRINV % _Q
-    y = sum(int(v) << (64 * i) for i, v in enumerate(j[1])) * _QRINV % _Q
-    out = bytearray(x.to_bytes(48, "little"))
-    if y > (_Q - y) % _Q:
-        out[47] |= 1 << 7
-    return bytes(out)
+def _proof_eq(self, other) -> bool:
+    """derive(PartialEq, Eq)"""
+    from . import wire
+
+    return isinstance(other, Proof) and wire.equal(wire.SNARK_PROOF, self, other)
 
 
-def serialize_compressed(proof: "Proof") -> bytes:
-    """derive(CanonicalSerialize) order of src/snark/mod.rs:76-82, sumcheck/prover.rs:9-14,
-    tensorcheck/mod.rs:110-121, kzg/mod.rs:107-112; Vec = u64 length + items, arrays = items."""
-    u64 = lambda n: int(n).to_bytes(8, "little")
-    out = bytearray()
-    out += _g1_compressed(proof.witness_commitment)
-    out += _fr_bytes(proof.zc_alpha)
-    for msgs, finals in (proof.first_sumcheck_msgs, proof.second_sumcheck_msgs):  # ProverMsgs(Vec<RoundMsg>, Vec<[F; 2]>)
-        out += u64(len(msgs))
-        for a, b in msgs:
-            out += _fr_bytes(a) + _fr_bytes(b)
-        out += u64(len(finals))
-        for f0, g0 in finals:
-            out += _fr_bytes(f0) + _fr_bytes(g0)
-    tc = proof.tensorcheck_proof
-    out += u64(len(tc.folded_polynomials_commitments))
-    for c in tc.folded_polynomials_commitments:
-        out += _g1_compressed(c)
-    out += u64(len(tc.folded_polynomials_evaluations))
-    for e2 in tc.folded_polynomials_evaluations:
-        for e in e2:
-            out += _fr_bytes(e)
-    out += _g1_compressed(tc.evaluation_proof)
-    out += u64(len(tc.base_polynomials_evaluations))
-    for e3 in tc.base_polynomials_evaluations:
-        for e in e3:
-            out += _fr_bytes(e)
-    return bytes(out)
-
-
-Proof.serialize_compressed = serialize_compressed
-Proof.compressed_size = lambda self: len(serialize_compressed(self))
+Proof.serialize = _proof_serialize
+Proof.serialize_compressed = lambda self, enc=0: _proof_serialize(self, True, enc)      # `proof-size` of examples/snark.rs:96
+Proof.serialize_uncompressed = lambda self, enc=0: _proof_serialize(self, False, enc)
+Proof.deserialize = staticmethod(_proof_deserialize)
+Proof.compressed_size = lambda self: len(_proof_serialize(self, True))
+Proof.__eq__ = _proof_eq
+Proof.__hash__ = None
 
 
 def _evaluate_be(stream: FrVec, xs) -> np.ndarray:

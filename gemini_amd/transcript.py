@@ -41,6 +41,10 @@ class Transcript:
         j = capi.u64(jac).reshape(-1, 18)
         capi.check(capi.load().gm_transcript_append_g1(C.c_uint64(self.handle), _b(label), C.c_size_t(len(label)), capi.ptr(j), C.c_size_t(len(j)), C.c_int(int(with_len))))
 
+    def set_g1_encoding(self, encoding: int):
+        """0: ark-ec default framing (ark-test-curves); 1: zcash framing (ark-bls12-381).  See gemini_amd/wire.py."""
+        capi.check(capi.load().gm_transcript_set_g1_encoding(C.c_uint64(self.handle), C.c_int(int(encoding))))
+
     def get_challenge(self, label: bytes) -> np.ndarray:
         out = np.empty(4, dtype=np.uint64)
         capi.check(capi.load().gm_transcript_challenge_fr(C.c_uint64(self.handle), _b(label), C.c_size_t(len(label)), capi.ptr(out)))

@@ -1,0 +1,410 @@
+"""ark-serialize wire formats of the prover's outputs: `CanonicalSerialize` (and the matching deserialisation)
+for Commitment / EvaluationProof (src/kzg/mod.rs:107-112), RoundMsg / ProverMsgs
+(src/subprotocols/sumcheck/prover.rs:9-14), TensorcheckProof (src/subprotocols/tensorcheck/mod.rs:110-121),
+entryproduct::ProverMsgs (src/subprotocols/entryproduct/mod.rs:48-52), snark::Proof (src/snark/mod.rs:75-82) and
+psnark::Proof (src/psnark/mod.rs:29-51), in both `Compress::Yes` and `Compress::No` modes.
+
+Framing (ark-serialize 0.4 derive): a struct is its fields in declaration order, `[T; N]` its N items, `Vec<T>` a
+u64 little-endian length followed by the items, a prime-field element its canonical value little-endian.  A G1 point
+(Commitment / EvaluationProof wrap `E::G1`, serialised through its affine form) has two encodings, chosen by the
+CURVE CRATE the maintainer builds against:
+
+  G1Encoding.ARKWORKS   ark-ec's default short-Weierstrass framing, used by ark-test-curves' bls12_381 (what the
+                        reference's examples and tests link, examples/snark.rs:11-13): x little-endian (48 B) with
+                        SWFlags in the two top bits of the LAST byte (bit 7: y is the larger of {y, -y}, bit 6:
+                        infinity); uncompressed appends y little-endian and puts the flags on y's last byte.
+  G1Encoding.ZCASH      ark-bls12-381's override (the crate of the reference's benches): big-endian coordinates,
+                        flags in the three top bits of the FIRST byte (bit 7: compressed, bit 6: infinity, bit 5:
+                        y is the larger root -- compressed only).
+
+The library side of the same switch is gm_transcript_set_g1_encoding (what `append_serializable` absorbs).
+
+Points are the library's result images (18 x u64: normalised Jacobian, Montgomery; identity = (R, R, 0)), scalars 4 x
+u64 Montgomery -- `deserialize(serialize(p))` gives back equal arrays.  This is I/O of O(log n)-sized proofs: plain
+Python integers, no device work.
+"""
+from __future__ import annotations
+
+import enum
+
+import numpy as np
+
+from .fr import R_MOD, fr_from_int, fr_to_int
+
+Q_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_QR = (1 << 384) % Q_MOD
+_QRINV = pow(1 << 384, -1, Q_MOD)
+
+
+class G1Encoding(enum.IntEnum):
+    ARKWORKS = 0
+    ZCASH = 1
+
+
+class WireError(ValueError):
+    """ark_serialize::SerializationError::{InvalidData, UnexpectedFlags, NotEnoughSpace}"""
+
+
+# ---- field / group elements <-> integers ---------------------------------------------------------------
+def _limbs_to_int(l) -> int:
+    return sum(int(v) << (64 * i) for i, v in enumerate(l))
+
+
+def _int_to_limbs(v: int, n: int) -> np.ndarray:
+    return np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(n)], dtype=np.uint64)
+
+
+def g1_to_affine_ints(jac):
+    """normalised Jacobian image -> (x, y) canonical integers, None for the identity"""
+    j = np.asarray(jac, dtype=np.uint64).reshape(3, 6)
+    if not j[2].any():
+        return None
+    assert _limbs_to_int(j[2]) == _QR, "wire: the point is not normalised (Z != 1)"
+    return _limbs_to_int(j[0]) * _QRINV % Q_MOD, _limbs_to_int(j[1]) * _QRINV % Q_MOD
+
+
+def g1_from_affine_ints(p) -> np.ndarray:
+    if p is None:
+        return np.concatenate([_int_to_limbs(_QR, 6), _int_to_limbs(_QR, 6), np.zeros(6, dtype=np.uint64)])
+    x, y = p
+    return np.concatenate([_int_to_limbs(x * _QR % Q_MOD, 6), _int_to_limbs(y * _QR % Q_MOD, 6), _int_to_limbs(_QR, 6)])
+
+
+def _y_is_larger(y: int) -> bool:
+    return y > (Q_MOD - y) % Q_MOD
+
+
+def _jac_dbl(P):
+    X, Y, Z = P
+    if Z == 0 or Y == 0:
+        return (1, 1, 0)
+    A, B = X * X % Q_MOD, Y * Y % Q_MOD
+    C = B * B % Q_MOD
+    D = 2 * ((X + B) * (X + B) - A - C) % Q_MOD
+    E = 3 * A % Q_MOD
+    X3 = (E * E - 2 * D) % Q_MOD
+    return X3, (E * (D - X3) - 8 * C) % Q_MOD, 2 * Y * Z % Q_MOD
+
+
+def _jac_add_affine(P, q):
+    X1, Y1, Z1 = P
+    if Z1 == 0:
+        return (q[0], q[1], 1)
+    Z1Z1 = Z1 * Z1 % Q_MOD
+    U2, S2 = q[0] * Z1Z1 % Q_MOD, q[1] * Z1 * Z1Z1 % Q_MOD
+    H, r = (U2 - X1) % Q_MOD, (S2 - Y1) % Q_MOD
+    if H == 0:
+        return _jac_dbl(P) if r == 0 else (1, 1, 0)
+    HH = H * H % Q_MOD
+    HHH, V = H * HH % Q_MOD, X1 * HH % Q_MOD
+    X3 = (r * r - HHH - 2 * V) % Q_MOD
+    return X3, (r * (V - X3) - Y1 * HHH) % Q_MOD, Z1 * H % Q_MOD
+
+
+def _in_prime_order_subgroup(p) -> bool:
+    """r * P == O (what ark-ec's Validate::Yes checks after the curve equation)"""
+    acc = (1, 1, 0)
+    for bit in bin(R_MOD)[2:]:
+        acc = _jac_dbl(acc)
+        if bit == "1":
+            acc = _jac_add_affine(acc, p)
+    return acc[2] == 0
+
+
+def _check_point(x: int, y: int, validate: bool):
+    if x >= Q_MOD or y >= Q_MOD:
+        raise WireError("G1 coordinate is not a canonical field element")
+    if validate:
+        if (y * y - x * x * x - 4) % Q_MOD:
+            raise WireError("G1 point is not on the curve")
+        if not _in_prime_order_subgroup((x, y)):
+            raise WireError("G1 point is not in the prime-order subgroup")
+
+
+def _sqrt_q(a: int):
+    """q = 3 mod 4"""
+    s = pow(a, (Q_MOD + 1) // 4, Q_MOD)
+    return s if s * s % Q_MOD == a % Q_MOD else None
+
+
+# ---- primitive codecs -----------------------------------------------------------------------------------
+def fr_serialize(x) -> bytes:
+    return fr_to_int(x).to_bytes(32, "little")
+
+
+def fr_deserialize(buf: bytes, pos: int):
+    if pos + 32 > len(buf):
+        raise WireError("not enough bytes for a scalar")
+    v = int.from_bytes(buf[pos: pos + 32], "little")
+    if v >= R_MOD:
+        raise WireError("scalar is not a canonical field element")
+    return fr_from_int(v), pos + 32
+
+
+def g1_size(compress: bool) -> int:
+    return 48 if compress else 96
+
+
+def g1_serialize(jac, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS) -> bytes:
+    p = g1_to_affine_ints(jac)
+    n = g1_size(compress)
+    if enc == G1Encoding.ARKWORKS:
+        out = bytearray(n)
+        if p is None:
+            out[n - 1] |= 1 << 6
+            return bytes(out)
+        x, y = p
+        out[:48] = x.to_bytes(48, "little")
+        if not compress:
+            out[48:] = y.to_bytes(48, "little")
+        if _y_is_larger(y):
+            out[n - 1] |= 1 << 7
+        return bytes(out)
+    out = bytearray(n)
+    if p is not None:
+        x, y = p
+        out[:48] = x.to_bytes(48, "big")
+        if not compress:
+            out[48:] = y.to_bytes(48, "big")
+        elif _y_is_larger(y):
+            out[0] |= 1 << 5
+    else:
+        out[0] |= 1 << 6
+    if compress:
+        out[0] |= 1 << 7
+    return bytes(out)
+
+
+def g1_deserialize(buf: bytes, pos: int, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS, validate: bool = True):
+    n = g1_size(compress)
+    if pos + n > len(buf):
+        raise WireError("not enough bytes for a G1 point")
+    raw = bytearray(buf[pos: pos + n])
+    if enc == G1Encoding.ARKWORKS:
+        flags = raw[n - 1] >> 6
+        raw[n - 1] &= 0x3F
+        if flags == 3:
+            raise WireError("G1 flags: infinity together with the y sign")
+        inf, larger = flags == 1, flags == 2
+        x = int.from_bytes(raw[:48], "little")
+        y = None if compress else int.from_bytes(raw[48:], "little")
+    else:
+        if bool(raw[0] >> 7) != compress:
+            raise WireError("G1 compression flag does not match the requested mode")
+        inf, larger = bool((raw[0] >> 6) & 1), bool((raw[0] >> 5) & 1)
+        if larger and (not compress or inf):
+            raise WireError("G1 flags: unexpected sort flag")
+        raw[0] &= 0x1F
+        x = int.from_bytes(raw[:48], "big")
+        y = None if compress else int.from_bytes(raw[48:], "big")
+    if inf:
+        if x or y:
+            raise WireError("G1 point at infinity with non-zero coordinates")
+        return g1_from_affine_ints(None), pos + n
+    if compress:
+        if x >= Q_MOD:
+            raise WireError("G1 coordinate is not a canonical field element")
+        y = _sqrt_q((x * x * x + 4) % Q_MOD)
+        if y is None:
+            raise WireError("G1 x coordinate is not on the curve")
+        if _y_is_larger(y) != larger:
+            y = (Q_MOD - y) % Q_MOD
+    elif enc == G1Encoding.ARKWORKS and validate and _y_is_larger(y) != larger:
+        raise WireError("G1 y-sign flag does not match y")
+    _check_point(x, y, validate)
+    return g1_from_affine_ints((x, y)), pos + n
+
+
+# ---- schema ---------------------------------------------------------------------------------------------
+class _T:
+    pass
+
+
+class _Fr(_T):
+    def ser(self, v, out, c, e):
+        out += fr_serialize(v)
+
+    def de(self, buf, pos, c, e, val):
+        return fr_deserialize(buf, pos)
+
+    def eq(self, a, b):
+        return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+class _G1(_T):
+    def ser(self, v, out, c, e):
+        out += g1_serialize(v, c, e)
+
+    def de(self, buf, pos, c, e, val):
+        return g1_deserialize(buf, pos, c, e, val)
+
+    def eq(self, a, b):
+        return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+class _Arr(_T):
+    """[T; N]: the items; scalars come back as one (N, 4) array like evaluate_le returns them"""
+
+    def __init__(self, t, n):
+        self.t, self.n = t, n
+
+    def ser(self, v, out, c, e):
+        assert len(v) == self.n, f"array of {len(v)} items where the type has {self.n}"
+        for x in v:
+            self.t.ser(x, out, c, e)
+
+    def de(self, buf, pos, c, e, val):
+        items = []
+        for _ in range(self.n):
+            x, pos = self.t.de(buf, pos, c, e, val)
+            items.append(x)
+        return (np.stack(items) if isinstance(self.t, _Fr) else items), pos
+
+    def eq(self, a, b):
+        return len(a) == len(b) and all(self.t.eq(x, y) for x, y in zip(a, b))
+
+
+class _Vec(_T):
+    def __init__(self, t):
+        self.t = t
+
+    def ser(self, v, out, c, e):
+        out += len(v).to_bytes(8, "little")
+        for x in v:
+            self.t.ser(x, out, c, e)
+
+    def de(self, buf, pos, c, e, val):
+        if pos + 8 > len(buf):
+            raise WireError("not enough bytes for a vector length")
+        n = int.from_bytes(buf[pos: pos + 8], "little")
+        pos += 8
+        if n > len(buf):  # every item takes at least one byte
+            raise WireError("vector length exceeds the input")
+        items = []
+        for _ in range(n):
+            x, pos = self.t.de(buf, pos, c, e, val)
+            items.append(x)
+        return items, pos
+
+    def eq(self, a, b):
+        return len(a) == len(b) and all(self.t.eq(x, y) for x, y in zip(a, b))
+
+
+class _Tuple(_T):
+    """tuple struct"""
+
+    def __init__(self, *ts):
+        self.ts = ts
+
+    def ser(self, v, out, c, e):
+        assert len(v) == len(self.ts)
+        for t, x in zip(self.ts, v):
+            t.ser(x, out, c, e)
+
+    def de(self, buf, pos, c, e, val):
+        items = []
+        for t in self.ts:
+            x, pos = t.de(buf, pos, c, e, val)
+            items.append(x)
+        return tuple(items), pos
+
+    def eq(self, a, b):
+        return len(a) == len(b) and all(t.eq(x, y) for t, x, y in zip(self.ts, a, b))
+
+
+class _Obj(_T):
+    """struct with named fields, mirrored by a Python class with the same attribute names"""
+
+    def __init__(self, cls_path, fields):
+        self.cls_path, self.fields = cls_path, fields
+
+    def _cls(self):
+        import importlib
+
+        mod, name = self.cls_path.rsplit(".", 1)
+        return getattr(importlib.import_module(mod), name)
+
+    def ser(self, v, out, c, e):
+        for name, t in self.fields:
+            t.ser(getattr(v, name), out, c, e)
+
+    def de(self, buf, pos, c, e, val):
+        cls = self._cls()
+        obj = cls.__new__(cls)
+        for name, t in self.fields:
+            x, pos = t.de(buf, pos, c, e, val)
+            setattr(obj, name, x)
+        if hasattr(cls, "spans") or "Proof" in cls.__name__:
+            obj.spans = {}
+        return obj, pos
+
+    def eq(self, a, b):
+        return all(t.eq(getattr(a, name), getattr(b, name)) for name, t in self.fields)
+
+
+FR, G1 = _Fr(), _G1()
+COMMITMENT = G1            # src/kzg/mod.rs:107-108
+EVALUATION_PROOF = G1      # src/kzg/mod.rs:111-112
+ROUND_MSG = _Tuple(FR, FR)                                  # sumcheck/prover.rs:9-10
+PROVER_MSGS = _Tuple(_Vec(ROUND_MSG), _Vec(_Arr(FR, 2)))    # sumcheck/prover.rs:13-14
+TENSORCHECK_PROOF = _Obj("gemini_amd.tensorcheck.TensorcheckProof", [   # tensorcheck/mod.rs:110-121
+    ("folded_polynomials_commitments", _Vec(COMMITMENT)),
+    ("folded_polynomials_evaluations", _Vec(_Arr(FR, 2))),
+    ("evaluation_proof", EVALUATION_PROOF),
+    ("base_polynomials_evaluations", _Vec(_Arr(FR, 3))),
+])
+ENTRYPRODUCT_MSGS = _Obj("gemini_amd.psnark.EntryProductMsgs", [        # entryproduct/mod.rs:48-52
+    ("acc_v_commitments", _Vec(COMMITMENT)),
+    ("claimed_sumchecks", _Vec(FR)),
+])
+SNARK_PROOF = _Obj("gemini_amd.snark.Proof", [                          # snark/mod.rs:75-82
+    ("witness_commitment", COMMITMENT),
+    ("zc_alpha", FR),
+    ("first_sumcheck_msgs", PROVER_MSGS),
+    ("second_sumcheck_msgs", PROVER_MSGS),
+    ("tensorcheck_proof", TENSORCHECK_PROOF),
+])
+PSNARK_PROOF = _Obj("gemini_amd.psnark.Proof", [                        # psnark/mod.rs:29-51
+    ("witness_commitment", COMMITMENT),
+    ("zc_alpha", FR),
+    ("first_sumcheck_msgs", PROVER_MSGS),
+    ("r_star_commitments", _Arr(COMMITMENT, 3)),
+    ("z_star_commitment", COMMITMENT),
+    ("second_sumcheck_msgs", PROVER_MSGS),
+    ("set_r_ep", FR),
+    ("subset_r_ep", FR),
+    ("sorted_r_commitment", COMMITMENT),
+    ("set_alpha_ep", FR),
+    ("subset_alpha_ep", FR),
+    ("sorted_alpha_commitment", COMMITMENT),
+    ("set_z_ep", FR),
+    ("subset_z_ep", FR),
+    ("sorted_z_commitment", COMMITMENT),
+    ("ep_msgs", ENTRYPRODUCT_MSGS),
+    ("ralpha_star_acc_mu_evals", _Vec(FR)),
+    ("ralpha_star_acc_mu_proof", EVALUATION_PROOF),
+    ("rstars_vals", _Arr(FR, 2)),
+    ("third_sumcheck_msgs", PROVER_MSGS),
+    ("tensorcheck_proof", TENSORCHECK_PROOF),
+])
+
+
+def serialize(schema: _T, value, compress: bool = True, enc: G1Encoding = G1Encoding.ARKWORKS) -> bytes:
+    """CanonicalSerialize::serialize_with_mode(value, Compress::{Yes, No})"""
+    out = bytearray()
+    schema.ser(value, out, compress, G1Encoding(enc))
+    return bytes(out)
+
+
+def deserialize(schema: _T, data: bytes, compress: bool = True, enc: G1Encoding = G1Encoding.ARKWORKS, validate: bool = True):
+    """CanonicalDeserialize::deserialize_with_mode(data, Compress::{Yes, No}, Validate::{Yes, No}); the whole input
+    must be consumed"""
+    value, pos = schema.de(bytes(data), 0, compress, G1Encoding(enc), validate)
+    if pos != len(data):
+        raise WireError(f"{len(data) - pos} trailing bytes")
+    return value
+
+
+def equal(schema: _T, a, b) -> bool:
+    """derive(PartialEq) of the reference's proof types"""
+    return schema.eq(a, b)

@@ -285,6 +285,12 @@ int gm_transcript_challenge_bytes(uint64_t handle, const uint8_t* label, size_t 
  * u64 length like Vec<Commitment>). */
 int gm_transcript_append_fr(uint64_t handle, const uint8_t* label, size_t llen, const uint64_t* mont, size_t count);
 int gm_transcript_append_g1(uint64_t handle, const uint8_t* label, size_t llen, const uint64_t* jac, size_t count, int with_len);
+/* The ark-serialize framing gm_transcript_append_g1 uses, fixed by the curve crate of the build: 0 (default) =
+ * ark-ec's short-Weierstrass default as in ark-test-curves' bls12_381 -- what the reference's examples and tests
+ * link (x || y little-endian, flags in the top bits of the last byte); 1 = the zcash framing that ark-bls12-381
+ * substitutes (big-endian, flags in the top bits of the first byte) -- what the reference's benches link.  A shim
+ * may instead pass pre-serialised bytes through gm_transcript_append_message. */
+int gm_transcript_set_g1_encoding(uint64_t handle, int encoding);
 /* GeminiTranscript::get_challenge::<Fr> (src/transcript.rs:26-34) */
 int gm_transcript_challenge_fr(uint64_t handle, const uint8_t* label, size_t llen, uint64_t out_mont[4]);
 /* Sumcheck::prove round loop (src/subprotocols/sumcheck/proof.rs:36-66) over a gm_sc_* prover.

@@ -143,6 +143,15 @@ def test_psnark_time_prover_random_r1cs(gm, oracle, pyref, n, seed):
     blob = proof.serialize_compressed()
     n_msgs = sum(len(getattr(proof, k)[0]) for k in ("first_sumcheck_msgs", "second_sumcheck_msgs", "third_sumcheck_msgs"))
     assert len(blob) == proof.compressed_size() and len(blob) > 48 * 10 + 64 * n_msgs
+    # byte equality with the oracle-side serialisation of the restatement's proof, every mode; round trip
+    from oracle import wire_ref as W
+
+    for compress in (True, False):
+        for enc, mode in ((0, "arkworks"), (1, "zcash")):
+            b2 = proof.serialize(compress, enc)
+            assert b2 == W.psnark_proof(exp, compress, mode)
+            assert Proof.deserialize(b2, compress, enc, validate=False) == proof
+    assert blob == W.psnark_proof(exp, True, "arkworks")
     r1cs.free()
 
 

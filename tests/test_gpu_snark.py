@@ -88,6 +88,15 @@ def test_snark_time_prover_dummy_r1cs(gm, oracle, pyref, logn):
     # 48 + 32 + 2*(8 + 64 logn + 8 + 64) + (8 + 48 (logn-1)) + (8 + 64 (logn-1)) + 48 + (8 + 96)  (= 6056 at logn 24)
     assert len(proof.first_sumcheck_msgs[0]) == logn and len(tc.folded_polynomials_commitments) == logn - 1
     assert proof.compressed_size() == 48 + 32 + 2 * (8 + 64 * logn + 8 + 64) + (8 + 48 * (logn - 1)) + (8 + 64 * (logn - 1)) + 48 + (8 + 96)
+    # wire formats: the bytes of the device proof equal the oracle-side serialisation of the restatement's proof in
+    # both ark-serialize modes and both G1 framings, and deserialise back to an equal proof
+    from oracle import wire_ref as W
+
+    for compress in (True, False):
+        for enc, mode in ((0, "arkworks"), (1, "zcash")):
+            blob = proof.serialize(compress, enc)
+            assert blob == W.snark_proof(exp, compress, mode)
+            assert Proof.deserialize(blob, compress, enc, validate=(logn == 3)) == proof
     r1cs.free()
 
 
