@@ -113,9 +113,21 @@ def _f2_gt(a, b) -> bool:
     return (a[1], a[0]) > (b[1], b[0])
 
 
-def serialize_uncompressed(p) -> bytes:
-    """ark-serialize short-Weierstrass affine over Fq2, Compress::No: x.c0 | x.c1 | y.c0 | y.c1 (48-byte
-    little-endian each), flags in the top bits of the last byte (bit 7: y > -y, bit 6: infinity)."""
+def serialize_uncompressed(p, enc: int | None = None) -> bytes:
+    """ark-serialize short-Weierstrass affine over Fq2, Compress::No.
+    enc 0 (ark-ec default, ark-test-curves): x.c0 | x.c1 | y.c0 | y.c1, 48-byte little-endian each, flags in the top
+    bits of the last byte (bit 7: y > -y, bit 6: infinity).
+    enc 1 (ark-bls12-381, zcash): x.c1 | x.c0 | y.c1 | y.c0 big-endian, flags in the top bits of the first byte
+    (bit 7 clear = uncompressed, bit 6: infinity).  Default: the process-wide curve crate (gemini_amd.transcript)."""
+    if enc is None:
+        from .transcript import default_group_encoding
+
+        enc = default_group_encoding()
+    if enc == 1:
+        if p is None:
+            return bytes([0x40]) + bytes(191)
+        x, y = p
+        return x[1].to_bytes(48, "big") + x[0].to_bytes(48, "big") + y[1].to_bytes(48, "big") + y[0].to_bytes(48, "big")
     if p is None:
         out = bytearray(192)
         out[-1] |= 1 << 6
@@ -127,6 +139,20 @@ def serialize_uncompressed(p) -> bytes:
     return bytes(out)
 
 
-def serialize_vec_uncompressed(points) -> bytes:
+def deserialize_uncompressed(b: bytes, enc: int = 0):
+    """inverse of serialize_uncompressed (no subgroup check: used on the reference's own outputs)"""
+    assert len(b) == 192
+    if enc == 1:
+        if b[0] & 0x40:
+            return None
+        v = [int.from_bytes(bytes([b[48 * i] & (0x1F if i == 0 else 0xFF)]) + b[48 * i + 1: 48 * i + 48], "big") for i in range(4)]
+        return ((v[1], v[0]), (v[3], v[2]))
+    if b[-1] & 0x40:
+        return None
+    v = [int.from_bytes(b[48 * i: 48 * i + 48], "little") for i in range(3)] + [int.from_bytes(b[144:191] + bytes([b[191] & 0x3F]), "little")]
+    return ((v[0], v[1]), (v[2], v[3]))
+
+
+def serialize_vec_uncompressed(points, enc: int | None = None) -> bytes:
     """Vec<G2Affine>: u64 length + items"""
-    return len(points).to_bytes(8, "little") + b"".join(serialize_uncompressed(p) for p in points)
+    return len(points).to_bytes(8, "little") + b"".join(serialize_uncompressed(p, enc) for p in points)

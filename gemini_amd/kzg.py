@@ -30,14 +30,16 @@ class CommitterKey:
         self.powers_of_g2 = powers_of_g2  # affine G2 points (gemini_amd.g2), only absorbed into transcripts
 
     @classmethod
-    def new(cls, max_degree: int, max_eval_points: int, tau_canonical: np.ndarray, g_affine: np.ndarray | None = None) -> "CommitterKey":
+    def new(cls, max_degree: int, max_eval_points: int, tau_canonical: np.ndarray, g_affine: np.ndarray | None = None, g2_affine=None) -> "CommitterKey":
         """src/kzg/time.rs:49-72 with the trapdoor passed in (the reference draws tau, g and g2 from rng;
-        ark_std::test_rng() is not reproducible without Rust): g, g2 = the standard generators."""
+        ark_std::test_rng() is not reproducible without Rust): g, g2 default to the standard generators, or are the
+        draws a reference run recorded (tools/refvectors)."""
         from . import g2 as G2
 
         g = g1_generator_mont() if g_affine is None else g_affine
         tau = sum(int(v) << (64 * i) for i, v in enumerate(np.asarray(tau_canonical, dtype=np.uint64).reshape(4)))
-        powers_of_g2 = [G2.mul(G2.generator(), pow(tau, i, R_MOD)) for i in range(max_eval_points + 1)]  # :60-67
+        g2 = G2.generator() if g2_affine is None else g2_affine
+        powers_of_g2 = [G2.mul(g2, pow(tau, i, R_MOD)) for i in range(max_eval_points + 1)]  # :60-67
         return cls(G1Bases.srs(g, tau_canonical, max_degree + 1), max_eval_points, powers_of_g2)
 
     def powers_of_g2_bytes(self) -> bytes:

@@ -10,6 +10,21 @@ from . import capi
 
 PROTOCOL_NAME = b"GEMINI-v0"  # src/lib.rs:74
 
+# The ark-serialize framing of group elements is a property of the CURVE CRATE the reference is built against
+# (gemini_amd/wire.py): 0 = ark-ec's default (ark-test-curves: the reference's examples and tests), 1 = the zcash
+# framing of ark-bls12-381 (the reference's benches).  Process-wide default for new transcripts and for the G2 powers
+# the preprocessing prover absorbs.
+_default_group_encoding = 0
+
+
+def set_curve_crate(name: str):
+    global _default_group_encoding
+    _default_group_encoding = {"ark-test-curves": 0, "ark-bls12-381": 1}[name]
+
+
+def default_group_encoding() -> int:
+    return _default_group_encoding
+
 
 def _b(x: bytes):
     return (C.c_uint8 * len(x)).from_buffer_copy(x) if x else None
@@ -20,6 +35,8 @@ class Transcript:
         h = C.c_uint64()
         capi.check(capi.load().gm_transcript_new(_b(label), C.c_size_t(len(label)), C.byref(h)))
         self.handle = h.value
+        if _default_group_encoding:
+            self.set_g1_encoding(_default_group_encoding)
 
     def append_message(self, label: bytes, message: bytes):
         capi.check(capi.load().gm_transcript_append_message(C.c_uint64(self.handle), _b(label), C.c_size_t(len(label)), _b(message), C.c_size_t(len(message))))

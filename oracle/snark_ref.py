@@ -17,10 +17,12 @@ from . import pyref as P
 R = P.R_MOD
 
 
-def srs(tau: int, n: int) -> np.ndarray:
-    """powers_of_g[i] = tau^i * g  (src/kzg/time.rs:51-59), g = the standard generator"""
+def srs(tau: int, n: int, g=None) -> np.ndarray:
+    """powers_of_g[i] = tau^i * g  (src/kzg/time.rs:51-59); g = the standard generator unless an affine integer
+    pair is given (the draw a reference run recorded, tools/refvectors)"""
     pw = orc.ints_to_limbs([pow(tau, i, R) for i in range(n)], 4)
-    return orc.g1_fixed_base_mul(orc.g1_generator(), pw)
+    base = orc.g1_generator() if g is None else np.concatenate([orc.fq_to_mont(orc.ints_to_limbs([g[0]], 6))[0], orc.fq_to_mont(orc.ints_to_limbs([g[1]], 6))[0]])
+    return orc.g1_fixed_base_mul(base, pw)
 
 
 def commit(powers_of_g: np.ndarray, poly) -> tuple | None:

@@ -45,6 +45,8 @@ def g1(p, compress: bool, mode: str = "arkworks") -> bytes:
 
 def prover_msgs(m) -> bytes:
     msgs, finals = m
+    if len(finals) == 2 and isinstance(finals[0], int):  # a single prover's (f0, g0): Vec<[F; 2]> of length one
+        finals = [finals]
     out = u64(len(msgs))
     for a, b in msgs:
         out += fr(a) + fr(b)
