@@ -176,6 +176,7 @@ int sp_fold(Context* C, SpaceProver* S, const uint64_t challenge[4]);
 int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
 int sp_final(Context* C, SpaceProver* S, uint64_t f0[4], uint64_t g0[4], int* has);
 int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle);
+int fr_stride_raw(Context* C, const uint8_t* in, size_t start, size_t stride, size_t count, uint8_t* out);
 int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out);
 int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out);
 int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out);
@@ -569,6 +570,19 @@ int gm_fr_reverse(uint64_t in, uint64_t out) {
   GM_VEC(vi, in, "fr_reverse");
   GM_VEC(vo, out, "fr_reverse");
   return fr_reverse(C, vi, vo);
+}
+int gm_fr_stride(uint64_t in, size_t start, size_t stride, size_t count, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vi, in, "fr_stride");
+  GM_VEC(vo, out, "fr_stride");
+  GM_CHECK(vi != vo, GM_EINVAL, "fr_stride: output must not alias the input");
+  GM_CHECK(stride >= 1 && (count == 0 || start + (count - 1) * stride < vi->len), GM_EINVAL,
+           "fr_stride: elements %zu + k * %zu, k < %zu, outside a vector of length %zu", start, stride, count, vi->len);
+  GM_CHECK(vo->cap >= count, GM_EINVAL, "fr_stride: output capacity %zu < %zu", vo->cap, count);
+  int rc = fr_stride_raw(C, vi->d, start, stride, count, vo->d);
+  if (rc) return rc;
+  vo->len = count;
+  return GM_OK;
 }
 int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out) {
   GM_CTX();

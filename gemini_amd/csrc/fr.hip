@@ -632,13 +632,19 @@ static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr
   A.log_threads = lt;
   const unsigned blocks = (unsigned)(((size_t)1 << lt) / 256);
   hipStream_t st = C->stream;
+  // stage timer of bench.py's sumcheck roofline: only when profiling is on, and then (one event pair) only
+  // with provers driven one at a time
+  Profiler& prof = C->prof;
+  prof.begin(PROF_SC_ROUND, st);
   if (fold && msg)
     hipLaunchKernelGGL((k_sc_round<true, true>), dim3(blocks), dim3(256), 0, st, A, S->partials);
   else if (fold)
     hipLaunchKernelGGL((k_sc_round<true, false>), dim3(blocks), dim3(256), 0, st, A, S->partials);
   else
     hipLaunchKernelGGL((k_sc_round<false, true>), dim3(blocks), dim3(256), 0, st, A, S->partials);
+  prof.end(PROF_SC_ROUND, st);
   GM_HIP(hipGetLastError());
+  if (prof.on && !msg) GM_HIP(hipStreamSynchronize(st));
   if (msg) {
     GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, st));
     GM_HIP(hipStreamSynchronize(st));
@@ -650,6 +656,7 @@ static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr
     a.to_limbs(a_out);
     b.to_limbs(b_out);
   }
+  prof.collect();
   if (fold) {
     S->cur ^= 1;
     S->nf = (S->nf + 1) / 2;

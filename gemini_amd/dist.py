@@ -137,41 +137,56 @@ class ShardedTimeProver:
         self.local.free()
 
 
+def cyclic_count(length: int, rank: int, world: int) -> int:
+    """how many of the indices 0 <= i < length satisfy i = rank (mod world)"""
+    return max(0, -(-(length - rank) // world))
+
+
 class ShardedCommitterKey:
-    """`CommitterKey` (src/kzg/time.rs:24-27) with powers_of_g[lo, hi) resident on this rank: the
-    "independent MSM chunks shard across the GPUs, final reduce of partial G1 points" of the north star.
-    Polynomials are replicated (every rank runs the same field arithmetic); each commitment is one local
-    MSM over the rank's slice + one 144-byte all-gather + EC add, so `Proof.new_time(r1cs, key)` runs
-    unchanged on N GPUs.
+    """`CommitterKey` (src/kzg/time.rs:24-27) sharded over the GPUs ELEMENT-CYCLICALLY: power i of the key lives on
+    rank i mod world (local index i // world) -- the "independent MSM chunks shard across the GPUs, final reduce of
+    partial G1 points" of the north star.
 
-    local_msm(polynomial, a, b) -> (18,) Jacobian of sum_{a <= i < b} polynomial[i] * powers_of_g[i];
-    by default the HIP MSM over the resident slice (gemini_amd.msm.G1Bases)."""
+    Why cyclic and not contiguous blocks: every polynomial the prover commits to is a PREFIX of the key, and the
+    tensor check commits to foldings of length n/2, n/4, ..., 1 (src/subprotocols/tensorcheck/mod.rs:124-133,
+    190-275) against a key of 2n + 1 powers (examples/snark.rs:75).  With contiguous blocks the upper half of the
+    ranks holds powers no commitment ever touches and every folding below n/4 lands on rank 0 alone; with the cyclic
+    layout every rank gets length/world pairs (+-1) of EVERY commitment, whatever its length
+    (tests/test_multi_gpu_gloo.py::test_cyclic_key_balance).
 
-    def __init__(self, local_powers, lo: int, n_global: int, max_eval_points: int, local_msm=None, powers_of_g2=None):
+    Polynomials are replicated (every rank runs the same field arithmetic); a commitment is a strided gather of the
+    rank's scalars (gm_fr_stride), one local MSM against the resident powers, one 144-byte all-gather and the EC adds,
+    so `Proof.new_time(r1cs, key)` runs unchanged on N GPUs.
+
+    local_msm(polynomial, m) -> (18,) Jacobian of sum over {i < m, i = rank mod world} of polynomial[i] *
+    powers_of_g[i]; by default the HIP path over the resident share (gemini_amd.msm.G1Bases)."""
+
+    def __init__(self, local_powers, rank: int, world: int, n_global: int, max_eval_points: int, local_msm=None, powers_of_g2=None):
         self.powers_of_g = local_powers
-        self.lo, self.hi = lo, lo + len(local_powers)
+        self.rank, self.world = rank, world
         self.n_global = n_global
+        assert len(local_powers) == cyclic_count(n_global, rank, world)
         self._max_eval_points = max_eval_points
         self._local_msm = local_msm or self._hip_msm
         self.powers_of_g2 = powers_of_g2  # replicated: max_eval_points + 1 G2 points
 
     @classmethod
     def new(cls, max_degree: int, max_eval_points: int, tau_canonical, rank: int, world: int, g_affine=None) -> "ShardedCommitterKey":
-        """src/kzg/time.rs:49-72, each rank generating only its slice: base tau^lo * g, ratio tau"""
+        """src/kzg/time.rs:49-72, each rank generating only its share: base tau^rank * g, ratio tau^world"""
         from .kzg import g1_generator_mont
         from .msm import G1Bases
 
         n = max_degree + 1
-        lo, hi = shard_range(n, rank, world)
         g = g1_generator_mont() if g_affine is None else g_affine
         tau = _to_int(np.asarray(tau_canonical, dtype=np.uint64))
-        first = G1Bases.fixed_base(g, np.array([_to_limbs(pow(tau, lo, R_MOD))], dtype=np.uint64))
+        first = G1Bases.fixed_base(g, np.array([_to_limbs(pow(tau, rank, R_MOD))], dtype=np.uint64))
         base = first.download()[0]
         first.free()
         from . import g2 as G2
 
         powers_of_g2 = [G2.mul(G2.generator(), pow(tau, i, R_MOD)) for i in range(max_eval_points + 1)]
-        return cls(G1Bases.srs(base, tau_canonical, hi - lo), lo, n, max_eval_points, powers_of_g2=powers_of_g2)
+        ratio = np.array(_to_limbs(pow(tau, world, R_MOD)), dtype=np.uint64)
+        return cls(G1Bases.srs(base, ratio, cyclic_count(n, rank, world)), rank, world, n, max_eval_points, powers_of_g2=powers_of_g2)
 
     def max_eval_points(self) -> int:
         return self._max_eval_points
@@ -179,28 +194,38 @@ class ShardedCommitterKey:
     def num_powers(self) -> int:
         return self.n_global
 
+    def global_indices(self) -> np.ndarray:
+        """the powers this rank holds, in local order"""
+        return np.arange(self.rank, self.n_global, self.world)
+
     def powers_of_g2_bytes(self) -> bytes:
         from .kzg import CommitterKey
 
         return CommitterKey.powers_of_g2_bytes(self)
 
-    def _hip_msm(self, polynomial, a: int, b: int) -> np.ndarray:
-        from .fr import _as_vec
+    def _hip_msm(self, polynomial, m: int) -> np.ndarray:
+        from .fr import _as_vec, stride
         from .msm import g1_zero
 
-        if b <= a:
+        cnt = cyclic_count(m, self.rank, self.world)
+        if cnt == 0:
             return g1_zero()
         v, tmp = _as_vec(polynomial)
         try:
-            return self.powers_of_g.msm_vec(v, n=b - a, voffset=a, offset=a - self.lo)
+            if self.world == 1:
+                return self.powers_of_g.msm_vec(v, n=cnt)
+            mine = stride(v, self.rank, self.world, cnt)
+            try:
+                return self.powers_of_g.msm_vec(mine, n=cnt)
+            finally:
+                mine.free()
         finally:
             if tmp:
                 v.free()
 
     def partial(self, polynomial) -> np.ndarray:
         """this rank's share of commit(polynomial)"""
-        n = min(len(polynomial), self.n_global)
-        return self._local_msm(polynomial, min(self.lo, n), min(self.hi, n))
+        return self._local_msm(polynomial, min(len(polynomial), self.n_global))
 
     def commit(self, polynomial) -> np.ndarray:
         return g1_sum(all_gather_u64(self.partial(polynomial)))
@@ -233,33 +258,44 @@ def _stream_key_base():
 
 
 class ShardedCommitterKeyStream(_stream_key_base()):
-    """`CommitterKeyStream` (src/kzg/space.rs:59-69) with powers_of_g[lo, hi) (time order) resident on this
-    rank -- "MSM chunks sharded across the GPUs" for the elastic prover (BASELINE config 4).  Every stream MSM
-    (commit, open, open_multi_points, commit_folding, open_folding all funnel into `_msm_stream`) is the local
-    part over the rank's powers + one all-gather of 144-byte partials + EC add; the streams are replicated."""
+    """`CommitterKeyStream` (src/kzg/space.rs:59-69) over the same element-cyclic shares -- "MSM chunks sharded across
+    the GPUs" for the elastic prover (BASELINE config 4).  Every stream MSM (commit, open, open_multi_points,
+    commit_folding, open_folding all funnel into `_msm_stream`) is: the stream positions whose power this rank
+    holds (a stride-`world` subsequence), one local MSM walking the resident share backwards, one all-gather of
+    144-byte partials, the EC adds.  The streams are replicated."""
 
-    def __init__(self, local_powers, lo: int, n_global: int, max_eval_points: int, powers_of_g2=None):
-        super().__init__(local_powers, max_eval_points, powers_of_g2)
-        self.lo, self.hi, self.n_global = lo, lo + len(local_powers), n_global
+    def __init__(self, local_powers, rank: int, world: int, n_global: int, max_eval_points: int, powers_of_g2=None, min_device_chunk=None):
+        super().__init__(local_powers, max_eval_points, powers_of_g2, min_device_chunk=min_device_chunk)
+        self.rank, self.world, self.n_global = rank, world, n_global
 
     @classmethod
-    def from_sharded_key(cls, key: "ShardedCommitterKey") -> "ShardedCommitterKeyStream":
-        return cls(key.powers_of_g, key.lo, key.n_global, key.max_eval_points(), getattr(key, "powers_of_g2", None))
+    def from_sharded_key(cls, key: "ShardedCommitterKey", min_device_chunk=None) -> "ShardedCommitterKeyStream":
+        return cls(key.powers_of_g, key.rank, key.world, key.n_global, key.max_eval_points(), getattr(key, "powers_of_g2", None), min_device_chunk)
 
     def _n(self) -> int:
         return self.n_global
 
     def _msm_stream(self, scalars_stream, first_stream_pos: int, chunk: int) -> np.ndarray:
+        from .fr import stride
         from .msm import g1_zero
 
-        n, total = self.n_global, len(scalars_stream)
-        chunk = max(chunk, self.min_device_chunk)
-        # stream position p <-> power n - 1 - p; this rank holds powers [lo, hi)
-        k_lo = max(0, n - first_stream_pos - self.hi)
-        k_hi = min(total, n - first_stream_pos - self.lo)
+        n, total, w = self.n_global, len(scalars_stream), self.world
+        # stream position p pairs with power i = n - 1 - (first_stream_pos + p); this rank holds i = rank (mod w):
+        # positions p0, p0 + w, ... with local base indices j0, j0 - 1, ...
+        top = n - 1 - first_stream_pos
+        p0 = (top - self.rank) % w
+        cnt = cyclic_count(total, p0, w)
         part = g1_zero()
-        for off in range(k_lo, max(k_lo, k_hi), chunk):
-            m = min(chunk, k_hi - off)
-            p = self.powers_of_g.msm_vec(scalars_stream, n=m, voffset=off, offset=n - 1 - (first_stream_pos + off) - self.lo, reversed_=True)
-            part = g1_sum(np.stack([part, p]))
+        if cnt:
+            j0 = (top - p0 - self.rank) // w
+            mine = scalars_stream if w == 1 else stride(scalars_stream, p0, w, cnt)
+            try:
+                step = max(1, max(chunk, self.min_device_chunk) // w)  # the caller's flush size, in this rank's pairs
+                for off in range(0, cnt, step):
+                    m = min(step, cnt - off)
+                    p = self.powers_of_g.msm_vec(mine, n=m, voffset=off, offset=j0 - off, reversed_=True)
+                    part = g1_sum(np.stack([part, p]))
+            finally:
+                if w != 1:
+                    mine.free()
         return g1_sum(all_gather_u64(part))

@@ -113,6 +113,18 @@ def reverse(v) -> FrVec:
     return out
 
 
+def stride(v, start: int, step: int, count: int) -> FrVec:
+    """out[k] = v[start + k * step], k < count"""
+    vv, tmp = _as_vec(v)
+    out = FrVec.alloc(count)
+    try:
+        capi.check(capi.load().gm_fr_stride(C.c_uint64(vv.handle), C.c_size_t(start), C.c_size_t(step), C.c_size_t(count), C.c_uint64(out.handle)))
+    finally:
+        if tmp:
+            vv.free()
+    return out
+
+
 def fold_polynomial(f, r_mont) -> FrVec:
     """src/misc.rs:52-56"""
     fv, tmp = _as_vec(f)

@@ -163,6 +163,9 @@ int gm_fr_vec_set_len(uint64_t handle, size_t n);
 /* ---- field vector helpers (src/misc.rs) ------------------------------------------------------ */
 /* out[i] = in[n-1-i]: big-endian stream <-> little-endian vector        src/iterable/slice.rs:17-39 */
 int gm_fr_reverse(uint64_t in, uint64_t out);
+/* out[k] = in[start + k * stride], k < count: the scalars a rank multiplies against its share of a key sharded
+ * element-cyclically over the GPUs (power i lives on rank i mod g; gemini_amd/dist.py), herring's even / odd halves. */
+int gm_fr_stride(uint64_t in, size_t start, size_t stride, size_t count, uint64_t out);
 /* out = [f[2i] + r * f[2i+1]], len ceil(n/2)                       src/misc.rs:52-56 */
 int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out);
 /* out = [1, x, x^2, ...]                                          src/misc.rs:59-65 */

@@ -262,7 +262,8 @@ def test_snark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
 
 def test_sharded_committer_key_single_process(gm, oracle, pyref):
     """north star: the KZG key shards by powers across GPUs.  Here both shards live on the one GPU:
-    each rank-local slice is generated from (tau^lo g, tau) and equals the slice of the full key; the
+    each rank-local share (powers i = rank mod world) is generated from (tau^rank g, tau^world) and equals those powers
+    of the full key; the
     partial commitments add up (gm_g1_sum) to the full key's commitment; with a world of one
     (gloo, single rank) Proof.new_time over the sharded key gives the byte-identical proof."""
     import os
@@ -281,9 +282,9 @@ def test_sharded_committer_key_single_process(gm, oracle, pyref):
     ck = CommitterKey.new(2 * n, 5, tau_l)
     full = ck.powers_of_g.download()
     shards = [ShardedCommitterKey.new(2 * n, 5, tau_l, r, 3) for r in range(3)]
-    assert [s.lo for s in shards] == [0, 683, 1366] and shards[-1].hi == 2 * n + 1
-    for s in shards:
-        assert (s.powers_of_g.download() == full[s.lo:s.hi]).all()
+    assert [len(s.powers_of_g) for s in shards] == [683, 683, 683] and sum(len(s.powers_of_g) for s in shards) == 2 * n + 1
+    for s in shards:  # power i lives on rank i mod 3
+        assert (s.powers_of_g.download() == full[s.global_indices()]).all()
     for m in (2 * n + 1, 1500, 700, 5, 0):
         poly = oracle.fr_to_mont(oracle.random_fr(100 + m, m)) if m else np.empty((0, 4), dtype=np.uint64)
         want = ck.commit(poly)

@@ -105,20 +105,21 @@ def _worker(rank, world, port, q):
         fr_, fs_ = ref.final_foldings(), sp.final_foldings()
         ok_sc &= bool((fr_[0] == fs_[0]).all() and (fr_[1] == fs_[1]).all()) and sp.replicated
 
-        # ---- KZG key sharded by powers: commit / batch_commit = local MSM + all-gather + EC add
-        n_srs = 600
+        # ---- KZG key sharded element-cyclically: commit / batch_commit = strided local MSM + all-gather + EC add
+        n_srs = 601
         srs = orc.g1_fixed_base_mul(orc.g1_generator(), orc.ints_to_limbs([pow(7, i, P.R_MOD) for i in range(n_srs)], 4))
-        lo, hi = gd.shard_range(n_srs, rank, world)
+        mine = np.arange(rank, n_srs, world)
 
-        def local_msm(poly, a, b):
-            if b <= a:
+        def local_msm(poly, m):
+            idx = mine[mine < m]
+            if len(idx) == 0:
                 from gemini_amd.msm import g1_zero
 
                 return g1_zero()
-            return orc.msm_pippenger(srs[a:b], orc.fr_from_mont(poly[a:b]))
+            return orc.msm_pippenger(srs[idx], orc.fr_from_mont(np.asarray(poly)[idx]))
 
-        key = gd.ShardedCommitterKey(srs[lo:hi], lo, n_srs, 3, local_msm=local_msm)
-        polys = [orc.fr_to_mont(orc.random_fr(20 + k, m)) for k, m in enumerate((600, 250, 700, 1))]
+        key = gd.ShardedCommitterKey(srs[mine], rank, world, n_srs, 3, local_msm=local_msm)
+        polys = [orc.fr_to_mont(orc.random_fr(20 + k, m)) for k, m in enumerate((601, 250, 700, 1))]
         aff = lambda j: orc.affine_to_ints(orc.g1_to_affine(j))
         want = [aff(orc.msm_pippenger(srs[: min(len(p_), n_srs)], orc.fr_from_mont(p_[:n_srs]))) for p_ in polys]
         ok_msm &= [aff(c) for c in key.batch_commit(polys)] == want
@@ -145,3 +146,31 @@ def test_world2_gloo_msm_and_sumcheck(oracle):
         assert ok_msm, f"rank {rank}: sharded MSM differs from the one-shot MSM"
         assert ok_sc, f"rank {rank}: sharded sumcheck differs"
         assert k == 13
+
+
+def test_cyclic_key_balance():
+    """Load balance of the element-cyclic key (gemini_amd/dist.py::ShardedCommitterKey) for EVERY MSM of a
+    `snark -i 24` proof -- the witness (n - 1 scalars), the 23 foldings (n/2 ... 2), the batched quotient (n - 3) --
+    and of `-i 28` / `psnark -i 26` shapes, at 2, 4 and 8 GPUs: the ranks' pair counts differ by at most one, i.e.
+    max / min <= 1.1 wherever a rank holds at least ten pairs.  (The contiguous-block layout of round 1 left half of
+    the ranks idle: a 2n + 1-power key against polynomials of <= n coefficients, foldings < n/4 on rank 0 alone.)"""
+    from gemini_amd.dist import cyclic_count
+
+    for logn in (24, 26, 28):
+        n = 1 << logn
+        lengths = [n - 1, n, n - 3, 3 * n] + [n >> k for k in range(1, logn)]
+        for world in (2, 4, 8):
+            for L in lengths:
+                per = [cyclic_count(L, r, world) for r in range(world)]
+                assert sum(per) == L and max(per) - min(per) <= 1, (logn, world, L)
+                if min(per) >= 10:
+                    assert max(per) / min(per) <= 1.1
+    # stream view: position p pairs with power n - 1 - (first + p); every rank again gets its share of any window
+    n, world = 1000, 8
+    for first in (0, 1, 7, 123):
+        for total in (1, 8, 9, 500, n - first):
+            per = []
+            for r in range(world):
+                p0 = (n - 1 - first - r) % world
+                per.append(cyclic_count(total, p0, world))
+            assert sum(per) == total and max(per) - min(per) <= 1

@@ -187,3 +187,17 @@ def test_field_vector_helpers_vs_pyref(oracle, pyref):
     q, rem = oracle.poly_div_monic(M(f), M(z))
     qp, rp = pyref.poly_divmod(f, z)
     assert I(q) == qp and I(rem) == rp
+
+
+def test_c_backed_new_time_equals_the_python_restatement(oracle, pyref):
+    """oracle/snark_c.py (every O(n) pass a C call; the CPU baseline of bench.py's time_prover leg) against
+    oracle/snark_ref.py (Python integers) on dummy_r1cs: byte-identical proofs, hence identical challenges"""
+    from oracle import snark_c, snark_ref as sr, wire_ref as W
+
+    for logn in (3, 4, 7):
+        n = 1 << logn
+        e, tau = 777 + logn, 31337 * (logn + 1)
+        srs = sr.srs(tau, 2 * n + 1)
+        a = sr.snark_new_time(sr.dummy_r1cs(e, n), srs)
+        b = snark_c.new_time_dummy(e, n, srs)
+        assert W.snark_proof(a, True) == W.snark_proof(b, True) and W.snark_proof(a, False) == W.snark_proof(b, False)
