@@ -362,23 +362,20 @@ def main():
     stages = {k: (ms[i] / args.steps if cnt[i] else None) for i, k in enumerate(stage_names)}
     launches = {k: (cnt[i] / args.steps if cnt[i] else None) for i, k in enumerate(stage_names)}
 
-    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
-    # this same command; profiles/r1_pmc_msm20.json says how it was collected and corrected)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_msm20.json")) as fh:
-            if args.logn == LOG_N:
-                traffic = json.load(fh)["kernels"]["gm::k_acc0"]["hbm_bytes_corrected"]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    # HBM traffic of the dominant kernel: NOT measured in this run -- hardware counters need rocprofv3 --pmc passes
+    # of their own (tools/profile_round.sh); the figure of the committed passes of this library is quoted with its
+    # source (profiles/r2_pmc_msm20.json says how it was collected and corrected)
+    traffic, traffic_source = None, None
+    for tag in ("r2", "r1"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_msm20.json")) as fh:
+                if args.logn == LOG_N:
+                    traffic = json.load(fh)["kernels"]["gm::k_acc0"]["hbm_bytes_corrected"]
+                    traffic_source = f"profiles/{tag}_pmc_msm20.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --headline-only`; not re-measured in this run)"
+                    break
+        except (OSError, KeyError, ValueError):
+            continue
 
-    # second metric (every rank takes part when N > 1: the key is sharded)
-    tp = None
-    hb_for_cpu = bases.download() if (world == 1 and not args.no_cpu_baseline) else None
-    if args.snark_logn > 0:
-        bases.free()  # the prover's key (2^25 + 1 points) and its vectors want the memory
-        tp = snark_time_prover(gm, args.snark_logn, with_tables=not args.no_tables, world=world, rank=rank,
-                               cpu_logn=0 if args.no_cpu_baseline else args.cpu_snark_logn)
     if rank == 0:
         pairs = world * n * args.steps
         value = pairs / elapsed / 1e6
@@ -410,6 +407,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved * 1e9 / HBM_PEAK, 6) if achieved else None,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 # k_acc0 is launched `launches_per_step` times per step (one per window group, back to back on one
                 # stream); kernel_ms is their SUM, i.e. the time the kernel needs for the bytes of one whole MSM
                 "kernel_ms": round(acc0_ms, 4) if acc0_ms else None,
@@ -417,13 +415,15 @@ def main():
                 "kernel_ms_per_launch": round(acc0_ms / launches["acc0"], 4) if acc0_ms else None,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n / launches["acc0"] if acc0_ms else None,
                 "algorithmic_bytes_per_step": BYTES_PER_PAIR * n,
-                "note": "integer-ALU bound (~300 v_mad_u64_u32 per Fq product); HBM fraction reported as the contract asks",
-                # the truthful utilisation figure: Fq products per second of the kernel (10 per mixed
-                # addition, 16 windows) against the multiplier's instruction-issue bound -- 288 v_mad_u64_u32 + 288 v_addc_co_u32,
-                # both 4.5 cycles per wave (tools/ubench_isa.hip, profiles/r1_ubench_isa.txt), 1024 SIMDs x 64 lanes at 2.4 GHz
+                "note": "integer-ALU bound (338 v_mad_u64_u32 per Fq product, 260 per square, radix 2^30); HBM fraction reported as the contract asks",
+                # the truthful utilisation figure: Fq products per second of the kernel (8 products + 2
+                # squares per mixed addition, 16 windows) against the multiplier's instruction-issue bound -- product: 416
+                # half-rate (338 v_mad_u64_u32 + shifts / v_mul_lo) + 103 full-rate instructions, square: 327 + 102
+                # (gen_field_mul30.py), 4.5 / 2.35 cycles per wave each (tools/ubench_isa.hip, tools/gen_ubench_regs.py),
+                # 1024 SIMDs x 64 lanes at 2.4 GHz -> 77.4 G products/s for the 8M + 2S mix
                 "fq_mul_per_s": round(10 * 16 * n / (acc0_ms * 1e-3)) if acc0_ms and args.logn == LOG_N else None,
-                "fq_mul_issue_bound": 60.7e9,
-                "alu_frac": round(10 * 16 * n / (acc0_ms * 1e-3) / 60.7e9, 4) if acc0_ms and args.logn == LOG_N else None,
+                "fq_mul_issue_bound": 77.4e9,
+                "alu_frac": round(10 * 16 * n / (acc0_ms * 1e-3) / 77.4e9, 4) if acc0_ms and args.logn == LOG_N else None,
             },
             "stage_ms": {k: (round(v, 4) if v is not None else None) for k, v in stages.items()},
         }

@@ -1,46 +1,67 @@
 #!/usr/bin/env python3
-"""Copy the measurement artefacts of a `gpurun` session from gpurun_out/ into profiles/ (tracked):
-bench JSON, rocprofv3 kernel stats (csv + markdown), PMC traffic per kernel, prover / size sweeps."""
+"""Copy the measurement artefacts of tools/profile_round.sh <tag> from gpurun_out/prof_<tag>/ into profiles/ (tracked):
+rocprofv3 kernel stats of the headline command and of `snark -i 24` (csv + markdown) and the PMC traffic per kernel.
+Usage: python tools/refresh_profiles.py r2 "library description" """
 import collections
 import csv
+import glob
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G = os.path.join(ROOT, "gpurun_out")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r2"
+DESC = sys.argv[2] if len(sys.argv) > 2 else "round 2 library"
+G = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 P = os.path.join(ROOT, "profiles")
 
-rows = list(csv.DictReader(open(os.path.join(G, "prof_final", "msm20_kernel_stats.csv"))))
-out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --headline-only (MI355X, round 1 final library)", "",
-       "23 one-call 2^20-pair MSMs (3 warm-up + 20 timed), nothing else in the command.", "",
-       "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
-for r in rows:
-    out.append("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
-                                                              float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-open(os.path.join(P, "r1_final_msm20_kernel_stats.md"), "w").write("\n".join(out) + "\n")
-shutil.copy(os.path.join(G, "prof_final", "msm20_kernel_stats.csv"), os.path.join(P, "r1_final_msm20_kernel_stats.csv"))
-shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, "r1_final_bench.json"))
+
+def find(sub, pattern):
+    hits = glob.glob(os.path.join(G, sub, "**", pattern), recursive=True)
+    assert hits, (sub, pattern)
+    return hits[0]
+
+
+def stats_md(csv_path, title, note, out_name, top=40):
+    rows = list(csv.DictReader(open(csv_path)))
+    out = [f"# {title}", "", note, "", "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
+    for r in rows[:top]:
+        out.append("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+                                                                  float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    open(os.path.join(P, out_name + ".md"), "w").write("\n".join(out) + "\n")
+    shutil.copy(csv_path, os.path.join(P, out_name + ".csv"))
+    return rows
+
+
+rows = stats_md(find("msm20", "*kernel_stats.csv"),
+                f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --headline-only (MI355X, {DESC})",
+                "23 one-call 2^20-pair MSMs (3 warm-up + 20 timed), nothing else in the command.", f"{TAG}_msm20_kernel_stats")
+shutil.copy(os.path.join(G, "msm20_bench.json"), os.path.join(P, f"{TAG}_msm20_bench_under_rocprof.json"))
+stats_md(find("snark24", "*kernel_stats.csv"),
+         f"rocprofv3 --kernel-trace --stats -- python tools/run_snark.py -i 24 --repeat 3 (MI355X, {DESC})",
+         "dummy_r1cs(2^24) + SRS generation (2^25 + 1 points, listed by their own kernel names) + three Proof::new_time runs.", f"{TAG}_snark24_kernel_stats")
+shutil.copy(os.path.join(G, "snark24_run.json"), os.path.join(P, f"{TAG}_snark24_run.json"))
 
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(G, f"pmc_{c}", "pmc_counter_collection.csv"))):
+    for r in csv.DictReader(open(find(f"pmc_{c}", "*counter_collection.csv"))):
         if r["Counter_Name"] == c:
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     res[c] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
-old = json.load(open(os.path.join(P, "r1_pmc_msm20.json")))
-pm = {"source": old["source"], "units": old["units"], "kernels": {}}
+pm = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 3 --warmup 1 --headline-only`, "
+                f"MI355X, {DESC}; averages over all dispatches of a kernel in that command (four one-call 2^20-pair MSMs)",
+      "units": "counter values are KiB per dispatch; bytes = value * 1024; gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE tallies 128-B requests "
+               "at 64 B for 16-B/lane loads, so read bytes = 2 * FETCH_SIZE * 1024 (calibrated there on streaming reads, uncalibrated for this gather pattern; "
+               "Infinity-Cache hits are included); WRITE_SIZE as reported",
+      "kernels": {}}
 for k, (f, n) in sorted(res["FETCH_SIZE"].items()):
     if "gm::" not in k:
         continue
     w = res["WRITE_SIZE"].get(k, (0, 0))[0]
     pm["kernels"][k] = {"dispatches": n, "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "hbm_bytes_uncorrected": int((f + w) * 1024),
                         "hbm_bytes_corrected": int((2 * f + w) * 1024)}
-json.dump(pm, open(os.path.join(P, "r1_pmc_msm20.json"), "w"), indent=1)
-for src, dst in (("time_prover_sweep.jsonl", "r1_time_prover_sweep.jsonl"), ("psnark_sweep.jsonl", "r1_psnark_time_prover_sweep.jsonl"),
-                 ("msm_sizes_final.txt", "r1_final_msm_sizes.txt")):
-    if os.path.exists(os.path.join(G, src)):
-        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+json.dump(pm, open(os.path.join(P, f"{TAG}_pmc_msm20.json"), "w"), indent=1)
 print("k_acc0 PMC:", pm["kernels"].get("gm::k_acc0"))
 print("k_acc0 rocprof avg us:", [float(r["AverageNs"]) / 1e3 for r in rows if r["Name"].startswith("gm::k_acc0")])
