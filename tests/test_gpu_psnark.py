@@ -302,3 +302,51 @@ def test_evaluate_index_poly(gm, oracle, pyref, n):
     assert F.fr_to_int(F.element(vec, n - 1)) == n - 1
     idx.free()
     vec.free()
+
+
+@pytest.mark.parametrize("logn", [18, 20])
+def test_psnark_config5_shape_time_equals_elastic(gm, oracle, pyref, logn):
+    """BASELINE configs[4] (`examples/psnark -i 26`) in its own shape at a suite-sized instance: dummy_r1cs(2^logn) and
+    the recipe of examples/psnark.rs:70-81 (key of num_constraints + num_variables powers, index from the key).  The
+    elastic prover on the stream view of the same key, max_msm_buffer = 2^20 as in :52, must return the byte-identical
+    proof (`assert!(elastic_proof == time_proof)`, src/psnark/tests.rs:124), and what the dummy instance fixes in
+    closed form must hold on the device proof: z_a = z_b = z_c = [1; n] (src/circuit.rs:349-365), so
+    zc(alpha) = (alpha^n - 1) / (alpha - 1) with alpha re-derived by the oracle's transcript from the proof's own
+    witness commitment and the key's G2 powers."""
+    from gemini_amd.circuit import R1csStream, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from gemini_amd.psnark import Proof
+    from oracle import psnark_ref as pr
+
+    R = pyref.R_MOD
+    n = 1 << logn
+    e = oracle.limbs_to_ints(oracle.random_fr(2600 + logn, 1))[0]
+    tau = oracle.limbs_to_ints(oracle.random_fr(2700 + logn, 1))[0]
+    # 3 n + 1 powers: the stream key of the elastic example (examples/psnark.rs:61); the streaming committer insists on
+    # a key at least as long as every stream (src/kzg/space.rs:169-175), the time committer truncates silently
+    ck = CommitterKey.new(3 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    r1cs = dummy_r1cs(e, n)
+    index = Proof.index(ck, r1cs)
+    time_proof = Proof.new_time(ck, r1cs, index)
+    stream = R1csStream(r1cs)
+    elastic_proof = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20)
+    assert elastic_proof == time_proof and elastic_proof.serialize_compressed() == time_proof.serialize_compressed()
+    # closed forms
+    I = gm.fr.fr_to_int
+    tr = pyref.GeminiTranscript(pyref.PROTOCOL_NAME)
+    g2p = pr.powers_of_g2(tau, 5)
+    w_aff = jac_to_affine_ints(oracle, time_proof.witness_commitment)
+    # commitment(w) = e (tau^(n-1) - 1) / (tau - 1) g
+    k = e * (pow(tau, n - 1, R) - 1) % R * pow(tau - 1, -1, R) % R
+    assert w_aff == pyref.g1_mul(pyref.G1_GEN, k)
+    # absorb order of src/psnark/time_prover.rs:80-87: witness, ck (G2 powers), instance (the index), then alpha
+    G1 = pyref.g1_serialize_uncompressed
+    tr.append_message(b"witness", G1(w_aff))
+    tr.append_message(b"ck", len(g2p).to_bytes(8, "little") + b"".join(pr.g2_serialize_uncompressed(p) for p in g2p))
+    tr.append_message(b"instance", len(index).to_bytes(8, "little") + b"".join(G1(jac_to_affine_ints(oracle, c)) for c in index))
+    alpha = tr.get_challenge(b"alpha")
+    assert I(time_proof.zc_alpha) == (pow(alpha, n, R) - 1) * pow(alpha - 1, -1, R) % R
+    assert len(time_proof.first_sumcheck_msgs[0]) == logn
+    stream.free()
+    r1cs.free()
+    ck.powers_of_g.free()

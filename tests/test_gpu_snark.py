@@ -484,3 +484,69 @@ def test_open_polynomials_no_longer_than_the_point_set(gm, oracle, pyref):
     assert [I(r) for r in rem2] == [72, (9 - 150) % pyref.R_MOD]
     assert (np.asarray(mp2) == np.asarray(time_ck.commit(M([5])))).all()
     assert (np.asarray(time_ck.open_multi_points(M([9, 7, 5]), M(pts[:2]))) == np.asarray(mp2)).all()
+
+
+def test_snark_elastic_config4_shape_at_logn_22(gm, oracle, pyref):
+    """BASELINE configs[3] (`examples/snark -i 28`, elastic prover) in its own shape at the largest size the suite
+    budget allows: dummy_r1cs_stream(2^22), the GENERATOR-COPIES key of examples/snark.rs:59-63 (n + 1 copies of g),
+    max_msm_buffer = 2^20 (:57) cut LITERALLY (min_device_chunk = 1: every ChunkedPippenger / HashMapPippenger flush of
+    src/kzg/space.rs:105,139,205,244 is its own device MSM -- 2^20 / depth pairs in commit_folding), and the real
+    SPACE_TIME_THRESHOLD = 22, so the space prover -> time prover hand-off of src/subprotocols/sumcheck/
+    elastic_prover.rs:44-57 happens after the first round.  The proof must be byte-identical to Proof::new_time on the
+    same key (`assert_eq!(time_proof, space_proof)`, src/snark/tests.rs:14-57) and to the default, merged-flush run."""
+    from gemini_amd import sumcheck as S
+    from gemini_amd.circuit import R1csStream, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream, g1_generator_mont
+    from gemini_amd.msm import G1Bases
+    from gemini_amd.snark import Proof
+
+    assert S.SPACE_TIME_THRESHOLD == 22
+    logn = 22
+    n = 1 << logn
+    ones = np.zeros((n + 1, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    ck = CommitterKey(G1Bases.fixed_base(g1_generator_mont(), ones), 3)
+    r1cs = dummy_r1cs(oracle.limbs_to_ints(oracle.random_fr(2228, 1))[0], n)
+    time_bytes = Proof.new_time(r1cs, ck).serialize_compressed()
+    stream = R1csStream(r1cs)
+    literal = CommitterKeyStream.from_committer_key(ck, min_device_chunk=1)
+    flushes = []
+    inner = literal.powers_of_g.msm_vec
+
+    def counting(*a, **k):
+        flushes.append(k.get("n"))
+        return inner(*a, **k)
+
+    literal.powers_of_g.msm_vec = counting
+    try:
+        elastic = Proof.new_elastic(stream, literal, 1 << 20)
+    finally:
+        literal.powers_of_g.msm_vec = inner
+    assert elastic.serialize_compressed() == time_bytes
+    assert max(flushes) <= 1 << 20 and len(flushes) >= 100 and min(flushes) < 1 << 16, (len(flushes), max(flushes))  # the chunked paths really ran
+    merged = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << 20)
+    assert merged.serialize_compressed() == time_bytes
+    assert len(elastic.first_sumcheck_msgs[0]) == logn
+    stream.free()
+    r1cs.free()
+    ck.powers_of_g.free()
+
+
+def test_stream_commit_default_settings_cross_the_merge_floor(gm, oracle):
+    """the DEFAULT CommitterKeyStream (flushes shorter than 2^22 pairs merged) on a stream longer than the merge floor:
+    2^22 + 5 coefficients cross one chunk boundary of _msm_stream; time == stream (src/kzg/tests.rs:16-29)"""
+    from gemini_amd.fr import FrVec, powers, fr_from_int
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+
+    m = (1 << 22) + 5
+    ck = CommitterKey.new(m, 3, oracle.random_fr(2229, 1)[0])
+    stream_ck = CommitterKeyStream.from_committer_key(ck)
+    assert stream_ck.min_device_chunk == 1 << 22
+    poly = powers(fr_from_int(oracle.limbs_to_ints(oracle.random_fr(2230, 1))[0]), m)  # dense, no host upload
+    from gemini_amd.fr import reverse
+
+    be = reverse(poly)
+    assert (stream_ck.commit(be) == ck.commit(poly)).all()
+    for v in (poly, be):
+        v.free()
+    ck.powers_of_g.free()
