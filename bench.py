@@ -376,6 +376,13 @@ def main():
         except (OSError, KeyError, ValueError):
             continue
 
+    # second metric (every rank takes part when N > 1: the key is sharded)
+    tp = None
+    hb_for_cpu = bases.download() if (world == 1 and not args.no_cpu_baseline) else None
+    if args.snark_logn > 0:
+        bases.free()  # the prover's key (2^25 + 1 points) and its vectors want the memory
+        tp = snark_time_prover(gm, args.snark_logn, with_tables=not args.no_tables, world=world, rank=rank,
+                               cpu_logn=0 if args.no_cpu_baseline else args.cpu_snark_logn)
     if rank == 0:
         pairs = world * n * args.steps
         value = pairs / elapsed / 1e6

@@ -82,6 +82,9 @@ class Prog:
                 out.append(f"v_alignbit_b32 {ins[1]}, {o(ins[2])}, {o(ins[3])}, {o(ins[4])}")
             elif op == "lshl_or":
                 out.append(f"v_lshl_or_b32 {ins[1]}, {o(ins[2])}, {o(ins[3])}, {o(ins[4])}")
+            elif op == "lshr64":
+                d, sh, a = ins[1:]
+                out.append(f"v_lshrrev_b64 v[{d}:{d + 1}], {o(sh)}, v[{a}:{a + 1}]")
             elif op == "mov":
                 out.append(f"v_mov_b32 {ins[1]}, {o(ins[2])}")
             elif op == "smov":
@@ -138,6 +141,10 @@ class Prog:
                 regs[ins[1]] = (((g(ins[2]) << 32) | g(ins[3])) >> (g(ins[4]) & 31)) & M32
             elif op == "lshl_or":
                 regs[ins[1]] = ((g(ins[2]) << (g(ins[3]) & 31)) | g(ins[4])) & M32
+            elif op == "lshr64":
+                d, sh, a = ins[1:]
+                v = (regs[f"v{a}"] | (regs[f"v{a + 1}"] << 32)) >> (g(sh) & 63)
+                regs[f"v{d}"], regs[f"v{d + 1}"] = v & M32, v >> 32
             elif op in ("mov", "smov"):
                 regs[ins[1]] = g(ins[2])
             elif op == "add_co":
@@ -234,8 +241,7 @@ def gen(square, loose=False):
             for i in range(lo_i, hi_i + 1):
                 mad(A[i], B[k - i], LB[i], LB[k - i])
         if split:
-            p.emit("alignbit", f"v{SPL}", f"v{ACC + 1}", f"v{ACC}", 30)
-            p.emit("lshr", f"v{SPL + 1}", 30, f"v{ACC + 1}")
+            p.emit("lshr64", SPL, 30, ACC)
             p.emit("and", f"v{ACC}", MASK30, f"v{ACC}")
             p.emit("mov", f"v{ACC + 1}", 0)
             spl_bound = bound >> 30
@@ -249,8 +255,7 @@ def gen(square, loose=False):
             mad(M[k], SP[0], MASK30, P30[0])
         else:
             p.emit("and", T[k - 13], MASK30, f"v{ACC}")
-        p.emit("alignbit", f"v{ACC}", f"v{ACC + 1}", f"v{ACC}", 30)
-        p.emit("lshr", f"v{ACC + 1}", 30, f"v{ACC + 1}")
+        p.emit("lshr64", ACC, 30, ACC)  # one half-rate instruction; v_alignbit_b32 (half rate too) + v_lshrrev_b32 cost 1.5
         bound >>= 30
         if split:
             p.emit("add_co", f"v{ACC}", f"v{ACC}", f"v{SPL}")

@@ -566,6 +566,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAV
                                               const uint8_t* __restrict__ bases, long long first, long long step,
                                               long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
                                               uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets) {
+  __shared__ uint64_t ebuf[8][256];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = *total_ptr;
   const uint64_t start = (uint64_t)t * L;
@@ -579,7 +580,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAV
     // multiplier, so an early-issued gather cannot overlap the addition inside one wave (measured:
     // no change).  The second resident wave per SIMD hides the gather latency instead.
     for (uint64_t i = start; i < end; i++) {
-      const uint64_t e = entries[i];
+      // Entries are staged eight at a time through LDS: a lane walks its own chunk, so lane t reads entries[t L + i]
+      // -- 8 bytes out of a different 128-byte line per lane and iteration, and with one addition (~20 k cycles)
+      // between two reads of a line it is long gone from L1 / L2 by then (the PMC pass counted every line ~16 times:
+      // 2.1 GB of the 4.5 GB per launch).  Four 16-byte loads per eight iterations fetch each line twice; the
+      // transposed LDS image [k][lane] is written and read conflict-free and only by its own lane (no barrier).
+      const uint32_t k8 = (uint32_t)(i - start) & 7u;
+      if (k8 == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(entries + i);  // start = t * L with L even: 16-byte aligned
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint4 v = src[q];  // may run past `end` inside the (padded) entry buffer; those slots are never used
+          ebuf[2 * q][threadIdx.x] = ((uint64_t)v.y << 32) | v.x;
+          ebuf[2 * q + 1][threadIdx.x] = ((uint64_t)v.w << 32) | v.z;
+        }
+      }
+      const uint64_t e = ebuf[k8][threadIdx.x];
       long long idx;
       if (tab_stride) {  // fixed-base tables: row = window, column = pair
         const uint32_t lo = (uint32_t)e & 0x7fffffffu;
@@ -1625,6 +1641,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint64_t lanes0 = Nacc_all >= ((uint64_t)1 << 24) ? 262144 : 131072;
   uint32_t L = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(4, (Nacc_all + lanes0 - 1) / lanes0));
   if (L_env > 0) L = (uint32_t)L_env;
+  L = (L + 1u) & ~1u;  // even: every lane's chunk starts 16-byte aligned (k_acc0 reads its entries in 16-byte words)
   const uint64_t T0 = (Nacc + L - 1) / L;
   const uint64_t T0pad = (T0 + 255) / 256 * 256;
   const uint64_t E1 = 2 * T0pad;

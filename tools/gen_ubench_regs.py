@@ -18,6 +18,10 @@ tests["alignbit"] = rep([f"v_alignbit_b32 v{50+i}, v{24+i}, v{25+i}, 30" for i i
 tests["lshl_or"] = rep([f"v_lshl_or_b32 v{50+i}, v{24+i}, 30, v{25+i}" for i in range(6)])
 tests["and_lit"] = rep([f"v_and_b32 v{50+i}, 0x3fffffff, v{24+i}" for i in range(6)])
 tests["lshr"] = rep([f"v_lshrrev_b32 v{50+i}, 30, v{24+i}" for i in range(6)])
+tests["lshr_b64"] = rep([f"v_lshrrev_b64 v[{50+2*i}:{51+2*i}], 30, v[{24+2*i}:{25+2*i}]" for i in range(3)])
+tests["bfe_u32"] = rep([f"v_bfe_u32 v{50+i}, v{24+i}, 3, 30" for i in range(6)])
+tests["and_or_b32"] = rep([f"v_and_or_b32 v{50+i}, v{24+i}, v{30+i}, v{31+i}" for i in range(6)])
+tests["add3_u32"] = rep([f"v_add3_u32 v{50+i}, v{24+i}, v{30+i}, v{31+i}" for i in range(6)])
 tests["mul_lo_sgpr"] = rep([f"v_mul_lo_u32 v{50+i}, v{24+i}, s4" for i in range(6)])
 tests["mov_lit"] = rep([f"v_mov_b32 v{50+i}, 0x12345678" for i in range(6)])
 # one reduction-style column: 8 mads then the m / shift tail
