@@ -1,0 +1,45 @@
+"""Two ranks over gloo sharing the one GPU of the test box (the N > 1 code path of gemini_amd/dist.py with the real
+device library on every rank): `snark --time-prover` and the elastic prover over the element-cyclic sharded KZG key
+must produce the proof of the single-GPU run, byte for byte (compared through its SHA-256).  The driver's multi-GPU
+bench launches the same entry points with the nccl backend, one rank per GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, extra):
+    env = dict(os.environ, GM_BENCH_BACKEND="gloo", GM_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = [os.path.join(ROOT, "tools", "run_snark.py"), "-i", "12", "--repeat", "1"] + extra
+    if world == 1:
+        cmd = [sys.executable] + script
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_port())] + script
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("extra", [[], ["--elastic"]], ids=["time", "elastic"])
+def test_two_ranks_one_gpu_same_proof(extra):
+    one = _run(1, extra)
+    for world in (2, 3):
+        many = _run(world, extra)
+        assert many["n_gpus"] == world
+        assert many["proof_sha256"] == one["proof_sha256"], (world, extra)
