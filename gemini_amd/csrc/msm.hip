@@ -556,6 +556,98 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// Small calls (n * W <= 2^18 entries): one thread per (scalar, window).  The signed-digit recurrence of
+// variable_base.rs:21-61 carries from window to window, but the carry INTO window w is just the carry of the
+// integer addition s + K out of the low c*w bits, K = sum_{j < W-1} 2^(c j + c - 1) (half a window in every
+// window but the top one): coef_j >= 2^(c-1)  <=>  raw_j + carry_j + 2^(c-1) >= 2^c.  So digit_w = window w of
+// (s + K) minus 2^(c-1), and the top window, which absorbs the final carry (:58), is window W-1 of s + K as it is.
+// That makes every digit independent: a 2^10-pair call has 44 k threads instead of the 4 blocks of the
+// per-scalar kernels (whose ~170 sequential digit extractions per thread run at lone-wave speed: 0.14 ms of a
+// 0.68 ms call), and one counting pass with global atomics (wave-aggregated: lanes of a wave hold consecutive
+// scalars of ONE window, so the all-equal-scalars instance costs one atomic per wave) replaces the two-pass
+// block-local sort -- 3 launches instead of 9.
+// ------------------------------------------------------------------------------------------
+struct FlatGeom {
+  int c, W;
+  uint32_t B;
+  uint32_t K[8];  // sum_{j < W-1} 2^(c j + c - 1), little-endian limbs
+};
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_digits_flat(const uint32_t* __restrict__ scalars, uint32_t n, int mont, FlatGeom fg,
+                                                     uint32_t* __restrict__ counts_or_cursor, uint64_t* __restrict__ entries,
+                                                     uint32_t* __restrict__ err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = (int)blockIdx.y;
+  const bool active = i < n;
+  uint32_t key = KEY_INV;
+  bool neg = false;
+  if (active) {
+    Fr v = fp_load<FrParams>(scalars + 8 * (size_t)i);
+    if (mont) v = fp_from_mont<FrParams>(v);
+    if (!SCATTER && w == 0 && (v.l[7] >> 31)) atomicOr(err, 1u);  // >= 2^255: not an Fr image
+    uint32_t t[9];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+      uint32_t cy;
+      t[l] = __builtin_addc(v.l[l], fg.K[l], carry, &cy);
+      carry = cy;
+    }
+    t[8] = carry;
+    const uint32_t bit = (uint32_t)(fg.c * w), lo = bit >> 5, sh = bit & 31u;
+    uint64_t two = 0;
+#pragma unroll
+    for (int l = 0; l < 9; l++) {  // limbs lo, lo + 1 without dynamic register indexing
+      if ((uint32_t)l == lo) two |= (uint64_t)t[l];
+      if ((uint32_t)l == lo + 1) two |= (uint64_t)t[l] << 32;
+    }
+    uint32_t u = (uint32_t)(two >> sh);
+    int32_t d;
+    if (w == fg.W - 1) {
+      // the top window keeps every remaining bit (c * W >= 256, so they fit 32 bits only for a canonical scalar;
+      // anything beyond the bucket range is clamped -- the call fails through the flag above)
+      d = (int32_t)min(u, fg.B);
+    } else {
+      u &= (1u << fg.c) - 1u;
+      d = (int32_t)u - (int32_t)(1u << (fg.c - 1));
+    }
+    if (d != 0) {
+      neg = d < 0;
+      key = (uint32_t)w * fg.B + ((uint32_t)(neg ? -d : d) - 1u);
+    }
+  }
+  const uint32_t pos = wave_atomic_inc(counts_or_cursor, key);
+  if (SCATTER && key != KEY_INV) entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(neg ? 1u : 0u) << 31) | (uint64_t)i;
+}
+
+// exclusive scan of m <= 2^18 counters in one block (the three-launch scan is for the millions of buckets of big calls)
+__global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ offsets,
+                                                     uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (m + 1023u) / 1024u;
+  const uint32_t lo = min(tid * per, m), hi = min(lo + per, m);
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; k++) s += counts[k];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const uint32_t x = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += x;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - s;
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t c = counts[k];
+    offsets[k] = run;
+    cursor[k] = run;
+    run += c;
+  }
+  if (tid == 1023) offsets[m] = part[1023];
+}
+
+// ------------------------------------------------------------------------------------------
 // level 0: chunk-per-thread accumulation of sorted entries
 // ------------------------------------------------------------------------------------------
 #ifndef GM_ACC0_WAVES
@@ -1394,11 +1486,14 @@ static int choose_window(size_t n) {
   int lg = ceil_log2_sz(n);
   if (lg >= 25) return 20;  // 13 windows: another -4 % at 2^25 and 2^26
   if (lg >= 23) return 19;  // 14 windows: -2.5 % at 2^23, -7 % at 2^24, -11 % at 2^26 against c = 16 (the 3.7 M buckets cost 2.7 ms to reduce)
-  if (lg >= 15) return 16;
-  if (lg >= 13) return 13;
-  int c = lg - 4;
-  if (c < 4) c = 4;
-  return c;
+  if (lg >= 14) return 16;
+  // small calls, re-tuned with the flat digit kernels (tools/tune_small.py, round 2): the launch chain and the
+  // merge depth dominate, so sparse buckets (c = 8: <= 2 lanes per bucket at L = 4) win from 2^11 pairs on --
+  // 0.72 vs 0.97 ms (c = 13) at 2^13, 0.89 vs 1.07 ms at 2^14 with c = 16
+  if (lg >= 11) return 8;
+  if (lg >= 8) return lg - 4;
+  if (lg >= 5) return lg + 1;
+  return 4;
 }
 
 constexpr size_t MSM_SMALL_N = (size_t)1 << 17;
@@ -1675,8 +1770,28 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
                        ws.misc.as<uint32_t>(), ws.offsets.as<uint32_t>(), ws.cursor.as<uint32_t>());
   };
   static const bool sort_atomic_env = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
+  static const bool sort_flat_env = !(getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "blocks"));
   const bool sort_atomic = sort_atomic_env && !use_table && nparts == 1;
-  if (sort_atomic) {
+  const bool sort_flat = sort_flat_env && !sort_atomic && !use_table && nparts == 1 && N <= ((uint64_t)1 << 21) && nbuckets <= ((size_t)1 << 18);
+  if (sort_flat) {
+    FlatGeom fg{};
+    fg.c = c;
+    fg.W = W;
+    fg.B = B;
+    for (int j = 0; j + 1 < W; j++) {
+      const int b = c * j + c - 1;
+      if (b < 256) fg.K[b >> 5] |= 1u << (b & 31);
+    }
+    const dim3 grid((uint32_t)((n + 255) / 256), (uint32_t)W);
+    pf.begin(part, PROF_DIGITS, st);
+    hipLaunchKernelGGL(k_digits_flat<false>, grid, dim3(256), 0, st, sc, (uint32_t)n, mont, fg, ws.counts.as<uint32_t>(), (uint64_t*)nullptr, d_err);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets, ws.offsets.as<uint32_t>(),
+                       ws.cursor.as<uint32_t>());
+    pf.end(part, PROF_DIGITS, st);
+    pf.begin(part, PROF_SCATTER, st);
+    hipLaunchKernelGGL(k_digits_flat<true>, grid, dim3(256), 0, st, sc, (uint32_t)n, mont, fg, ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>(), d_err);
+    pf.end(part, PROF_SCATTER, st);
+  } else if (sort_atomic) {
     pf.begin(part, PROF_DIGITS, st);
     hipLaunchKernelGGL(k_msm_digits<false>, dim3(dblocks), dim3(256), 0, st, sc, (uint32_t)n, mont, c, W, B,
                        ws.counts.as<uint32_t>(), (uint64_t*)nullptr, d_err);
