@@ -68,7 +68,7 @@ template <class F> float timeit(F f) {
 int main(int argc, char** argv) {
   const uint32_t Qw[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
   int bad = 0;
-  for (int wps : {8, 2}) {
+  for (int wps : {8, 4, 3, 2, 1}) {
     const int blocks = 256 * wps, threads = 256, n = blocks * threads;
     std::vector<uint32_t> ha(12 * n), hb(12 * n);
     uint64_t s = 88172645463325252ull;
