@@ -156,6 +156,7 @@ int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* 
                         std::unique_ptr<Bases>& out);
 int bases_precompute(Context* C, Bases* b, int c);
 int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out96);
+int bases_build_phi(Context* C, Bases* b);
 int sc_set_herring(Sumcheck* S, int on);
 int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist[4],
                uint64_t* handle);
@@ -236,6 +237,7 @@ void gm_shutdown(void) {
   (void)hipStreamSynchronize(C->stream);
   for (auto& kv : C->bases) {
     if (kv.second->table) (void)hipFree(kv.second->table);
+    if (kv.second->phi) (void)hipFree(kv.second->phi);
     if (kv.second->d) (void)hipFree(kv.second->d);
   }
   for (auto& kv : C->vecs)
@@ -309,6 +311,12 @@ int gm_set_msm_window(int c) {
   return GM_OK;
 }
 
+int gm_set_msm_glv(int on) {
+  GM_CTX();
+  C->msm_glv = on != 0;
+  return GM_OK;
+}
+
 int gm_set_msm_split(int on) {
   GM_CTX();
   C->msm_split = on != 0;
@@ -329,6 +337,7 @@ int gm_g1_bases_register(const void* bases, size_t base_stride, size_t n, uint64
   std::unique_ptr<Bases> b;
   int rc = bases_from_host(C, bases, base_stride, n, b);
   if (rc) return rc;
+  if ((rc = bases_build_phi(C, b.get()))) return rc;
   *handle = put_bases(std::move(b));
   return GM_OK;
 }
@@ -344,6 +353,7 @@ int gm_g1_bases_free(uint64_t handle) {
     C->bases.erase(it);
   }
   if (b->table) (void)hipFree(b->table);
+  if (b->phi) (void)hipFree(b->phi);
   if (b->d) GM_HIP(hipFree(b->d));
   return GM_OK;
 }
@@ -464,6 +474,7 @@ int gm_g1_fixed_base_register(const uint64_t base_affine[12], const uint64_t* sc
   int rc = fixed_base_generate(C, base_affine, d_sc, 0, n, b);
   if (d_sc) (void)hipFree(d_sc);
   if (rc) return rc;
+  if ((rc = bases_build_phi(C, b.get()))) return rc;
   *handle = put_bases(std::move(b));
   return GM_OK;
 }
@@ -483,6 +494,7 @@ int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], si
   if (!rc) rc = fixed_base_generate(C, base_affine, v->d, 1, n, b);
   if (v->d) (void)hipFree(v->d);
   if (rc) return rc;
+  if ((rc = bases_build_phi(C, b.get()))) return rc;
   *handle = put_bases(std::move(b));
   return GM_OK;
 }

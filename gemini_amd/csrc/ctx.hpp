@@ -48,6 +48,9 @@ struct DevBuf {
 
 struct Bases {
   uint8_t* d = nullptr;  // n x 96 bytes: x, y Montgomery; identity = all zero
+  // phi(P_i) = (beta x_i, y_i) = lambda P_i, the image under the curve's endomorphism, same layout; built at
+  // registration (bases_build_phi) for the GLV split of the MSM, nullptr for one-shot / borrowed bases
+  uint8_t* phi = nullptr;
   size_t n = 0;
   // optional fixed-base window tables: table[w * n + i] = 2^(tab_c * w) * base[i], w < tab_W
   // (table row 0 is a copy of d so one pointer serves every window)
@@ -196,6 +199,7 @@ struct Context {
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
   int msm_c_override = 0;
+  int msm_glv = 0;            // build phi(P) at registration and split scalars by the GLV endomorphism (gm_set_msm_glv)
   int msm_split = 0;          // one-call MSMs as two window groups over three streams (gm_set_msm_split)
   int msm_affine_levels = 0;  // affine tree levels in front of the XYZZ accumulation; -1 = automatic
   size_t msm_table_min = (size_t)1 << 17;  // smallest MSM that uses fixed-base tables when present

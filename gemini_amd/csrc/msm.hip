@@ -65,6 +65,12 @@ struct DigitIter {
     carry = 0;
     bad = (s[7] >> 31) != 0;  // >= 2^255: not the BigInt image of an Fr element (< r < 2^255)
   }
+  GM_DEV void init_mag(const uint32_t m4[4], bool active, bool bad_in) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = (active && i < 4) ? m4[i] : 0u;
+    carry = 0;
+    bad = bad_in;
+  }
   // top-window digit with the final carry folded back in (variable_base.rs:58: digits[last] += carry << w).
   // For a canonical scalar (< r < 2^255) |d| <= 2^(c-1); a larger value would index past the bucket array
   // (the reference panics there), so it is clamped and flagged instead.
@@ -88,6 +94,176 @@ struct DigitIter {
     uint32_t coef = raw + carry;
     carry = (coef + (1u << (c - 1))) >> c;
     return (int32_t)coef - (int32_t)(carry << c);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// GLV split.  BLS12-381 G1 has the endomorphism phi(x, y) = (beta x, y) = lambda (x, y) with lambda = z^2 - 1 (128
+// bits, z the curve parameter) and lambda^2 + lambda + 1 = r.  A scalar s < r is written s = v1 + v2 lambda (mod r)
+// with |v1|, |v2| < 2^127 (top 16 bits <= 0x5622), so s P = v1 P + v2 phi(P): the same number of bucket additions
+// (two half-length digit strings instead of one), but HALF the windows -- half the bucket sets to reduce (k_group_sum
+// level 1 is two full additions per bucket) and half the doublings of the final Horner.  phi(P_i) is stored next to
+// the registered bases (one product per point, once).  The group element is the same: bit-exact after normalisation.
+//   q = floor(s / lambda) by Barrett (mu = floor(2^256 / lambda)), r1 = s - q lambda;
+//   r1 > lambda / 2      ->  v1 = r1 - lambda, q += 1
+//   q  > (lambda + 1)/2  ->  v2 = q - (lambda + 1), v1 -= 1            (r = lambda (lambda + 1) + 1)
+// ------------------------------------------------------------------------------------------
+struct GlvHalves {
+  uint32_t m[2][4];  // magnitudes of v1, v2
+  bool neg[2];
+};
+GM_DEV GlvHalves glv_split(const uint32_t s_in[8]) {
+  constexpr uint32_t LAM[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};
+  constexpr uint32_t MU[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};
+  constexpr uint32_t HALF_LAM[4] = {0x7fffffffu, 0x00000000u, 0x8000d201u, 0x5622d200u};   // floor(lambda / 2)
+  constexpr uint32_t HALF_LAM1[4] = {0x80000000u, 0x00000000u, 0x8000d201u, 0x5622d200u};  // (lambda + 1) / 2
+  uint32_t s[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) s[i] = s_in[i];
+  // s mod r (a canonical scalar is already reduced; anything below 2^256 needs at most four subtractions)
+#pragma unroll 1
+  for (int it = 0; it < 4; it++) {
+    uint32_t t[8], borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint32_t b;
+      t[i] = __builtin_subc(s[i], FrParams::MOD[i], borrow, &b);
+      borrow = b;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = borrow ? s[i] : t[i];
+  }
+  // q = (s * mu) >> 256   (q <= floor(s / lambda) <= q + 2)
+  uint32_t prod[13];
+#pragma unroll
+  for (int i = 0; i < 13; i++) prod[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const uint64_t x = (uint64_t)s[i] * MU[j] + prod[i + j] + carry;
+      prod[i + j] = (uint32_t)x;
+      carry = x >> 32;
+    }
+    prod[i + 5] = (uint32_t)carry;
+  }
+  uint32_t q[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) q[i] = prod[8 + i];
+  // r1 = s - q * lambda  (< 3 lambda: five limbs)
+  uint32_t ql[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) ql[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (i + j < 6) {
+        const uint64_t x = (uint64_t)q[i] * LAM[j] + ql[i + j] + carry;
+        ql[i + j] = (uint32_t)x;
+        carry = x >> 32;
+      }
+    }
+    if (i + 4 < 6) ql[i + 4] += (uint32_t)carry;
+  }
+  uint32_t r1[5];
+  {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint32_t b;
+      r1[i] = __builtin_subc(s[i], ql[i], borrow, &b);
+      borrow = b;
+    }
+  }
+#pragma unroll 1
+  for (int it = 0; it < 3; it++) {  // while (r1 >= lambda) { r1 -= lambda; q += 1; }
+    uint32_t t[5], borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint32_t b;
+      t[i] = __builtin_subc(r1[i], i < 4 ? LAM[i] : 0u, borrow, &b);
+      borrow = b;
+    }
+    const bool ge = borrow == 0;
+    uint32_t carry = ge ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      r1[i] = ge ? t[i] : r1[i];
+      uint32_t c2;
+      q[i] = __builtin_addc(q[i], 0u, carry, &c2);
+      carry = c2;
+    }
+  }
+  // signed values in five-limb two's complement
+  auto gt4 = [](const uint32_t* a, const uint32_t* b) {  // a (five limbs, non-negative) > b (four limbs)
+    if (a[4]) return true;
+    for (int i = 3; i >= 0; i--) {
+      if (a[i] != b[i]) return a[i] > b[i];
+    }
+    return false;
+  };
+  uint32_t v1[5], v2[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    v1[i] = r1[i];
+    v2[i] = q[i];
+  }
+  if (gt4(r1, HALF_LAM)) {  // v1 = r1 - lambda, v2 += 1
+    uint32_t borrow = 0, carry = 1;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint32_t b, c2;
+      v1[i] = __builtin_subc(r1[i], i < 4 ? LAM[i] : 0u, borrow, &b);
+      borrow = b;
+      v2[i] = __builtin_addc(v2[i], 0u, carry, &c2);
+      carry = c2;
+    }
+  }
+  if (gt4(v2, HALF_LAM1)) {  // v2 -= lambda + 1, v1 -= 1
+    constexpr uint32_t LAM1[5] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u, 0x00000000u};
+    uint32_t borrow = 0, borrow1 = 1;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint32_t b, b1;
+      v2[i] = __builtin_subc(v2[i], LAM1[i], borrow, &b);
+      borrow = b;
+      v1[i] = __builtin_subc(v1[i], 0u, borrow1, &b1);
+      borrow1 = b1;
+    }
+  }
+  GlvHalves h;
+  const uint32_t* v[2] = {v1, v2};
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const bool neg = (v[k][4] >> 31) != 0;
+    h.neg[k] = neg;
+    uint32_t carry = neg ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // |v| = neg ? ~v + 1 : v   (fits four limbs: |v| < 2^127)
+      uint32_t c2;
+      h.m[k][i] = __builtin_addc(neg ? ~v[k][i] : v[k][i], 0u, carry, &c2);
+      carry = c2;
+    }
+  }
+  return h;
+}
+
+constexpr int ENTRY_HALF_SHIFT = 30;  // entry idx field, GLV calls: pair index in bits 0..25, bit 30 = the phi(P) half
+// the digit strings of one scalar: one string over the whole scalar, or -- GLV -- two strings over |v1|, |v2|
+struct ScalarDigits {
+  DigitIter it;
+  GlvHalves h;
+  bool bad;
+  GM_DEV void load(const uint32_t* p, bool active, int mont, int glv) {
+    it.init(p, active, mont);
+    bad = it.bad;
+    if (glv) h = glv_split(it.s);
+  }
+  GM_DEV void start(int half, bool active, int glv) {
+    if (glv) it.init_mag(h.m[half], active, bad);
   }
 };
 
@@ -151,6 +327,7 @@ constexpr uint32_t SORT_FMAX = 4096;   // fine bins (10 key bits by default, up 
 struct SortGeom {
   int c, W;      // W: windows of the whole scalar (the signed-digit recurrence always runs from window 0)
   int w_lo, Wg;  // this call sorts windows [w_lo, w_lo + Wg) only; keys are relative to w_lo
+  int glv;       // 1: every scalar contributes two half-length digit strings (v1 on P, v2 on phi(P)) over the same W windows
   uint32_t B, FB, G;
   int shared;  // 1: fixed-base tables in use -> one bucket set for all windows, window index rides in the entry
 };
@@ -167,17 +344,21 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
   for (uint32_t s = threadIdx.x; s < SORT_TS; s += 256) {
     const uint32_t i = first + s;
     const bool active = i < n;
-    DigitIter it;
-    it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
-    for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
-      int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
-      if (w < sg.w_lo) continue;  // wave-uniform
-      // (wave_atomic_inc: one LDS atomic per wave when all lanes hit the same bin -- the all-equal-scalars
-      // instance of the reference's benchmark would otherwise serialise 64 same-address atomics)
-      const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-      wave_atomic_inc(cnt, (active && d != 0) ? (((sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
+    ScalarDigits sd;
+    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, sg.glv);
+    DigitIter& it = sd.it;
+    for (int half = 0; half <= sg.glv; half++) {
+      sd.start(half, active, sg.glv);
+      for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
+        int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
+        if (w < sg.w_lo) continue;  // wave-uniform
+        // (wave_atomic_inc: one LDS atomic per wave when all lanes hit the same bin -- the all-equal-scalars
+        // instance of the reference's benchmark would otherwise serialise 64 same-address atomics)
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        wave_atomic_inc(cnt, (active && d != 0) ? (((sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
+      }
     }
-    if (!SCATTER && it.bad) atomicOr(err, 1u);  // a scalar >= 2^255 (not an Fr image): the call fails with GM_EINVAL
+    if (!SCATTER && sd.bad) atomicOr(err, 1u);  // a scalar >= 2^255 (not an Fr image): the call fails with GM_EINVAL
   }
   __syncthreads();
   if (!SCATTER) {
@@ -194,19 +375,24 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
   for (uint32_t s = threadIdx.x; s < SORT_TS; s += 256) {
     const uint32_t i = first + s;
     const bool active = i < n;
-    DigitIter it;
-    it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
-    for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
-      int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
-      if (w < sg.w_lo) continue;
-      const bool live = active && d != 0;
-      const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-      const uint32_t key = (sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u);
-      const uint32_t g = key >> sg.FB;
-      const uint32_t r = wave_atomic_inc(cnt, live ? g : KEY_INV);
-      if (live) {
-        const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : i;
-        tmp[(SCATTER ? base[g] : 0u) + r] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
+    ScalarDigits sd;
+    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, sg.glv);
+    DigitIter& it = sd.it;
+    for (int half = 0; half <= sg.glv; half++) {
+      sd.start(half, active, sg.glv);
+      const bool hneg = sg.glv && sd.h.neg[half];
+      for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
+        int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
+        if (w < sg.w_lo) continue;
+        const bool live = active && d != 0;
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        const uint32_t key = (sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u);
+        const uint32_t g = key >> sg.FB;
+        const uint32_t r = wave_atomic_inc(cnt, live ? g : KEY_INV);
+        if (live) {
+          const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : (i | ((uint32_t)half << ENTRY_HALF_SHIFT));
+          tmp[(SCATTER ? base[g] : 0u) + r] = ((uint64_t)key << 32) | ((uint64_t)(((d < 0) != hneg) ? 1u : 0u) << 31) | (uint64_t)idx;
+        }
       }
     }
   }
@@ -221,7 +407,7 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
                                                        uint32_t* __restrict__ gcursor, uint64_t* __restrict__ tmp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + (size_t)SORT_TS * sg.Wg);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + (size_t)SORT_TS * sg.Wg * (1 + sg.glv));
   uint32_t* base = cnt + sg.G;
   uint32_t* lst = base + sg.G;
   uint32_t* scan = lst + sg.G;
@@ -232,23 +418,36 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
   const bool active = i < n;
   uint64_t e[SORT1_STAGE_WMAX];
   {
-    DigitIter it;
-    it.init(scalars + 8 * (size_t)(active ? i : 0), active, mont);
-    for (int w = 0; w < sg.w_lo; w++) it.next(sg.c);  // the recurrence starts at window 0
+    ScalarDigits sd;
+    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, sg.glv);
+    DigitIter& it = sd.it;
+    // GLV: the register slots are split between the halves (Wg <= SORT1_STAGE_WMAX / 2 windows each)
+    constexpr int HS = SORT1_STAGE_WMAX / 2;
 #pragma unroll
-    for (int j = 0; j < SORT1_STAGE_WMAX; j++) {
-      const int w = sg.w_lo + j;
-      e[j] = ~0ull;
-      if (j < sg.Wg) {
-        int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
-        if (active && d != 0) {
-          const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-          const uint32_t key = (sg.shared ? 0u : (uint32_t)j * sg.B) + (mag - 1u);
-          const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : i;
-          e[j] = ((uint64_t)key << 32) | ((uint64_t)(d < 0 ? 1u : 0u) << 31) | (uint64_t)idx;
-        }
+    for (int half = 0; half < 2; half++) {
+      if (half <= sg.glv) {
+        sd.start(half, active, sg.glv);
+        for (int w = 0; w < sg.w_lo; w++) it.next(sg.c);  // the recurrence starts at window 0
       }
-      wave_atomic_inc(cnt, e[j] != ~0ull ? ((uint32_t)(e[j] >> 32) >> sg.FB) : KEY_INV);
+      const bool hneg = sg.glv && half <= sg.glv && sd.h.neg[half];
+#pragma unroll
+      for (int jj = 0; jj < HS; jj++) {
+        // without GLV the one string fills all SORT1_STAGE_WMAX slots: "half 1" continues it at window w_lo + HS
+        const int j = half * HS + jj;
+        const int jw = sg.glv ? jj : j;  // window of this slot, relative to w_lo
+        const int w = sg.w_lo + jw;
+        e[j] = ~0ull;
+        if (jw < sg.Wg && (sg.glv || half == 0 || sg.Wg > HS)) {
+          int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
+          if (active && d != 0) {
+            const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            const uint32_t key = (sg.shared ? 0u : (uint32_t)jw * sg.B) + (mag - 1u);
+            const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : (i | ((uint32_t)(sg.glv ? half : 0) << ENTRY_HALF_SHIFT));
+            e[j] = ((uint64_t)key << 32) | ((uint64_t)(((d < 0) != hneg) ? 1u : 0u) << 31) | (uint64_t)idx;
+          }
+        }
+        wave_atomic_inc(cnt, e[j] != ~0ull ? ((uint32_t)(e[j] >> 32) >> sg.FB) : KEY_INV);
+      }
     }
   }
   __syncthreads();
@@ -569,6 +768,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 // ------------------------------------------------------------------------------------------
 struct FlatGeom {
   int c, W;
+  int glv;  // grid.y = 2 W: rows [0, W) are the v1 half, rows [W, 2 W) the v2 half (on phi(P))
   uint32_t B;
   uint32_t K[8];  // sum_{j < W-1} 2^(c j + c - 1), little-endian limbs
 };
@@ -577,14 +777,22 @@ __global__ __launch_bounds__(256) void k_digits_flat(const uint32_t* __restrict_
                                                      uint32_t* __restrict__ counts_or_cursor, uint64_t* __restrict__ entries,
                                                      uint32_t* __restrict__ err) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int w = (int)blockIdx.y;
+  const int half = (int)blockIdx.y >= fg.W ? 1 : 0;
+  const int w = (int)blockIdx.y - half * fg.W;
   const bool active = i < n;
   uint32_t key = KEY_INV;
   bool neg = false;
   if (active) {
     Fr v = fp_load<FrParams>(scalars + 8 * (size_t)i);
     if (mont) v = fp_from_mont<FrParams>(v);
-    if (!SCATTER && w == 0 && (v.l[7] >> 31)) atomicOr(err, 1u);  // >= 2^255: not an Fr image
+    if (!SCATTER && blockIdx.y == 0 && (v.l[7] >> 31)) atomicOr(err, 1u);  // >= 2^255: not an Fr image
+    bool hneg = false;
+    if (fg.glv) {
+      const GlvHalves h = glv_split(v.l);
+      hneg = h.neg[half];
+#pragma unroll
+      for (int l = 0; l < 8; l++) v.l[l] = l < 4 ? h.m[half][l] : 0u;
+    }
     uint32_t t[9];
     uint32_t carry = 0;
 #pragma unroll
@@ -612,12 +820,13 @@ __global__ __launch_bounds__(256) void k_digits_flat(const uint32_t* __restrict_
       d = (int32_t)u - (int32_t)(1u << (fg.c - 1));
     }
     if (d != 0) {
-      neg = d < 0;
-      key = (uint32_t)w * fg.B + ((uint32_t)(neg ? -d : d) - 1u);
+      key = (uint32_t)w * fg.B + ((uint32_t)(d < 0 ? -d : d) - 1u);
+      neg = (d < 0) != hneg;
     }
   }
   const uint32_t pos = wave_atomic_inc(counts_or_cursor, key);
-  if (SCATTER && key != KEY_INV) entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(neg ? 1u : 0u) << 31) | (uint64_t)i;
+  if (SCATTER && key != KEY_INV)
+    entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(neg ? 1u : 0u) << 31) | (uint64_t)(i | ((uint32_t)half << ENTRY_HALF_SHIFT));
 }
 
 // exclusive scan of m <= 2^18 counters in one block (the three-launch scan is for the millions of buckets of big calls)
@@ -657,7 +866,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAV
                                               const uint32_t* __restrict__ total_ptr,
                                               const uint8_t* __restrict__ bases, long long first, long long step,
                                               long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
-                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets) {
+                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi) {
   __shared__ uint64_t ebuf[8][256];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = *total_ptr;
@@ -693,9 +902,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAV
         const uint32_t lo = (uint32_t)e & 0x7fffffffu;
         idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
       } else {
-        idx = first + step * (long long)(e & 0x7fffffffull);
+        idx = first + step * (long long)(e & 0x3fffffffull);
       }
-      G1Affine p = g1_load_affine(bases + (size_t)idx * AFF_BYTES);
+      // GLV calls: bit 30 of the index field selects phi(P) (same addressing, second array)
+      const uint8_t* src = (phi != nullptr && ((e >> ENTRY_HALF_SHIFT) & 1ull)) ? phi : bases;
+      G1Affine p = g1_load_affine(src + (size_t)idx * AFF_BYTES);
       const uint32_t key = (uint32_t)(e >> 32);
       if (key != cur) {
         if (cur != KEY_INV) {
@@ -1321,6 +1532,30 @@ __global__ void k_export_bases(const uint8_t* __restrict__ src, size_t n, uint8_
   fp_store<FqParams>(dst + i * AFF_BYTES + 48, fqe_export(a.y));
 }
 
+// phi(P) = (beta x, y): the image of every registered base under the GLV endomorphism (see glv_split)
+__global__ void k_phi_bases(const uint8_t* __restrict__ src, size_t n, uint8_t* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine a = g1_load_affine(src + i * AFF_BYTES);
+  // beta in the device's Montgomery form (a * 2^390 with the radix-2^30 product core, a * 2^384 otherwise)
+#if GM_FQ30
+  constexpr uint32_t BETA[12] = {0x9c907181u, 0xef2f7921u, 0xb26574c3u, 0x1bcc91d7u, 0x191c3ebcu, 0x856e7b9au,
+                                 0x67fd6ffau, 0xbd16b0d2u, 0xeb0c0550u, 0x18c86532u, 0x6567dd7du, 0x09c6d485u};
+#else
+  constexpr uint32_t BETA[12] = {0x8671f071u, 0xcd03c9e4u, 0x1fcda5d2u, 0x5dab2246u, 0xd3851b95u, 0x587042afu,
+                                 0x01bacb9eu, 0x8eb60ebeu, 0x83d050d2u, 0x03f97d6eu, 0x54638741u, 0x18f02065u};
+#endif
+  Fq b;
+#pragma unroll
+  for (int k = 0; k < 12; k++) b.l[k] = BETA[k];
+#if GM_FQ30 == 1
+  a.x = fq_mul(a.x, fq30_unpack(b));
+#else
+  a.x = fq_mul(a.x, b);
+#endif
+  g1_store_affine(dst + i * AFF_BYTES, a);  // the identity (0, 0) maps to itself
+}
+
 // out[i] = k_i * base via 32 windows of 8 bits against a (32 x 256)-entry affine table
 __global__ __launch_bounds__(256) void k_fixed_base_table(const uint8_t* __restrict__ base, uint8_t* __restrict__ table) {
   // table[w][d] = d * 2^(8w) * base ; one thread per (w, d): double-and-add of the 13-bit... d*2^(8w)
@@ -1703,7 +1938,11 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const bool use_table = bases->table != nullptr && !C->msm_c_override && n >= tab_min && n < ((size_t)1 << ENTRY_W_SHIFT);
   const int c = use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
-  const int W = (256 + c - 1) / c;
+  // GLV (glv_split): two 128-bit digit strings per scalar over HALF the windows, the second one on phi(P)
+  static const bool sort_atomic_env0 = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
+  static const bool acc0_lds = getenv("GM_ACC0") ? !strcmp(getenv("GM_ACC0"), "lds") : (GM_FQ30 == 1);  // experimental accumulate kernel
+  const bool use_glv = bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && !acc0_lds && n <= ((size_t)1 << 26);
+  const int W = ((use_glv ? 128 : 256) + c - 1) / c;
   GM_CHECK(nparts == 1 || !use_table, GM_EINVAL, "msm: the fixed-base table path is not split into window groups");
   const int w_lo = part * W / nparts, Wg = (part + 1) * W / nparts - w_lo;  // this call's window group
   const uint32_t B = 1u << (c - 1);
@@ -1711,8 +1950,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const size_t nbuckets = (size_t)Wb * B;
   const uint8_t* d_bases = use_table ? bases->table : bases->d;
   const long long tab_stride = use_table ? (long long)bases->n : 0;
-  const uint64_t Nall = (uint64_t)n * (uint64_t)W;
-  const uint64_t N = (uint64_t)n * (uint64_t)(use_table ? W : Wg);  // entries of this window group
+  const uint64_t Nall = (uint64_t)n * (uint64_t)W * (use_glv ? 2u : 1u);
+  const uint64_t N = (uint64_t)n * (uint64_t)(use_table ? W : Wg) * (use_glv ? 2u : 1u);  // entries of this window group
   GM_CHECK(Nall < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)Nall);
 
   // affine tree levels in front of the XYZZ accumulation (see k_lvl_*): automatic = as many as leave ~4
@@ -1777,12 +2016,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     FlatGeom fg{};
     fg.c = c;
     fg.W = W;
+    fg.glv = use_glv ? 1 : 0;
     fg.B = B;
     for (int j = 0; j + 1 < W; j++) {
       const int b = c * j + c - 1;
       if (b < 256) fg.K[b >> 5] |= 1u << (b & 31);
     }
-    const dim3 grid((uint32_t)((n + 255) / 256), (uint32_t)W);
+    const dim3 grid((uint32_t)((n + 255) / 256), (uint32_t)(W * (use_glv ? 2 : 1)));
     pf.begin(part, PROF_DIGITS, st);
     hipLaunchKernelGGL(k_digits_flat<false>, grid, dim3(256), 0, st, sc, (uint32_t)n, mont, fg, ws.counts.as<uint32_t>(), (uint64_t*)nullptr, d_err);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets, ws.offsets.as<uint32_t>(),
@@ -1809,6 +2049,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     sg.W = W;
     sg.w_lo = use_table ? 0 : w_lo;
     sg.Wg = use_table ? W : Wg;
+    sg.glv = use_glv ? 1 : 0;
     sg.B = B;
     sg.shared = use_table ? 1 : 0;
     sg.FB = std::min<uint32_t>((uint32_t)(c - 1), 10u);
@@ -1827,9 +2068,9 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     pf.begin(part, PROF_DIGITS, st);
     hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcount, (uint64_t*)nullptr, d_err);
     hipLaunchKernelGGL(k_sort1_scan, dim3(1), dim3(1024), 0, st, gcount, sg.G, goff, gcursor, blkoff);
-    const size_t stage1_lds = (size_t)SORT_TS * sg.Wg * 8 + (size_t)3 * sg.G * 4 + 1024 * 4;
+    const size_t stage1_lds = (size_t)SORT_TS * sg.Wg * (use_glv ? 2 : 1) * 8 + (size_t)3 * sg.G * 4 + 1024 * 4;
     static const bool sort1_staged_env = !(getenv("GM_MSM_SORT1") && !strcmp(getenv("GM_MSM_SORT1"), "direct"));
-    if (sort1_staged_env && sg.Wg <= SORT1_STAGE_WMAX && stage1_lds <= 160 * 1024) {
+    if (sort1_staged_env && sg.Wg * (use_glv ? 2 : 1) <= SORT1_STAGE_WMAX && stage1_lds <= 160 * 1024) {
       static bool attr_set = false;
       if (!attr_set) {
         GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort1_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1962,13 +2203,12 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   }
   st = sts.acc;
   pf.begin(part, PROF_ACC0, st);
-  static const bool acc0_lds = getenv("GM_ACC0") ? !strcmp(getenv("GM_ACC0"), "lds") : (GM_FQ30 == 1);
   if (acc0_lds)
     hipLaunchKernelGGL(k_acc0_lds, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
   else
     hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
-                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
   pf.end(part, PROF_ACC0, st);
   if (sts.tail != st) {
     GM_HIP(hipEventRecord(ws.acc_ev, st));
@@ -2295,6 +2535,24 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
     GM_HIP(hipStreamSynchronize(C->stream));
   }
   out = std::move(b);
+  return GM_OK;
+}
+
+// gm_g1_bases_register / fixed_base_register / srs_register, when gm_set_msm_glv(1) is in force (off by default:
+// measured below): the GLV images next to the bases (one product per point, +96 bytes per point).  Calls on bases
+// without them take the one-string path.
+//   MI355X, one-call MSMs, GLV vs plain (ms): n = 2: 0.31 / 0.36, 2^12: 0.59 / 0.63, 2^16: 1.57 / 1.04, 2^18: 1.44 / 1.52,
+//   2^20: 3.91 / 3.67 (3.70 with L = 128), 2^22: 13.2 / 12.7, 2^24: 42.6 / 43.3.  Half the bucket sets halve k_group_sum's
+//   level 1 (0.45 -> 0.35 ms at 2^20) and the host's doublings, but the buckets are twice as dense, k_merge pays for
+//   it (0.16 -> 0.52 ms at the tuned chunk length), the gathers touch two arrays (k_acc0 +1.8 %) and the key doubles in
+//   HBM: no net gain where it matters.  Results are identical (tests/test_gpu_msm.py::test_msm_glv_same_results).
+int bases_build_phi(Context* C, Bases* b) {
+  static const bool glv_env = getenv("GM_GLV") && !strcmp(getenv("GM_GLV"), "1");
+  if (!(glv_env || C->msm_glv) || b->n == 0 || b->phi) return GM_OK;
+  GM_HIP(hipMalloc((void**)&b->phi, b->n * AFF_BYTES));
+  hipLaunchKernelGGL(k_phi_bases, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, C->stream, b->d, b->n, b->phi);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
 

@@ -130,6 +130,10 @@ int gm_set_msm_window(int c);
 /* Smallest pair count for which an MSM uses the fixed-base tables of its handle (default 2^17:
  * below that the MSM is latency-bound and few buckets win).  Tuning/test knob. */
 int gm_set_msm_table_min(size_t n);
+/* Tuning knob (default 0), read when bases are REGISTERED: also store phi(P_i) = (beta x_i, y_i) = lambda P_i and run
+ * MSMs on those bases with every scalar split as s = v1 + v2 lambda, |v1|, |v2| < 2^127 (GLV): half the windows, twice
+ * the base memory.  Same results; no net gain on MI355X as measured (gemini_amd/csrc/msm.hip: bases_build_phi). */
+int gm_set_msm_glv(int on);
 /* Tuning knob (default 0): run one-call MSMs of >= 2^17 pairs as two window groups pipelined over three streams.
  * Same results; slower on MI355X as measured (gemini_amd/csrc/msm.hip: msm_run_one). */
 int gm_set_msm_split(int on);

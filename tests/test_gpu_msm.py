@@ -456,3 +456,34 @@ def test_msm_window_group_split(gm, oracle):
     assert (split[0] == plain[0]).all() and (split[1] == plain[1]).all()
     assert_same_point(oracle, plain[0], oracle.msm_pippenger(bases.download(), sc))
     bases.free()
+
+
+@pytest.mark.parametrize("n", [1, 33, 1000, 5000, (1 << 14) + 1, (1 << 17) + 3])
+def test_msm_glv_same_results(gm, oracle, pyref, n):
+    """gm_set_msm_glv: bases registered with their images under the curve endomorphism, scalars split as
+    s = v1 + v2 lambda with |v1|, |v2| < 2^127 (half the windows, two digit strings per scalar).  Same group element as
+    the plain path and as the CPU Pippenger, incl. the scalars that sit on the decomposition's edges."""
+    lib = gm.capi.load()
+    R = pyref.R_MOD
+    lam = 0xAC45A4010001A40200000000FFFFFFFF
+    host = rand_bases(oracle, 93, n)
+    sc = oracle.random_fr(94, n)
+    special = [0, 1, R - 1, lam, lam - 1, lam + 1, R - lam, lam // 2, lam // 2 + 1, ((lam + 1) // 2) * lam % R, ((lam + 1) // 2 + 1) * lam % R, 1 << 254, R // 2]
+    sp = oracle.ints_to_limbs(special[: min(n, len(special))], 4)
+    sc[: len(sp)] = sp
+    plain = gm.G1Bases.register(host)
+    gm.capi.check(lib.gm_set_msm_glv(C.c_int(1)))
+    try:
+        glv = gm.G1Bases.register(host)
+    finally:
+        gm.capi.check(lib.gm_set_msm_glv(C.c_int(0)))
+    a, b = plain.msm_bigint(sc), glv.msm_bigint(sc)
+    assert (a == b).all()
+    assert_same_point(oracle, b, oracle.msm_pippenger(host, sc))
+    eq = np.repeat(oracle.random_fr(95, 1), n, axis=0)  # the benchmark instance's shape
+    assert (plain.msm_bigint(eq) == glv.msm_bigint(eq)).all()
+    # reversed / offset addressing (the stream key's view) goes through the same two arrays
+    if n > 40:
+        assert (plain.msm_bigint(sc[:30], offset=n - 5, reversed_=True) == glv.msm_bigint(sc[:30], offset=n - 5, reversed_=True)).all()
+    plain.free()
+    glv.free()
