@@ -487,3 +487,57 @@ def test_msm_glv_same_results(gm, oracle, pyref, n):
         assert (plain.msm_bigint(sc[:30], offset=n - 5, reversed_=True) == glv.msm_bigint(sc[:30], offset=n - 5, reversed_=True)).all()
     plain.free()
     glv.free()
+
+
+def test_msm_randomised_differential(gm, oracle):
+    """seeded fuzz over the addressing and input forms of the MSM entry points -- sizes straddling the window-rule and
+    sort-path thresholds, prefix / offset / reversed views of registered bases (CommitterKey::commit's prefix slice and
+    CommitterKeyStream's Reverse + advance_by, src/kzg/space.rs:38-40,291-296), canonical and Montgomery scalars, sparse
+    scalars (zeros, ones, small values: what real witnesses look like), identity bases, batches -- each against the CPU
+    Pippenger on the same pairs"""
+    from gemini_amd.fr import FrVec
+
+    rng = np.random.default_rng(20240928)
+    NB = 9000
+    host = rand_bases(oracle, 96, NB)
+    host[17] = 0  # identity records inside the key
+    host[4099] = 0
+    bases = gm.G1Bases.register(host)
+    sizes = [1, 2, 7, 64, 255, 256, 257, 1023, 1025, 2047, 2049, 4097, 8191, 8193]
+    for case in range(40):
+        n = int(sizes[case % len(sizes)] if case < 28 else rng.integers(1, NB // 2))
+        sc = oracle.random_fr(1000 + case, n)
+        kind = case % 4
+        if kind == 1:  # sparse: mostly 0 / 1 / small
+            mask = rng.integers(0, 4, size=n)
+            sc[mask == 0] = 0
+            sc[mask == 1] = 0
+            sc[mask == 1, 0] = 1
+            small = mask == 2
+            sc[small, 1:] = 0
+            sc[small, 0] &= np.uint64(0xFFFF)
+        reversed_ = bool(case & 1)
+        off = int(rng.integers(n - 1, NB)) if reversed_ else int(rng.integers(0, NB - n + 1))
+        idx = (off - np.arange(n)) if reversed_ else (off + np.arange(n))
+        want = oracle.msm_pippenger(host[idx], sc)
+        got = bases.msm_bigint(sc, offset=off, reversed_=reversed_)
+        assert_same_point(oracle, got, want)
+        assert is_normalised(oracle, got)
+        if kind in (2, 3):  # the same through a resident Montgomery vector, and as a member of a batch
+            v = FrVec.from_host(oracle.fr_to_mont(sc))
+            assert (bases.msm_vec(v, offset=off, reversed_=reversed_) == got).all()
+            if not reversed_ and off == 0:
+                pass
+            v.free()
+    # batches of mixed sizes over the key's prefix (CommitterKey::batch_commit, src/kzg/time.rs:98-107)
+    vecs, wants = [], []
+    for j, n in enumerate([5000, 1, 300, 4096, 77, 2048, 9000, 13]):
+        sc = oracle.random_fr(2000 + j, n)
+        vecs.append(FrVec.from_host(oracle.fr_to_mont(sc)))
+        wants.append(oracle.msm_pippenger(host[:n], sc))
+    got = bases.msm_vec_batch(vecs, [len(v) for v in vecs])
+    for g, w in zip(got, wants):
+        assert_same_point(oracle, g, w)
+    for v in vecs:
+        v.free()
+    bases.free()
