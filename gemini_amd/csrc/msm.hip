@@ -2411,8 +2411,10 @@ class HornerPool {
  private:
   HornerPool() {
     const char* e = getenv("GM_HOST_THREADS");
-    int want = e ? atoi(e) : 12;
     const int hw = (int)std::thread::hardware_concurrency();
+    // default: 12 threads on the many-core hosts of GPU nodes, never more than half the cores (the helpers poll
+    // for up to 20 ms once pre-woken; one process per GPU shares the host)
+    int want = e ? atoi(e) : std::min(12, std::max(2, hw / 2));
     if (hw > 0 && want > hw) want = hw;
     for (int i = 1; i < want; i++) workers_.emplace_back([this] { loop(); });
   }
