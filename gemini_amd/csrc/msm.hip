@@ -1736,7 +1736,7 @@ constexpr size_t MSM_SPLIT_MIN_N = (size_t)1 << 17;  // smaller calls are launch
 static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
                        bool normalize, uint64_t out_jac[18]);
 static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64_t step, const size_t* pair_offsets, const void* const* d_scalars,
-                            int mont, const size_t* ns, size_t k, bool normalize, uint64_t* out_jac);
+                            int mont, const size_t* ns, size_t k, bool normalize, uint64_t* out_jac, const int64_t* firsts = nullptr);
 
 // One MSM is an enqueue (every kernel + the async copy of the window bit-planes to pinned memory, no host
 // wait) and a finish (wait for the copy, Horner over the bit positions on the host).  Splitting them lets
@@ -1834,21 +1834,20 @@ static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t st
 // (ii) small calls (<= MSM_SMALL_N pairs) are latency-bound chains of a dozen tiny launches, so they go
 // round-robin to MSM_SMALL_LANES extra workspaces with their own streams and run side by side -- the
 // folding commitments of the tensor check are ~20 MSMs of sizes n/2, n/4, ..., 1.
-static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64_t step, const size_t* pair_offsets, const void* const* d_scalars,
-                            int mont, const size_t* ns, size_t k, bool normalize, uint64_t* out_jac);
 int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, const void* const* d_scalars, int mont, const size_t* ns,
                   size_t k, bool normalize, uint64_t* out_jac) {
   return msm_run_batch_at(C, bases, first, step, nullptr, d_scalars, mont, ns, k, normalize, out_jac);
 }
 // pair_offsets[j] (optional): call j starts at base first + step * pair_offsets[j]
+// firsts[j] (optional): call j starts at base firsts[j] instead of `first` (herring: even / odd halves of one array)
 static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64_t step, const size_t* pair_offsets, const void* const* d_scalars,
-                            int mont, const size_t* ns, size_t k, bool normalize, uint64_t* out_jac) {
+                            int mont, const size_t* ns, size_t k, bool normalize, uint64_t* out_jac, const int64_t* firsts) {
   const size_t CH = (size_t)1 << 26;
   bool pipelined = !C->prof.on;
   for (size_t j = 0; j < k; j++) pipelined = pipelined && ns[j] <= CH;
   if (!pipelined) {
     for (size_t j = 0; j < k; j++) {
-      int rc = msm_run(C, bases, first + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont, ns[j], normalize,
+      int rc = msm_run(C, bases, (firsts ? firsts[j] : first) + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont, ns[j], normalize,
                        out_jac + 18 * j);
       if (rc) return rc;
     }
@@ -1906,7 +1905,8 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     MsmWorkspace& ws = lane > 0 ? C->msm_small[lane - 1] : (lane < 0 ? C->msm_b : C->msm);
     hipStream_t st = lane > 0 ? C->small_stream[lane - 1] : (lane < 0 ? C->stream_b : C->stream);
     if (st != C->stream) GM_HIP(hipStreamWaitEvent(st, C->start_ev, 0));  // scalars produced on the main stream
-    int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, first + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont, ns[j], hslot, &e.P);
+    int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, (firsts ? firsts[j] : first) + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont,
+                         ns[j], hslot, &e.P);
     if (rc) return fail(rc);
     q.push_back(e);
   }
@@ -2610,7 +2610,7 @@ int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const 
   GM_HIP(hipMalloc((void**)&H->f[1], ((nf + 1) / 2) * AFF_BYTES));
   if ((rc = C->pool.alloc(ng * 32, (void**)&H->g[0], &H->gcap[0]))) return rc;
   if ((rc = C->pool.alloc(((ng + 1) / 2) * 32, (void**)&H->g[1], &H->gcap[1]))) return rc;
-  if ((rc = C->pool.alloc(((ng + 1) / 2) * 32 + 32, (void**)&H->tmp, &H->tmpcap))) return rc;
+  if ((rc = C->pool.alloc(3 * ((((ng + 1) / 2) + 1) * 32), (void**)&H->tmp, &H->tmpcap))) return rc;  // three compacted scalar vectors
   GM_HIP(hipMemcpyAsync(H->g[0], g_mont, ng * 32, hipMemcpyHostToDevice, C->stream));
   GM_HIP(hipStreamSynchronize(C->stream));
   memcpy(H->twist, twist, 32);
@@ -2671,16 +2671,24 @@ int hg1_round(Context* C, HerringG1* H, const uint64_t* challenge, uint64_t a_ja
   fb.n = H->nf;
   const uint8_t* g = H->g[H->cur];
   const size_t fe = (H->nf + 1) / 2, fo = H->nf / 2, ge = (H->ng + 1) / 2, go = H->ng / 2;
-  auto ip = [&](int f_first, size_t fcount, size_t g_first, size_t gcount, uint64_t out[18]) -> int {
-    const size_t cnt = fcount < gcount ? fcount : gcount;  // zip
-    int r2 = fr_stride_raw(C, g, g_first, 2, cnt, H->tmp);
-    if (r2) return r2;
-    return msm_run(C, &fb, f_first, 2, H->tmp, 1, cnt, true, out);
-  };
-  uint64_t b1[18], b2[18];
-  if ((rc = ip(0, fe, 0, ge, a_jac))) return rc;
-  if ((rc = ip(0, fe, 1, go, b1))) return rc;
-  if ((rc = ip(1, fo, 0, ge, b2))) return rc;
+  // a = <f_even, g_even>, b = <f_even, g_odd> + <f_odd, g_even>: three strided MSMs over the same point array, issued
+  // as ONE batch (these are small calls -- 2^10 points in the reference's tests -- and run side by side on the small lanes)
+  const size_t slot = (ge + 1) * 32;  // bytes per compacted scalar vector inside H->tmp
+  const int64_t firsts[3] = {0, 0, 1};
+  const size_t g_first[3] = {0, 1, 0};
+  const size_t fcount[3] = {fe, fe, fo}, gcount[3] = {ge, go, ge};
+  size_t cnts[3];
+  const void* sc[3];
+  for (int j = 0; j < 3; j++) {
+    cnts[j] = fcount[j] < gcount[j] ? fcount[j] : gcount[j];  // zip
+    uint8_t* dst = H->tmp + (size_t)j * slot;
+    if ((rc = fr_stride_raw(C, g, g_first[j], 2, cnts[j], dst))) return rc;
+    sc[j] = dst;
+  }
+  uint64_t res[3 * 18];
+  if ((rc = msm_run_batch_at(C, &fb, 0, 2, nullptr, sc, 1, cnts, 3, true, res, firsts))) return rc;
+  memcpy(a_jac, res, 18 * sizeof(uint64_t));
+  const uint64_t *b1 = res + 18, *b2 = res + 36;
   gmh::G1 bsum = gmh::G1::from_limbs(b1).add(gmh::G1::from_limbs(b2)).normalized();
   bsum.to_limbs(b_jac);
   H->round += 1;
