@@ -357,6 +357,33 @@ def main():
                 "bases_and_scalars_from_host_Mscalar_per_s": round(n / t_o / 1e6, 2), "bases_and_scalars_from_host_ms": round(t_o * 1e3, 3),
                 "note": "pageable numpy buffers; PCIe-inclusive, reported for DESIGN.md only"}
         del hb_full
+        # a stream larger than one call: 2^23 pairs resident in page-locked HOST memory through two 2^20-pair device
+        # slots (gm_g1_msm_stream_*: copy of chunk i + 1 under the kernels of chunk i) -- the bounded-memory form
+        from gemini_amd.msm import HostMsmStream, pinned_empty
+
+        ns = 1 << 23
+        big = gm.G1Bases.fixed_base(g_aff, uniform_fr(rng, ns))
+        pb, ps = pinned_empty((ns, 12)), pinned_empty((ns, 4))
+        pb[:] = big.download()
+        ps[:] = uniform_fr(rng, ns)
+        d_big = torch.from_numpy(np.asarray(ps).view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        r_res = big.msm_device(d_big.data_ptr(), ns, mont=False)
+        st = HostMsmStream(1 << 20)
+        t_s = 1e9
+        for _ in range(2):
+            barrier()
+            tp0 = time.perf_counter()
+            st.add(pb, ps)
+            r_s = st.finalize()
+            t_s = min(t_s, time.perf_counter() - tp0)
+        st.free()
+        assert (r_s == r_res).all(), "streamed MSM differs from the resident one"
+        pcie["streamed_2p23_pairs_from_pinned_host_Mscalar_per_s"] = round(ns / t_s / 1e6, 2)
+        pcie["streamed_ms"] = round(t_s * 1e3, 2)
+        pcie["streamed_note"] = "bases AND scalars host-resident (1 GiB), 2 device slots of 2^20 pairs, same result as the resident one-call MSM"
+        big.free()
+        del pb, ps, d_big
     stage_names = ["digits_hist", "scan", "scatter", "acc0", "merge", "reduce", "sc_round"]
     # per CALL: a one-call MSM of >= 2^17 pairs runs as two window groups, so each stage is launched twice per step
     stages = {k: (ms[i] / args.steps if cnt[i] else None) for i, k in enumerate(stage_names)}

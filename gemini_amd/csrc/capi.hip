@@ -178,6 +178,10 @@ int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a[4
 int sp_final(Context* C, SpaceProver* S, uint64_t f0[4], uint64_t g0[4], int* has);
 int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle);
 int fr_stride_raw(Context* C, const uint8_t* in, size_t start, size_t stride, size_t count, uint8_t* out);
+int msm_stream_create(Context* C, uint64_t bases_handle, size_t offset, int reversed, size_t chunk, size_t stride, int mont, uint64_t* handle);
+void msm_stream_destroy(Context* C, MsmStream* S);
+int msm_stream_add(Context* C, MsmStream* S, const void* bases_host, const void* scalars_host, size_t n);
+int msm_stream_finalize(Context* C, MsmStream* S, uint64_t out_jac[18], size_t* pairs);
 int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out);
 int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out);
 int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out);
@@ -242,6 +246,7 @@ void gm_shutdown(void) {
   }
   for (auto& kv : C->vecs)
     if (kv.second->d) (void)hipFree(kv.second->d);
+  for (auto& kv : C->msm_streams) msm_stream_destroy(C, kv.second.get());
   C->pool.release_all();
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
   for (auto& kv : C->space_provers) sp_destroy(C, kv.second.get());
@@ -393,6 +398,25 @@ static int msm_host_scalars(Context* C, Bases* b, size_t offset, int reversed, c
 int gm_g1_msm(const void* bases, size_t base_stride, const uint64_t* scalars, size_t n, uint64_t out_jac[18]) {
   GM_CTX();
   GM_CHECK(out_jac != nullptr && ((bases != nullptr && scalars != nullptr) || n == 0), GM_EINVAL, "msm: null pointer");
+  if (n >= ((size_t)1 << 22)) {
+    // large one-shot calls stream: the copy of chunk i + 1 (and the conversion of its bases) under the kernels of
+    // chunk i, O(chunk) device memory.  The sum does not depend on the cut (tests/test_gpu_msm_stream.py).
+    uint64_t h = 0;
+    int rc = msm_stream_create(C, 0, 0, 0, n >= ((size_t)1 << 24) ? (size_t)1 << 22 : (size_t)1 << 20, base_stride, 0, &h);
+    if (rc) return rc;
+    std::unique_ptr<MsmStream> S;
+    {
+      std::lock_guard<std::mutex> lk(C->mu);
+      auto it = C->msm_streams.find(h);
+      S = std::move(it->second);
+      C->msm_streams.erase(it);
+    }
+    rc = msm_stream_add(C, S.get(), bases, scalars, n);
+    if (!rc) rc = msm_stream_finalize(C, S.get(), out_jac, nullptr);
+    GM_MSM_LOCK(C);
+    msm_stream_destroy(C, S.get());
+    return rc;
+  }
   std::unique_ptr<Bases> b;
   int rc = bases_from_host(C, bases, base_stride, n, b);
   if (rc) return rc;
@@ -452,6 +476,64 @@ int gm_g1_msm_d_partial(uint64_t bases_handle, size_t offset, int reversed, cons
   GM_CHECK(b != nullptr, GM_EHANDLE, "msm_d_partial: unknown bases handle %llu", (unsigned long long)bases_handle);
   GM_CHECK(out_jac != nullptr && (d_scalars != nullptr || n == 0), GM_EINVAL, "msm_d_partial: null pointer");
   return msm_run(C, b, (int64_t)offset, reversed ? -1 : 1, d_scalars, mont, n, false, out_jac);
+}
+
+// ---- streaming MSM over host-resident pairs (ChunkedPippenger / msm_chunks) ------------------------
+static MsmStream* find_msm_stream(Context* C, uint64_t h) {
+  std::lock_guard<std::mutex> lk(C->mu);
+  auto it = C->msm_streams.find(h);
+  return it == C->msm_streams.end() ? nullptr : it->second.get();
+}
+int gm_g1_msm_stream_new(size_t chunk_pairs, size_t base_stride, int scalars_mont, uint64_t* stream) {
+  GM_CTX();
+  GM_CHECK(stream != nullptr, GM_EINVAL, "msm_stream_new: null pointer");
+  return msm_stream_create(C, 0, 0, 0, chunk_pairs, base_stride, scalars_mont, stream);
+}
+int gm_g1_msm_stream_new_h(uint64_t bases_handle, size_t offset, int reversed, size_t chunk_pairs, int scalars_mont, uint64_t* stream) {
+  GM_CTX();
+  GM_CHECK(stream != nullptr, GM_EINVAL, "msm_stream_new_h: null pointer");
+  GM_CHECK(find_bases(bases_handle) != nullptr, GM_EHANDLE, "msm_stream_new_h: unknown bases handle %llu", (unsigned long long)bases_handle);
+  return msm_stream_create(C, bases_handle, offset, reversed, chunk_pairs, 96, scalars_mont, stream);
+}
+int gm_g1_msm_stream_add(uint64_t stream, const void* bases_host, const void* scalars_host, size_t n) {
+  GM_CTX();
+  MsmStream* S = find_msm_stream(C, stream);
+  GM_CHECK(S != nullptr, GM_EHANDLE, "msm_stream_add: unknown stream handle %llu", (unsigned long long)stream);
+  GM_CHECK(n == 0 || (scalars_host != nullptr && (bases_host != nullptr || S->bases_handle != 0)), GM_EINVAL, "msm_stream_add: null pointer");
+  return msm_stream_add(C, S, bases_host, scalars_host, n);
+}
+int gm_g1_msm_stream_finalize(uint64_t stream, uint64_t out_jac[18], size_t* pairs_or_null) {
+  GM_CTX();
+  MsmStream* S = find_msm_stream(C, stream);
+  GM_CHECK(S != nullptr, GM_EHANDLE, "msm_stream_finalize: unknown stream handle %llu", (unsigned long long)stream);
+  GM_CHECK(out_jac != nullptr, GM_EINVAL, "msm_stream_finalize: null pointer");
+  return msm_stream_finalize(C, S, out_jac, pairs_or_null);
+}
+int gm_g1_msm_stream_free(uint64_t stream) {
+  GM_CTX();
+  std::unique_ptr<MsmStream> p;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->msm_streams.find(stream);
+    GM_CHECK(it != C->msm_streams.end(), GM_EHANDLE, "msm_stream_free: unknown handle %llu", (unsigned long long)stream);
+    p = std::move(it->second);
+    C->msm_streams.erase(it);
+  }
+  GM_MSM_LOCK(C);
+  msm_stream_destroy(C, p.get());
+  return GM_OK;
+}
+// page-locked host memory for the streams: copied by DMA at the PCIe rate instead of through the runtime's staging buffer
+int gm_host_alloc(size_t bytes, void** p) {
+  GM_CTX();
+  GM_CHECK(p != nullptr, GM_EINVAL, "host_alloc: null pointer");
+  GM_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+  return GM_OK;
+}
+int gm_host_free(void* p) {
+  GM_CTX();
+  if (p) GM_HIP(hipHostFree(p));
+  return GM_OK;
 }
 
 int gm_g1_sum(const uint64_t* points_jac, size_t k, uint64_t out_jac[18]) {

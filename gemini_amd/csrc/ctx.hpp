@@ -127,6 +127,41 @@ struct HerringG1 {
   std::mutex mu;
 };
 
+// ChunkedPippenger / msm_chunks over HOST-resident pairs (src/kzg/msm/stream_pippenger.rs:209-272, src/kzg/space.rs:22-55):
+// the device holds two chunks; chunk i + 1 is copied in while the MSM of chunk i runs (msm.hip: msm_stream_*)
+struct MsmWorkspace;
+// One MSM between its enqueue (all kernels + the async copy of the window bit-planes) and its finish (host Horner)
+struct MsmPending {
+  MsmWorkspace* ws = nullptr;  // the workspace (and stream) the call was enqueued on
+  int slot = 0;
+  bool empty = true;
+  int Wb = 0, c = 0, m = 0;
+  uint32_t nbits = 0, wf[3] = {0, 0, 0};
+  size_t plane_off[3] = {0, 0, 0};
+  size_t plane_count = 0;
+};
+struct MsmStreamSlot {
+  uint8_t *raw = nullptr, *packed = nullptr, *scalars = nullptr;  // staged records, device-form bases, scalars
+  size_t raw_cap = 0, packed_cap = 0, scalars_cap = 0;
+  hipEvent_t copied;
+  bool have_ev = false;
+  bool inflight = false;
+  MsmPending P;
+};
+struct MsmStream {
+  std::mutex mu;
+  size_t chunk = 0, stride = 96;
+  int mont = 0;
+  uint64_t bases_handle = 0;  // 0: the pairs carry their bases; else scalars only, against registered bases
+  int64_t base0 = 0, next_base = 0, step = 1;
+  MsmStreamSlot s[2];
+  int cur = 0;
+  size_t fill = 0, total = 0;
+  hipStream_t copy = nullptr;
+  uint64_t acc[18];  // running sum (Jacobian, host)
+  bool acc_set = false;
+};
+
 constexpr int MSM_SMALL_LANES = 4;
 struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
@@ -185,6 +220,7 @@ struct Context {
   std::unordered_map<uint64_t, std::unique_ptr<SparseMatrix>> matrices;
   std::unordered_map<uint64_t, std::unique_ptr<SpaceProver>> space_provers;
   std::unordered_map<uint64_t, std::unique_ptr<HerringG1>> herring_g1;
+  std::unordered_map<uint64_t, std::unique_ptr<MsmStream>> msm_streams;
   std::unordered_map<uint64_t, std::unique_ptr<IdxVec>> indices;
   MsmWorkspace msm;
   // extra workspaces + streams for the small calls of a batch (msm_run_batch)

@@ -1741,15 +1741,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
 // One MSM is an enqueue (every kernel + the async copy of the window bit-planes to pinned memory, no host
 // wait) and a finish (wait for the copy, Horner over the bit positions on the host).  Splitting them lets
 // a batch of MSMs overlap the host tail of call i with the kernels of call i+1 (msm_run_batch).
-struct MsmPending {
-  MsmWorkspace* ws = nullptr;  // the workspace (and stream) the call was enqueued on
-  int slot = 0;
-  bool empty = true;
-  int Wb = 0, c = 0, m = 0;
-  uint32_t nbits = 0, wf[3] = {0, 0, 0};
-  size_t plane_off[3] = {0, 0, 0};
-  size_t plane_count = 0;
-};
+// (struct MsmPending: ctx.hpp)
 // A call may be enqueued in `nparts` window groups (part p owns windows [p W / nparts, (p + 1) W / nparts)), each with
 // its own workspace; `sts` names the streams of its three phases -- sort, accumulate, merge + reduce + copy-out.
 struct MsmStreams {
@@ -2595,6 +2587,174 @@ static int build_fixed_table(Context* C, const uint64_t base_affine[12], uint8_t
 // ---- herring TimeProver over G1Module (src/herring/time_prover.rs:42-137, module.rs:81-102) ------
 int fr_stride_raw(Context* C, const uint8_t* in, size_t start, size_t stride, size_t count, uint8_t* out);
 int fr_fold_raw(Context* C, const uint8_t* f, size_t n, const uint64_t r[4], uint8_t* out);
+
+// ------------------------------------------------------------------------------------------
+// ChunkedPippenger / msm_chunks over HOST-resident pairs: bounded device memory
+//
+// The reference's streaming MSMs (ChunkedPippenger, src/kzg/msm/stream_pippenger.rs:209-272; msm_chunks,
+// src/kzg/space.rs:22-55) collect `max_msm_buffer` pairs from the streams, run one MSM, add it to the running
+// sum and start over: memory is O(buffer), not O(stream).  Here the buffer is a pair of device slots of
+// `chunk` pairs each.  Pairs arrive from host memory in blocks of any size (msm_stream_add); they are copied
+// straight into the current slot on a copy stream, and when the slot is full its MSM is enqueued on one of the
+// two full-size lanes while the host goes on copying the next block into the other slot -- H2D copy of chunk
+// i + 1 under the kernels of chunk i, host Horner of chunk i - 1 under both.  The sum does not depend on where
+// the stream is cut (tests/test_gpu_msm_stream.py), so results equal the one-call MSM of the whole stream.
+// Device memory: 2 slots x chunk x (stride + 96 + 32) bytes + the MSM workspace of one chunk per lane; the
+// stream itself (SRS and polynomial larger than HBM) stays on the host.
+//
+// No MSM stays in flight on the shared lane workspaces when an API call returns (another thread may use them
+// next): add() drains what it enqueued before returning, so the overlap is within one add() call -- push
+// blocks of several chunks.  Pinned host buffers (gm_host_alloc) are copied by DMA; pageable ones go through
+// the runtime's staging copy at a fraction of the PCIe rate.
+// ------------------------------------------------------------------------------------------
+static void msm_stream_reset(MsmStream* S) {
+  S->acc_set = false;
+  S->fill = 0;
+  S->total = 0;
+  S->cur = 0;
+  S->next_base = S->base0;
+}
+static int msm_stream_drain(Context* C, MsmStream* S, MsmStreamSlot& sl) {
+  if (!sl.inflight) return GM_OK;
+  sl.inflight = false;
+  uint64_t part[18];
+  int rc = msm_finish(C, sl.P, false, part);
+  if (rc) return rc;
+  if (!S->acc_set) {
+    memcpy(S->acc, part, sizeof(part));
+    S->acc_set = true;
+  } else {
+    gmh::G1::from_limbs(S->acc).add(gmh::G1::from_limbs(part)).to_limbs(S->acc);
+  }
+  return GM_OK;
+}
+
+static int msm_stream_flush(Context* C, MsmStream* S) {
+  MsmStreamSlot& sl = S->s[S->cur];
+  const size_t m = S->fill;
+  if (m == 0) return GM_OK;
+  MsmWorkspace& ws = S->cur == 0 ? C->msm : C->msm_b;
+  hipStream_t st = S->cur == 0 ? C->stream : C->stream_b;
+  Bases own;
+  const Bases* b = &own;
+  int64_t first = 0, step = 1;
+  if (S->bases_handle) {
+    b = find_bases(S->bases_handle);
+    GM_CHECK(b != nullptr, GM_EHANDLE, "msm_stream: the bases (handle %llu) were freed under the stream", (unsigned long long)S->bases_handle);
+    first = S->next_base;
+    step = S->step;
+    S->next_base += step * (int64_t)m;
+  } else {
+    hipLaunchKernelGGL(k_pack_bases, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, S->copy, sl.raw, S->stride, m, sl.packed);
+    own.d = sl.packed;
+    own.n = m;
+  }
+  GM_HIP(hipEventRecord(sl.copied, S->copy));
+  GM_HIP(hipStreamWaitEvent(st, sl.copied, 0));
+  int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, b, first, step, sl.scalars, S->mont, m, 0, &sl.P);
+  if (rc) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  sl.inflight = true;
+  S->total += m;
+  S->fill = 0;
+  S->cur ^= 1;
+  // the stage timers hold one call at a time
+  if (C->prof.on) return msm_stream_drain(C, S, sl);
+  return GM_OK;
+}
+
+int msm_stream_create(Context* C, uint64_t bases_handle, size_t offset, int reversed, size_t chunk, size_t stride, int mont, uint64_t* handle) {
+  GM_CHECK(chunk >= 1 && chunk <= ((size_t)1 << 26), GM_EINVAL, "msm_stream: chunk of %zu pairs outside [1, 2^26]", chunk);
+  GM_CHECK(stride >= 96 && (stride % 8) == 0, GM_EINVAL, "msm_stream: stride %zu must be >= 96 and a multiple of 8", stride);
+  auto S = std::make_unique<MsmStream>();
+  S->chunk = chunk;
+  S->stride = stride;
+  S->mont = mont ? 1 : 0;
+  S->bases_handle = bases_handle;
+  S->base0 = S->next_base = (int64_t)offset;
+  S->step = reversed ? -1 : 1;
+  GM_HIP(hipStreamCreateWithFlags(&S->copy, hipStreamNonBlocking));
+  std::lock_guard<std::mutex> lk(C->mu);
+  *handle = C->next_handle++;
+  C->msm_streams[*handle] = std::move(S);
+  return GM_OK;
+}
+
+void msm_stream_destroy(Context* C, MsmStream* S) {
+  if (S->copy) (void)hipStreamSynchronize(S->copy);
+  for (auto& sl : S->s) {
+    if (sl.inflight) {
+      uint64_t part[18];
+      (void)msm_finish(C, sl.P, false, part);
+    }
+    if (C) {
+      C->pool.free(sl.raw, sl.raw_cap);
+      C->pool.free(sl.packed, sl.packed_cap);
+      C->pool.free(sl.scalars, sl.scalars_cap);
+    }
+    if (sl.have_ev) (void)hipEventDestroy(sl.copied);
+  }
+  if (S->copy) (void)hipStreamDestroy(S->copy);
+}
+
+int msm_stream_add(Context* C, MsmStream* S, const void* bases_host, const void* scalars_host, size_t n) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_MSM_LOCK(C);
+  const uint8_t* bp = reinterpret_cast<const uint8_t*>(bases_host);
+  const uint8_t* sp = reinterpret_cast<const uint8_t*>(scalars_host);
+  const bool own_bases = S->bases_handle == 0;
+  int rc = GM_OK;
+  while (n && !rc) {
+    MsmStreamSlot& sl = S->s[S->cur];
+    if ((rc = msm_stream_drain(C, S, sl))) break;  // the MSM that reads this slot's buffers
+    if (!sl.have_ev) {
+      GM_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+      sl.have_ev = true;
+    }
+    if (!sl.scalars) {
+      if ((rc = C->pool.alloc(S->chunk * 32 + 32, (void**)&sl.scalars, &sl.scalars_cap))) break;
+      if (own_bases) {
+        if ((rc = C->pool.alloc(S->chunk * S->stride, (void**)&sl.raw, &sl.raw_cap))) break;
+        if ((rc = C->pool.alloc(S->chunk * AFF_BYTES, (void**)&sl.packed, &sl.packed_cap))) break;
+      }
+    }
+    const size_t take = std::min(n, S->chunk - S->fill);
+    if (own_bases) GM_HIP(hipMemcpyAsync(sl.raw + S->fill * S->stride, bp, take * S->stride, hipMemcpyHostToDevice, S->copy));
+    GM_HIP(hipMemcpyAsync(sl.scalars + S->fill * 32, sp, take * 32, hipMemcpyHostToDevice, S->copy));
+    S->fill += take;
+    n -= take;
+    if (own_bases) bp += take * S->stride;
+    sp += take * 32;
+    if (S->fill == S->chunk) rc = msm_stream_flush(C, S);
+  }
+  // the caller's buffers are free again on return, and nothing of this stream stays on the shared lanes
+  (void)hipStreamSynchronize(S->copy);
+  for (auto& sl : S->s) {
+    int r2 = msm_stream_drain(C, S, sl);
+    if (!rc) rc = r2;
+  }
+  if (rc) msm_stream_reset(S);  // a failed add leaves an empty stream, not a partial sum
+  return rc;
+}
+
+int msm_stream_finalize(Context* C, MsmStream* S, uint64_t out_jac[18], size_t* pairs) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_MSM_LOCK(C);
+  int rc = msm_stream_flush(C, S);
+  for (auto& sl : S->s) {
+    int r2 = msm_stream_drain(C, S, sl);
+    if (!rc) rc = r2;
+  }
+  if (!rc) {
+    gmh::G1 r = S->acc_set ? gmh::G1::from_limbs(S->acc).normalized() : gmh::G1::identity();
+    r.to_limbs(out_jac);
+    if (pairs) *pairs = S->total;
+  }
+  msm_stream_reset(S);  // ready for the next stream (the reference's finalize consumes the object)
+  return rc;
+}
 
 int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist[4],
                uint64_t* handle) {

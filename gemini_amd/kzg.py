@@ -160,7 +160,9 @@ class CommitterKeyStream:
     # `min_device_chunk` pairs are merged into one device MSM (2^20 / 26 = 40 k-pair flushes would each cost a
     # latency-bound launch chain: snark -i 26 elastic 4.4 s instead of 1.46 s).  Pass min_device_chunk=1 to cut
     # literally where the caller says (tests/test_gpu_snark.py does, at logn 22 with max_msm_buffer 2^20).
-    DEFAULT_MIN_DEVICE_CHUNK = 1 << 22
+    # The floor is 2^26 pairs (2 GB of scalars, ~15 GB of sort workspace): an MSM gets cheaper per pair up to there
+    # (wider windows, one launch chain) -- snark -i 26 elastic 0.84 s with a 2^22 floor, 0.72 s with 2^24, 0.67 s with 2^26.
+    DEFAULT_MIN_DEVICE_CHUNK = 1 << 26
 
     def __init__(self, powers_of_g: G1Bases, max_eval_points: int, powers_of_g2=None, min_device_chunk: int = None):
         self.powers_of_g = powers_of_g
@@ -201,7 +203,11 @@ class CommitterKeyStream:
         return result
 
     def commit(self, polynomial_stream) -> np.ndarray:
-        """:169-177 -> msm_chunks (:22-55): skip len(powers) - len(poly) bases, 2^20-pair MSMs, summed"""
+        """:169-177 -> msm_chunks (:22-55): skip len(powers) - len(poly) bases, 2^20-pair MSMs, summed.
+        A HOST-resident coefficient stream (numpy array) of 2^22 or more elements is not uploaded whole: it goes
+        through two 2^20-element device slots (HostMsmStream), copy under compute."""
+        if isinstance(polynomial_stream, np.ndarray) and len(polynomial_stream) >= (1 << 22) and type(self) is CommitterKeyStream:
+            return self._commit_host_stream(polynomial_stream)
         v, tmp = _as_vec(polynomial_stream)
         try:
             assert self._n() >= len(v)
@@ -209,6 +215,19 @@ class CommitterKeyStream:
         finally:
             if tmp:
                 v.free()
+
+    def _commit_host_stream(self, coeffs_be: np.ndarray, chunk: int = 1 << 20) -> np.ndarray:
+        from .msm import HostMsmStream
+
+        n = self._n()
+        assert n >= len(coeffs_be)
+        # stream position k pairs with time-order power n - 1 - (n - len) - k = len - 1 - k: walk down from len - 1
+        st = HostMsmStream(chunk, mont=True, bases=self.powers_of_g, offset=len(coeffs_be) - 1, reversed_=True)
+        try:
+            st.add(None, coeffs_be)
+            return st.finalize()
+        finally:
+            st.free()
 
     def open(self, polynomial_stream, alpha_mont, max_msm_buffer: int):
         """:95-125 -> (evaluation, proof): pairs (base_i, previous_i), previous_{i+1} = previous_i*alpha + c_i"""
@@ -310,3 +329,31 @@ class CommitterKeyStream:
         s.free()
         batched.free()
         return remainders, proof
+
+
+class HostCommitterKeyStream:
+    """A committer key whose powers stay in HOST memory, in stream order (`Reverse(powers_of_g)`: highest power first,
+    src/kzg/space.rs:287-296) -- for keys that do not fit in HBM or are not worth registering.  commit() is msm_chunks
+    (src/kzg/space.rs:22-55, 169-177) over a HostMsmStream: both streams pass through two device slots of `chunk` pairs
+    (copy of chunk i + 1 under the kernels of chunk i), device memory is O(chunk), the result equals
+    CommitterKey.commit of the same polynomial.  Page-locked arrays (gemini_amd.msm.pinned_empty) stream several times
+    faster than pageable ones."""
+
+    def __init__(self, powers_of_g_stream: np.ndarray, max_eval_points: int, chunk: int = 1 << 20):
+        self.powers_of_g = capi.u64(powers_of_g_stream)
+        self._max_eval_points = max_eval_points
+        self.chunk = chunk
+
+    def commit(self, polynomial_stream: np.ndarray) -> np.ndarray:
+        from .msm import HostMsmStream
+
+        sc = capi.u64(polynomial_stream).reshape(-1, 4)
+        assert len(self.powers_of_g) >= len(sc)
+        if len(sc) == 0:
+            return g1_zero()
+        st = HostMsmStream(self.chunk, mont=True, base_words=self.powers_of_g.shape[1])
+        try:
+            st.add(self.powers_of_g[len(self.powers_of_g) - len(sc):], sc)  # align the streams (:36-40)
+            return st.finalize()
+        finally:
+            st.free()

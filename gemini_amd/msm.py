@@ -163,35 +163,130 @@ class VariableBaseMSM:
         return VariableBaseMSM.msm_unchecked(bases, sc), None
 
 
+class _PinnedBlock:
+    def __init__(self, nbytes: int):
+        self.p = C.c_void_p()
+        capi.check(capi.load().gm_host_alloc(C.c_size_t(nbytes), C.byref(self.p)))
+
+    def __del__(self):
+        try:
+            if self.p:
+                capi.load().gm_host_free(self.p)
+                self.p = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.uint64) -> np.ndarray:
+    """numpy array over page-locked host memory (gm_host_alloc): HostMsmStream copies it by DMA at the PCIe rate
+    instead of through the runtime's staging buffer.  Freed when the array (and every view of it) is gone."""
+    capi.ensure_init()
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    blk = _PinnedBlock(max(nbytes, 1))
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(blk.p.value)
+    buf._gm_block = blk  # keeps the allocation alive as long as numpy holds the buffer
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+
+class HostMsmStream:
+    """gm_g1_msm_stream_*: an MSM over HOST-resident pairs in bounded device memory -- two device slots of `chunk`
+    pairs, the copy of chunk i + 1 under the kernels of chunk i.  The MI355X form of the reference's streaming
+    MSMs (ChunkedPippenger, src/kzg/msm/stream_pippenger.rs:209-272; msm_chunks, src/kzg/space.rs:22-55) for keys
+    and polynomials that do not fit (or are not wanted) in HBM.
+
+    HostMsmStream(chunk, mont=False)                         pairs carry their bases (n x 12 or n x 13 uint64 records)
+    HostMsmStream(chunk, bases=G1Bases, offset, reversed_)   scalars only, against registered bases"""
+
+    def __init__(self, chunk: int, mont: bool = False, bases: "G1Bases | None" = None, offset: int = 0, reversed_: bool = False, base_words: int = 12):
+        capi.ensure_init()
+        h = C.c_uint64()
+        self.bases = bases
+        self.base_words = base_words
+        if bases is None:
+            capi.check(capi.load().gm_g1_msm_stream_new(C.c_size_t(chunk), C.c_size_t(base_words * 8), C.c_int(int(mont)), C.byref(h)))
+        else:
+            capi.check(capi.load().gm_g1_msm_stream_new_h(C.c_uint64(bases.handle), C.c_size_t(offset), C.c_int(int(reversed_)), C.c_size_t(chunk),
+                                                          C.c_int(int(mont)), C.byref(h)))
+        self.handle = h.value
+
+    def add(self, bases, scalars):
+        """push a block of pairs (bases: (n, base_words) uint64 or None for a stream over registered bases; scalars:
+        (n, 4) uint64).  Blocks of several chunks overlap copy and compute; the arrays are free again on return."""
+        sc = np.ascontiguousarray(capi.u64(scalars).reshape(-1, 4))
+        n = len(sc)
+        if self.bases is None:
+            b = np.ascontiguousarray(capi.u64(bases).reshape(-1, self.base_words))
+            assert len(b) == n, "one base per scalar"
+            bp = capi.ptr(b)
+        else:
+            bp = None
+        if n:
+            capi.check(capi.load().gm_g1_msm_stream_add(C.c_uint64(self.handle), bp, capi.ptr(sc), C.c_size_t(n)))
+
+    def finalize(self) -> np.ndarray:
+        """the normalised sum of everything pushed; the stream starts over"""
+        out = np.empty(18, dtype=np.uint64)
+        capi.check(capi.load().gm_g1_msm_stream_finalize(C.c_uint64(self.handle), capi.ptr(out), None))
+        return out
+
+    def free(self):
+        if self.handle:
+            capi.check(capi.load().gm_g1_msm_stream_free(C.c_uint64(self.handle)))
+            self.handle = 0
+
+
 class ChunkedPippenger:
-    """src/kzg/msm/stream_pippenger.rs:209-271: buffer pairs, flush an MSM every buf_size pairs."""
+    """src/kzg/msm/stream_pippenger.rs:209-271: buffer pairs, flush an MSM every buf_size pairs.  The buffer is the
+    device slot of a HostMsmStream (chunk = buf_size); pairs added one at a time are staged on the host in blocks."""
+
+    _STAGE = 1 << 14
 
     def __init__(self, max_msm_buffer: int):
         self.buf_size = max_msm_buffer
-        self.scalars_buffer: list = []
-        self.bases_buffer: list = []
-        self.result = g1_zero()
+        self._stream = None
+        self._bases = None
+        self._scalars = np.empty((min(self._STAGE, max_msm_buffer), 4), dtype=np.uint64)
+        self._fill = 0
 
     @classmethod
     def with_size(cls, buf_size: int) -> "ChunkedPippenger":
         return cls(buf_size)
 
-    def _flush(self):
-        part = VariableBaseMSM.msm_bigint(np.stack(self.bases_buffer), np.stack(self.scalars_buffer))
-        self.result = g1_sum(np.stack([self.result, part]))
-        self.scalars_buffer.clear()
-        self.bases_buffer.clear()
+    def _push(self):
+        if self._fill:
+            self._stream.add(self._bases[: self._fill], self._scalars[: self._fill])
+            self._fill = 0
+
+    def _open(self, words: int):
+        if self._stream is None:
+            self._stream = HostMsmStream(min(self.buf_size, 1 << 26), mont=False, base_words=words)
+            self._bases = np.empty((len(self._scalars), words), dtype=np.uint64)
 
     def add(self, base: np.ndarray, scalar_bigint: np.ndarray):
-        self.scalars_buffer.append(capi.u64(scalar_bigint).reshape(4))
-        self.bases_buffer.append(capi.u64(base).reshape(-1))
-        if len(self.scalars_buffer) == self.buf_size:
-            self._flush()
+        b = capi.u64(base).reshape(-1)
+        self._open(len(b))
+        self._bases[self._fill] = b
+        self._scalars[self._fill] = capi.u64(scalar_bigint).reshape(4)
+        self._fill += 1
+        if self._fill == len(self._scalars):
+            self._push()
+
+    def add_pairs(self, bases: np.ndarray, scalars_bigint: np.ndarray):
+        """a whole block at once (no per-pair Python work)"""
+        bases = capi.u64(bases)
+        self._open(bases.shape[1])
+        self._push()
+        self._stream.add(bases, scalars_bigint)
 
     def finalize(self) -> np.ndarray:
-        if self.scalars_buffer:
-            self._flush()
-        return self.result
+        if self._stream is None:
+            return g1_zero()
+        self._push()
+        out = self._stream.finalize()
+        self._stream.free()
+        self._stream = None
+        return out
 
 
 class HashMapPippenger:
@@ -227,15 +322,16 @@ class HashMapPippenger:
 
 
 def msm_chunks(bases_stream: np.ndarray, scalars_stream_mont: np.ndarray) -> np.ndarray:
-    """src/kzg/space.rs:22-55: skip len(bases) - len(scalars) bases, then 2^20-pair MSMs, summed."""
+    """src/kzg/space.rs:22-55: skip len(bases) - len(scalars) bases, then 2^20-pair MSMs, summed -- one
+    HostMsmStream with 2^20-pair slots (the streams stay on the host)."""
     bases = capi.u64(bases_stream)
     sc = capi.u64(scalars_stream_mont).reshape(-1, 4)
     assert len(sc) <= len(bases)
-    bases = bases[len(bases) - len(sc):]
-    step = 1 << 20
-    result = g1_zero()
-    for off in range(0, len(sc), step):
-        part, err = VariableBaseMSM.msm(bases[off:off + step], sc[off:off + step])
-        assert err is None
-        result = g1_sum(np.stack([result, part]))
-    return result
+    if len(sc) == 0:
+        return g1_zero()
+    st = HostMsmStream(1 << 20, mont=True, base_words=bases.shape[1])
+    try:
+        st.add(bases[len(bases) - len(sc):], sc)
+        return st.finalize()
+    finally:
+        st.free()

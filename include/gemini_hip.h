@@ -116,6 +116,33 @@ int gm_g1_msm_d_partial(uint64_t bases_handle, size_t offset, int reversed, cons
  * ChunkedPippenger's `result += chunk` (src/kzg/msm/stream_pippenger.rs:248-256). */
 int gm_g1_sum(const uint64_t* points_jac, size_t k, uint64_t out_jac[18]);
 
+/* ---- streaming MSM over HOST-resident pairs: bounded device memory ---------------------------------
+ * ChunkedPippenger (src/kzg/msm/stream_pippenger.rs:209-272: with_size / add / finalize) and msm_chunks
+ * (src/kzg/space.rs:22-55) collect a buffer of pairs from the streams, run one MSM, add it to the running sum
+ * and start over.  Here the buffer is two device slots of `chunk_pairs` pairs: the stream (a key and a
+ * polynomial that may be larger than HBM) stays in host memory, blocks of any size are pushed with _add, the
+ * copy of chunk i + 1 runs under the kernels of chunk i, and _finalize returns the normalised sum -- equal to
+ * the one-call MSM of the whole stream wherever it is cut.  chunk_pairs <= 2^26.  Overlap happens inside one
+ * _add call (nothing of a stream stays in flight on the shared MSM lanes when a call returns): push blocks of
+ * several chunks.  Host buffers may be pageable or page-locked (gm_host_alloc: copied by DMA, several times
+ * faster) and are free to be reused when _add returns.  A stream is used by one thread at a time; distinct
+ * streams from distinct threads are safe (their MSMs queue behind each other).
+ *   _new:   every pair carries its base: records of base_stride bytes as in gm_g1_bases_register
+ *           (x, y Montgomery; optional infinity flag at byte 96), scalars 32-byte integers < r
+ *           (scalars_mont != 0: ark-ff Montgomery form instead).
+ *   _new_h: scalars only, against registered bases starting at `offset` and walking up (reversed != 0: down,
+ *           the big-endian stream view of src/kzg/space.rs:287-296); bases_host of _add is ignored.
+ *   _finalize also resets the stream (the reference's finalize consumes the object); pairs_or_null receives
+ *           the number of pairs summed.  A failed _add (scalar >= 2^255, bases exhausted, ...) resets it as well. */
+int gm_g1_msm_stream_new(size_t chunk_pairs, size_t base_stride, int scalars_mont, uint64_t* stream);
+int gm_g1_msm_stream_new_h(uint64_t bases_handle, size_t offset, int reversed, size_t chunk_pairs, int scalars_mont, uint64_t* stream);
+int gm_g1_msm_stream_add(uint64_t stream, const void* bases_host, const void* scalars_host, size_t n);
+int gm_g1_msm_stream_finalize(uint64_t stream, uint64_t out_jac[18], size_t* pairs_or_null);
+int gm_g1_msm_stream_free(uint64_t stream);
+/* page-locked host memory for the streams above (hipHostMalloc / hipHostFree) */
+int gm_host_alloc(size_t bytes, void** p);
+int gm_host_free(void* p);
+
 /* Fixed-base generation on device: out[i] = scalars[i] * base (affine, 96-byte stride), registered
  * directly as a bases handle.  Replaces FixedBase::msm + normalize_batch in CommitterKey::new
  * (src/kzg/time.rs:49-59; setup, outside the prover timer) and builds benchmark inputs.

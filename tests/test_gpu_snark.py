@@ -532,16 +532,16 @@ def test_snark_elastic_config4_shape_at_logn_22(gm, oracle, pyref):
     ck.powers_of_g.free()
 
 
-def test_stream_commit_default_settings_cross_the_merge_floor(gm, oracle):
-    """the DEFAULT CommitterKeyStream (flushes shorter than 2^22 pairs merged) on a stream longer than the merge floor:
-    2^22 + 5 coefficients cross one chunk boundary of _msm_stream; time == stream (src/kzg/tests.rs:16-29)"""
+def test_stream_commit_crosses_the_merge_floor(gm, oracle):
+    """a CommitterKeyStream that merges flushes shorter than 2^22 pairs (the default floor is 2^26) on a stream longer
+    than the floor: 2^22 + 5 coefficients cross one chunk boundary of _msm_stream; time == stream (src/kzg/tests.rs:16-29)"""
     from gemini_amd.fr import FrVec, powers, fr_from_int
     from gemini_amd.kzg import CommitterKey, CommitterKeyStream
 
     m = (1 << 22) + 5
     ck = CommitterKey.new(m, 3, oracle.random_fr(2229, 1)[0])
-    stream_ck = CommitterKeyStream.from_committer_key(ck)
-    assert stream_ck.min_device_chunk == 1 << 22
+    assert CommitterKeyStream.from_committer_key(ck).min_device_chunk == CommitterKeyStream.DEFAULT_MIN_DEVICE_CHUNK == 1 << 26
+    stream_ck = CommitterKeyStream.from_committer_key(ck, min_device_chunk=1 << 22)
     poly = powers(fr_from_int(oracle.limbs_to_ints(oracle.random_fr(2230, 1))[0]), m)  # dense, no host upload
     from gemini_amd.fr import reverse
 

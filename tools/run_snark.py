@@ -21,6 +21,7 @@ def main():
                     "examples/snark.rs:59-63 (elastic main) instead of tau^i * g")
     ap.add_argument("--max-msm-buffer-log", type=int, default=20, help="max_msm_buffer of the elastic prover (examples/snark.rs:57: 2^20)")
     ap.add_argument("--tables", action="store_true", help="gm_g1_bases_precompute on the committer key before proving (13 x the key in HBM)")
+    ap.add_argument("--min-device-chunk-log", type=int, default=None, help="CommitterKeyStream.min_device_chunk = 2^k (default: the class default)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/snark.rs elastic_snark_main) instead of --time-prover")
     args = ap.parse_args()
@@ -90,7 +91,7 @@ def main():
 
                 cks = ShardedCommitterKeyStream.from_sharded_key(ck)
             else:
-                cks = CommitterKeyStream.from_committer_key(ck)
+                cks = CommitterKeyStream.from_committer_key(ck, min_device_chunk=None if args.min_device_chunk_log is None else 1 << args.min_device_chunk_log)
             proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log)
             stream.free()
         else:
