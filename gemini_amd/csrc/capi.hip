@@ -28,7 +28,14 @@ int DevBuf::ensure(size_t bytes) {
     cap = 0;
   }
   size_t want = bytes + bytes / 8 + 256;
-  GM_HIP(hipMalloc(&p, want));
+  hipError_t e = hipMalloc(&p, want);
+  if (e == hipErrorOutOfMemory && context()) {  // the vector pool may be hoarding freed blocks: give them back and retry once
+    (void)hipGetLastError();
+    context()->pool.release_all();
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) p = nullptr;
+  GM_HIP(e);
   cap = want;
   return GM_OK;
 }

@@ -5,6 +5,7 @@
 //
 //   gm::VariableBaseMSM::{msm, msm_unchecked, msm_bigint}   ark-ec 0.4.2 (in-tree: src/kzg/msm/variable_base.rs)
 //   gm::ChunkedPippenger / gm::HashMapPippenger             src/kzg/msm/stream_pippenger.rs:143-271
+//   gm::msm_chunks                                          src/kzg/space.rs:22-55
 //   gm::CommitterKey::{commit, batch_commit}                src/kzg/time.rs:81-107
 //   gm::TimeProver (trait Prover)                           src/subprotocols/sumcheck/prover.rs:30-45
 //   gm::Transcript (GeminiTranscript over merlin)           src/transcript.rs:8-34
@@ -85,35 +86,66 @@ struct VariableBaseMSM {
   }
 };
 
-// src/kzg/msm/stream_pippenger.rs:209-271
+// src/kzg/msm/stream_pippenger.rs:209-271.  The buffer is the device slot of a gm_g1_msm_stream (chunk =
+// max_msm_buffer pairs, two slots: the copy of one flush runs under the kernels of the previous one); pairs
+// added one at a time are staged on the host and pushed in blocks, add_pairs pushes a whole block.
 class ChunkedPippenger {
  public:
-  explicit ChunkedPippenger(size_t max_msm_buffer) : buf_size_(max_msm_buffer), result_(g1_zero()) {
-    scalars_.reserve(max_msm_buffer);
-    bases_.reserve(max_msm_buffer);
+  explicit ChunkedPippenger(size_t max_msm_buffer) {
+    check(gm_g1_msm_stream_new(max_msm_buffer < kMaxChunk ? max_msm_buffer : kMaxChunk, sizeof(G1Affine), 0, &h_));
+    stage_ = max_msm_buffer < kStage ? max_msm_buffer : kStage;
+    scalars_.reserve(stage_);
+    bases_.reserve(stage_);
+  }
+  ChunkedPippenger(const ChunkedPippenger&) = delete;
+  ChunkedPippenger& operator=(const ChunkedPippenger&) = delete;
+  ChunkedPippenger(ChunkedPippenger&& o) noexcept : h_(o.h_), stage_(o.stage_), scalars_(std::move(o.scalars_)), bases_(std::move(o.bases_)) { o.h_ = 0; }
+  ~ChunkedPippenger() {
+    if (h_) gm_g1_msm_stream_free(h_);
   }
   static ChunkedPippenger with_size(size_t buf_size) { return ChunkedPippenger(buf_size); }
   void add(const G1Affine& base, const BigInt& scalar) {
     scalars_.push_back(scalar);
     bases_.push_back(base);
-    if (scalars_.size() == buf_size_) flush();
+    if (scalars_.size() == stage_) push();
+  }
+  void add_pairs(const G1Affine* bases, const BigInt* scalars, size_t n) {
+    push();
+    if (n) check(gm_g1_msm_stream_add(h_, bases, scalars, n));
   }
   G1Projective finalize() {
-    if (!scalars_.empty()) flush();
-    return result_;
+    push();
+    G1Projective r;
+    check(gm_g1_msm_stream_finalize(h_, r.data(), nullptr));
+    return r;
   }
 
  private:
-  void flush() {
-    result_ = g1_add(result_, VariableBaseMSM::msm_bigint(bases_, scalars_));
+  static constexpr size_t kMaxChunk = (size_t)1 << 26, kStage = (size_t)1 << 14;
+  void push() {
+    if (!scalars_.empty()) check(gm_g1_msm_stream_add(h_, bases_.data(), scalars_.data(), scalars_.size()));
     scalars_.clear();
     bases_.clear();
   }
-  size_t buf_size_;
+  uint64_t h_ = 0;
+  size_t stage_ = 0;
   std::vector<BigInt> scalars_;
   std::vector<G1Affine> bases_;
-  G1Projective result_;
 };
+
+// src/kzg/space.rs:22-55: skip len(bases) - len(scalars) bases, then 2^20-pair MSMs, summed; the streams stay on the host
+inline G1Projective msm_chunks(const std::vector<G1Affine>& bases_stream, const std::vector<Fr>& scalars_stream) {
+  if (scalars_stream.size() > bases_stream.size()) throw Error(GM_EINVAL, "msm_chunks: bases not long enough");
+  if (scalars_stream.empty()) return g1_zero();
+  uint64_t h = 0;
+  check(gm_g1_msm_stream_new((size_t)1 << 20, sizeof(G1Affine), 1, &h));
+  int rc = gm_g1_msm_stream_add(h, bases_stream.data() + (bases_stream.size() - scalars_stream.size()), scalars_stream.data(), scalars_stream.size());
+  G1Projective r;
+  if (!rc) rc = gm_g1_msm_stream_finalize(h, r.data(), nullptr);
+  gm_g1_msm_stream_free(h);
+  check(rc);
+  return r;
+}
 
 // src/kzg/msm/stream_pippenger.rs:143-206: scalars of equal bases are added in Fr before the MSM
 class HashMapPippenger {

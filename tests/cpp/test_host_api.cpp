@@ -41,6 +41,12 @@ int main(int argc, char** argv) {
     gm::ChunkedPippenger cp(7);
     for (size_t i = 0; i < bases.size(); i++) cp.add(bases[i], bigints[i]);
     print("chunked", cp.finalize());
+    gm::ChunkedPippenger cp2 = gm::ChunkedPippenger::with_size(64);
+    cp2.add(bases[0], bigints[0]);
+    cp2.add_pairs(bases.data() + 1, bigints.data() + 1, bases.size() - 1);
+    print("chunked_blocks", cp2.finalize());
+    auto tail = std::vector<gm::Fr>(scalars.begin(), scalars.begin() + 100);
+    print("msm_chunks", gm::msm_chunks(bases, tail));
     gm::HashMapPippenger hp(16);
     for (size_t i = 0; i < bases.size(); i++) hp.add(bases[i % 20], scalars[i]);
     print("hashmap", hp.finalize());

@@ -47,8 +47,10 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
     assert "FAILED" not in vals, out
     J = lambda key, k=0: np.array([int(x, 16) for x in vals[key][k]], dtype=np.uint64)
     exp = oracle.msm_pippenger(bases, sc)
-    for key in ("msm_bigint", "msm_unchecked", "chunked", "commit"):
+    for key in ("msm_bigint", "msm_unchecked", "chunked", "chunked_blocks", "commit"):
         assert jac_to_affine_ints(oracle, J(key)) == jac_to_affine_ints(oracle, exp), key
+    # msm_chunks aligns the streams: the last 100 bases with the 100 scalars (src/kzg/space.rs:36-40)
+    assert jac_to_affine_ints(oracle, J("msm_chunks")) == jac_to_affine_ints(oracle, oracle.msm_pippenger(bases[n - 100:], sc[:100]))
     assert vals["msm_err"][0] == ["1", str(n - 5)]
     dup = bases[np.arange(n) % 20]
     assert jac_to_affine_ints(oracle, J("hashmap")) == jac_to_affine_ints(oracle, oracle.hashmap_pippenger(dup, mont, 16))
