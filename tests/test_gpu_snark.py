@@ -550,3 +550,49 @@ def test_stream_commit_crosses_the_merge_floor(gm, oracle):
     for v in (poly, be):
         v.free()
     ck.powers_of_g.free()
+
+
+@pytest.mark.parametrize("logn", [3, 8, 12])
+def test_device_proofs_are_accepted_by_the_reference_verifier(gm, oracle, pyref, logn):
+    """src/snark/tests.rs:20-24, 42-46 (`proof.verify(&r1cs, &vk).is_ok()`): the proofs of the device provers, time and
+    elastic, pass the reference's verification equations -- sumcheck subclaims, the tensor relation and the pairing check
+    of the batched KZG opening against a key built from the trapdoor (oracle/verifier_ref.py, a restatement of the
+    VERIFIER that never sees how the proof was made) -- and a proof with one altered element does not.  Unlike the
+    comparison with the restated prover this holds at sizes the Python prover cannot reach."""
+    from gemini_amd.circuit import R1csStream, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from gemini_amd.snark import Proof
+    from oracle import snark_ref as sr
+    from oracle import verifier_ref as V
+    from tests.util import snark_proof_to_ints
+
+    n = 1 << logn
+    e = oracle.limbs_to_ints(oracle.random_fr(3100 + logn, 1))[0]
+    tau = oracle.limbs_to_ints(oracle.random_fr(3200 + logn, 1))[0]
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    vk = V.VerifierKey.from_trapdoor(tau, 5)
+    # the device key's G2 half is the verifier's (src/kzg/time.rs:29-40)
+    assert ck.powers_of_g2 == vk.powers_of_g2[: len(ck.powers_of_g2)]
+    r1cs = dummy_r1cs(e, n)
+    inst = sr.dummy_r1cs(e, n)
+    proof = Proof.new_time(r1cs, ck)
+    ints = snark_proof_to_ints(gm, oracle, proof)
+    V.snark_verify(ints, inst, vk)
+    if logn <= 8:
+        stream = R1csStream(r1cs)
+        elastic = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << 5)
+        V.snark_verify(snark_proof_to_ints(gm, oracle, elastic), inst, vk)
+        stream.free()
+    bad = dict(ints)
+    bad["tensorcheck_proof"] = dict(ints["tensorcheck_proof"])
+    fe = [list(x) for x in ints["tensorcheck_proof"]["folded_polynomials_evaluations"]]
+    fe[-1][1] = (fe[-1][1] + 1) % pyref.R_MOD
+    bad["tensorcheck_proof"]["folded_polynomials_evaluations"] = fe
+    with pytest.raises(V.VerificationError):
+        V.snark_verify(bad, inst, vk)
+    bad = dict(ints)
+    bad["witness_commitment"] = pyref.g1_add(ints["witness_commitment"], ints["witness_commitment"])
+    with pytest.raises(V.VerificationError):
+        V.snark_verify(bad, inst, vk)
+    r1cs.free()
+    ck.powers_of_g.free()
