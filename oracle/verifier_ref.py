@@ -208,3 +208,163 @@ def snark_verify(proof, r1cs, vk: VerifierKey) -> None:
     z_neg = (P.evaluate_le(x, (-beta) % R) + beta_power * base_evals[2]) % R
     direct = [[(m_pos + gamma * z_pos) % R, (m_neg + gamma * z_neg) % R]]
     tensorcheck_verify(tc, tr, vk, [list(ff2)], [proof["witness_commitment"]], direct, [ch2], beta, gamma)
+
+
+# ---- src/psnark/verifier.rs ------------------------------------------------------------------------------------
+def evaluate_tensor_poly(elements, x: int) -> int:
+    """src/misc.rs:373-382"""
+    res, s = 1, x % R
+    for el in elements:
+        res = res * (1 + el * s) % R
+        s = s * s % R
+    return res
+
+
+def evaluate_geometric_poly(rx: int, n: int) -> int:
+    """src/misc.rs:387-389: 1 + rx + ... + rx^(n-1)"""
+    return (pow(rx, n, R) - 1) * pow(rx - 1, -1, R) % R
+
+
+def evaluate_index_poly(x: int, n: int) -> int:
+    """src/misc.rs:394-399: 0 + x + 2 x^2 + ... + (n-1) x^(n-1)"""
+    assert x % R != 1
+    x1 = (1 - x) % R
+    x_n = pow(x, n - 1, R)
+    return (x * (1 - x_n) % R * pow(x1 * x1 % R, -1, R) - (n - 1) * x_n % R * x % R * pow(x1, -1, R)) % R
+
+
+def _plookup_subset_eval(subset_eval, index_eval, x, y, zeta, n):
+    """:37-63: shift(f + zeta * index + y * geometric)(x) = x (..) + 1"""
+    return (x * (subset_eval + zeta * index_eval + y * evaluate_geometric_poly(x, n)) + 1) % R
+
+
+def _plookup_set_eval(set_eval, x, y, z, n):
+    """:68-84: shift((1 + z) y geometric(n + 1) + (x + z) f)(x)"""
+    return (x * ((1 + z) * y % R * evaluate_geometric_poly(x, n + 1) + (x + z) * set_eval) + 1) % R
+
+
+def subclaim_new_batch(tr: P.GeminiTranscript, messages, final_foldings, asserted_sums):
+    """src/subprotocols/sumcheck/subclaim.rs:45-75"""
+    coefficients = [tr.get_challenge(b"batch-sumcheck") for _ in asserted_sums]
+    reduced = P.ip(coefficients, [s % R for s in asserted_sums])
+    challenges = []
+    for a, b in messages:
+        tr.append_round_msg(b"evaluations", a, b)
+        r = tr.get_challenge(b"challenge")
+        challenges.append(r)
+        c = (reduced - a) % R
+        reduced = (a + r * b + c * r * r) % R
+    expected = 0
+    for (f0, f1), coeff in zip(final_foldings, coefficients):
+        tr.append_fr(b"final-folding-lhs", f0)
+        tr.append_fr(b"final-folding-rhs", f1)
+        expected = (expected + f0 * f1 % R * coeff) % R
+    if expected != reduced:
+        raise VerificationError("batched sumcheck: final foldings do not meet the reduced claim")
+    return challenges, final_foldings
+
+
+def psnark_verify(proof, r1cs, vk: VerifierKey, index, num_non_zero: int) -> None:
+    """:86-565; raises VerificationError on rejection.  `proof` in the layout of psnark_ref.psnark_new_time, `index` the
+    five index commitments (affine integer points)."""
+    from .psnark_ref import g2_serialize_uncompressed
+
+    G1 = P.g1_serialize_uncompressed
+    tr = P.GeminiTranscript(P.PROTOCOL_NAME)
+    tr.append_message(b"witness", G1(proof["witness_commitment"]))
+    tr.append_message(b"ck", len(vk.powers_of_g2).to_bytes(8, "little") + b"".join(g2_serialize_uncompressed(p) for p in vk.powers_of_g2))
+    tr.append_message(b"instance", len(index).to_bytes(8, "little") + b"".join(G1(p) for p in index))
+    alpha = tr.get_challenge(b"alpha")
+    zc_alpha = proof["zc_alpha"]
+    tr.append_fr(b"zc(alpha)", zc_alpha)
+    m1, ff1 = proof["first_sumcheck_msgs"]
+    ch1, ff1 = subclaim_new(tr, m1, ff1, zc_alpha)
+    num_variables = len(r1cs["z"])
+    for label, c in zip((b"ra*", b"rb*", b"rc*"), proof["r_star_commitments"]):
+        tr.append_message(label, G1(c))
+    tr.append_message(b"z*", G1(proof["z_star_commitment"]))
+    eta = tr.get_challenge(b"chal")
+    challenges = P.powers(eta, 3)
+    asserted_sum_2 = (ff1[0] + ff1[1] * challenges[1] + zc_alpha * challenges[2]) % R
+    m2, ff2 = proof["second_sumcheck_msgs"]
+    ch2, ff2 = subclaim_new(tr, m2, ff2, asserted_sum_2)
+    zeta = tr.get_challenge(b"zeta")
+    for label, key in ((b"sorted_alpha_commitment", "sorted_alpha_commitment"), (b"sorted_r_commitment", "sorted_r_commitment"),
+                       (b"sorted_z_commitment", "sorted_z_commitment")):
+        tr.append_message(label, G1(proof[key]))
+    y = tr.get_challenge(b"gamma")
+    z = tr.get_challenge(b"chi")
+    # (the labels repeat "set_r_ep" / "subset_r_ep" for the alpha products: :169-176)
+    for label, key in ((b"set_r_ep", "set_alpha_ep"), (b"subset_r_ep", "subset_alpha_ep"), (b"set_r_ep", "set_r_ep"),
+                       (b"subset_r_ep", "subset_r_ep"), (b"set_z_ep", "set_z_ep"), (b"subset_z_ep", "subset_z_ep")):
+        tr.append_fr(label, proof[key])
+    ep = proof["ep_msgs"]
+    for c in ep["acc_v_commitments"]:
+        tr.append_message(b"acc_v", G1(c))
+    mu = tr.get_challenge(b"ep-chal")
+    open_chal = tr.get_challenge(b"open-chal")
+    commitments = [proof["r_star_commitments"][0]] + list(ep["acc_v_commitments"])
+    mu_evals = proof["ralpha_star_acc_mu_evals"]
+    verify_multi_points(vk, commitments, [mu], [[e] for e in mu_evals], proof["ralpha_star_acc_mu_proof"], open_chal)
+    for e in mu_evals:
+        tr.append_fr(b"ralpha_star_acc_mu", e)
+    tr.append_message(b"ralpha_star_mu_proof", G1(proof["ralpha_star_acc_mu_proof"]))
+    rstars = proof["rstars_vals"]
+    asserted_sum_3 = list(ep["claimed_sumchecks"]) + list(rstars)
+    asserted_sum_3.append((ff2[1] - rstars[0] - rstars[1] * eta) * pow(eta * eta % R, -1, R) % R)
+    asserted_sum_3.append(mu_evals[0])
+    m3, ff3 = proof["third_sumcheck_msgs"]
+    ch3, ff3 = subclaim_new_batch(tr, m3, ff3, asserted_sum_3)
+    batch_consistency = tr.get_challenge(b"batch_challenge")
+    tc = proof["tensorcheck_proof"]
+    for c in tc["folded_polynomials_commitments"]:
+        tr.append_message(b"commitment", G1(c))
+    beta = tr.get_challenge(b"evaluation-chal")
+    nbeta = (-beta) % R
+    res1 = [ff3[i][0] for i in range(9)] + [ff3[12][0]]
+    res2 = [ff3[i][1] for i in range(9)] + [ff3[i][1] for i in range(9, 13)]
+    res3 = [ff2[0]]
+    res4 = [ff3[9][0], ff3[10][0], ff3[11][0]]
+    be = tc["base_polynomials_evaluations"]
+    bc = batch_consistency
+
+    # first body: the nine accumulated products, then r*
+    d1 = [0, 0]
+    tmp = 1
+    for i in list(range(13, 22)) + [2]:
+        d1[0] = (d1[0] + tmp * be[i][1]) % R
+        d1[1] = (d1[1] + tmp * be[i][2]) % R
+        tmp = tmp * bc % R
+    # second body: the nine shifted monic lookup vectors, then val_a, val_b, val_c, alpha*
+    set_len = 1 << len(ch1)
+    x = r1cs["x"]
+    beta_power = pow(beta, len(x), R)
+    z_pos = (P.evaluate_le(x, beta) + beta_power * be[0][1]) % R
+    z_neg = (P.evaluate_le(x, nbeta) + (beta_power if len(x) % 2 == 0 else -beta_power) * be[0][2]) % R
+    terms = []
+    for pt, col, zval in ((beta, 1, z_pos), (nbeta, 2, z_neg)):
+        terms.append([
+            # lookup r*
+            _plookup_set_eval((evaluate_tensor_poly(ch1, pt) + zeta * evaluate_index_poly(pt, set_len)) % R, pt, y, z, set_len),
+            _plookup_subset_eval(be[2][col], be[5][col], pt, y, zeta, num_non_zero),
+            _plookup_set_eval(be[10][col], pt, y, z, set_len + num_non_zero),
+            # lookup alpha*
+            _plookup_set_eval((evaluate_geometric_poly(alpha * pt % R, set_len) + zeta * evaluate_index_poly(pt, set_len)) % R, pt, y, z, set_len),
+            _plookup_subset_eval(be[3][col], be[5][col], pt, y, zeta, num_non_zero),
+            _plookup_set_eval(be[11][col], pt, y, z, set_len + num_non_zero),
+            # lookup z*
+            _plookup_set_eval((zval + zeta * evaluate_index_poly(pt, num_variables)) % R, pt, y, z, num_variables),
+            _plookup_subset_eval(be[4][col], be[6][col], pt, y, zeta, num_non_zero),
+            _plookup_set_eval(be[12][col], pt, y, z, num_variables + num_non_zero),
+            # val_a, val_b, val_c, alpha*
+            be[7][col], be[8][col], be[9][col], be[3][col],
+        ])
+    d2 = [P.ip(t, P.powers(bc, len(t))) for t in terms]
+    d3 = [be[4][1], be[4][2]]
+    d4 = [P.ip([be[1][c], be[2][c], be[3][c]], P.powers(bc, 3)) for c in (1, 2)]
+    base_commitments = [proof["witness_commitment"]] + list(proof["r_star_commitments"]) + [proof["z_star_commitment"]] + list(index) + \
+        [proof["sorted_r_commitment"], proof["sorted_alpha_commitment"], proof["sorted_z_commitment"]] + list(ep["acc_v_commitments"])
+    mu_powers2 = P.powers2(mu, len(ch3))
+    head = ch3[: len(ch2)]
+    tensorcheck_verify(tc, tr, vk, [res1, res2, res3, res4], base_commitments, [d1, d2, d3, d4],
+                       [P.hadamard(ch3, mu_powers2), list(ch3), list(ch2), P.hadamard(ch2, head)], beta, batch_consistency)

@@ -128,6 +128,11 @@ def test_snark_time_prover_general_r1cs(gm, oracle, pyref):
     assert jac_to_affine_ints(oracle, proof.witness_commitment) == exp["witness_commitment"]
     assert [(I(x), I(y)) for x, y in proof.second_sumcheck_msgs[0]] == exp["second_sumcheck_msgs"][0]
     assert jac_to_affine_ints(oracle, proof.tensorcheck_proof.evaluation_proof) == exp["tensorcheck_proof"]["evaluation_proof"]
+    # and the reference's verifier accepts it (src/snark/tests.rs:71)
+    from oracle import verifier_ref as V
+    from tests.util import snark_proof_to_ints
+
+    V.snark_verify(snark_proof_to_ints(gm, oracle, proof), inst, V.VerifierKey.from_trapdoor(tau, 5))
     r1cs.free()
 
 

@@ -60,16 +60,10 @@ def test_verifier_accepts_the_restated_prover(honest):
     r1cs, proof, vk = honest
     V.snark_verify(proof, r1cs, vk)
     # a general (non-diagonal) instance
-    n = 16
-    rng = P.SplitMix64(99)
-    z = [rng.fr() for _ in range(n)]
-    mk = lambda: [[(rng.fr(), int(rng.next() % n)) for _ in range(1 + int(rng.next() % 3))] for _ in range(n)]  # noqa: E731
-    a, b = mk(), mk()
-    za, zb = sr.matvec(a, z), sr.matvec(b, z)
-    c = [[(za[i] * zb[i] % R * pow(z[i], -1, R) % R, i)] for i in range(n)]
-    inst = {"a": a, "b": b, "c": c, "z": z, "w": z[2:], "x": z[:2]}
-    tau = rng.fr()
-    V.snark_verify(sr.snark_new_time(inst, sr.srs(tau, 2 * n + 1)), inst, V.VerifierKey.from_trapdoor(tau, 5))
+    from tests.util import random_r1cs_instance
+
+    inst, tau = random_r1cs_instance(P, sr, 16, 99, nx=2)
+    V.snark_verify(sr.snark_new_time(inst, sr.srs(tau, 2 * 16 + 1)), inst, V.VerifierKey.from_trapdoor(tau, 5))
 
 
 def _tamper(proof, path):
@@ -125,3 +119,44 @@ def test_verifier_rejects_altered_sumcheck_messages_and_a_wrong_key(honest):
     r2["x"] = [(r1cs["x"][0] + 1) % R]
     with pytest.raises(V.VerificationError):
         V.snark_verify(proof, r2, vk)
+
+
+@pytest.fixture(scope="module")
+def honest_psnark():
+    from oracle import psnark_ref as pr
+
+    from tests.util import random_r1cs_instance
+
+    n = 8
+    inst, tau = random_r1cs_instance(P, sr, n, 2024)
+    a, b, c = inst["a"], inst["b"], inst["c"]
+    srs = sr.srs(tau, 12 * n + 1)
+    index = pr.index(srs, inst)
+    proof = pr.psnark_new_time(srs, pr.powers_of_g2(tau, 3), inst, index)
+    jm = pr.sum_matrices(a, b, c, n)
+    nnz = len(pr.joint_matrices(jm, a, b, c)[0])
+    return inst, proof, V.VerifierKey.from_trapdoor(tau, 3), index, nnz
+
+
+def test_psnark_verifier_accepts_the_restated_prover_and_rejects_alterations(honest_psnark):
+    """src/psnark/tests.rs:130-145 (test_psnark_correctness: `time_proof.verify(&r1cs, &vk, &index, num_non_zero).is_ok()`)"""
+    inst, proof, vk, index, nnz = honest_psnark
+    V.psnark_verify(proof, inst, vk, index, nnz)
+    for path in (("zc_alpha",), ("rstars_vals", 1), ("ralpha_star_acc_mu_evals", 3), ("ep_msgs", "claimed_sumchecks", 4), ("set_z_ep",),
+                 ("sorted_alpha_commitment",), ("ep_msgs", "acc_v_commitments", 8), ("ralpha_star_acc_mu_proof",),
+                 ("tensorcheck_proof", "base_polynomials_evaluations", 17, 2), ("tensorcheck_proof", "folded_polynomials_evaluations", 0, 1),
+                 ("tensorcheck_proof", "evaluation_proof")):
+        with pytest.raises(V.VerificationError):
+            V.psnark_verify(_tamper(proof, path), inst, vk, index, nnz)
+    msgs, ff = proof["third_sumcheck_msgs"]
+    bad = copy.deepcopy(proof)
+    ff2 = [tuple(f) for f in ff]
+    ff2[12] = (ff2[12][0], (ff2[12][1] + 1) % R)
+    bad["third_sumcheck_msgs"] = (list(msgs), ff2)
+    with pytest.raises(V.VerificationError):
+        V.psnark_verify(bad, inst, vk, index, nnz)
+    # the index commitments are part of the statement
+    with pytest.raises(V.VerificationError):
+        V.psnark_verify(proof, inst, vk, [index[1], index[0]] + list(index[2:]), nnz)
+    with pytest.raises(V.VerificationError):
+        V.psnark_verify(proof, inst, vk, index, nnz + 1)

@@ -37,3 +37,54 @@ def snark_proof_to_ints(gm, orc, proof) -> dict:
                                   "folded_polynomials_evaluations": [[I(x) for x in e2] for e2 in tc.folded_polynomials_evaluations],
                                   "evaluation_proof": J(tc.evaluation_proof),
                                   "base_polynomials_evaluations": [[I(x) for x in e3] for e3 in tc.base_polynomials_evaluations]}}
+
+
+def random_r1cs_instance(pyref, sr, n: int, seed: int, nx: int = 1):
+    """A satisfied random R1CS over n variables / n constraints in the layout of oracle/snark_ref.py: A and B have 1-3
+    entries per row in DISTINCT columns (rows of ark-relations matrices never repeat a column; the joint-matrix encoding of
+    the preprocessing SNARK relies on it -- a proof for an instance with a repeated column is rejected by the verifier),
+    C is the diagonal that makes Az . Bz = Cz.  Returns (instance, a further random field element)."""
+    rng = pyref.SplitMix64(seed)
+    R = pyref.R_MOD
+    z = [rng.fr() for _ in range(n)]
+
+    def mk():
+        rows = []
+        for _ in range(n):
+            cols = []
+            while len(cols) < 1 + int(rng.next() % 3):
+                c = int(rng.next() % n)
+                if c not in cols:
+                    cols.append(c)
+            rows.append([(rng.fr(), c) for c in cols])
+        return rows
+
+    a, b = mk(), mk()
+    za, zb = sr.matvec(a, z), sr.matvec(b, z)
+    c = [[(za[i] * zb[i] % R * pow(z[i], -1, R) % R, i)] for i in range(n)]
+    return {"a": a, "b": b, "c": c, "z": z, "w": z[nx:], "x": z[:nx]}, rng.fr()
+
+
+def psnark_proof_to_ints(gm, orc, proof) -> dict:
+    """a device `psnark::Proof` in the layout oracle/psnark_ref.py and oracle/verifier_ref.py use"""
+    I = gm.fr.fr_to_int
+    J = lambda p: jac_to_affine_ints(orc, p)  # noqa: E731
+
+    def msgs(m):
+        finals = [(I(a), I(b)) for a, b in m[1]]
+        return ([(I(a), I(b)) for a, b in m[0]], finals[0] if len(finals) == 1 else finals)
+
+    tc = proof.tensorcheck_proof
+    out = {k: J(getattr(proof, k)) for k in ("witness_commitment", "z_star_commitment", "sorted_r_commitment", "sorted_alpha_commitment",
+                                             "sorted_z_commitment", "ralpha_star_acc_mu_proof")}
+    out.update({k: I(getattr(proof, k)) for k in ("zc_alpha", "set_r_ep", "subset_r_ep", "set_alpha_ep", "subset_alpha_ep", "set_z_ep", "subset_z_ep")})
+    out.update({k: msgs(getattr(proof, k)) for k in ("first_sumcheck_msgs", "second_sumcheck_msgs", "third_sumcheck_msgs")})
+    out["r_star_commitments"] = [J(c) for c in proof.r_star_commitments]
+    out["ep_msgs"] = {"acc_v_commitments": [J(c) for c in proof.ep_msgs.acc_v_commitments], "claimed_sumchecks": [I(e) for e in proof.ep_msgs.claimed_sumchecks]}
+    out["ralpha_star_acc_mu_evals"] = [I(e) for e in proof.ralpha_star_acc_mu_evals]
+    out["rstars_vals"] = [I(e) for e in proof.rstars_vals]
+    out["tensorcheck_proof"] = {"folded_polynomials_commitments": [J(c) for c in tc.folded_polynomials_commitments],
+                                "folded_polynomials_evaluations": [[I(x) for x in e2] for e2 in tc.folded_polynomials_evaluations],
+                                "evaluation_proof": J(tc.evaluation_proof),
+                                "base_polynomials_evaluations": [[I(x) for x in e3] for e3 in tc.base_polynomials_evaluations]}
+    return out
