@@ -44,6 +44,12 @@ def joint_matrices(a, b, c, num_constraints: int, num_variables: int):
         ks = k[order]
         last = np.ones(len(ks), dtype=bool)
         last[:-1] = ks[1:] != ks[:-1]  # the last occurrence of every key
+        if not last.all():
+            import warnings
+
+            warnings.warn("psnark: a matrix row repeats a column; the joint-matrix encoding keeps the last entry only (as the "
+                          "reference's BTreeMap does, src/misc.rs:269-366) and the resulting proof will NOT verify -- coalesce "
+                          "repeated (row, column) entries before building the R1CS", RuntimeWarning, stacklevel=3)
         d[np.searchsorted(union, ks[last])] = vals[mid][order][last]
         dense[mid] = d
     return row_index, col_index, dense[id(a)], dense[id(b)], dense[id(c)]
