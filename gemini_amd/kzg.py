@@ -20,6 +20,18 @@ def g1_generator_mont() -> np.ndarray:
     return np.array(mont(_GX) + mont(_GY), dtype=np.uint64)
 
 
+def _warn_truncated(poly_len: int, key_len: int):
+    """`msm_unchecked` pairs as many coefficients as there are powers and drops the rest without a word
+    (src/kzg/time.rs:81-83) -- kept, because callers rely on it, but a commitment that ignores coefficients opens to
+    nothing: e.g. examples/psnark.rs:76 builds its time-prover key with 2n + 1 powers while the accumulated products of
+    the sorted vectors have 2n + 2 coefficients, and that proof does not verify."""
+    if poly_len > key_len:
+        import warnings
+
+        warnings.warn(f"commit: polynomial of {poly_len} coefficients against {key_len} powers -- the top {poly_len - key_len} "
+                      "are dropped as in the reference (src/kzg/time.rs:82); the commitment will not verify", RuntimeWarning, stacklevel=3)
+
+
 class CommitterKey:
     """src/kzg/time.rs:24-27.  powers_of_g lives on the GPU; powers_of_g2 is only used by the
     verifier (out of scope) so just its length (max_eval_points + 1) is kept."""
@@ -61,6 +73,7 @@ class CommitterKey:
         v, tmp = _as_vec(polynomial)
         try:
             n = min(len(v), len(self.powers_of_g))
+            _warn_truncated(len(v), len(self.powers_of_g))
             return self.powers_of_g.msm_vec(v, n=n)
         finally:
             if tmp:
@@ -71,6 +84,8 @@ class CommitterKey:
         vecs = [_as_vec(p) for p in polynomials]
         try:
             nb = len(self.powers_of_g)
+            for v, _ in vecs:
+                _warn_truncated(len(v), nb)
             out = self.powers_of_g.msm_vec_batch([v for v, _ in vecs], [min(len(v), nb) for v, _ in vecs])
             return [out[j] for j in range(len(vecs))]
         finally:

@@ -394,3 +394,31 @@ def test_device_proofs_are_accepted_by_the_reference_verifier(gm, oracle, pyref,
         V.psnark_verify(bad, inst, vk, index_ints, nnz)
     r1cs.free()
     ck.powers_of_g.free()
+
+
+@pytest.mark.parametrize("logn", [20, 22])
+def test_full_size_device_proof_is_accepted_by_the_reference_verifier(gm, oracle, pyref, logn):
+    """examples/psnark.rs:70-81 at 2^20 / 2^22 constraints (BASELINE configs[4] shape, smaller): the preprocessing
+    verifier is O(log n) -- it never touches the matrices -- so the device proof of a full-size instance is checked
+    against the reference's acceptance predicate directly (three sumcheck subclaims, plookup / entry-product relations,
+    two pairing checks over ~25 commitments each)."""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.psnark import Proof
+    from oracle import verifier_ref as V
+    from tests.util import psnark_proof_to_ints
+
+    n = 1 << logn
+    e, tau = 0x1D2C3B4A59687766554433221100FFEE % pyref.R_MOD, 0x0123456789ABCDEF0FEDCBA987654321 % pyref.R_MOD
+    r1cs = dummy_r1cs(e, n)
+    # examples/psnark.rs:76 asks for max_degree 2n (2n + 1 powers); the accumulated products of the sorted vectors have
+    # 2n + 2 coefficients, the commitment would silently drop the top one (src/kzg/time.rs:82) and the proof would not
+    # verify -- in the reference as here (oracle: test_reference_example_key_is_one_power_short).  One more power:
+    ck = CommitterKey.new(2 * n + 1, 5, oracle.ints_to_limbs([tau], 4)[0])
+    index = Proof.index(ck, r1cs)
+    proof = Proof.new_time(ck, r1cs, index)
+    vk = V.VerifierKey.from_trapdoor(tau, 5)
+    stub = {"x": [e], "z": range(n)}  # the verifier reads the public input and the number of variables only
+    V.psnark_verify(psnark_proof_to_ints(gm, oracle, proof), stub, vk, [jac_to_affine_ints(oracle, c) for c in index], n)
+    r1cs.free()
+    ck.powers_of_g.free()

@@ -601,3 +601,22 @@ def test_device_proofs_are_accepted_by_the_reference_verifier(gm, oracle, pyref,
         V.snark_verify(bad, inst, vk)
     r1cs.free()
     ck.powers_of_g.free()
+
+
+def test_device_proof_of_2p16_constraints_is_accepted_by_the_reference_verifier(gm, oracle, pyref):
+    """the O(n) verifier of the non-preprocessing SNARK on a 2^16-constraint device proof (the restated PROVER stops at 2^9)"""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+    from oracle import snark_ref as sr
+    from oracle import verifier_ref as V
+    from tests.util import snark_proof_to_ints
+
+    n = 1 << 16
+    e, tau = 0x1D2C3B4A59687766554433221100FFEE % pyref.R_MOD, 0x0123456789ABCDEF0FEDCBA987654321 % pyref.R_MOD
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    r1cs = dummy_r1cs(e, n)
+    proof = Proof.new_time(r1cs, ck)
+    V.snark_verify(snark_proof_to_ints(gm, oracle, proof), sr.dummy_r1cs(e, n), V.VerifierKey.from_trapdoor(tau, 5))
+    r1cs.free()
+    ck.powers_of_g.free()

@@ -160,3 +160,28 @@ def test_psnark_verifier_accepts_the_restated_prover_and_rejects_alterations(hon
         V.psnark_verify(proof, inst, vk, [index[1], index[0]] + list(index[2:]), nnz)
     with pytest.raises(V.VerificationError):
         V.psnark_verify(proof, inst, vk, index, nnz + 1)
+
+
+def test_reference_example_key_is_one_power_short():
+    """examples/psnark.rs:76 (`CommitterKey::new(num_constraints + num_variables, 5, rng)`, i.e. 2n + 1 powers for
+    dummy_r1cs(n)) against the prover's longest polynomials: the accumulated products of the three sorted vectors have
+    set_len + nnz + 2 = 2n + 2 coefficients, `msm_unchecked` drops the top one (src/kzg/time.rs:82) and the proof is
+    rejected; with one more power it is accepted.  The example only times the prover and never verifies; the test key of
+    src/psnark/tests.rs:137 (num_non_zero + num_variables + num_constraints) is long enough."""
+    from oracle import psnark_ref as pr
+
+    n = 16
+    e, tau = 987654321987654321, 1234567890123456789012345
+    inst = sr.dummy_r1cs(e, n)
+    vk = V.VerifierKey.from_trapdoor(tau, 5)
+    verdict = {}
+    for max_degree in (2 * n, 2 * n + 1):
+        srs = sr.srs(tau, max_degree + 1)
+        index = pr.index(srs, inst)
+        proof = pr.psnark_new_time(srs, pr.powers_of_g2(tau, 5), inst, index)
+        try:
+            V.psnark_verify(proof, inst, vk, index, n)
+            verdict[max_degree] = True
+        except V.VerificationError:
+            verdict[max_degree] = False
+    assert verdict == {2 * n: False, 2 * n + 1: True}

@@ -19,11 +19,19 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/psnark.rs elastic_snark_main) instead of --time-prover")
+    ap.add_argument("--verifiable-key", action="store_true", help="one more power than examples/psnark.rs:76 asks for: the reference's "
+                    "time-prover key (2n + 1 powers) is one short of the longest committed polynomial (2n + 2 coefficients), so the proof "
+                    "of the example's configuration does not verify (tests/test_oracle_verifier.py::test_reference_example_key_is_one_power_short)")
     args = ap.parse_args()
+    import warnings
+
     import gemini_amd as gm
     from gemini_amd.circuit import dummy_r1cs
     from gemini_amd.kzg import CommitterKey
     from gemini_amd.psnark import Proof
+
+    if not args.verifiable_key:
+        warnings.filterwarnings("ignore", message="commit: polynomial of", category=RuntimeWarning)  # the reference's shape, knowingly
 
     # N > 1 (torch.distributed.run): KZG key sharded by powers (gemini_amd.dist.ShardedCommitterKey), the
     # field arithmetic replicated; GM_BENCH_BACKEND / GM_BENCH_SINGLE_DEVICE as in bench.py
@@ -54,7 +62,7 @@ def main():
         assert not args.elastic, "the sharded preprocessing prover runs the time prover"
         ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
     else:
-        ck = CommitterKey.new(3 * n if args.elastic else 2 * n, 5, tau)
+        ck = CommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
     index = Proof.index(ck, r1cs)
