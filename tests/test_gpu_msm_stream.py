@@ -204,6 +204,8 @@ def test_stream_full_size_property(gm, oracle):
         finally:
             st.free()
         assert (gm.msm_chunks(host_bases, oracle.fr_to_mont(sc)) == exp).all()
+        # the one-shot entry with host pointers (gm_g1_msm) streams from 2^22 pairs on
+        assert (gm.VariableBaseMSM.msm_bigint(host_bases, sc) == exp).all()
     finally:
         reg.free()
 
