@@ -195,7 +195,7 @@ struct DevPool {
   std::mutex mu;
   std::multimap<size_t, void*> free_list;  // capacity -> pointer
   size_t pooled_bytes = 0;
-  static constexpr size_t MAX_POOLED = (size_t)96 << 30;
+  size_t max_pooled = (size_t)96 << 30;  // GM_POOL_MAX_GB overrides (gm_init)
   int alloc(size_t bytes, void** p, size_t* cap);
   void free(void* p, size_t cap);
   void release_all();
