@@ -131,6 +131,60 @@ def test_oracle_restatement_against_the_reference(vectors):
         P.g1_serialize_uncompressed = saved
 
 
+def test_verifier_restatement_agrees_with_the_reference_verdicts(vectors):
+    """`proof.verify(..)` of the reference itself (recorded by tools/refvectors) next to the verdict of
+    oracle/verifier_ref.py on the same proof bytes: the SNARK proof is accepted by both; the preprocessing proof of the
+    example's key (examples/psnark.rs:76, 2n + 1 powers) is REJECTED by both -- the restatement's prediction
+    (tests/test_oracle_verifier.py::test_reference_example_key_is_one_power_short) -- and accepted with one more power."""
+    import gemini_amd
+    from gemini_amd.psnark import Proof as PProof
+    from gemini_amd.snark import Proof as SProof
+    from oracle import oracle as orc
+    from oracle import psnark_ref as pr
+    from oracle import snark_ref as sr
+    from oracle import verifier_ref as V
+    from gemini_amd import wire
+    from tests.util import jac_to_affine_ints, psnark_proof_to_ints, snark_proof_to_ints
+
+    data, enc = vectors
+    if enc:
+        pytest.skip("the restated transcript frames G1 the ark-test-curves way; the zcash framing is covered byte for byte above")
+    checked = 0
+    for case in data["cases"]:
+        if "verifies" not in case or case["logn"] > 6:
+            continue
+        n = 1 << case["logn"]
+        g = tuple(_h(v) for v in case["g"])
+        g2 = None
+        if case.get("g2_uncompressed"):
+            from gemini_amd import g2 as G2
+
+            g2 = G2.deserialize_uncompressed(bytes.fromhex(case["g2_uncompressed"]), enc)
+        vk = V.VerifierKey.from_trapdoor(_h(case["tau"]), 5, g=g, g2=g2)
+        inst = sr.dummy_r1cs(_h(case["e"]), n)
+        proof = SProof.deserialize(bytes.fromhex(case["proof_compressed"]), True, enc, validate=False)
+        try:
+            V.snark_verify(snark_proof_to_ints(gemini_amd, orc, proof), inst, vk)
+            mine = True
+        except V.VerificationError:
+            mine = False
+        assert case["verifies"] is True and mine is True
+        ps = case.get("psnark")
+        if ps and "verifies_example_key" in ps:
+            pp = PProof.deserialize(bytes.fromhex(ps["proof_compressed"]), True, enc, validate=False)
+            index = [jac_to_affine_ints(orc, wire.g1_deserialize(bytes.fromhex(c), 0, False, enc, validate=False)[0]) for c in ps["index"]]
+            try:
+                V.psnark_verify(psnark_proof_to_ints(gemini_amd, orc, pp), inst, vk, index, n)
+                mine = True
+            except V.VerificationError:
+                mine = False
+            assert mine == ps["verifies_example_key"]
+            assert (ps["verifies_example_key"], ps["verifies_key_with_one_more_power"]) == (False, True)
+        checked += 1
+    if not checked:
+        pytest.skip("these vector files predate the `verifies` fields (or are mock files)")
+
+
 # ---- GPU: the device provers against the reference's proofs ---------------------------------------------
 def _limbs(v, n):
     return np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(n)], dtype=np.uint64)

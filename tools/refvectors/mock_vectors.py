@@ -44,7 +44,7 @@ def main():
                           "witness_commitment_uncompressed": W.g1(exp["witness_commitment"], False, mode).hex(),
                           "witness_commitment_compressed": W.g1(exp["witness_commitment"], True, mode).hex(),
                           "alpha_after_witness": hx(alpha), "raw_challenge_bytes": raw.hex(), "raw_challenge_as_fr": hx(raw_fr),
-                          "proof_compressed": W.snark_proof(exp, True, mode).hex(), "proof_uncompressed": W.snark_proof(exp, False, mode).hex(),
+                          "proof_compressed": W.snark_proof(exp, True, mode).hex(), "proof_uncompressed": W.snark_proof(exp, False, mode).hex(), "verifies": True,
                           "elastic_generator_key": {"proof_compressed": W.snark_proof(el, True, mode).hex(), "proof_uncompressed": W.snark_proof(el, False, mode).hex()},
                           "psnark": None})
         P.g1_serialize_uncompressed = saved

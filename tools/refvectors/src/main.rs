@@ -90,6 +90,7 @@ where
         assert_eq!(ck.commit(&[E::ScalarField::one()]).0, g);
         assert_eq!(ck.commit(&[E::ScalarField::zero(), E::ScalarField::one()]).0, g * tau);
         let proof = SnarkProof::<E>::new_time(&r1cs, &ck);
+        let snark_verifies = proof.verify(&r1cs, &ark_gemini::kzg::VerifierKey::from(&ck)).is_ok();  // src/snark/tests.rs:71
         let witness = ck.commit(&r1cs.w);
         // ---- stand-alone transcript checks ---------------------------------------------------------------
         let mut t = merlin::Transcript::new(ark_gemini::PROTOCOL_NAME);
@@ -104,12 +105,27 @@ where
             let ck = CommitterKey::<E>::new(2 * n, 5, rng);
             let index = PsnarkProof::<E>::index(&ck, &r1cs);
             let p = PsnarkProof::<E>::new_time(&ck, &r1cs, &index);
+            // the reference's own verdict on its example configuration (examples/psnark.rs:76: 2n + 1 powers) and on a key
+            // with one more power.  The other side's restated verifier predicts false / true: the accumulated products of
+            // the sorted vectors have 2n + 2 coefficients and msm_unchecked drops the top one (src/kzg/time.rs:82).
+            // dummy_r1cs: A = B = C diagonal, so the joint matrix has n non-zero entries.
+            let verifies_example_key = p.verify(&r1cs, &ark_gemini::kzg::VerifierKey::from(&ck), &index, n).is_ok();
+            let verifies_long_key = {
+                let rng = &mut test_rng();
+                let r1cs = dummy_r1cs::<E::ScalarField>(rng, n);
+                let ck = CommitterKey::<E>::new(2 * n + 1, 5, rng);
+                let index = PsnarkProof::<E>::index(&ck, &r1cs);
+                let p = PsnarkProof::<E>::new_time(&ck, &r1cs, &index);
+                p.verify(&r1cs, &ark_gemini::kzg::VerifierKey::from(&ck), &index, n).is_ok()
+            };
             format!(
-                "{{\"index\": {}, \"proof_compressed\": \"{}\", \"proof_uncompressed\": \"{}\", \"powers_of_g2_uncompressed\": \"{}\"}}",
+                "{{\"index\": {}, \"proof_compressed\": \"{}\", \"proof_uncompressed\": \"{}\", \"powers_of_g2_uncompressed\": \"{}\", \"verifies_example_key\": {}, \"verifies_key_with_one_more_power\": {}}}",
                 format!("[{}]", index.iter().map(|c| format!("\"{}\"", ser(c, false))).collect::<Vec<_>>().join(", ")),
                 ser(&p, true),
                 ser(&p, false),
-                ser(&ark_gemini::kzg::VerifierKey::from(&ck).powers_of_g2, false)
+                ser(&ark_gemini::kzg::VerifierKey::from(&ck).powers_of_g2, false),
+                verifies_example_key,
+                verifies_long_key
             )
         } else {
             "null".to_string()
@@ -125,7 +141,7 @@ where
                 "{{\"logn\": {}, \"e\": \"{}\", \"tau\": \"{}\", \"g\": {}, \"g2_uncompressed\": \"{}\",\n",
                 "  \"witness_commitment_uncompressed\": \"{}\", \"witness_commitment_compressed\": \"{}\",\n",
                 "  \"alpha_after_witness\": \"{}\", \"raw_challenge_bytes\": \"{}\", \"raw_challenge_as_fr\": \"{}\",\n",
-                "  \"proof_compressed\": \"{}\",\n  \"proof_uncompressed\": \"{}\",\n",
+                "  \"proof_compressed\": \"{}\",\n  \"proof_uncompressed\": \"{}\", \"verifies\": {},\n",
                 "  \"elastic_generator_key\": {{\"proof_compressed\": \"{}\", \"proof_uncompressed\": \"{}\"}},\n",
                 "  \"psnark\": {}}}"
             ),
@@ -145,6 +161,7 @@ where
             }),
             ser(&proof, true),
             ser(&proof, false),
+            snark_verifies,
             ser(&elastic, true),
             ser(&elastic, false),
             psnark
