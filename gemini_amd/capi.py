@@ -50,6 +50,21 @@ class GeminiHipError(RuntimeError):
 _lib = None
 
 
+def _load_torch_runtime_first():
+    """The PyTorch-ROCm wheel ships its own libamdhip64.so / libhsa-runtime64.so (ROCm 7.0 here) while this library links
+    the system ones (/opt/rocm, 7.2, different sonames): both HIP runtimes end up in the process.  That works -- device
+    pointers of either are valid for the kernels of the other -- as long as torch's libraries are mapped FIRST; the other
+    way round torch binds to the system HSA runtime and reports "No HIP GPUs are available" (tools/torch_order_probe.py).
+    Python callers of this package use torch for device memory and torch.distributed, so import it before the dlopen.
+    C / C++ / Rust embedders of the C ABI are not concerned.  GM_NO_TORCH_PRELOAD=1 skips this."""
+    if os.environ.get("GM_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the C ABI itself
+        pass
+
+
 def load() -> C.CDLL:
     """dlopen the library (no GPU needed for this step)."""
     global _lib
@@ -59,6 +74,7 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path."
             )
+        _load_torch_runtime_first()
         lib = C.CDLL(LIB_PATH)
         lib.gm_last_error.restype = C.c_char_p
         _lib = lib

@@ -541,3 +541,32 @@ def test_msm_randomised_differential(gm, oracle):
     for v in vecs:
         v.free()
     bases.free()
+
+
+def test_msm_beyond_one_call_is_the_sum_of_its_slices(gm, oracle):
+    """2^26 + 2^25 + 3 pairs (the sizes of `snark -i 27/28` commitments): msm_run cuts the call at 2^26 pairs and both
+    pieces take the widest window (c = 20, 13 windows), a path no oracle-sized test reaches.  Additivity pins it to the
+    paths that are checked against the oracle: the same pairs as twelve slices of 2^23 (c = 19, checked at 2^23 - 3)."""
+    import torch
+
+    from gemini_amd.kzg import g1_generator_mont
+    from gemini_amd.msm import g1_sum
+
+    n = (1 << 26) + (1 << 25) + 3
+    reg = gm.G1Bases.srs(g1_generator_mont(), oracle.random_fr(2601, 1)[0], n)  # tau^i * g: cheap to generate, distinct points
+    try:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(2602)
+        sc = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda", generator=gen)  # < 2^254 < r
+        torch.cuda.synchronize()
+        full = reg.msm_device(sc.data_ptr(), n, mont=False)
+        step = 1 << 23
+        parts = [reg.msm_device(sc[off:].data_ptr(), min(step, n - off), mont=False, offset=off, partial=True) for off in range(0, n, step)]
+        assert (g1_sum(np.stack(parts)) == full).all()
+        # and reversed addressing over the whole range (the stream view of the elastic prover)
+        rev = reg.msm_device(sc.data_ptr(), n, mont=False, offset=n - 1, reversed_=True)
+        parts = [reg.msm_device(sc[off:].data_ptr(), min(step, n - off), mont=False, offset=n - 1 - off, reversed_=True, partial=True) for off in range(0, n, step)]
+        assert (g1_sum(np.stack(parts)) == rev).all()
+        del sc
+    finally:
+        reg.free()
