@@ -1719,7 +1719,10 @@ static int ceil_log2_sz(size_t n) {
 // the smaller bucket count of a narrower window, e.g. 3.52 vs 3.96 ms at 2^19, 1.61 vs 1.84 ms at 2^16)
 static int choose_window(size_t n) {
   int lg = ceil_log2_sz(n);
-  if (lg >= 25) return 20;  // 13 windows: another -4 % at 2^25 and 2^26
+  // 13 windows: another -4 % at 2^25 and 2^26, -2 % at 2^24 (43.2 vs 44.1 ms); at 2^23 the 6.8 M buckets still cost more
+  // than the saved window (25.2 vs 23.7 ms), so the switch sits at 7 * 2^21 pairs
+  static const size_t c20_min = getenv("GM_MSM_C20_MIN") ? (size_t)strtoull(getenv("GM_MSM_C20_MIN"), nullptr, 10) : ((size_t)7 << 21);  // tuning override
+  if (n >= c20_min) return 20;
   if (lg >= 23) return 19;  // 14 windows: -2.5 % at 2^23, -7 % at 2^24, -11 % at 2^26 against c = 16 (the 3.7 M buckets cost 2.7 ms to reduce)
   if (lg >= 14) return 16;
   // small calls, re-tuned with the flat digit kernels (tools/tune_small.py, round 2): the launch chain and the
