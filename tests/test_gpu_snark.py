@@ -620,3 +620,21 @@ def test_device_proof_of_2p16_constraints_is_accepted_by_the_reference_verifier(
     V.snark_verify(snark_proof_to_ints(gm, oracle, proof), sr.dummy_r1cs(e, n), V.VerifierKey.from_trapdoor(tau, 5))
     r1cs.free()
     ck.powers_of_g.free()
+
+
+def test_stream_commit_default_settings_cross_the_default_floor(gm, oracle):
+    """the DEFAULT CommitterKeyStream (flushes merged up to 2^26 pairs) on a stream longer than that: 2^26 + 5 coefficients
+    cross one chunk boundary of _msm_stream with nothing overridden; time == stream (src/kzg/tests.rs:16-29)"""
+    from gemini_amd.fr import fr_from_int, powers, reverse
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+
+    m = (1 << 26) + 5
+    ck = CommitterKey.new(m, 3, oracle.random_fr(2231, 1)[0])
+    stream_ck = CommitterKeyStream.from_committer_key(ck)
+    assert stream_ck.min_device_chunk == 1 << 26
+    poly = powers(fr_from_int(oracle.limbs_to_ints(oracle.random_fr(2232, 1))[0]), m)  # dense, no host upload
+    be = reverse(poly)
+    assert (stream_ck.commit(be) == ck.commit(poly)).all()
+    for v in (poly, be):
+        v.free()
+    ck.powers_of_g.free()
