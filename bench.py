@@ -125,8 +125,13 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
             sc = {"bound": "hbm", "kernel": "k_sc_round (fold + next message, one launch per round)", "launches": int(cnt[6]),
                   "kernel_ms_total": round(ms[6], 4), "algorithmic_bytes": bytes_sc, "achieved": round(bytes_sc / (ms[6] * 1e-3) / 1e9, 2),
                   "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(bytes_sc / (ms[6] * 1e-3) / HBM_PEAK, 4),
-                  "fr_mul_per_s": round(2 * 9 * n / (ms[6] * 1e-3)),
-                  "note": "two sumchecks of length N = 2^logn; ~9 Fr products per element pair, integer-ALU and launch-latency bound in the late rounds"}
+                  # products: 3 N in the first round (no fold), 2.5 per input element of every folding round (N + N/2 + ...): 8 N
+                  "fr_mul_per_s": round(2 * 8 * n / (ms[6] * 1e-3)),
+                  # 129 v_mad_u64_u32 + 128 v_addc_co_u32 + 8 v_mul_lo_u32 at 4.3 cycles + ~40 plain instructions per product
+                  "fr_mul_issue_bound": 1.25e11,
+                  "alu_frac": round(2 * 8 * n / (ms[6] * 1e-3) / 1.25e11, 4),
+                  "note": "two sumchecks of length N = 2^logn; 8 N Fr products per sumcheck = 1 per 24 bytes: with a 1260-cycle product the kernel "
+                          "is integer-ALU bound at <= 3 TB/s (37 % of the HBM peak) in the large rounds and launch-latency bound in the last ~15"}
 
     tables = None
     if with_tables and world == 1:
