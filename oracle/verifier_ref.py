@@ -87,6 +87,14 @@ def _g2_msm(points, scalars):
     return acc
 
 
+def verify(vk: VerifierKey, commitment, alpha: int, evaluation: int, proof) -> None:
+    """:155-175: e(C - [evaluation] g, g2) == e(proof, [tau - alpha] g2)"""
+    ep = _g2_msm(vk.powers_of_g2, [(-alpha) % R, 1])
+    lhs = P.g1_add(commitment, P.g1_neg(P.g1_mul(vk.powers_of_g[0], evaluation % R)))
+    if not E.pairing_product_is_one([(lhs, vk.powers_of_g2[0]), (P.g1_neg(proof), ep)]):
+        raise VerificationError("verify: pairing check failed")
+
+
 def verify_multi_points(vk: VerifierKey, commitments, eval_points, evaluations, proof, open_chal: int) -> None:
     """:181-244: e(sum eta^i C_i - [I(tau)] g, g2) == e(proof, [Z(tau)] g2), I = the eta-combination of the
     interpolations of the claimed evaluations, Z = the vanishing polynomial of the points"""

@@ -638,3 +638,44 @@ def test_stream_commit_default_settings_cross_the_default_floor(gm, oracle):
     for v in (poly, be):
         v.free()
     ck.powers_of_g.free()
+
+
+def test_device_openings_pass_the_pairing_checks(gm, oracle, pyref):
+    """src/kzg/time.rs:193-211 (open at a random point, `vk.verify` accepts), src/kzg/tests.rs:43-59 (the same through the
+    stream key) and src/kzg/tests.rs:62-102 (test_open_multipoints_correctness: 15 polynomials of degree 100, five points,
+    batch_commit + batch_open_multi_points, `verify_multi_points` accepts) on the device committer, checked with the
+    restated pairing verifier (oracle/verifier_ref.py)."""
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from oracle import verifier_ref as V
+
+    I = gm.fr.fr_to_int
+    R = pyref.R_MOD
+    d = 100
+    tau = oracle.limbs_to_ints(oracle.random_fr(5100, 1))[0]
+    pts = oracle.limbs_to_ints(oracle.random_fr(5101, 5))
+    polys = [oracle.limbs_to_ints(oracle.random_fr(5110 + k, d + 1)) for k in range(15)]
+    ck = CommitterKey.new(d + 1, len(pts), oracle.ints_to_limbs([tau], 4)[0])
+    vk = V.VerifierKey.from_trapdoor(tau, len(pts))
+    A = lambda p: jac_to_affine_ints(oracle, p)  # noqa: E731
+    dev = [_M(oracle, p) for p in polys]
+    comms = [A(c) for c in ck.batch_commit(dev)]
+    eta = oracle.limbs_to_ints(oracle.random_fr(5102, 1))[0] % (1 << 128)  # `u128::rand(..).into()`
+    proof = A(ck.batch_open_multi_points(dev, _M(oracle, pts), _M(oracle, [eta])[0]))
+    evals = [[pyref.evaluate_le(p, x) for x in pts] for p in polys]
+    V.verify_multi_points(vk, comms, pts, evals, proof, eta)
+    evals[7][3] = (evals[7][3] + 1) % R
+    with pytest.raises(V.VerificationError):
+        V.verify_multi_points(vk, comms, pts, evals, proof, eta)
+    # single point, time key and stream key
+    alpha = pts[0]
+    ev, pr = ck.open(dev[0], _M(oracle, [alpha])[0])
+    assert I(ev) == pyref.evaluate_le(polys[0], alpha)
+    V.verify(vk, comms[0], alpha, I(ev), A(pr))
+    with pytest.raises(V.VerificationError):
+        V.verify(vk, comms[0], alpha, (I(ev) + 1) % R, A(pr))
+    stream_ck = CommitterKeyStream.from_committer_key(ck)
+    be = dev[0][::-1].copy()
+    ev2, pr2 = stream_ck.open(be, _M(oracle, [alpha])[0], 16)
+    assert I(ev2) == I(ev)
+    V.verify(vk, A(stream_ck.commit(be)), alpha, I(ev2), A(pr2))
+    ck.powers_of_g.free()

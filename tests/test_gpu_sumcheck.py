@@ -377,3 +377,45 @@ def test_sharded_prover_on_device(gm, oracle, pyref):
         assert (fa[0] == fb[0]).all() and (fa[1] == fb[1]).all()
         for s in shards + [ref, tail]:
             s.free()
+
+
+def test_device_sumchecks_are_accepted_by_the_reference_verifier(gm, oracle, pyref):
+    """src/subprotocols/sumcheck/tests.rs:203-224 (test_sumcheck_correctness, d = 2^10) and :227-269
+    (test_batch_sumcheck_correctness, d = 2^5 and 2^10): the verifier's Subclaim accepts the device prover's messages for
+    the naively computed inner product <f . powers(twist), g> (oracle/verifier_ref.py restates subclaim.rs)."""
+    from oracle import verifier_ref as V
+
+    I = lambda a: oracle.limbs_to_ints(oracle.fr_from_mont(np.asarray(a).reshape(-1, 4)))
+    R = pyref.R_MOD
+
+    def instance(seed, d):
+        f, g = oracle.fr_to_mont(oracle.random_fr(seed, d + 1)), oracle.fr_to_mont(oracle.random_fr(seed + 1, d + 1))
+        tw = oracle.fr_to_mont(oracle.random_fr(seed + 2, 1))[0]
+        twi = I(tw)[0]
+        asserted = sum(x * y % R * pow(twi, i, R) for i, (x, y) in enumerate(zip(I(f), I(g)))) % R
+        return f, g, tw, asserted
+
+    f, g, tw, asserted = instance(4100, 1 << 10)
+    t = gm.Transcript()
+    sc = gm.Sumcheck.new_time(t, f, g, tw)
+    msgs = [(I(a)[0], I(b)[0]) for a, b in sc.messages]
+    ff = (I(sc.final_foldings[0][0])[0], I(sc.final_foldings[0][1])[0])
+    ch, _ = V.subclaim_new(pyref.GeminiTranscript(pyref.PROTOCOL_NAME), msgs, ff, asserted)
+    assert ch == [I(x)[0] for x in sc.challenges]
+    with pytest.raises(V.VerificationError):
+        V.subclaim_new(pyref.GeminiTranscript(pyref.PROTOCOL_NAME), msgs, ff, (asserted + 1) % R)
+    t.free()
+    # batch of two provers of different lengths
+    f1, g1, tw1, s1 = instance(4200, 1 << 5)
+    f2, g2, tw2, s2 = instance(4300, 1 << 10)
+    t = gm.Transcript()
+    provers = [gm.TimeProver(f1, g1, tw1), gm.TimeProver(f2, g2, tw2)]
+    sc = gm.Sumcheck.prove_batch(t, provers)
+    msgs = [(I(a)[0], I(b)[0]) for a, b in sc.messages]
+    finals = [(I(a)[0], I(b)[0]) for a, b in sc.final_foldings]
+    V.subclaim_new_batch(pyref.GeminiTranscript(pyref.PROTOCOL_NAME), msgs, finals, [s1, s2])
+    with pytest.raises(V.VerificationError):
+        V.subclaim_new_batch(pyref.GeminiTranscript(pyref.PROTOCOL_NAME), msgs, finals, [s1, (s2 + 1) % R])
+    for p in provers:
+        p.free()
+    t.free()
