@@ -175,6 +175,33 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
                "gpu_same_instance_s": round(sorted(g_runs)[1], 4), "matches_gpu_proof_bytes": bool(same)}
         r2.free()
         ck2.powers_of_g.free()
+    # checker leg (like the CPU baseline: outside the timed region, oracle/ as the checker only): the proof that was
+    # just timed goes through the restated VERIFIER of the reference (src/snark/verifier.rs:19-119 -- sumcheck
+    # subclaims, tensor relation, pairing check against the key built from the trapdoor)
+    verdict = None
+    if cpu_logn and world == 1:
+        from oracle import oracle as orc
+        from oracle import verifier_ref as V
+
+        p = runs[-1][1]
+        I = gm.fr.fr_to_int
+        J = lambda pt: orc.affine_to_ints(orc.g1_to_affine(np.asarray(pt, dtype=np.uint64)))
+        msgs = lambda m: ([(I(a), I(b)) for a, b in m[0]], (I(m[1][0][0]), I(m[1][0][1])))
+        tc = p.tensorcheck_proof
+        ints = {"witness_commitment": J(p.witness_commitment), "zc_alpha": I(p.zc_alpha), "first_sumcheck_msgs": msgs(p.first_sumcheck_msgs),
+                "second_sumcheck_msgs": msgs(p.second_sumcheck_msgs),
+                "tensorcheck_proof": {"folded_polynomials_commitments": [J(c) for c in tc.folded_polynomials_commitments],
+                                      "folded_polynomials_evaluations": [[I(x) for x in e2] for e2 in tc.folded_polynomials_evaluations],
+                                      "evaluation_proof": J(tc.evaluation_proof),
+                                      "base_polynomials_evaluations": [[I(x) for x in e3] for e3 in tc.base_polynomials_evaluations]}}
+        t0 = time.perf_counter()
+        try:
+            V.snark_verify(ints, {"a": range(n), "x": [e]}, V.VerifierKey.from_trapdoor(tau_i, 5), m_of=V.dummy_matrix_evaluations(e, n))
+            accepted = True
+        except V.VerificationError:
+            accepted = False
+        verdict = {"accepted": accepted, "seconds": round(time.perf_counter() - t0, 2),
+                   "what": "oracle/verifier_ref.py (restatement of src/snark/verifier.rs + pairing check, CPU) on the timed proof"}
     return {
         "metric": "snark time_prover",
         "unit": "s",
@@ -188,6 +215,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         "sumcheck_roofline": sc,
         "with_fixed_base_tables": tables,
         "cpu_baseline": cpu,
+        "verifier": verdict,
         "proof_sha256": digest,
         "note": "median of 3 after one warm-up; instance (diagonal CSR) and SRS resident in HBM before the timer; proof elements equal the CPU "
                 "restatement at logn 3/6/9 (tests/test_gpu_snark.py)",

@@ -177,8 +177,35 @@ def tensorcheck_verify(tc, tr, vk, asserted_res_vec, base_commitments, direct_ba
 
 
 # ---- src/snark/verifier.rs -------------------------------------------------------------------------------------
-def snark_verify(proof, r1cs, vk: VerifierKey) -> None:
-    """:19-119; raises VerificationError on rejection.  `r1cs` as in snark_ref (rows of (value, column) pairs)."""
+def dummy_matrix_evaluations(e: int, n: int):
+    """The O(n) part of the verifier (src/snark/verifier.rs:63-88) for dummy_r1cs(e, n) -- A = B = C = diag(1 / e)
+    (src/circuit.rs:349-365) -- with every vector pass a call into the C restatement (oracle/gemini_oracle.c: powers,
+    tensor, hadamard, ip) instead of a Python loop: the verifier of a 2^24-constraint proof in seconds.  Returns the
+    `m_of` hook of snark_verify; the generic (Python) hook computes the same values (tests/test_oracle_verifier.py)."""
+    import numpy as np
+
+    from . import oracle as orc
+
+    M = lambda v: orc.fr_to_mont(orc.ints_to_limbs([v % R], 4))[0]  # noqa: E731
+    I = lambda x: orc.limbs_to_ints(orc.fr_from_mont(np.asarray(x, dtype=np.uint64).reshape(1, 4)))[0]  # noqa: E731
+    inv_e = pow(e, -1, R)
+    cache = {}
+
+    def m_of(point: int, ch1, alpha: int, etas):
+        if "tensor" not in cache:
+            t = orc.tensor(np.stack([M(c) for c in ch1]))
+            ap = orc.powers(M(alpha), n)
+            cache["tensor"], cache["alpha"], cache["had"] = t, ap, orc.hadamard(t[:n], ap)
+        bp = orc.powers(M(point), n)  # A * powers = powers / e for the diagonal matrices
+        parts = [I(orc.ip(bp, cache["had"])), I(orc.ip(bp, cache["tensor"][:n])), I(orc.ip(bp, cache["alpha"]))]
+        return inv_e * P.ip(parts, etas) % R
+
+    return m_of
+
+
+def snark_verify(proof, r1cs, vk: VerifierKey, m_of=None) -> None:
+    """:19-119; raises VerificationError on rejection.  `r1cs` as in snark_ref (rows of (value, column) pairs); `m_of`
+    (optional) replaces the O(n) evaluation of the matrices at the powers of +-beta (dummy_matrix_evaluations)."""
     tr = P.GeminiTranscript(P.PROTOCOL_NAME)
     tr.append_message(b"witness", P.g1_serialize_uncompressed(proof["witness_commitment"]))
     alpha = tr.get_challenge(b"alpha")
@@ -188,9 +215,6 @@ def snark_verify(proof, r1cs, vk: VerifierKey) -> None:
     eta = tr.get_challenge(b"eta")
     etas = P.powers(eta, 3)
     num_constraints = len(r1cs["a"])
-    tensor_challenges = P.tensor(ch1)
-    alpha_powers = P.powers(alpha, num_constraints)
-    hadamard_randomness = _hadamard_unsafe(tensor_challenges, alpha_powers)
     asserted_sum_2 = P.ip([ff1[0], ff1[1], proof["zc_alpha"]], etas)
     m2, ff2 = proof["second_sumcheck_msgs"]
     ch2, ff2 = subclaim_new(tr, m2, ff2, asserted_sum_2)
@@ -199,16 +223,20 @@ def snark_verify(proof, r1cs, vk: VerifierKey) -> None:
     for c in tc["folded_polynomials_commitments"]:
         tr.append_message(b"commitment", P.g1_serialize_uncompressed(c))
     beta = tr.get_challenge(b"evaluation-chal")
-    beta_powers = P.powers(beta, num_constraints)
-    minus_beta_powers = P.powers((-beta) % R, num_constraints)
+    if m_of is None:
+        tensor_challenges = P.tensor(ch1)
+        alpha_powers = P.powers(alpha, num_constraints)
+        hadamard_randomness = _hadamard_unsafe(tensor_challenges, alpha_powers)
 
-    def m_of(pw):
-        return P.ip([P.ip(sr.matvec(r1cs["a"], pw), hadamard_randomness), _ip_unsafe(sr.matvec(r1cs["b"], pw), tensor_challenges),
-                     P.ip(sr.matvec(r1cs["c"], pw), alpha_powers)], etas)
+        def generic(pw):
+            return P.ip([P.ip(sr.matvec(r1cs["a"], pw), hadamard_randomness), _ip_unsafe(sr.matvec(r1cs["b"], pw), tensor_challenges),
+                         P.ip(sr.matvec(r1cs["c"], pw), alpha_powers)], etas)
 
-    m_pos, m_neg = m_of(beta_powers), m_of(minus_beta_powers)
+        m_pos, m_neg = generic(P.powers(beta, num_constraints)), generic(P.powers((-beta) % R, num_constraints))
+    else:
+        m_pos, m_neg = m_of(beta, ch1, alpha, etas), m_of((-beta) % R, ch1, alpha, etas)
     x = r1cs["x"]
-    beta_power = beta_powers[len(x)]
+    beta_power = pow(beta, len(x), R)
     base_evals = tc["base_polynomials_evaluations"][0]
     z_pos = (P.evaluate_le(x, beta) + beta_power * base_evals[1]) % R
     if len(x) & 1:

@@ -396,9 +396,9 @@ def test_device_proofs_are_accepted_by_the_reference_verifier(gm, oracle, pyref,
     ck.powers_of_g.free()
 
 
-@pytest.mark.parametrize("logn", [20, 22])
+@pytest.mark.parametrize("logn", [20, 22, 24])
 def test_full_size_device_proof_is_accepted_by_the_reference_verifier(gm, oracle, pyref, logn):
-    """examples/psnark.rs:70-81 at 2^20 / 2^22 constraints (BASELINE configs[4] shape, smaller): the preprocessing
+    """examples/psnark.rs:70-81 at 2^20 / 2^22 / 2^24 constraints (BASELINE configs[4] shape, smaller): the preprocessing
     verifier is O(log n) -- it never touches the matrices -- so the device proof of a full-size instance is checked
     against the reference's acceptance predicate directly (three sumcheck subclaims, plookup / entry-product relations,
     two pairing checks over ~25 commitments each)."""

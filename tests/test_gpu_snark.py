@@ -603,8 +603,10 @@ def test_device_proofs_are_accepted_by_the_reference_verifier(gm, oracle, pyref,
     ck.powers_of_g.free()
 
 
-def test_device_proof_of_2p16_constraints_is_accepted_by_the_reference_verifier(gm, oracle, pyref):
-    """the O(n) verifier of the non-preprocessing SNARK on a 2^16-constraint device proof (the restated PROVER stops at 2^9)"""
+@pytest.mark.parametrize("logn", [16, 20])
+def test_device_proof_of_2p16_and_2p20_constraints_is_accepted_by_the_reference_verifier(gm, oracle, pyref, logn):
+    """the O(n) verifier of the non-preprocessing SNARK on 2^16- and 2^20-constraint device proofs (BASELINE configs[2]
+    shape, smaller; the restated PROVER stops at 2^9)"""
     from gemini_amd.circuit import dummy_r1cs
     from gemini_amd.kzg import CommitterKey
     from gemini_amd.snark import Proof
@@ -612,7 +614,7 @@ def test_device_proof_of_2p16_constraints_is_accepted_by_the_reference_verifier(
     from oracle import verifier_ref as V
     from tests.util import snark_proof_to_ints
 
-    n = 1 << 16
+    n = 1 << logn
     e, tau = 0x1D2C3B4A59687766554433221100FFEE % pyref.R_MOD, 0x0123456789ABCDEF0FEDCBA987654321 % pyref.R_MOD
     ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
     r1cs = dummy_r1cs(e, n)
@@ -679,3 +681,25 @@ def test_device_openings_pass_the_pairing_checks(gm, oracle, pyref):
     assert I(ev2) == I(ev)
     V.verify(vk, A(stream_ck.commit(be)), alpha, I(ev2), A(pr2))
     ck.powers_of_g.free()
+
+
+def test_baseline_config_proof_is_accepted_by_the_reference_verifier(gm, oracle, pyref):
+    """BASELINE configs[2], `snark --time-prover -i 24` (examples/snark.rs:69-79): the device proof of dummy_r1cs(2^24) is
+    ACCEPTED by the restated verifier of src/snark/verifier.rs -- both sumcheck subclaims, the tensor relation and the
+    pairing check of the batched opening against the trapdoor key; the O(n) evaluation of the matrices at the powers of
+    +-beta runs in the C restatement (oracle/verifier_ref.py::dummy_matrix_evaluations)."""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+    from oracle import verifier_ref as V
+    from tests.util import snark_proof_to_ints
+
+    n = 1 << 24
+    e, tau = 0x1D2C3B4A59687766554433221100FFEE % pyref.R_MOD, 0x0123456789ABCDEF0FEDCBA987654321 % pyref.R_MOD
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    r1cs = dummy_r1cs(e, n)
+    proof = Proof.new_time(r1cs, ck)
+    ints = snark_proof_to_ints(gm, oracle, proof)
+    r1cs.free()
+    ck.powers_of_g.free()
+    V.snark_verify(ints, {"a": range(n), "x": [e]}, V.VerifierKey.from_trapdoor(tau, 5), m_of=V.dummy_matrix_evaluations(e, n))

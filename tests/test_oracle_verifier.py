@@ -185,3 +185,23 @@ def test_reference_example_key_is_one_power_short():
         except V.VerificationError:
             verdict[max_degree] = False
     assert verdict == {2 * n: False, 2 * n + 1: True}
+
+
+def test_c_backed_matrix_evaluations_equal_the_generic_ones(honest):
+    """the hook that lets the verifier take 2^24-constraint dummy proofs (C vector passes) computes what the Python loops do"""
+    n = 64
+    e, tau = 0xABCDEF0123456789 % R, 0x13579BDF02468ACE13579BDF % R
+    inst = sr.dummy_r1cs(e, n)
+    proof = sr.snark_new_time(inst, sr.srs(tau, 2 * n + 1))
+    vk = V.VerifierKey.from_trapdoor(tau, 5)
+    V.snark_verify(proof, inst, vk)
+    V.snark_verify(proof, {"a": range(n), "x": [e]}, vk, m_of=V.dummy_matrix_evaluations(e, n))
+    rng = P.SplitMix64(11)
+    ch1, alpha, beta, etas = [rng.fr() for _ in range(6)], rng.fr(), rng.fr(), P.powers(rng.fr(), 3)
+    t, ap, bp = P.tensor(ch1), P.powers(alpha, n), P.powers(beta, n)
+    a_bp = sr.matvec(inst["a"], bp)
+    want = P.ip([P.ip(a_bp, [x * y % R for x, y in zip(t, ap)]), sum(x * y for x, y in zip(a_bp, t)) % R, P.ip(a_bp, ap)], etas)
+    assert V.dummy_matrix_evaluations(e, n)(beta, ch1, alpha, etas) == want
+    # a proof for another instance value is rejected through the hook as well
+    with pytest.raises(V.VerificationError):
+        V.snark_verify(proof, {"a": range(n), "x": [e]}, vk, m_of=V.dummy_matrix_evaluations((e + 1) % R, n))
