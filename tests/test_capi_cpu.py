@@ -83,3 +83,16 @@ def test_g1_sum_host(lib, oracle, pyref):
     z = g1_sum(np.stack([jac[0], neg]))
     assert not z[12:].any() and (z[:6] == one).all() and (z[6:12] == one).all()
     assert not g1_sum(np.empty((0, 18), dtype=np.uint64))[12:].any()
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the boundary is a C ABI: include/gemini_hip.h compiles as C99 with -pedantic and links against the library"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "gemini_hip.h"\nint main(void) { return gm_abi_version() == 1 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                           "-L", os.path.join(root, "gemini_amd"), "-lgemini_hip", "-Wl,-rpath," + os.path.join(root, "gemini_amd"), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0  # gm_abi_version needs no GPU
