@@ -175,6 +175,8 @@ int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_
               const uint64_t twist[4], uint64_t* handle);
 void sc_destroy(Sumcheck* S);
 int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
+int sc_round_begin(Context* C, Sumcheck* S, const uint64_t* challenge, int* has_msg);
+int sc_round_end(Context* C, Sumcheck* S, uint64_t a[4], uint64_t b[4]);
 int sc_fold(Context* C, Sumcheck* S, const uint64_t challenge[4]);
 int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has);
 int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream, size_t ng, bool src_is_device,
@@ -898,6 +900,20 @@ int gm_sc_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_m
   GM_SC(S, handle, "sc_round");
   GM_CHECK(a_mont && b_mont && has_msg, GM_EINVAL, "sc_round: null pointer");
   return sc_round(C, S, challenge_or_null, a_mont, b_mont, has_msg);
+}
+int gm_sc_round_begin(uint64_t handle, const uint64_t* challenge_or_null, int* has_msg) {
+  GM_CTX();
+  Sumcheck* S = find_prover(handle);
+  GM_CHECK(S != nullptr, GM_EHANDLE, "sc_round_begin: unknown prover handle %llu", (unsigned long long)handle);
+  GM_CHECK(has_msg != nullptr, GM_EINVAL, "sc_round_begin: null pointer");
+  return sc_round_begin(C, S, challenge_or_null, has_msg);
+}
+int gm_sc_round_end(uint64_t handle, uint64_t a_mont[4], uint64_t b_mont[4]) {
+  GM_CTX();
+  Sumcheck* S = find_prover(handle);
+  GM_CHECK(S != nullptr, GM_EHANDLE, "sc_round_end: unknown prover handle %llu", (unsigned long long)handle);
+  GM_CHECK(a_mont && b_mont, GM_EINVAL, "sc_round_end: null pointer");
+  return sc_round_end(C, S, a_mont, b_mont);
 }
 int gm_sc_fold(uint64_t handle, const uint64_t challenge_mont[4]) {
   GM_CTX();

@@ -94,6 +94,7 @@ struct Sumcheck {
   bool herring = false;      // herring FModule prover: messages carry no twist (src/herring/time_prover.rs:91-123)
   uint8_t* partials = nullptr;   // per-block (a, b) partial sums
   uint64_t* host_partials = nullptr;  // pinned
+  unsigned pending_blocks = 0;        // blocks of the round whose partial sums are on their way to host_partials
   std::mutex mu;
 };
 

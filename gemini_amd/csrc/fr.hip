@@ -589,7 +589,10 @@ static unsigned grid_for(size_t n, unsigned max_blocks = 2048) {
   return (unsigned)b;
 }
 
-static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho, uint64_t a_out[4], uint64_t b_out[4]) {
+// A round is an enqueue (the kernel and the asynchronous copy of its per-block partial sums) and a collect (after the
+// stream has been waited for: the host adds the partials).  Driven one prover at a time the two run back to back
+// (sc_launch); Sumcheck::prove_batch enqueues the round of EVERY prover before it waits once (sc_round_begin / _end).
+static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho) {
   ScArgs A;
   memset(&A, 0, sizeof A);
   gmh::Fr tau = gmh::Fr::from_limbs(S->twist);
@@ -645,18 +648,11 @@ static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr
   prof.end(PROF_SC_ROUND, st);
   GM_HIP(hipGetLastError());
   if (prof.on && !msg) GM_HIP(hipStreamSynchronize(st));
+  S->pending_blocks = 0;
   if (msg) {
     GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, st));
-    GM_HIP(hipStreamSynchronize(st));
-    gmh::Fr a = gmh::Fr::zero(), b = gmh::Fr::zero();
-    for (unsigned i = 0; i < blocks; i++) {
-      a = a + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8);
-      b = b + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8 + 4);
-    }
-    a.to_limbs(a_out);
-    b.to_limbs(b_out);
+    S->pending_blocks = blocks;
   }
-  prof.collect();
   if (fold) {
     S->cur ^= 1;
     S->nf = (S->nf + 1) / 2;
@@ -712,6 +708,31 @@ void sc_destroy(Sumcheck* S) {
   if (S->host_partials) (void)hipHostFree(S->host_partials);
 }
 
+// the stream the round was enqueued on has been waited for
+static void sc_collect(Context* C, Sumcheck* S, uint64_t a_out[4], uint64_t b_out[4]) {
+  gmh::Fr a = gmh::Fr::zero(), b = gmh::Fr::zero();
+  for (unsigned i = 0; i < S->pending_blocks; i++) {
+    a = a + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8);
+    b = b + gmh::Fr::from_limbs(S->host_partials + (size_t)i * 8 + 4);
+  }
+  a.to_limbs(a_out);
+  b.to_limbs(b_out);
+  S->pending_blocks = 0;
+  C->prof.collect();
+}
+
+static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho, uint64_t a_out[4], uint64_t b_out[4]) {
+  int rc = sc_enqueue(C, S, fold, msg, rho);
+  if (rc) return rc;
+  if (msg) {
+    GM_HIP(hipStreamSynchronize(C->stream));
+    sc_collect(C, S, a_out, b_out);
+  } else {
+    C->prof.collect();
+  }
+  return GM_OK;
+}
+
 // Prover::next_message                                                      time_prover.rs:83-123
 int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg) {
   std::lock_guard<std::mutex> lk(S->mu);
@@ -729,6 +750,34 @@ int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], 
   }
   S->round += 1;
   *has_msg = 1;
+  return GM_OK;
+}
+
+// split-phase round (see sc_enqueue): _begin launches, _end waits for the stream and returns the message
+int sc_round_begin(Context* C, Sumcheck* S, const uint64_t* challenge, int* has_msg) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_CHECK(S->round <= S->tot_rounds, GM_ESTATE, "More rounds than needed.");
+  GM_CHECK(S->pending_blocks == 0, GM_ESTATE, "sc_round_begin: the previous round has not been collected");
+  const bool fold = challenge != nullptr;
+  const bool msg = S->round != S->tot_rounds;
+  gmh::Fr rho = fold ? gmh::Fr::from_limbs(challenge) : gmh::Fr::zero();
+  if (fold || msg) {
+    int rc = sc_enqueue(C, S, fold, msg, rho);
+    if (rc) return rc;
+  }
+  if (!msg) {
+    *has_msg = 0;
+    return GM_OK;
+  }
+  S->round += 1;
+  *has_msg = 1;
+  return GM_OK;
+}
+int sc_round_end(Context* C, Sumcheck* S, uint64_t a[4], uint64_t b[4]) {
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_CHECK(S->pending_blocks != 0, GM_ESTATE, "sc_round_end: no round in flight");
+  GM_HIP(hipStreamSynchronize(C->stream));
+  sc_collect(C, S, a, b);
   return GM_OK;
 }
 

@@ -355,23 +355,38 @@ int gm_sumcheck_prove_batch(uint64_t transcript, const uint64_t* provers, size_t
     coeff[j] = gmh::Fr::from_limbs(c);
   }
   const uint64_t* vm = nullptr;
+  // a prover that has run out contributes (f0 * g0, 0) in every later round: read its final foldings once
+  std::vector<char> finished(k, 0), has(k, 0);
+  std::vector<gmh::Fr> final_product(k);
   for (size_t r = 0; r < rounds; r++) {
     gmh::Fr ma = gmh::Fr::zero(), mb = gmh::Fr::zero();
+    // the round of every live prover is enqueued before the first wait (the reference runs them on rayon threads, :85)
     for (size_t j = 0; j < k; j++) {
-      uint64_t a[4], b[4];
-      int has = 0;
-      int rc = gm_sc_round(provers[j], vm, a, b, &has);
+      if (finished[j]) continue;
+      int h = 0;
+      int rc = gm_sc_round_begin(provers[j], vm, &h);
       if (rc) return rc;
+      has[j] = (char)h;
+    }
+    for (size_t j = 0; j < k; j++) {
       gmh::Fr fa, fb;
-      if (has) {
+      if (!finished[j] && has[j]) {
+        uint64_t a[4], b[4];
+        int rc = gm_sc_round_end(provers[j], a, b);
+        if (rc) return rc;
         fa = gmh::Fr::from_limbs(a);
         fb = gmh::Fr::from_limbs(b);
       } else {
-        uint64_t f0[4], g0[4];
-        int hf = 0;
-        if ((rc = gm_sc_final(provers[j], f0, g0, &hf))) return rc;
-        T_CHECK(hf, GM_ESTATE, "If next_message is None, we expect final foldings to be available");
-        fa = gmh::Fr::from_limbs(f0) * gmh::Fr::from_limbs(g0);
+        if (!finished[j]) {
+          uint64_t f0[4], g0[4];
+          int hf = 0;
+          int rc = gm_sc_final(provers[j], f0, g0, &hf);
+          if (rc) return rc;
+          T_CHECK(hf, GM_ESTATE, "If next_message is None, we expect final foldings to be available");
+          final_product[j] = gmh::Fr::from_limbs(f0) * gmh::Fr::from_limbs(g0);
+          finished[j] = 1;
+        }
+        fa = final_product[j];
         fb = gmh::Fr::zero();
       }
       ma = ma + fa * coeff[j];

@@ -244,6 +244,14 @@ int gm_spm_register(const uint64_t* rowptr, const uint32_t* cols, const uint64_t
 int gm_spm_free(uint64_t handle);
 int gm_spm_mul(uint64_t matrix, uint64_t x, uint64_t y);
 
+/* Split-phase round for callers that drive MANY provers in lock-step (Sumcheck::prove_batch maps its provers over
+ * rayon, src/subprotocols/sumcheck/proof.rs:85): _begin does what gm_sc_round does up to the launch of the kernel
+ * and the asynchronous copy of its partial sums, _end waits for the stream and returns the message.  Begin the
+ * round of every prover, then end them: one wait instead of one per prover.  has_msg = 0 means the prover is out
+ * of rounds (no _end call then); a second _begin before the _end of the same prover is GM_ESTATE. */
+int gm_sc_round_begin(uint64_t handle, const uint64_t* challenge_or_null, int* has_msg);
+int gm_sc_round_end(uint64_t handle, uint64_t a_mont[4], uint64_t b_mont[4]);
+
 /* ---- sumcheck time prover --------------------------------------------------------------------- */
 /* Replaces TimeProver<F> behind `trait Prover<F>` (src/subprotocols/sumcheck/prover.rs:30-45,
  * src/subprotocols/sumcheck/time_prover.rs:42-137).  f, g are copied (Witness::new copies too,
