@@ -419,3 +419,35 @@ def test_device_sumchecks_are_accepted_by_the_reference_verifier(gm, oracle, pyr
     for p in provers:
         p.free()
     t.free()
+
+
+def test_fr_vector_ops_randomised_differential(gm, oracle, pyref):
+    """seeded sweep over lengths (0, 1, odd, just around block and wave sizes, a few thousand) of every dense Fr pass of
+    src/misc.rs and of the vanishing-polynomial division against the CPU restatement -- the ragged shapes the folding
+    levels of a non-power-of-two instance produce"""
+    from gemini_amd.fr import div_vanishing
+
+    rng = np.random.default_rng(20240607)
+    lengths = [0, 1, 2, 3, 5, 63, 64, 65, 127, 255, 256, 257, 1023, 1025, 4097] + [int(x) for x in rng.integers(2, 9000, size=12)]
+    for it, n in enumerate(lengths):
+        f = oracle.fr_to_mont(oracle.random_fr(7000 + it, max(n, 1)))[:n]
+        m = int(rng.integers(0, n + 3)) if n else 0
+        g = oracle.fr_to_mont(oracle.random_fr(7100 + it, max(m, 1)))[:m]
+        x = oracle.fr_to_mont(oracle.random_fr(7200 + it, 4))
+        if n:
+            assert (gm.fold_polynomial(f, x[0]).to_host() == oracle.fold_polynomial(f, x[0])).all(), n
+            ev = gm.evaluate_le(f, x[:3])
+            assert all((ev[k] == oracle.evaluate_le(f, x[k])).all() for k in range(3)), n
+            assert (gm.hadamard(f, f[::-1].copy()).to_host() == oracle.hadamard(f, f[::-1].copy())).all(), n
+            assert (gm.ip(f, f[::-1].copy()) == oracle.ip(f, f[::-1].copy())).all(), n
+        assert (gm.powers(x[1], n).to_host() == oracle.powers(x[1], n)).all(), n
+        polys = [p for p in (f, g, f[: n // 3]) if len(p)]
+        if polys:
+            got = gm.linear_combination(polys, x[: len(polys)]).to_host()
+            assert (got == oracle.linear_combination(polys, x[: len(polys)])).all(), (n, m)
+        k = int(rng.integers(1, 4))
+        if n > k:
+            pts_i = oracle.limbs_to_ints(oracle.random_fr(7300 + it, k))
+            q, _ = div_vanishing(f, _mont(oracle, pts_i))
+            q_exp, _ = oracle.poly_div_monic(f, _mont(oracle, pyref.vanishing_polynomial(pts_i)))
+            assert (q.to_host() == q_exp).all(), (n, k)
