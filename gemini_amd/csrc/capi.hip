@@ -863,6 +863,20 @@ int gm_spm_free(uint64_t handle) {
   if (M->vals) (void)hipFree(M->vals);
   return GM_OK;
 }
+int gm_spm_shape(uint64_t handle, size_t* nrows, size_t* ncols, size_t* nnz) {
+  GM_CTX();
+  SparseMatrix* M = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->matrices.find(handle);
+    if (it != C->matrices.end()) M = it->second.get();
+  }
+  GM_CHECK(M != nullptr, GM_EHANDLE, "spm_shape: unknown matrix handle %llu", (unsigned long long)handle);
+  if (nrows) *nrows = M->nrows;
+  if (ncols) *ncols = M->ncols;
+  if (nnz) *nnz = M->nnz;
+  return GM_OK;
+}
 int gm_spm_mul(uint64_t matrix, uint64_t x, uint64_t y) {
   GM_CTX();
   SparseMatrix* M;

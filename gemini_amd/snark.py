@@ -26,7 +26,11 @@ class Proof:
         self.spans = {}
 
     @staticmethod
-    def new_time(r1cs: R1cs, ck: CommitterKey) -> "Proof":
+    def new_time(r1cs: R1cs, ck: CommitterKey, native: bool = False) -> "Proof":
+        """src/snark/time_prover.rs:19-117.  native=True: the same sequence compiled into the library
+        (gm_snark_new_time, gemini_amd/csrc/snark.cpp), one call per proof; the two are byte for byte equal."""
+        if native and type(ck) is CommitterKey:
+            return _new_time_native(r1cs, ck)
         spans = {}
         t_all = time.perf_counter()
         z_a = r1cs.a.mul(r1cs.z)  # :32-34
@@ -84,6 +88,52 @@ class Proof:
                       (second_proof.messages, second_proof.final_foldings), tensorcheck_proof)
         proof.spans = spans
         return proof
+
+
+class _GmSnarkProof(__import__("ctypes").Structure):
+    import ctypes as _C
+
+    _fields_ = [("witness_commitment", _C.c_uint64 * 18), ("zc_alpha", _C.c_uint64 * 4), ("rounds", _C.c_size_t * 2),
+                ("messages", _C.POINTER(_C.c_uint64) * 2), ("final_foldings", (_C.c_uint64 * 8) * 2), ("nfold", _C.c_size_t),
+                ("fold_commitments", _C.POINTER(_C.c_uint64)), ("fold_evaluations", _C.POINTER(_C.c_uint64)),
+                ("evaluation_proof", _C.c_uint64 * 18), ("base_evaluations", _C.c_uint64 * 12), ("spans", _C.c_double * 7)]
+
+
+_SPAN_NAMES = ["product_matrix_vector x3", "Commitment to w", "First sumcheck", "tensor/powers/hadamard/abc_tensored", "Second sumcheck",
+               "Tensorcheck", "ark_gemini::snark::time_prover"]
+
+
+def _new_time_native(r1cs: R1cs, ck: CommitterKey) -> "Proof":
+    import ctypes as C
+
+    from . import capi
+    from .transcript import default_group_encoding
+
+    cap = max(len(r1cs.z), 2).bit_length() + 2
+    m = [np.zeros((cap, 8), dtype=np.uint64) for _ in range(2)]
+    fc = np.zeros((cap, 18), dtype=np.uint64)
+    fe = np.zeros((cap, 8), dtype=np.uint64)
+    P = _GmSnarkProof()
+    U = C.POINTER(C.c_uint64)
+    for k in range(2):
+        P.messages[k] = m[k].ctypes.data_as(U)
+    P.fold_commitments = fc.ctypes.data_as(U)
+    P.fold_evaluations = fe.ctypes.data_as(U)
+    mats = (C.c_uint64 * 6)(*[x.handle for x in (r1cs.a, r1cs.b, r1cs.c, r1cs.at, r1cs.bt, r1cs.ct)])
+    capi.check(capi.load().gm_snark_new_time(mats, C.c_uint64(r1cs.z.handle), C.c_uint64(r1cs.w.handle), C.c_uint64(ck.powers_of_g.handle),
+                                             C.c_int(int(default_group_encoding())), C.c_size_t(cap), C.byref(P)))
+    A = lambda a: np.array(a, dtype=np.uint64)  # noqa: E731
+    msgs = []
+    for k in range(2):
+        r = P.rounds[k]
+        ff = A(P.final_foldings[k])
+        msgs.append(([(m[k][i, :4].copy(), m[k][i, 4:].copy()) for i in range(r)], [(ff[:4].copy(), ff[4:].copy())]))
+    nf = P.nfold
+    be = A(P.base_evaluations).reshape(3, 4)
+    tc = TensorcheckProof([fc[i].copy() for i in range(nf)], [fe[i].reshape(2, 4).copy() for i in range(nf)], A(P.evaluation_proof), [be])
+    proof = Proof(A(P.witness_commitment), A(P.zc_alpha), msgs[0], msgs[1], tc)
+    proof.spans = {name: P.spans[i] for i, name in enumerate(_SPAN_NAMES)}
+    return proof
 
 
 # ---- CanonicalSerialize of the proof (src/snark/mod.rs:75-82): gemini_amd/wire.py holds the formats ------------

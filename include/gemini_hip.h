@@ -243,6 +243,7 @@ int gm_spm_register(const uint64_t* rowptr, const uint32_t* cols, const uint64_t
                     size_t nnz, uint64_t* handle);
 int gm_spm_free(uint64_t handle);
 int gm_spm_mul(uint64_t matrix, uint64_t x, uint64_t y);
+int gm_spm_shape(uint64_t matrix, size_t* nrows_or_null, size_t* ncols_or_null, size_t* nnz_or_null);
 
 /* Split-phase round for callers that drive MANY provers in lock-step (Sumcheck::prove_batch maps its provers over
  * rayon, src/subprotocols/sumcheck/proof.rs:85): _begin does what gm_sc_round does up to the launch of the kernel
@@ -344,6 +345,33 @@ int gm_sumcheck_prove(uint64_t transcript, uint64_t prover, uint64_t* messages, 
  * messages: cap_rounds x 8, challenges: cap_rounds x 4, final_foldings: k x 8 (lhs || rhs). */
 int gm_sumcheck_prove_batch(uint64_t transcript, const uint64_t* provers, size_t k, uint64_t* messages, uint64_t* challenges,
                             size_t cap_rounds, uint64_t* final_foldings, size_t* rounds_out);
+
+/* ---- the whole prover in one call ---------------------------------------------------------------------
+ * snark::Proof::new_time (src/snark/time_prover.rs:19-117) with its tensor check (tensorcheck/mod.rs:190-275) and KZG
+ * openings (src/kzg/time.rs:81-159): the orchestration the reference compiles into the prover, compiled into the
+ * library over the entry points above (gemini_amd/csrc/snark.cpp) -- one FFI call per proof for a shim that replaces
+ * `Proof::new_time(&r1cs, &ck)`.  matrices = {A, B, C, A^T, B^T, C^T} (gm_spm_register handles; the transposes serve
+ * the column sums of :63-81), z and w vector handles, ck_bases the registered powers_of_g, g1_encoding as in
+ * gm_transcript_set_g1_encoding.  The caller provides messages[k] (cap_rounds x 8), fold_commitments (cap_rounds x 18)
+ * and fold_evaluations (cap_rounds x 8); cap_rounds >= ceil(log2 |z|) + 1.  Everything is in the memory images of the
+ * rest of this header (Montgomery Fr limbs, 18-limb Jacobian points).  spans: seconds of the reference's
+ * start_timer! spans -- matrix products, commitment to w, first sumcheck, tensor/powers/hadamard/abc_tensored, second
+ * sumcheck, tensor check, the whole prover.  Same bytes as the step-by-step drivers (tests/test_gpu_snark.py). */
+typedef struct gm_snark_proof {
+  uint64_t witness_commitment[18];
+  uint64_t zc_alpha[4];
+  size_t rounds[2];            /* messages of the first / second sumcheck */
+  uint64_t* messages[2];       /* RoundMsg(a, b) = 8 limbs per round */
+  uint64_t final_foldings[2][8];
+  size_t nfold;                /* folded polynomials of the tensor check = rounds[1] - 1 */
+  uint64_t* fold_commitments;
+  uint64_t* fold_evaluations;  /* at beta and -beta */
+  uint64_t evaluation_proof[18];
+  uint64_t base_evaluations[12]; /* w at beta^2, beta, -beta */
+  double spans[7];
+} gm_snark_proof;
+int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_t w, uint64_t ck_bases, int g1_encoding, size_t cap_rounds,
+                      gm_snark_proof* proof);
 
 #ifdef __cplusplus
 }

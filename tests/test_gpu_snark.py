@@ -703,3 +703,42 @@ def test_baseline_config_proof_is_accepted_by_the_reference_verifier(gm, oracle,
     r1cs.free()
     ck.powers_of_g.free()
     V.snark_verify(ints, {"a": range(n), "x": [e]}, V.VerifierKey.from_trapdoor(tau, 5), m_of=V.dummy_matrix_evaluations(e, n))
+
+
+@pytest.mark.parametrize("logn", [1, 3, 6, 9, 14])
+def test_native_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
+    """gm_snark_new_time (the orchestration of src/snark/time_prover.rs:19-117 compiled into the library,
+    gemini_amd/csrc/snark.cpp) against the step-by-step driver of gemini_amd/snark.py: the same proof, byte for byte,
+    on the dummy instance and on a general sparse one; and the restatement's proof at the sizes it reaches."""
+    from gemini_amd.circuit import R1cs, SparseMatrix, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+    from oracle import snark_ref as sr
+    from oracle import wire_ref as W
+    from tests.util import random_r1cs_instance
+
+    n = 1 << logn
+    e = oracle.limbs_to_ints(oracle.random_fr(6100 + logn, 1))[0]
+    tau = oracle.limbs_to_ints(oracle.random_fr(6200 + logn, 1))[0]
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    r1cs = dummy_r1cs(e, n)
+    stepwise = Proof.new_time(r1cs, ck)
+    native = Proof.new_time(r1cs, ck, native=True)
+    assert native == stepwise
+    for compress in (True, False):
+        assert native.serialize(compress, 0) == stepwise.serialize(compress, 0)
+    assert set(native.spans) == set(stepwise.spans)
+    if logn <= 9 and logn >= 3:
+        exp = sr.snark_new_time(sr.dummy_r1cs(e, n), sr.srs(tau, 2 * n + 1))
+        assert native.serialize(True, 0) == W.snark_proof(exp, True, "arkworks")
+    r1cs.free()
+    if 3 <= logn <= 6:  # a general instance (distinct sparse A, B, C; public input of two elements)
+        inst, _ = random_r1cs_instance(pyref, sr, n, 6300 + logn, nx=2)
+        M = lambda v: gm.fr.fr_from_int(v)  # noqa: E731
+        dev = lambda rows: [[(M(v), col) for v, col in row] for row in rows]  # noqa: E731
+        mats = [SparseMatrix.from_rows(dev(inst[k]), n) for k in "abc"] + [SparseMatrix.from_rows(dev(inst[k]), n, transpose=True) for k in "abc"]
+        g = R1cs(*mats, gm.FrVec.from_host(_M(oracle, inst["z"])), gm.FrVec.from_host(_M(oracle, inst["w"])), gm.FrVec.from_host(_M(oracle, inst["x"])))
+        p1, p2 = Proof.new_time(g, ck), Proof.new_time(g, ck, native=True)
+        assert p1 == p2 and p2.serialize(True, 0) == W.snark_proof(sr.snark_new_time(inst, sr.srs(tau, 2 * n + 1)), True, "arkworks")
+        g.free()
+    ck.powers_of_g.free()

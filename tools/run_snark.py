@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--max-msm-buffer-log", type=int, default=20, help="max_msm_buffer of the elastic prover (examples/snark.rs:57: 2^20)")
     ap.add_argument("--tables", action="store_true", help="gm_g1_bases_precompute on the committer key before proving (13 x the key in HBM)")
     ap.add_argument("--min-device-chunk-log", type=int, default=None, help="CommitterKeyStream.min_device_chunk = 2^k (default: the class default)")
+    ap.add_argument("--native", action="store_true", help="gm_snark_new_time: the prover's orchestration compiled into the library (one call per proof)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/snark.rs elastic_snark_main) instead of --time-prover")
     args = ap.parse_args()
@@ -95,7 +96,7 @@ def main():
             proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log)
             stream.free()
         else:
-            proof = Proof.new_time(r1cs, ck)
+            proof = Proof.new_time(r1cs, ck, native=args.native)
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         out["proof_size_B"] = proof.compressed_size()  # examples/snark.rs:96 "proof-size {}B"
     key = "ark_gemini::snark::elastic_prover" if args.elastic else "ark_gemini::snark::time_prover"
