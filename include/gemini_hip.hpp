@@ -10,6 +10,7 @@
 //   gm::TimeProver (trait Prover)                           src/subprotocols/sumcheck/prover.rs:30-45
 //   gm::Transcript (GeminiTranscript over merlin)           src/transcript.rs:8-34
 //   gm::Sumcheck::{prove, new_time}                         src/subprotocols/sumcheck/proof.rs:36-66,125-130
+//   gm::R1cs, gm::SnarkProof::new_time                      src/circuit.rs, src/snark/time_prover.rs:19-117
 #pragma once
 #include <array>
 #include <cstdint>
@@ -226,6 +227,7 @@ class CommitterKey {
   }
   CommitterKey(const CommitterKey&) = delete;
   CommitterKey& operator=(const CommitterKey&) = delete;
+  uint64_t handle() const { return h_; }
   G1Projective commit(const std::vector<Fr>& polynomial) const {
     size_t n = polynomial.size() < n_ ? polynomial.size() : n_;
     if (n == 0) return g1_zero();
@@ -356,6 +358,122 @@ struct Sumcheck {
   static Sumcheck new_time(Transcript& transcript, const std::vector<Fr>& f, const std::vector<Fr>& g, const Fr& twist) {
     TimeProver prover(f, g, twist);
     return prove(transcript, prover);
+  }
+};
+
+// `Matrix<F> = Vec<Vec<(F, usize)>>` (src/circuit.rs:43) resident in HBM as CSR, together with its transpose (the
+// prover needs column sums, src/snark/time_prover.rs:63-81)
+using Matrix = std::vector<std::vector<std::pair<Fr, size_t>>>;
+class DeviceMatrix {
+ public:
+  DeviceMatrix(const Matrix& rows, size_t ncols, bool transpose) {
+    const size_t out_rows = transpose ? ncols : rows.size(), out_cols = transpose ? rows.size() : ncols;
+    std::vector<uint64_t> rowptr(out_rows + 1, 0);
+    for (size_t i = 0; i < rows.size(); i++)
+      for (auto& e : rows[i]) rowptr[(transpose ? e.second : i) + 1]++;
+    for (size_t i = 0; i < out_rows; i++) rowptr[i + 1] += rowptr[i];
+    const size_t nnz = rowptr[out_rows];
+    std::vector<uint32_t> cols(nnz);
+    std::vector<Fr> vals(nnz);
+    std::vector<uint64_t> cur(rowptr.begin(), rowptr.end() - 1);
+    for (size_t i = 0; i < rows.size(); i++)
+      for (auto& e : rows[i]) {
+        const size_t r = transpose ? e.second : i, c = transpose ? i : e.second;
+        cols[cur[r]] = (uint32_t)c;
+        vals[cur[r]++] = e.first;
+      }
+    check(gm_spm_register(rowptr.data(), cols.data(), nnz ? vals[0].data() : nullptr, out_rows, out_cols, nnz, &h_));
+  }
+  ~DeviceMatrix() {
+    if (h_) gm_spm_free(h_);
+  }
+  DeviceMatrix(const DeviceMatrix&) = delete;
+  DeviceMatrix& operator=(const DeviceMatrix&) = delete;
+  uint64_t handle() const { return h_; }
+
+ private:
+  uint64_t h_ = 0;
+};
+
+// src/circuit.rs `R1cs { a, b, c, z, w, x }` with everything the prover touches on the device
+class R1cs {
+ public:
+  R1cs(const Matrix& a, const Matrix& b, const Matrix& c, const std::vector<Fr>& z, const std::vector<Fr>& w)
+      : a_(a, z.size(), false), b_(b, z.size(), false), c_(c, z.size(), false), at_(a, z.size(), true), bt_(b, z.size(), true),
+        ct_(c, z.size(), true), nz_(z.size()) {
+    check(gm_fr_vec_alloc(z.size(), &z_));
+    check(gm_fr_vec_alloc(w.size(), &w_));
+    if (!z.empty()) check(gm_fr_vec_upload(z_, 0, z[0].data(), z.size()));
+    if (!w.empty()) check(gm_fr_vec_upload(w_, 0, w[0].data(), w.size()));
+  }
+  ~R1cs() {
+    if (z_) gm_fr_vec_free(z_);
+    if (w_) gm_fr_vec_free(w_);
+  }
+  R1cs(const R1cs&) = delete;
+  R1cs& operator=(const R1cs&) = delete;
+
+ private:
+  friend struct SnarkProof;
+  DeviceMatrix a_, b_, c_, at_, bt_, ct_;
+  uint64_t z_ = 0, w_ = 0;
+  size_t nz_;
+};
+
+// src/subprotocols/tensorcheck/mod.rs:110-121
+struct TensorcheckProof {
+  std::vector<G1Projective> folded_polynomials_commitments;
+  std::vector<std::array<Fr, 2>> folded_polynomials_evaluations;
+  G1Projective evaluation_proof;
+  std::vector<std::array<Fr, 3>> base_polynomials_evaluations;
+};
+
+// src/snark/mod.rs:76-82 + Proof::new_time (src/snark/time_prover.rs:19-117): one call into the library
+struct SnarkProof {
+  G1Projective witness_commitment;
+  Fr zc_alpha;
+  std::vector<RoundMsg> first_sumcheck_msgs, second_sumcheck_msgs;
+  std::array<Fr, 2> first_final_foldings, second_final_foldings;
+  TensorcheckProof tensorcheck_proof;
+
+  static SnarkProof new_time(const R1cs& r1cs, const CommitterKey& ck, int g1_encoding = 0) {
+    size_t cap = 2;
+    for (size_t n = r1cs.nz_; n > 1; n = (n + 1) / 2) cap++;
+    std::vector<uint64_t> m0(cap * 8), m1(cap * 8), fc(cap * 18), fe(cap * 8);
+    gm_snark_proof p;
+    memset(&p, 0, sizeof p);
+    p.messages[0] = m0.data();
+    p.messages[1] = m1.data();
+    p.fold_commitments = fc.data();
+    p.fold_evaluations = fe.data();
+    const uint64_t mats[6] = {r1cs.a_.handle(), r1cs.b_.handle(), r1cs.c_.handle(), r1cs.at_.handle(), r1cs.bt_.handle(), r1cs.ct_.handle()};
+    check(gm_snark_new_time(mats, r1cs.z_, r1cs.w_, ck.handle(), g1_encoding, cap, &p));
+    SnarkProof out;
+    memcpy(out.witness_commitment.data(), p.witness_commitment, 144);
+    memcpy(out.zc_alpha.data(), p.zc_alpha, 32);
+    auto msgs = [](const uint64_t* m, size_t rounds) {
+      std::vector<RoundMsg> v(rounds);
+      for (size_t i = 0; i < rounds; i++) {
+        memcpy(v[i].a.data(), m + 8 * i, 32);
+        memcpy(v[i].b.data(), m + 8 * i + 4, 32);
+      }
+      return v;
+    };
+    out.first_sumcheck_msgs = msgs(m0.data(), p.rounds[0]);
+    out.second_sumcheck_msgs = msgs(m1.data(), p.rounds[1]);
+    memcpy(out.first_final_foldings.data(), p.final_foldings[0], 64);
+    memcpy(out.second_final_foldings.data(), p.final_foldings[1], 64);
+    auto& tc = out.tensorcheck_proof;
+    tc.folded_polynomials_commitments.resize(p.nfold);
+    tc.folded_polynomials_evaluations.resize(p.nfold);
+    for (size_t i = 0; i < p.nfold; i++) {
+      memcpy(tc.folded_polynomials_commitments[i].data(), fc.data() + 18 * i, 144);
+      memcpy(tc.folded_polynomials_evaluations[i].data(), fe.data() + 8 * i, 64);
+    }
+    memcpy(tc.evaluation_proof.data(), p.evaluation_proof, 144);
+    tc.base_polynomials_evaluations.resize(1);
+    memcpy(tc.base_polynomials_evaluations[0].data(), p.base_evaluations, 96);
+    return out;
   }
 };
 

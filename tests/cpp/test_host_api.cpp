@@ -62,6 +62,39 @@ int main(int argc, char** argv) {
     print("ff0", sc.final_foldings[0][0]);
     print("ff1", sc.final_foldings[0][1]);
     print("after", t.get_challenge("after"));
+    // snark::Proof::new_time on dummy_r1cs(e, n): A = B = C = diag(1 / e), z = [e; n], w = [e; n - 1]
+    if (in.peek() != EOF) {
+      auto ev = read_vec<gm::Fr>(in);  // e, 1 / e
+      auto srs = read_vec<gm::G1Affine>(in);
+      const size_t n = (srs.size() - 1) / 2;
+      gm::Matrix diag(n);
+      for (size_t i = 0; i < n; i++) diag[i].push_back({ev[1], i});
+      std::vector<gm::Fr> z(n, ev[0]), w(n - 1, ev[0]);
+      gm::R1cs r1cs(diag, diag, diag, z, w);
+      gm::CommitterKey key(srs);
+      auto proof = gm::SnarkProof::new_time(r1cs, key);
+      print("snark_witness", proof.witness_commitment);
+      print("snark_zc_alpha", proof.zc_alpha);
+      for (auto& m : proof.first_sumcheck_msgs) {
+        print("snark_m1a", m.a);
+        print("snark_m1b", m.b);
+      }
+      for (auto& m : proof.second_sumcheck_msgs) {
+        print("snark_m2a", m.a);
+        print("snark_m2b", m.b);
+      }
+      print("snark_ff1", proof.first_final_foldings[0]);
+      print("snark_ff1", proof.first_final_foldings[1]);
+      print("snark_ff2", proof.second_final_foldings[0]);
+      print("snark_ff2", proof.second_final_foldings[1]);
+      for (auto& c : proof.tensorcheck_proof.folded_polynomials_commitments) print("snark_fc", c);
+      for (auto& e2 : proof.tensorcheck_proof.folded_polynomials_evaluations) {
+        print("snark_fe", e2[0]);
+        print("snark_fe", e2[1]);
+      }
+      print("snark_open", proof.tensorcheck_proof.evaluation_proof);
+      for (auto& e : proof.tensorcheck_proof.base_polynomials_evaluations[0]) print("snark_be", e);
+    }
     // error behaviour: hadamard-style length mismatch surfaces as gm::Error, not a crash
     try {
       gm::check(gm_g1_bases_free(0xdeadbeef));

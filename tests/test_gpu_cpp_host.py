@@ -36,8 +36,18 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
     g = oracle.fr_to_mont(oracle.random_fr(304, nf))
     tw = oracle.fr_to_mont(oracle.random_fr(305, 1))
     inp = str(tmp_path / "in.bin")
+    # snark::Proof::new_time through the C++ mirror: dummy_r1cs(e, 16) and an SRS of 2 n + 1 powers in the Rust layout
+    from oracle import snark_ref as sr
+
+    ns = 16
+    e_i = oracle.limbs_to_ints(oracle.random_fr(306, 1))[0]
+    tau_i = oracle.limbs_to_ints(oracle.random_fr(307, 1))[0]
+    ev = oracle.fr_to_mont(oracle.ints_to_limbs([e_i, pow(e_i, -1, pyref.R_MOD)], 4))
+    srs = sr.srs(tau_i, 2 * ns + 1)
+    srs_rust = np.zeros((2 * ns + 1, 13), dtype=np.uint64)
+    srs_rust[:, :12] = srs
     with open(inp, "wb") as fh:
-        for a in (rust, sc, mont, f, g, tw):
+        for a in (rust, sc, mont, f, g, tw, ev, srs_rust):
             _wvec(fh, a)
     out = subprocess.check_output([exe, inp], text=True)
     vals = {}
@@ -65,3 +75,17 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
     assert (I(J("ff0"))[0], I(J("ff1"))[0]) == ff
     assert I(J("after"))[0] == tr.get_challenge(b"after")
     assert vals["error_path"][0] == ["-3"]  # GM_EHANDLE surfaced as an exception, no crash
+    # the proof of gm::SnarkProof::new_time equals the restatement's, element by element
+    exp = sr.snark_new_time(sr.dummy_r1cs(e_i, ns), srs)
+    A = lambda key, k=0: jac_to_affine_ints(oracle, J(key, k))
+    F = lambda key, k=0: I(J(key, k))[0]
+    assert A("snark_witness") == exp["witness_commitment"] and F("snark_zc_alpha") == exp["zc_alpha"]
+    for tag, name in (("1", "first_sumcheck_msgs"), ("2", "second_sumcheck_msgs")):
+        msgs, ff = exp[name]
+        assert [(F(f"snark_m{tag}a", k), F(f"snark_m{tag}b", k)) for k in range(len(vals[f"snark_m{tag}a"]))] == msgs
+        assert (F(f"snark_ff{tag}", 0), F(f"snark_ff{tag}", 1)) == ff
+    tc = exp["tensorcheck_proof"]
+    assert [A("snark_fc", k) for k in range(len(vals["snark_fc"]))] == tc["folded_polynomials_commitments"]
+    assert [[F("snark_fe", 2 * k), F("snark_fe", 2 * k + 1)] for k in range(len(vals["snark_fe"]) // 2)] == tc["folded_polynomials_evaluations"]
+    assert A("snark_open") == tc["evaluation_proof"]
+    assert [[F("snark_be", k) for k in range(3)]] == tc["base_polynomials_evaluations"]
