@@ -227,8 +227,10 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: 0.4 s of timed steps behind 75 ms of warm-up -- one 75 ms window of 20 steps was seen to catch a clock
+    # ramp after an idle period (238 instead of 278 Mscalar/s once in ~30 runs)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--logn", type=int, default=LOG_N, help="pairs per GPU per step = 2^logn (default: BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="only the timed headline loop (what the rocprofv3 summary under profiles/ is taken "
