@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 LOG_N = 20
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+MADD_ISSUE_BOUND = round(1024 * 64 * 2.4e9 / (3517 * 4.5 + 876 * 2.35))  # mixed additions / s, see the roofline note
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_PAIR = 128  # 32 B scalar + 96 B affine base
 
@@ -486,15 +487,16 @@ def main():
                 "kernel_ms_per_launch": round(acc0_ms / launches["acc0"], 4) if acc0_ms else None,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR * n / launches["acc0"] if acc0_ms else None,
                 "algorithmic_bytes_per_step": BYTES_PER_PAIR * n,
-                "note": "integer-ALU bound (338 v_mad_u64_u32 per Fq product, 260 per square, radix 2^30); HBM fraction reported as the contract asks",
-                # the truthful utilisation figure: Fq products per second of the kernel (8 products + 2
-                # squares per mixed addition, 16 windows) against the multiplier's instruction-issue bound -- product: 416
-                # half-rate (338 v_mad_u64_u32 + shifts / v_mul_lo) + 103 full-rate instructions, square: 327 + 102
-                # (gen_field_mul30.py), 4.5 / 2.35 cycles per wave each (tools/ubench_isa.hip, tools/gen_ubench_regs.py),
-                # 1024 SIMDs x 64 lanes at 2.4 GHz -> 77.4 G products/s for the 8M + 2S mix
-                "fq_mul_per_s": round(10 * 16 * n / (acc0_ms * 1e-3)) if acc0_ms and args.logn == LOG_N else None,
-                "fq_mul_issue_bound": 77.4e9,
-                "alu_frac": round(10 * 16 * n / (acc0_ms * 1e-3) / 77.4e9, 4) if acc0_ms and args.logn == LOG_N else None,
+                "note": "integer-ALU bound: one XYZZ mixed addition = one asm statement of 3055 v_mad_u64_u32 (radix 2^30, 13 limbs, 9 Montgomery "
+                        "reductions; gen_madd30.py); HBM fraction reported as the contract asks",
+                # the truthful utilisation figure: mixed additions per second of the kernel (16 windows x n)
+                # against the instruction-issue bound of the statement -- 3517 half-rate (v_mad_u64_u32, v_mul_lo_u32,
+                # v_lshrrev_b64, v_addc_co_u32, v_alignbit_b32, v_or3_b32) + 876 full-rate instructions
+                # (`python3 gemini_amd/csrc/gen_madd30.py --selftest` prints the mix), 4.5 / 2.35 cycles per wave each
+                # (tools/ubench_isa.hip, tools/gen_ubench_regs.py), 1024 SIMDs x 64 lanes at 2.4 GHz -> 8.79 G additions/s
+                "madd_per_s": round(16 * n / (acc0_ms * 1e-3)) if acc0_ms and args.logn == LOG_N else None,
+                "madd_issue_bound": MADD_ISSUE_BOUND,
+                "alu_frac": round(16 * n / (acc0_ms * 1e-3) / MADD_ISSUE_BOUND, 4) if acc0_ms and args.logn == LOG_N else None,
             },
             "stage_ms": {k: (round(v, 4) if v is not None else None) for k, v in stages.items()},
         }

@@ -240,9 +240,14 @@ int gm_init(int device) {
   // allocation that fails gives them back and retries (DevPool::alloc, DevBuf::ensure)
   C->pool.max_pooled = prop.totalGlobalMem / 100 * 55;
   if (const char* e = getenv("GM_POOL_MAX_GB")) C->pool.max_pooled = (size_t)strtoull(e, nullptr, 10) << 30;
-  GM_HIP(hipStreamCreateWithFlags(&C->stream, hipStreamNonBlocking));
-  for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithFlags(&C->small_stream[k], hipStreamNonBlocking));
-  GM_HIP(hipStreamCreateWithFlags(&C->stream_b, hipStreamNonBlocking));
+  // GM_STREAM_PRIO=1 (experiment): the side streams (small-call lanes, second big lane / tails of a split call) get the
+  // highest priority, so their short latency-bound kernels take freed wave slots ahead of the next k_acc0 blocks
+  int prio_lo = 0, prio_hi = 0;
+  GM_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  const bool prio = getenv("GM_STREAM_PRIO") && atoi(getenv("GM_STREAM_PRIO")) != 0;
+  GM_HIP(hipStreamCreateWithPriority(&C->stream, hipStreamNonBlocking, prio ? prio_lo : 0));
+  for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithPriority(&C->small_stream[k], hipStreamNonBlocking, prio ? prio_hi : 0));
+  GM_HIP(hipStreamCreateWithPriority(&C->stream_b, hipStreamNonBlocking, prio ? prio_hi : 0));
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
   g_ctx = C;
   return GM_OK;
@@ -345,6 +350,9 @@ int gm_set_msm_split(int on) {
 int gm_set_msm_affine_levels(int levels) {
   GM_CTX();
   GM_CHECK(levels >= -1 && levels <= 8, GM_EINVAL, "gm_set_msm_affine_levels: %d not in [-1, 8]", levels);
+#ifndef GM_EXPERIMENTS
+  GM_CHECK(levels == 0, GM_ESTATE, "gm_set_msm_affine_levels: the affine-level experiment is not in this build (make EXTRA=-DGM_EXPERIMENTS; DESIGN.md section 8)");
+#endif
   C->msm_affine_levels = levels;
   return GM_OK;
 }

@@ -141,6 +141,49 @@ GM_DEV FqE fqe_import(const Fq& ark) { return ark; }
 GM_DEV Fq fqe_export(const FqE& dev) { return dev; }
 #endif
 
+#if GM_FQ30 == 2
+// ---- the bucket accumulator of k_acc0 lives in the product's own representation: 13 x 30-bit LOOSE limbs (field30.cuh),
+// the whole mixed addition one asm statement (gen_madd30.py).  Buckets and level-0 partials are written as 208-byte
+// records of 4 x 13 limbs (X, Y, ZZ, ZZZ; any representative < 2^386 of the residue; the identity is ZZ == 0 exactly)
+// and canonicalised by their consumers (k_merge, k_group_sum) on load: one product by R' mod q per coordinate.
+#include "field_mul30l_gen.inc"  // fq30_mul_asm / fq30_sqr_asm: the loose product on registers, out of line
+#include "g1_madd30_gen.inc"     // Acc30, g1_madd30_asm
+constexpr int XYZZ30_BYTES = 208;
+
+GM_DEV Fq fq30_loose_to_canonical(const Fq30& v) {
+  const uint32_t* o = Fq30Consts::ONE;
+  Fq30 t = fq30_mul_asm(v.l[0], v.l[1], v.l[2], v.l[3], v.l[4], v.l[5], v.l[6], v.l[7], v.l[8], v.l[9], v.l[10], v.l[11], v.l[12],
+                        o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12]);
+  return fq30_pack(fq30_canonical_tail(t));  // < q + v q / 2^390 < 1.07 q before the conditional subtraction
+}
+GM_DEV uint32_t acc30_limb(const Acc30& A, int i) {
+  return i < 8 ? A.a0[i] : i < 16 ? A.a1[i - 8] : i < 24 ? A.a2[i - 16] : i < 32 ? A.a3[i - 24] : i < 40 ? A.a4[i - 32] : i < 48 ? A.a5[i - 40] : A.a6[i - 48];
+}
+GM_DEV void acc30_set_limb(Acc30& A, int i, uint32_t v) {
+  if (i < 8) A.a0[i] = v;
+  else if (i < 16) A.a1[i - 8] = v;
+  else if (i < 24) A.a2[i - 16] = v;
+  else if (i < 32) A.a3[i - 24] = v;
+  else if (i < 40) A.a4[i - 32] = v;
+  else if (i < 48) A.a5[i - 40] = v;
+  else A.a6[i - 48] = v;
+}
+GM_DEV void acc30_zero(Acc30& A) {
+  A.a0 = A.a1 = A.a2 = A.a3 = A.a4 = A.a5 = gm_u8v{0, 0, 0, 0, 0, 0, 0, 0};
+  A.a6 = gm_u4v{0, 0, 0, 0};
+}
+// limbs 26..38 are ZZ
+GM_DEV void acc30_set_identity(Acc30& A) {
+#pragma unroll
+  for (int i = 26; i < 39; i++) acc30_set_limb(A, i, 0u);
+}
+GM_DEV void acc30_store(void* p, const Acc30& A) {
+  gm_u4v* o = reinterpret_cast<gm_u4v*>(p);
+  o[0] = A.a0.lo; o[1] = A.a0.hi; o[2] = A.a1.lo; o[3] = A.a1.hi; o[4] = A.a2.lo; o[5] = A.a2.hi; o[6] = A.a3.lo;
+  o[7] = A.a3.hi; o[8] = A.a4.lo; o[9] = A.a4.hi; o[10] = A.a5.lo; o[11] = A.a5.hi; o[12] = A.a6;
+}
+#endif
+
 // Affine point, identity encoded as (0, 0) -- not on y^2 = x^3 + 4, hence unambiguous.
 // Coordinates of a loaded point are fully reduced (< q).
 struct G1Affine {
@@ -311,5 +354,89 @@ void g1_store_xyzz(void* p, const G1Xyzz a) {
   fqe_store(c + 96, a.zz);
   fqe_store(c + 144, a.zzz);
 }
+
+#if GM_FQ30 == 2
+// 208-byte loose record (see Acc30) -> canonical XYZZ
+GM_DEV G1Xyzz g1_load_xyzz30(const void* p) {
+  const gm_u4v* s = reinterpret_cast<const gm_u4v*>(p);
+  uint32_t w[52];
+#pragma unroll
+  for (int i = 0; i < 13; i++) {
+    const gm_u4v v = s[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  uint32_t zz = 0;
+#pragma unroll
+  for (int i = 26; i < 39; i++) zz |= w[i];
+  if (zz == 0) return G1Xyzz::identity();
+  G1Xyzz r;
+  Fq30 t;
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = w[i];
+  r.x = fq30_loose_to_canonical(t);
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = w[13 + i];
+  r.y = fq30_loose_to_canonical(t);
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = w[26 + i];
+  r.zz = fq30_loose_to_canonical(t);
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = w[39 + i];
+  r.zzz = fq30_loose_to_canonical(t);
+  return r;
+}
+// canonical XYZZ -> 208-byte record (limbs of the canonical values)
+GM_DEV void g1_store_xyzz30(void* p, const G1Xyzz& a) {
+  gm_u4v* o = reinterpret_cast<gm_u4v*>(p);
+  uint32_t w[52];
+  if (a.is_identity()) {
+#pragma unroll
+    for (int i = 0; i < 52; i++) w[i] = 0;
+  } else {
+    const Fq30 x = fq30_unpack(a.x), y = fq30_unpack(a.y), zz = fq30_unpack(a.zz), zzz = fq30_unpack(a.zzz);
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+      w[i] = x.l[i]; w[13 + i] = y.l[i]; w[26 + i] = zz.l[i]; w[39 + i] = zzz.l[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 13; i++) o[i] = gm_u4v{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+}
+GM_DEV G1Xyzz acc30_to_canonical(const Acc30& A) {
+  uint32_t zz = 0;
+#pragma unroll
+  for (int i = 26; i < 39; i++) zz |= acc30_limb(A, i);
+  if (zz == 0) return G1Xyzz::identity();
+  G1Xyzz r;
+  Fq30 t;
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = acc30_limb(A, i);
+  r.x = fq30_loose_to_canonical(t);
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = acc30_limb(A, 13 + i);
+  r.y = fq30_loose_to_canonical(t);
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = acc30_limb(A, 26 + i);
+  r.zz = fq30_loose_to_canonical(t);
+#pragma unroll
+  for (int i = 0; i < 13; i++) t.l[i] = acc30_limb(A, 39 + i);
+  r.zzz = fq30_loose_to_canonical(t);
+  return r;
+}
+GM_DEV void acc30_from_canonical(Acc30& A, const G1Xyzz& c) {
+  if (c.is_identity()) {
+    acc30_zero(A);
+    return;
+  }
+  const Fq30 x = fq30_unpack(c.x), y = fq30_unpack(c.y), zz = fq30_unpack(c.zz), zzz = fq30_unpack(c.zzz);
+#pragma unroll
+  for (int i = 0; i < 13; i++) {
+    acc30_set_limb(A, i, x.l[i]);
+    acc30_set_limb(A, 13 + i, y.l[i]);
+    acc30_set_limb(A, 26 + i, zz.l[i]);
+    acc30_set_limb(A, 39 + i, zzz.l[i]);
+  }
+}
+#endif
 
 }  // namespace gm

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict_
 #ifndef GM_ACC0_WAVES
 #define GM_ACC0_WAVES 2
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAVES, GM_ACC0_WAVES))) void k_acc0(const uint64_t* __restrict__ entries,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAVES, GM_ACC0_WAVES))) void k_acc0_canon(const uint64_t* __restrict__ entries,
                                               const uint32_t* __restrict__ total_ptr,
                                               const uint8_t* __restrict__ bases, long long first, long long step,
                                               long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
@@ -936,380 +936,112 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAV
   pk[2 * (size_t)t + 1] = tail_key;
 }
 
-// ------------------------------------------------------------------------------------------
-// k_acc0 with the bucket accumulator in LDS.  The XYZZ accumulator (4 x FQE_LIMBS dwords per lane) is the
-// largest long-lived value of the kernel; parked in LDS (limb-major, conflict-free: word [c][i][lane]) it
-// is fetched coordinate by coordinate where the addition law needs it and written back as soon as a
-// coordinate is final, so at most four field elements are live across a multiplier call.  That is what
-// lets the 13-limb representation (GM_FQ30) run without scratch spills; LDS traffic is ~1 KiB per lane
-// per addition against ~26 k cycles of multiplier time.
-// ------------------------------------------------------------------------------------------
-struct AccLds {
-  uint32_t (*w)[FQE_LIMBS][256];  // [coordinate][limb][lane]
-  uint32_t lane;
-  GM_DEV FqE get(int c) const {
-    FqE r;
-#pragma unroll
-    for (int i = 0; i < FQE_LIMBS; i++) r.l[i] = w[c][i][lane];
-    return r;
-  }
-  GM_DEV void put(int c, const FqE& v) const {
-#pragma unroll
-    for (int i = 0; i < FQE_LIMBS; i++) w[c][i][lane] = v.l[i];
-  }
-  GM_DEV G1Xyzz all() const {
-    G1Xyzz a;
-    a.x = get(0);
-    a.y = get(1);
-    a.zz = get(2);
-    a.zzz = get(3);
-    return a;
-  }
-  GM_DEV void put_all(const G1Xyzz& a) const {
-    put(0, a.x);
-    put(1, a.y);
-    put(2, a.zz);
-    put(3, a.zzz);
-  }
-};
-// the exceptional additions, out of line so that their registers do not count against the hot loop:
-// equal x with equal y doubles the affine operand, equal x with opposite y gives the identity.
-// Returns the new identity flag.
-__device__ __noinline__ bool madd_lds_rare(uint32_t (*w)[FQE_LIMBS][256], uint32_t lane, const G1Affine q, bool same_y) {
-  if (!same_y) return true;
-  AccLds A;
-  A.w = w;
-  A.lane = lane;
-  const G1Xyzz d = xyzz_dbl_affine(q);
-  A.put_all(d);
-  return d.is_identity();
-}
-// run result -> memory (canonicalises), out of line for the same reason
-__device__ __noinline__ void acc_lds_flush(uint32_t (*w)[FQE_LIMBS][256], uint32_t lane, bool ident, uint8_t* dst) {
-  AccLds A;
-  A.w = w;
-  A.lane = lane;
-  if (ident) {
-    const Fq z = Fq::zero();
-    for (int c = 0; c < 4; c++) fp_store<FqParams>(dst + 48 * c, z);
-    return;
-  }
-#pragma unroll 1
-  for (int c = 0; c < 4; c++) fqe_store(dst + 48 * c, A.get(c));  // one coordinate live at a time
-}
-// acc += q with the same formulas, bounds and exceptional cases as xyzz_madd (g1.cuh); `ident` is the
-// accumulator's identity flag (kept in a register instead of testing zz)
-GM_DEV void madd_lds(const AccLds& A, bool& ident, const G1Affine& q) {
-  if (q.is_identity()) return;
-  if (ident) {
-    A.put(0, q.x);
-    A.put(1, q.y);
-    A.put(2, fqe_one());
-    A.put(3, fqe_one());
-    ident = false;
-    return;
-  }
-  const FqE p = fq_sub<8>(fq_mul(q.x, A.get(2)), A.get(0));
-  const FqE r = fq_sub<4>(fq_mul(q.y, A.get(3)), A.get(1));
-  if (fq_is_zero_mod(p)) {
-    ident = madd_lds_rare(A.w, A.lane, q, fq_is_zero_mod(r));
-    return;
-  }
-  const FqE pp = fq_sqr(p);
-  A.put(2, fq_mul(A.get(2), pp));
-  const FqE ppp = fq_mul(p, pp);
-  A.put(3, fq_mul(A.get(3), ppp));
-  const FqE qq = fq_mul(A.get(0), pp);
-  const FqE x3 = fq_sub<4>(fq_sub<2>(fq_sqr(r), ppp), fq_dbl(qq));
-  A.put(0, x3);
-  A.put(1, fq_sub<2>(fq_mul(r, fq_sub<8>(qq, x3)), fq_mul(A.get(1), ppp)));
-}
 
-__global__ __launch_bounds__(256) void k_acc0_lds(const uint64_t* __restrict__ entries, const uint32_t* __restrict__ total_ptr,
-                                                  const uint8_t* __restrict__ bases, long long first, long long step,
-                                                  long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
-                                                  uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets) {
-  __shared__ uint32_t accw[4][FQE_LIMBS][256];
-  AccLds A;
-  A.w = accw;
-  A.lane = threadIdx.x;
+// ------------------------------------------------------------------------------------------
+// k_acc0: the same chunk-per-lane accumulation with the accumulator in the product's own representation
+// (13 x 30-bit loose limbs, 52 pinned VGPRs) and the whole mixed addition ONE asm statement (gen_madd30.py,
+// g1_madd30_gen.inc): no unpack / repack / conditional subtraction per product, no calls, one reduction for
+// Y3 = R (Q - X3) - Y1 PPP.  Runs are written as 208-byte loose records (buckets, level-0 partials) that the
+// consumers canonicalise on load.  The statement handles an identity accumulator itself; p == 0 (doubling /
+// cancellation: every base equal in the reference's elastic benchmark) makes the wave leave it with flag = 1
+// before anything is modified, and that iteration takes the canonical, complete addition of g1.cuh.
+// k_acc0_canon above is the round-2 kernel (canonical 12 x 32-bit accumulator), kept for A/B runs (GM_ACC0=canon).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_acc0(const uint64_t* __restrict__ entries,
+                                              const uint32_t* __restrict__ total_ptr,
+                                              const uint8_t* __restrict__ bases, long long first, long long step,
+                                              long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
+                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi) {
+  __shared__ uint64_t ebuf[8][256];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t total = *total_ptr;
   const uint64_t start = (uint64_t)t * L;
   uint32_t head_key = KEY_INV, tail_key = KEY_INV;
   if (start < total) {
     const uint64_t end = min(start + (uint64_t)L, total);
-    bool ident = true;
+    Acc30 acc;
+    acc30_zero(acc);
     uint32_t cur = KEY_INV;
     bool first_run = true;
-    auto flush = [&](uint8_t* dst) { acc_lds_flush(accw, threadIdx.x, ident, dst); };
     for (uint64_t i = start; i < end; i++) {
-      const uint64_t e = entries[i];
+      // entries staged eight at a time through a transposed LDS image (see k_acc0_canon)
+      const uint32_t k8 = (uint32_t)(i - start) & 7u;
+      if (k8 == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(entries + i);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint4 v = src[q];
+          ebuf[2 * q][threadIdx.x] = ((uint64_t)v.y << 32) | v.x;
+          ebuf[2 * q + 1][threadIdx.x] = ((uint64_t)v.w << 32) | v.z;
+        }
+      }
+      const uint64_t e = ebuf[k8][threadIdx.x];
       long long idx;
       if (tab_stride) {
         const uint32_t lo = (uint32_t)e & 0x7fffffffu;
         idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
       } else {
-        idx = first + step * (long long)(e & 0x7fffffffull);
+        idx = first + step * (long long)(e & 0x3fffffffull);
       }
-      G1Affine p = g1_load_affine(bases + (size_t)idx * AFF_BYTES);
+      const uint8_t* src = (phi != nullptr && ((e >> ENTRY_HALF_SHIFT) & 1ull)) ? phi : bases;
+      const gm_u4v* bp = reinterpret_cast<const gm_u4v*>(src + (size_t)idx * AFF_BYTES);
+      const gm_u4v x0 = bp[0], x1 = bp[1], x2 = bp[2];
+      gm_u4v y0 = bp[3], y1 = bp[4], y2 = bp[5];
       const uint32_t key = (uint32_t)(e >> 32);
       if (key != cur) {
         if (cur != KEY_INV) {
           if (first_run) {
             head_key = cur;
-            flush(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES);
+            acc30_store(pp + (size_t)(2 * (size_t)t) * XYZZ30_BYTES, acc);
             first_run = false;
           } else {
-            flush(buckets + (size_t)cur * XYZZ_BYTES);
+            acc30_store(buckets + (size_t)cur * XYZZ30_BYTES, acc);  // interior run = whole bucket
           }
         }
         cur = key;
-        ident = true;
+        acc30_set_identity(acc);
       }
-      if ((e >> 31) & 1ull) p.y = fq_neg_canonical(p.y);
-      madd_lds(A, ident, p);
+      const uint32_t nz = x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w | x2.x | x2.y | x2.z | x2.w | y0.x | y0.y | y0.z | y0.w |
+                          y1.x | y1.y | y1.z | y1.w | y2.x | y2.y | y2.z | y2.w;
+      if (nz == 0) continue;  // the identity base (0, 0)
+      if ((e >> 31) & 1ull) {
+        Fq y;
+        y.l[0] = y0.x; y.l[1] = y0.y; y.l[2] = y0.z; y.l[3] = y0.w; y.l[4] = y1.x; y.l[5] = y1.y; y.l[6] = y1.z; y.l[7] = y1.w;
+        y.l[8] = y2.x; y.l[9] = y2.y; y.l[10] = y2.z; y.l[11] = y2.w;
+        y = fq_neg_canonical(y);
+        y0 = gm_u4v{y.l[0], y.l[1], y.l[2], y.l[3]};
+        y1 = gm_u4v{y.l[4], y.l[5], y.l[6], y.l[7]};
+        y2 = gm_u4v{y.l[8], y.l[9], y.l[10], y.l[11]};
+      }
+      const uint32_t flag = g1_madd30_asm(acc, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                          __builtin_shufflevector(x2, y0, 0, 1, 2, 3, 4, 5, 6, 7),
+                                          __builtin_shufflevector(y1, y2, 0, 1, 2, 3, 4, 5, 6, 7));
+      if (flag) {  // wave-uniform over the lanes that ran the statement; rare
+        G1Affine p;
+        p.x.l[0] = x0.x; p.x.l[1] = x0.y; p.x.l[2] = x0.z; p.x.l[3] = x0.w; p.x.l[4] = x1.x; p.x.l[5] = x1.y; p.x.l[6] = x1.z; p.x.l[7] = x1.w;
+        p.x.l[8] = x2.x; p.x.l[9] = x2.y; p.x.l[10] = x2.z; p.x.l[11] = x2.w;
+        p.y.l[0] = y0.x; p.y.l[1] = y0.y; p.y.l[2] = y0.z; p.y.l[3] = y0.w; p.y.l[4] = y1.x; p.y.l[5] = y1.y; p.y.l[6] = y1.z; p.y.l[7] = y1.w;
+        p.y.l[8] = y2.x; p.y.l[9] = y2.y; p.y.l[10] = y2.z; p.y.l[11] = y2.w;
+        G1Xyzz c = acc30_to_canonical(acc);
+        xyzz_madd(c, p);
+        acc30_from_canonical(acc, c);
+      }
     }
     if (first_run) {
       head_key = cur;
-      flush(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES);
+      acc30_store(pp + (size_t)(2 * (size_t)t) * XYZZ30_BYTES, acc);
     } else {
       tail_key = cur;
-      flush(pp + (size_t)(2 * (size_t)t + 1) * XYZZ_BYTES);
+      acc30_store(pp + (size_t)(2 * (size_t)t + 1) * XYZZ30_BYTES, acc);
     }
   }
   pk[2 * (size_t)t] = head_key;
   pk[2 * (size_t)t + 1] = tail_key;
 }
 
-// ------------------------------------------------------------------------------------------
-// Affine tree levels (optional, gm_set_msm_affine_levels): before the XYZZ accumulation, neighbours
-// of the sorted list that fall into the same bucket are added pairwise in AFFINE coordinates, level
-// by level, with ONE field inversion per level shared by all pairs (Montgomery's trick): an affine
-// addition is then 1 product (running prefix) + 2 (inverse hand-back) + 3 (lambda, x3, y3) = 6
-// products instead of the 10 of an XYZZ mixed addition.  Pair u of a level is (in[2u], in[2u+1]); if
-// the keys differ (a bucket boundary) both elements are copied through, so the list stays sorted and
-// every level roughly halves deep buckets.  After a few levels k_acc0 / k_merge finish on short lists.
-//   count   out-slots per pair (1 merged / 2 copied) + the exclusive scan -> output positions
-//   pass A  lane-strided over the pairs: denominator x2 - x1 (only the x coordinates are read), the
-//           lane's running product stored per pair, lane totals
-//   pass B  prefix / suffix products of the lane totals (two block levels); the grand total is
-//           inverted on the host (one Fq inversion ~ 30 us on a CPU core; ~1 ms on a lone GPU lane)
-//   pass C  lanes walk their pairs backwards handing out 1/d, do the affine additions, write the next
-//           level (points + keys; on the last level the entry list k_acc0 consumes)
-// Exceptional pairs (an identity operand, P + P, P - P) are rare and take a slow path: P + P uses the
-// denominator 2y (y != 0: the curve has no 2-torsion), the others need no inverse.
-// ------------------------------------------------------------------------------------------
-struct LvlArgs {
-  const uint32_t* n_in;     // device: number of input elements (level 1: the entry count)
-  const uint64_t* entries;  // first level: sorted entries + bases
-  const uint8_t* bases;
-  long long first, step, tab_stride;
-  const uint8_t* pin;       // later levels: affine points + keys of the previous level
-  const uint32_t* kin;
-  uint32_t npairs_bound;    // host-side bound on ceil(n_in / 2)
-  uint32_t T;               // lanes in the grid
-  const uint32_t* outpos;   // exclusive scan of the per-pair output counts (npairs_bound + 1 entries)
-  uint8_t* pout;
-  uint32_t* kout;
-  uint64_t* entries_out;    // last level: key << 32 | slot
-  uint8_t* prefix;          // 48 B per pair: the lane's running product after the pair
-  uint8_t* lane_tot;        // pass A out
-  const uint8_t* lane_inv;  // pass C in
-};
-constexpr int FQ_BYTES = 48;
-
-template <bool FIRST>
-GM_DEV uint32_t lvl_key(const LvlArgs& A, uint32_t i) {
-  return FIRST ? (uint32_t)(A.entries[i] >> 32) : A.kin[i];
-}
-template <bool FIRST>
-GM_DEV const uint8_t* lvl_ptr(const LvlArgs& A, uint32_t i, bool* negate) {
-  if (FIRST) {
-    const uint64_t e = A.entries[i];
-    long long idx;
-    if (A.tab_stride) {
-      const uint32_t lo = (uint32_t)e & 0x7fffffffu;
-      idx = (long long)(lo >> ENTRY_W_SHIFT) * A.tab_stride + A.first + A.step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
-    } else {
-      idx = A.first + A.step * (long long)(e & 0x7fffffffull);
-    }
-    *negate = ((e >> 31) & 1ull) != 0;
-    return A.bases + (size_t)idx * AFF_BYTES;
-  }
-  *negate = false;
-  return A.pin + (size_t)i * AFF_BYTES;
-}
-GM_DEV G1Affine lvl_point(const uint8_t* ptr, bool negate) {
-  G1Affine p = g1_load_affine(ptr);
-  if (negate) p.y = fq_neg_canonical(p.y);
-  return p;
-}
-// 0: result = p, 1: result = q, 2: result = identity, 3: chord (d = x1 - x0), 4: tangent (d = 2 y0).
-// The common case (distinct non-zero x) is decided from the x coordinates alone; only equal or zero x
-// coordinates load the y's.  Passes A and C call this with the same inputs, so they agree.
-GM_DEV int lvl_mode(const FqE& x0, const FqE& x1, const uint8_t* p0, bool n0, const uint8_t* p1, bool n1, FqE& d) {
-  d = fq_sub<1>(x1, x0);
-  const bool dz = fq_is_zero_mod(d);
-  if (!dz && !fq_is_exact_zero(x0) && !fq_is_exact_zero(x1)) return 3;
-  const G1Affine p = lvl_point(p0, n0), q = lvl_point(p1, n1);
-  if (q.is_identity()) return 0;
-  if (p.is_identity()) return 1;
-  if (!dz) return 3;  // x = 0 on a real point
-  const FqE sy = fq_add(p.y, q.y);
-  if (fq_is_zero_mod(sy)) return 2;
-  d = sy;
-  return 4;
-}
-
-// out-slots per pair: 1 if the two elements share a bucket (or the list ends on a single), else 2
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_lvl_count(LvlArgs A, uint32_t* __restrict__ cnt) {
-  const uint32_t n = *A.n_in;
-  for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= A.npairs_bound; u += gridDim.x * blockDim.x) {
-    const uint32_t i0 = 2u * u;
-    uint32_t c = 0;
-    if (u < A.npairs_bound && i0 < n) c = (i0 + 1u < n && lvl_key<FIRST>(A, i0) != lvl_key<FIRST>(A, i0 + 1u)) ? 2u : 1u;
-    cnt[u] = c;
-  }
-}
-
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_lvl_a(LvlArgs A) {
-  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = *A.n_in;
-  const uint32_t npairs = (n + 1u) >> 1;
-  FqE run = fqe_one();
-  for (uint64_t u64 = lane; u64 < npairs; u64 += A.T) {
-    const uint32_t u = (uint32_t)u64, i0 = 2u * u;
-    if (i0 + 1u < n && lvl_key<FIRST>(A, i0) == lvl_key<FIRST>(A, i0 + 1u)) {
-      bool n0, n1;
-      const uint8_t* p0 = lvl_ptr<FIRST>(A, i0, &n0);
-      const uint8_t* p1 = lvl_ptr<FIRST>(A, i0 + 1u, &n1);
-      const FqE x0 = fqe_load(p0), x1 = fqe_load(p1);
-      FqE d;
-      if (lvl_mode(x0, x1, p0, n0, p1, n1, d) >= 3) run = fq_mul(run, d);
-    }
-    fqe_store(A.prefix + (size_t)u * FQ_BYTES, run);
-  }
-  fqe_store(A.lane_tot + (size_t)lane * FQ_BYTES, run);
-}
-
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_lvl_c(LvlArgs A) {
-  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = *A.n_in;
-  const uint32_t npairs = (n + 1u) >> 1;
-  if (lane >= npairs) return;
-  FqE inv_run = fqe_load(A.lane_inv + (size_t)lane * FQ_BYTES);
-  uint32_t u = lane + ((npairs - 1u - lane) / A.T) * A.T;  // the lane's last pair
-  for (;;) {
-    const uint32_t i0 = 2u * u, o = A.outpos[u];
-    const uint32_t k0 = lvl_key<FIRST>(A, i0);
-    bool n0, n1 = false;
-    const uint8_t* p0 = lvl_ptr<FIRST>(A, i0, &n0);
-    const bool second = i0 + 1u < n;
-    const uint32_t k1 = second ? lvl_key<FIRST>(A, i0 + 1u) : KEY_INV;
-    const uint8_t* p1 = second ? lvl_ptr<FIRST>(A, i0 + 1u, &n1) : p0;
-    if (second && k1 == k0) {
-      const FqE x0 = fqe_load(p0), x1 = fqe_load(p1);
-      FqE d;
-      const int mode = lvl_mode(x0, x1, p0, n0, p1, n1, d);
-      G1Affine r;
-      if (mode >= 3) {
-        FqE inv_d = inv_run;
-        if (u != lane) inv_d = fq_mul(inv_run, fqe_load(A.prefix + (size_t)(u - A.T) * FQ_BYTES));
-        inv_run = fq_mul(inv_run, d);
-        FqE y0 = fqe_load(p0 + 48);
-        if (n0) y0 = fq_neg_canonical(y0);
-        FqE num;
-        if (mode == 3) {
-          FqE y1 = fqe_load(p1 + 48);
-          if (n1) y1 = fq_neg_canonical(y1);
-          num = fq_sub<1>(y1, y0);
-        } else {
-          const FqE xx = fq_sqr(x0);
-          num = fq_add(fq_dbl(xx), xx);
-        }
-        const FqE lam = fq_mul(num, inv_d);
-        r.x = fq_sub<1>(fq_sub<1>(fq_sqr(lam), x0), x1);
-        r.y = fq_sub<1>(fq_mul(lam, fq_sub<1>(x0, r.x)), y0);
-      } else if (mode == 0) {
-        r = lvl_point(p0, n0);
-      } else if (mode == 1) {
-        r = lvl_point(p1, n1);
-      } else {
-        r.x = fqe_zero();
-        r.y = fqe_zero();
-      }
-      g1_store_affine(A.pout + (size_t)o * AFF_BYTES, r);
-      if (A.entries_out) A.entries_out[o] = ((uint64_t)k0 << 32) | (uint64_t)o;
-      else A.kout[o] = k0;
-    } else {
-      g1_store_affine(A.pout + (size_t)o * AFF_BYTES, lvl_point(p0, n0));
-      if (A.entries_out) A.entries_out[o] = ((uint64_t)k0 << 32) | (uint64_t)o;
-      else A.kout[o] = k0;
-      if (second) {
-        g1_store_affine(A.pout + (size_t)(o + 1u) * AFF_BYTES, lvl_point(p1, n1));
-        if (A.entries_out) A.entries_out[o + 1u] = ((uint64_t)k1 << 32) | (uint64_t)(o + 1u);
-        else A.kout[o + 1u] = k1;
-      }
-    }
-    if (u == lane) break;
-    u -= A.T;
-  }
-}
-
-// pass B: exclusive prefix and suffix products of n values inside blocks of 512, plus the block products
-__global__ __launch_bounds__(512) void k_lvl_b(const uint8_t* __restrict__ vals, uint32_t n, uint8_t* __restrict__ pre_excl,
-                                               uint8_t* __restrict__ suf_excl, uint8_t* __restrict__ blk_tot) {
-  __shared__ __attribute__((aligned(16))) uint8_t sh[512 * FQ_BYTES];
-  const uint32_t tid = threadIdx.x, i = blockIdx.x * 512u + tid;
-  const FqE v0 = i < n ? fqe_load(vals + (size_t)i * FQ_BYTES) : fqe_one();
-  // inclusive prefix
-  FqE v = v0;
-  for (uint32_t dlt = 1; dlt < 512; dlt <<= 1) {
-    fqe_store(sh + tid * FQ_BYTES, v);
-    __syncthreads();
-    const FqE o = tid >= dlt ? fqe_load(sh + (tid - dlt) * FQ_BYTES) : fqe_one();
-    __syncthreads();
-    v = fq_mul(v, o);
-  }
-  fqe_store(sh + tid * FQ_BYTES, v);
-  __syncthreads();
-  const FqE pe = tid ? fqe_load(sh + (tid - 1) * FQ_BYTES) : fqe_one();
-  if (tid == 511) fqe_store(blk_tot + (size_t)blockIdx.x * FQ_BYTES, v);
-  __syncthreads();
-  // inclusive suffix
-  v = v0;
-  for (uint32_t dlt = 1; dlt < 512; dlt <<= 1) {
-    fqe_store(sh + tid * FQ_BYTES, v);
-    __syncthreads();
-    const FqE o = tid + dlt < 512 ? fqe_load(sh + (tid + dlt) * FQ_BYTES) : fqe_one();
-    __syncthreads();
-    v = fq_mul(v, o);
-  }
-  fqe_store(sh + tid * FQ_BYTES, v);
-  __syncthreads();
-  const FqE se = tid + 1 < 512 ? fqe_load(sh + (tid + 1) * FQ_BYTES) : fqe_one();
-  if (i < n) {
-    fqe_store(pre_excl + (size_t)i * FQ_BYTES, pe);
-    fqe_store(suf_excl + (size_t)i * FQ_BYTES, se);
-  }
-}
-// 1 / T_l = (1 / prod of all) * (everything before l) * (everything after l)
-__global__ __launch_bounds__(256) void k_lvl_b3(uint32_t n, const uint8_t* __restrict__ inv_total, const uint8_t* __restrict__ pre_loc,
-                                                const uint8_t* __restrict__ suf_loc, const uint8_t* __restrict__ pre_blk,
-                                                const uint8_t* __restrict__ suf_blk, uint8_t* __restrict__ lane_inv) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t blk = i >> 9;
-  FqE r = fq_mul(fqe_load(inv_total), fqe_load(pre_loc + (size_t)i * FQ_BYTES));
-  r = fq_mul(r, fqe_load(suf_loc + (size_t)i * FQ_BYTES));
-  r = fq_mul(r, fqe_load(pre_blk + (size_t)blk * FQ_BYTES));
-  r = fq_mul(r, fqe_load(suf_blk + (size_t)blk * FQ_BYTES));
-  fqe_store(lane_inv + (size_t)i * FQ_BYTES, r);
-}
+#ifdef GM_EXPERIMENTS
+#include "msm_levels.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------
 // merge levels: one wave reduces 128 keyed slots (sorted by key, holes allowed) to <= 2
@@ -1317,7 +1049,13 @@ __global__ __launch_bounds__(256) void k_lvl_b3(uint32_t n, const uint8_t* __res
 __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_in, const uint8_t* __restrict__ pts_in,
                                               uint32_t E, uint32_t* __restrict__ keys_out,
                                               uint8_t* __restrict__ pts_out, uint8_t* __restrict__ buckets,
-                                              int final_level) {
+                                              int final_level, int in_loose, int bucket_loose) {
+  // in_loose: pts_in holds 208-byte loose records (k_acc0's level-0 partials); bucket_loose: the bucket array does
+  auto load_in = [&](size_t slot) { return in_loose ? g1_load_xyzz30(pts_in + slot * XYZZ30_BYTES) : g1_load_xyzz(pts_in + slot * XYZZ_BYTES); };
+  auto store_bucket = [&](uint32_t key, const G1Xyzz& v) {
+    if (bucket_loose) g1_store_xyzz30(buckets + (size_t)key * XYZZ30_BYTES, v);
+    else g1_store_xyzz(buckets + (size_t)key * XYZZ_BYTES, v);
+  };
   __shared__ __attribute__((aligned(16))) uint8_t lds[128 * XYZZ_BYTES];
   const int lane = threadIdx.x;
   const uint32_t wave = blockIdx.x;
@@ -1325,8 +1063,8 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
   uint32_t hk = s0 < E ? keys_in[s0] : KEY_INV;
   uint32_t tk = s0 + 1 < E ? keys_in[s0 + 1] : KEY_INV;
   uint32_t hs = 2 * lane, ts = 2 * lane + 1;  // LDS slot ids
-  if (hk != KEY_INV) g1_store_xyzz(lds + hs * XYZZ_BYTES, g1_load_xyzz(pts_in + (size_t)s0 * XYZZ_BYTES));
-  if (tk != KEY_INV) g1_store_xyzz(lds + ts * XYZZ_BYTES, g1_load_xyzz(pts_in + (size_t)(s0 + 1) * XYZZ_BYTES));
+  if (hk != KEY_INV) g1_store_xyzz(lds + hs * XYZZ_BYTES, load_in((size_t)s0));
+  if (tk != KEY_INV) g1_store_xyzz(lds + ts * XYZZ_BYTES, load_in((size_t)s0 + 1));
   // a producer emits (head, INV) or (head, tail) or (INV, INV); normalise (INV, tail) defensively
   if (hk == KEY_INV && tk != KEY_INV) {
     hk = tk;
@@ -1356,7 +1094,7 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
       if (give) {
         G1Xyzz a = g1_load_xyzz(lds + ts * XYZZ_BYTES);
         xyzz_add(a, g1_load_xyzz(lds + nhs * XYZZ_BYTES));
-        g1_store_xyzz(buckets + (size_t)tk * XYZZ_BYTES, a);
+        store_bucket(tk, a);
       }
     }
     __syncthreads();
@@ -1401,14 +1139,14 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
         g1_store_xyzz(lds + add_dst * XYZZ_BYTES, a);
       }
     }
-    if (f1k != KEY_INV) g1_store_xyzz(buckets + (size_t)f1k * XYZZ_BYTES, g1_load_xyzz(lds + f1s * XYZZ_BYTES));
-    if (f2k != KEY_INV) g1_store_xyzz(buckets + (size_t)f2k * XYZZ_BYTES, g1_load_xyzz(lds + f2s * XYZZ_BYTES));
+    if (f1k != KEY_INV) store_bucket(f1k, g1_load_xyzz(lds + f1s * XYZZ_BYTES));
+    if (f2k != KEY_INV) store_bucket(f2k, g1_load_xyzz(lds + f2s * XYZZ_BYTES));
     __syncthreads();
   }
   if (lane == 0) {
     if (final_level) {
-      if (hk != KEY_INV) g1_store_xyzz(buckets + (size_t)hk * XYZZ_BYTES, g1_load_xyzz(lds + hs * XYZZ_BYTES));
-      if (tk != KEY_INV) g1_store_xyzz(buckets + (size_t)tk * XYZZ_BYTES, g1_load_xyzz(lds + ts * XYZZ_BYTES));
+      if (hk != KEY_INV) store_bucket(hk, g1_load_xyzz(lds + hs * XYZZ_BYTES));
+      if (tk != KEY_INV) store_bucket(tk, g1_load_xyzz(lds + ts * XYZZ_BYTES));
     } else {
       keys_out[2 * (size_t)wave] = hk;
       keys_out[2 * (size_t)wave + 1] = tk;
@@ -1442,6 +1180,7 @@ struct GroupSumArgs {
   // GS_PLANE: input length 2^nb per set; r < nb: elements with bit r set; r == nb: all elements
   uint32_t nb;
   uint32_t lpo_shift;   // lanes per output = 2^lpo_shift
+  int in_loose;         // the input is the bucket array in 208-byte loose records (g1.cuh: g1_load_xyzz30)
 };
 struct GroupSumJobs {
   GroupSumArgs j[3];
@@ -1475,21 +1214,23 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
   const uint32_t lpo = 1u << a.lpo_shift;
   const uint32_t o = gt >> a.lpo_shift, q = gt & (lpo - 1u);
   G1Xyzz acc = G1Xyzz::identity();
+  const int in_loose = a.in_loose;
+  auto load = [&](size_t slot) { return in_loose ? g1_load_xyzz30(in + slot * XYZZ30_BYTES) : g1_load_xyzz(in + slot * XYZZ_BYTES); };
   if (o < a.n_out) {
     const uint32_t w = o / a.per_win, r = o % a.per_win;
     const size_t base = (size_t)w * a.win_stride;
     if (a.mode == GS_STRIDED) {
       const size_t b0 = base + (size_t)(r / a.n_lo) * a.s_hi + (size_t)(r % a.n_lo) * a.s_lo;
-      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, g1_load_xyzz(in + (b0 + (size_t)e * a.s_e) * XYZZ_BYTES));
+      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, load(b0 + (size_t)e * a.s_e));
     } else {
       const uint32_t nb = a.nb;
       if (r == nb) {  // total
-        for (uint32_t e = q; e < (1u << nb); e += lpo) xyzz_add(acc, g1_load_xyzz(in + (base + e) * XYZZ_BYTES));
+        for (uint32_t e = q; e < (1u << nb); e += lpo) xyzz_add(acc, load(base + e));
       } else {        // elements whose bit r is set
         const uint32_t half = nb ? (1u << (nb - 1)) : 0u;
         for (uint32_t e = q; e < half; e += lpo) {
           uint32_t v = ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u));
-          xyzz_add(acc, g1_load_xyzz(in + (base + v) * XYZZ_BYTES));
+          xyzz_add(acc, load(base + v));
         }
       }
     }
@@ -1935,8 +1676,10 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
   // GLV (glv_split): two 128-bit digit strings per scalar over HALF the windows, the second one on phi(P)
   static const bool sort_atomic_env0 = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
-  static const bool acc0_lds = getenv("GM_ACC0") ? !strcmp(getenv("GM_ACC0"), "lds") : (GM_FQ30 == 1);  // experimental accumulate kernel
-  const bool use_glv = bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && !acc0_lds && n <= ((size_t)1 << 26);
+  static const bool acc0_canon = getenv("GM_ACC0") && !strcmp(getenv("GM_ACC0"), "canon");  // A/B: the round-2 accumulate kernel
+  const int loose = acc0_canon ? 0 : 1;                       // k_acc0 writes 208-byte loose records (buckets, level-0 partials)
+  const size_t bucket_bytes = loose ? XYZZ30_BYTES : XYZZ_BYTES;
+  const bool use_glv = bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && n <= ((size_t)1 << 26);
   const int W = ((use_glv ? 128 : 256) + c - 1) / c;
   GM_CHECK(nparts == 1 || !use_table, GM_EINVAL, "msm: the fixed-base table path is not split into window groups");
   const int w_lo = part * W / nparts, Wg = (part + 1) * W / nparts - w_lo;  // this call's window group
@@ -1981,9 +1724,9 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   if ((rc = ws.cursor.ensure((nbuckets + 1) * 4))) return rc;
   if ((rc = ws.misc.ensure((nbuckets / SCAN_PER_BLOCK + 2) * 4))) return rc;
   if ((rc = ws.entries.ensure(N * 8))) return rc;
-  if ((rc = ws.buckets.ensure(nbuckets * XYZZ_BYTES))) return rc;
+  if ((rc = ws.buckets.ensure(nbuckets * bucket_bytes))) return rc;
   if ((rc = ws.pk[0].ensure(E1 * 4))) return rc;
-  if ((rc = ws.pp[0].ensure(E1 * XYZZ_BYTES))) return rc;
+  if ((rc = ws.pp[0].ensure(E1 * bucket_bytes))) return rc;
   const uint64_t E2 = 2 * ((E1 + 127) / 128);
   if ((rc = ws.pk[1].ensure(E2 * 4))) return rc;
   if ((rc = ws.pp[1].ensure(E2 * XYZZ_BYTES))) return rc;
@@ -1991,7 +1734,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
   GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 2) * 4, st));
   uint32_t* d_err = ws.counts.as<uint32_t>() + nbuckets + 1;
-  GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * XYZZ_BYTES, st));
+  GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * bucket_bytes, st));
   const uint32_t dblocks = (uint32_t)((n + 255) / 256);
   Profiler& pf = C->prof;
   auto run_scan = [&]() {
@@ -2093,98 +1836,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint32_t* acc_total = ws.offsets.as<uint32_t>() + nbuckets;
   const uint8_t* acc_bases = d_bases;
   long long acc_first = (long long)first, acc_step = (long long)step, acc_tab = tab_stride;
-  if (levels > 0) {
-    pf.begin(part, PROF_SCAN, st);
-    const uint32_t T = 1u << 18;  // lanes of passes A / C; pass B handles T / 512 <= 512 block products
-    // bounds per level: a level maps a bucket of m elements to at most m / 2 + 1.5 elements
-    uint64_t bnd[10];
-    bnd[0] = N;
-    for (int l = 0; l < levels; l++) bnd[l + 1] = bnd[l] / 2 + 2 * nbuckets + 2;
-    if ((rc = ws.lvl_pts[0].ensure(bnd[1] * AFF_BYTES))) return rc;
-    if (levels > 1 && (rc = ws.lvl_pts[1].ensure(bnd[2] * AFF_BYTES))) return rc;
-    if ((rc = ws.lvl_keys[0].ensure(bnd[1] * 4))) return rc;
-    if (levels > 1 && (rc = ws.lvl_keys[1].ensure(bnd[2] * 4))) return rc;
-    const uint64_t np0 = (bnd[0] + 1) / 2;
-    if ((rc = ws.lvl_prefix.ensure(np0 * FQ_BYTES))) return rc;
-    if ((rc = ws.lvl_cnt.ensure((np0 + 1) * 4))) return rc;
-    if ((rc = ws.lvl_pos.ensure((np0 + 2) * 4))) return rc;
-    if ((rc = ws.lvl_entries.ensure(bnd[levels] * 8))) return rc;
-    if ((rc = ws.lvl_lane.ensure(((size_t)4 * T + 3 * 512 + 8) * FQ_BYTES))) return rc;
-    if ((rc = ws.lvl_n.ensure(64))) return rc;
-    if ((rc = ws.misc.ensure((np0 / SCAN_PER_BLOCK + 4) * 4))) return rc;
-    uint8_t* lane_tot = ws.lvl_lane.as<uint8_t>();
-    uint8_t* lane_pre = lane_tot + (size_t)T * FQ_BYTES;
-    uint8_t* lane_suf = lane_pre + (size_t)T * FQ_BYTES;
-    uint8_t* lane_inv = lane_suf + (size_t)T * FQ_BYTES;
-    uint8_t* blk_tot = lane_inv + (size_t)T * FQ_BYTES;
-    uint8_t* blk_pre = blk_tot + 512 * FQ_BYTES;
-    uint8_t* blk_suf = blk_pre + 512 * FQ_BYTES;
-    uint8_t* grand = blk_suf + 512 * FQ_BYTES;  // the inverse of the product of everything
-    uint8_t* grand_tot = grand + FQ_BYTES;       // that product
-    const uint32_t* n_in = ws.offsets.as<uint32_t>() + nbuckets;  // the entry count left by the sort's scan
-    const uint8_t* pin = nullptr;
-    const uint32_t* kin = nullptr;
-    for (int l = 0; l < levels; l++) {
-      const uint32_t npb = (uint32_t)((bnd[l] + 1) / 2);
-      uint32_t* cnt = ws.lvl_cnt.as<uint32_t>();
-      uint32_t* pos = ws.lvl_pos.as<uint32_t>();
-      LvlArgs A{};
-      A.n_in = n_in;
-      A.entries = ws.entries.as<uint64_t>();
-      A.bases = d_bases;
-      A.first = (long long)first;
-      A.step = (long long)step;
-      A.tab_stride = tab_stride;
-      A.pin = pin;
-      A.kin = kin;
-      A.npairs_bound = npb;
-      A.T = T;
-      A.outpos = pos;
-      A.pout = ws.lvl_pts[l & 1].as<uint8_t>();
-      A.kout = ws.lvl_keys[l & 1].as<uint32_t>();
-      A.entries_out = l == levels - 1 ? ws.lvl_entries.as<uint64_t>() : nullptr;
-      A.prefix = ws.lvl_prefix.as<uint8_t>();
-      A.lane_tot = lane_tot;
-      A.lane_inv = lane_inv;
-      const uint32_t cb = (uint32_t)std::min<uint64_t>(2048, (npb + 256) / 256);
-      const uint32_t sb = (npb + 1 + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
-      if (l == 0) hipLaunchKernelGGL(k_lvl_count<true>, dim3(cb), dim3(256), 0, st, A, cnt);
-      else hipLaunchKernelGGL(k_lvl_count<false>, dim3(cb), dim3(256), 0, st, A, cnt);
-      // exclusive scan of cnt[0 .. npb] (cnt[npb] = 0) -> pos; pos[npb] = the level's output count
-      hipLaunchKernelGGL(k_scan_block_sums, dim3(sb), dim3(256), 0, st, cnt, npb + 1, ws.misc.as<uint32_t>());
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, ws.misc.as<uint32_t>(), sb, pos + npb + 1);
-      hipLaunchKernelGGL(k_scan_apply, dim3(sb), dim3(256), 0, st, cnt, npb + 1, ws.misc.as<uint32_t>(), pos, pos);
-      if (l == 0) hipLaunchKernelGGL(k_lvl_a<true>, dim3(T / 256), dim3(256), 0, st, A);
-      else hipLaunchKernelGGL(k_lvl_a<false>, dim3(T / 256), dim3(256), 0, st, A);
-      hipLaunchKernelGGL(k_lvl_b, dim3(T / 512), dim3(512), 0, st, lane_tot, T, lane_pre, lane_suf, blk_tot);
-      hipLaunchKernelGGL(k_lvl_b, dim3(1), dim3(512), 0, st, blk_tot, T / 512, blk_pre, blk_suf, grand_tot);
-      GM_HIP(hipGetLastError());
-      GM_FR_LOCK(C);  // host_small is shared with the vector entry points
-      uint64_t* hs = C->host_small;
-      GM_HIP(hipMemcpyAsync(hs, grand_tot, FQ_BYTES, hipMemcpyDeviceToHost, st));
-      GM_HIP(hipStreamSynchronize(st));
-      gmh::Fq tot = gmh::fq_from_device(hs);
-      GM_CHECK(!tot.is_zero(), GM_ESTATE, "msm: zero denominator product in an affine level");
-      gmh::fq_to_device(tot.inv(), hs + 8);
-      GM_HIP(hipMemcpyAsync(grand, hs + 8, FQ_BYTES, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_lvl_b3, dim3(T / 256), dim3(256), 0, st, T, grand, lane_pre, lane_suf, blk_pre, blk_suf, lane_inv);
-      if (l == 0) hipLaunchKernelGGL(k_lvl_c<true>, dim3(T / 256), dim3(256), 0, st, A);
-      else hipLaunchKernelGGL(k_lvl_c<false>, dim3(T / 256), dim3(256), 0, st, A);
-      // the next level's element count lives behind the scan output; copy it next to nothing else that
-      // the next scan overwrites
-      GM_HIP(hipMemcpyAsync(ws.lvl_n.as<uint32_t>() + (l & 1), pos + npb, 4, hipMemcpyDeviceToDevice, st));
-      n_in = ws.lvl_n.as<uint32_t>() + (l & 1);
-      pin = A.pout;
-      kin = A.kout;
-    }
-    acc_entries = ws.lvl_entries.as<uint64_t>();
-    acc_total = n_in;
-    acc_bases = pin;
-    acc_first = 0;
-    acc_step = 1;
-    acc_tab = 0;
-    pf.end(part, PROF_SCAN, st);
-  }
+#ifdef GM_EXPERIMENTS
+#define GM_MSM_LEVELS_HOST 1
+#include "msm_levels.inc"
+#undef GM_MSM_LEVELS_HOST
+#else
+  GM_CHECK(levels == 0, GM_EINVAL, "msm: affine tree levels are an experiment of round 2; rebuild with -DGM_EXPERIMENTS (DESIGN.md section 8)");
+#endif
   if (!ws.have_done_ev) {
     GM_HIP(hipEventCreateWithFlags(&ws.done_ev[0], hipEventDisableTiming));
     GM_HIP(hipEventCreateWithFlags(&ws.done_ev[1], hipEventDisableTiming));
@@ -2198,9 +1856,9 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   }
   st = sts.acc;
   pf.begin(part, PROF_ACC0, st);
-  if (acc0_lds)
-    hipLaunchKernelGGL(k_acc0_lds, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
-                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>());
+  if (acc0_canon)
+    hipLaunchKernelGGL(k_acc0_canon, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
   else
     hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
@@ -2214,12 +1872,12 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   {
     uint64_t E = E1;
     int src = 0;
-    for (;;) {
+    for (int lvl = 0;; lvl++) {
       uint32_t waves = (uint32_t)((E + 127) / 128);
       int final_level = waves == 1;
       hipLaunchKernelGGL(k_merge, dim3(waves), dim3(64), 0, st, ws.pk[src].as<uint32_t>(), ws.pp[src].as<uint8_t>(),
                          (uint32_t)E, ws.pk[src ^ 1].as<uint32_t>(), ws.pp[src ^ 1].as<uint8_t>(),
-                         ws.buckets.as<uint8_t>(), final_level);
+                         ws.buckets.as<uint8_t>(), final_level, (loose && lvl == 0) ? 1 : 0, loose);
       if (final_level) break;
       E = 2ull * waves;
       src ^= 1;
@@ -2262,14 +1920,14 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   auto strided = [&](const uint8_t* in, uint8_t* out, uint32_t win_in, uint32_t n_hi, uint32_t n_lo, uint32_t s_hi, uint32_t s_lo,
                      uint32_t s_e, uint32_t len) {
     GroupSumArgs g{};
-    g.in = in; g.out = out; g.mode = GS_STRIDED;
+    g.in = in; g.out = out; g.mode = GS_STRIDED; g.in_loose = (loose && in == ws.buckets.as<uint8_t>()) ? 1 : 0;
     g.per_win = n_hi * n_lo; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = win_in;
     g.n_lo = n_lo; g.s_hi = s_hi; g.s_lo = s_lo; g.s_e = s_e; g.len = len; g.lpo_shift = lpo_for(len, g.n_out);
     return g;
   };
   auto plane = [&](const uint8_t* in, uint8_t* out, uint32_t nb) {
     GroupSumArgs g{};
-    g.in = in; g.out = out; g.mode = GS_PLANE;
+    g.in = in; g.out = out; g.mode = GS_PLANE; g.in_loose = (loose && in == ws.buckets.as<uint8_t>()) ? 1 : 0;
     g.per_win = nb + 1; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = 1u << nb; g.nb = nb;
     g.lpo_shift = lpo_for(nb ? (1u << (nb - 1)) : 1u, g.n_out);
     return g;

@@ -221,8 +221,11 @@ class CommitterKeyStream:
         """:169-177 -> msm_chunks (:22-55): skip len(powers) - len(poly) bases, 2^20-pair MSMs, summed.
         A HOST-resident coefficient stream (numpy array) of 2^22 or more elements is not uploaded whole: it goes
         through two 2^20-element device slots (HostMsmStream), copy under compute."""
-        if isinstance(polynomial_stream, np.ndarray) and len(polynomial_stream) >= (1 << 22) and type(self) is CommitterKeyStream:
-            return self._commit_host_stream(polynomial_stream)
+        if isinstance(polynomial_stream, np.ndarray) and type(self) is CommitterKeyStream:
+            # normalise FIRST: flat (4n,) uint64 input is accepted everywhere else (FrVec.from_host, HostMsmStream.add)
+            coeffs = capi.u64(polynomial_stream).reshape(-1, 4)
+            if len(coeffs) >= (1 << 22):
+                return self._commit_host_stream(coeffs)
         v, tmp = _as_vec(polynomial_stream)
         try:
             assert self._n() >= len(v)
@@ -234,6 +237,7 @@ class CommitterKeyStream:
     def _commit_host_stream(self, coeffs_be: np.ndarray, chunk: int = 1 << 20) -> np.ndarray:
         from .msm import HostMsmStream
 
+        coeffs_be = capi.u64(coeffs_be).reshape(-1, 4)
         n = self._n()
         assert n >= len(coeffs_be)
         # stream position k pairs with time-order power n - 1 - (n - len) - k = len - 1 - k: walk down from len - 1

@@ -166,7 +166,9 @@ int gm_set_msm_glv(int on);
 int gm_set_msm_split(int on);
 /* Affine tree levels in front of the XYZZ bucket accumulation (0 = none, -1 = automatic, <= 8): every
  * level adds the sorted entries of each bucket pairwise in affine coordinates with one shared field
- * inversion (6 instead of 10 field products per addition).  The result does not depend on it. */
+ * inversion (6 instead of 10 field products per addition).  The result does not depend on it.
+ * A round-2 EXPERIMENT, slower at every size: the kernels are only in builds with -DGM_EXPERIMENTS
+ * (gemini_amd/csrc/msm_levels.inc); otherwise any levels != 0 returns GM_ESTATE. */
 int gm_set_msm_affine_levels(int levels);
 
 /* Per-stage device timing (HIP events on the library's stream).  Stages, in order:

@@ -224,6 +224,8 @@ def test_host_resident_key_and_polynomial_streams(gm, oracle):
         be = np.ascontiguousarray(poly.to_host()[::-1])  # big-endian coefficient stream, on the host
         poly.free()
         assert (CommitterKeyStream.from_committer_key(ck).commit(be) == exp).all()
+        # flat (4n,) uint64 input is the same polynomial (accepted by FrVec.from_host / HostMsmStream.add as well)
+        assert (CommitterKeyStream.from_committer_key(ck).commit(be.reshape(-1)) == exp).all()
         key_be = np.ascontiguousarray(ck.powers_of_g.download()[::-1])  # Reverse(powers_of_g), on the host
         assert (HostCommitterKeyStream(key_be, 3, chunk=1 << 19).commit(be) == exp).all()
         ck.powers_of_g.free()
