@@ -134,17 +134,18 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
                   "note": "two sumchecks of length N = 2^logn; 8 N Fr products per sumcheck = 1 per 24 bytes: with a 1260-cycle product the kernel "
                           "is integer-ALU bound at <= 3 TB/s (37 % of the HBM peak) in the large rounds and launch-latency bound in the last ~15"}
 
-    tables = None
-    if with_tables and world == 1:
-        # the same prover with fixed-base window tables on the resident key (13 x the key in HBM, built once)
-        t0 = time.perf_counter()
-        ck.powers_of_g.precompute(0)
-        t_tab = time.perf_counter() - t0
-        truns = timed_runs(3)
-        tv = sorted(r[0][SPAN] for r in truns)
-        same = hashlib.sha256(truns[-1][1].serialize_compressed()).hexdigest() == digest
-        tables = {"value": round(tv[1], 4), "unit": "s", "runs_s": [round(v, 4) for v in tv], "table_build_s": round(t_tab, 3),
-                  "table_bytes": 13 * (2 * n + 1) * 96, "same_proof_bytes": same}
+    # The key was registered with the library's default: fixed-base window tables when they fit (gm_set_auto_tables), so the
+    # runs above ARE the default configuration.  The same prover on the plain path (no tables) beside it.
+    tab_c, tab_bytes = ck.powers_of_g.table_info() if world == 1 else (0, 0)
+    tables = {"window_bits": tab_c, "table_bytes": tab_bytes, "built_at": "key registration (CommitterKey::new, outside the prover span)"}
+    plain = None
+    if world == 1 and tab_c:
+        lib.gm_set_msm_table_min(C.c_size_t(1 << 62))
+        pruns = timed_runs(3)
+        lib.gm_set_msm_table_min(C.c_size_t(1 << 17))
+        pv = sorted(r[0][SPAN] for r in pruns)
+        same = hashlib.sha256(pruns[-1][1].serialize_compressed()).hexdigest() == digest
+        plain = {"value": round(pv[1], 4), "unit": "s", "runs_s": [round(v, 4) for v in pv], "same_proof_bytes": same}
     r1cs.free()
     ck.powers_of_g.free()
 
@@ -214,7 +215,8 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         "spans_s": {k: round(v, 4) for k, v in med.items()},
         "setup_s": {"dummy_r1cs_to_hbm": round(t_inst, 3), "srs_generation_on_device": round(t_srs, 3)},
         "sumcheck_roofline": sc,
-        "with_fixed_base_tables": tables,
+        "fixed_base_tables": tables,
+        "without_tables": plain,
         "cpu_baseline": cpu,
         "verifier": verdict,
         "proof_sha256": digest,
@@ -283,6 +285,9 @@ def main():
     mont = lambda v: [(((v << 384) % q) >> (64 * i)) & (2**64 - 1) for i in range(6)]
     g_aff = np.array(mont(gx) + mont(gy), dtype=np.uint64)
     ks = uniform_fr(rng, n)
+    # the headline is the PLAIN one-call MSM: no fixed-base tables for these bases (the library builds them by default at
+    # registration; the table path is reported beside it as `with_fixed_base_tables`)
+    gm.capi.check(lib.gm_set_auto_tables(C.c_int(0), C.c_size_t(0)))
     bases = gm.G1Bases.fixed_base(g_aff, ks)
 
     # scalars: two resident sets, alternated, so no step can reuse anything from the previous one
@@ -446,6 +451,7 @@ def main():
     hb_for_cpu = bases.download() if (world == 1 and not args.no_cpu_baseline) else None
     if args.snark_logn > 0:
         bases.free()  # the prover's key (2^25 + 1 points) and its vectors want the memory
+        gm.capi.check(lib.gm_set_auto_tables(C.c_int(0 if args.no_tables else 1), C.c_size_t(0)))  # the library default
         tp = snark_time_prover(gm, args.snark_logn, with_tables=not args.no_tables, world=world, rank=rank,
                                cpu_logn=0 if args.no_cpu_baseline else args.cpu_snark_logn)
     if rank == 0:

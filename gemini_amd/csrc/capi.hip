@@ -20,6 +20,18 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return e == hipErrorOutOfMemory ? GM_ENOMEM : GM_EHIP;
 }
 
+// hipMalloc for the long-lived allocations outside the vector pool (bases, tables, matrices, index vectors): when the device
+// is out of memory the pool may be holding up to 55 % of it in freed blocks -- give them back and retry once
+hipError_t dev_malloc(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory && context()) {
+    (void)hipGetLastError();
+    context()->pool.release_all();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+
 int DevBuf::ensure(size_t bytes) {
   if (bytes <= cap) return GM_OK;
   if (p) {
@@ -328,6 +340,19 @@ int gm_set_msm_table_min(size_t n) {
   return GM_OK;
 }
 
+int gm_set_auto_tables(int on, size_t max_bytes) {
+  GM_CTX();
+  C->auto_tables = on != 0;
+  C->auto_tables_max = max_bytes;
+  return GM_OK;
+}
+
+int gm_pool_trim(void) {
+  GM_CTX();
+  C->pool.release_all();
+  return GM_OK;
+}
+
 int gm_set_msm_window(int c) {
   GM_CTX();
   GM_CHECK(c == 0 || (c >= 2 && c <= 22), GM_EINVAL, "gm_set_msm_window: c = %d not in {0} u [2, 22]", c);
@@ -358,6 +383,27 @@ int gm_set_msm_affine_levels(int levels) {
 }
 
 // ---- bases ---------------------------------------------------------------------------------
+// Fixed-base window tables by default (gm_set_auto_tables): a registered key is resident for many MSMs -- the KZG key of a
+// prover (src/kzg/time.rs:49-72 builds a window table of its own to GENERATE the key) -- so when W x n x 96 bytes fit the
+// budget (default: 30 % of the device memory) the tables are built at registration, outside every prover span.
+static int maybe_auto_tables(Context* C, Bases* b) {
+  if (!C->auto_tables || b->n < C->msm_table_min || b->n < ((size_t)1 << 17) || b->n >= ((size_t)1 << 26)) return GM_OK;  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT)
+  const int c = b->n >= ((size_t)1 << 23) ? 22 : 20;
+  const size_t W = (256 + c - 1) / c;
+  const size_t bytes = W * b->n * 96 + (std::min<size_t>(b->n, (size_t)1 << 22) * 192);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GM_OK;
+  const size_t budget = C->auto_tables_max ? C->auto_tables_max : total_b / 100 * 30;
+  size_t pooled = 0;
+  {
+    std::lock_guard<std::mutex> lk(C->pool.mu);
+    pooled = C->pool.pooled_bytes;
+  }
+  if (bytes > budget || bytes + ((size_t)2 << 30) > free_b + pooled) return GM_OK;  // no room: the plain path serves this key
+  const int rc = bases_precompute(C, b, 0);
+  return rc == GM_ENOMEM ? GM_OK : rc;
+}
+
 int gm_g1_bases_register(const void* bases, size_t base_stride, size_t n, uint64_t* handle) {
   GM_CTX();
   GM_CHECK(handle != nullptr && (bases != nullptr || n == 0), GM_EINVAL, "bases_register: null pointer");
@@ -365,6 +411,7 @@ int gm_g1_bases_register(const void* bases, size_t base_stride, size_t n, uint64
   int rc = bases_from_host(C, bases, base_stride, n, b);
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
+  if ((rc = maybe_auto_tables(C, b.get()))) return rc;
   *handle = put_bases(std::move(b));
   return GM_OK;
 }
@@ -390,6 +437,15 @@ int gm_g1_bases_precompute(uint64_t handle, int c) {
   Bases* b = find_bases(handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "bases_precompute: unknown handle %llu", (unsigned long long)handle);
   return bases_precompute(C, b, c);
+}
+
+int gm_g1_bases_table_info(uint64_t handle, int* c, size_t* bytes) {
+  GM_CTX();
+  Bases* b = find_bases(handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "bases_table_info: unknown handle %llu", (unsigned long long)handle);
+  if (c) *c = b->table ? b->tab_c : 0;
+  if (bytes) *bytes = b->table ? (size_t)b->tab_W * b->n * 96 : 0;
+  return GM_OK;
 }
 
 int gm_g1_bases_len(uint64_t handle, size_t* n) {
@@ -571,7 +627,7 @@ int gm_g1_fixed_base_register(const uint64_t base_affine[12], const uint64_t* sc
   GM_CHECK(base_affine && handle && (scalars || n == 0), GM_EINVAL, "fixed_base_register: null pointer");
   uint8_t* d_sc = nullptr;
   if (n) {
-    GM_HIP(hipMalloc((void**)&d_sc, n * 32));
+    GM_HIP(dev_malloc((void**)&d_sc, n * 32));
     GM_HIP(hipMemcpyAsync(d_sc, scalars, n * 32, hipMemcpyHostToDevice, C->stream));
   }
   std::unique_ptr<Bases> b;
@@ -579,6 +635,7 @@ int gm_g1_fixed_base_register(const uint64_t base_affine[12], const uint64_t* sc
   if (d_sc) (void)hipFree(d_sc);
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
+  if ((rc = maybe_auto_tables(C, b.get()))) return rc;
   *handle = put_bases(std::move(b));
   return GM_OK;
 }
@@ -589,7 +646,7 @@ int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], si
   // powers of tau on device (Montgomery), then fixed-base multiplication
   auto v = std::make_unique<FrVec>();
   v->cap = n;
-  if (n) GM_HIP(hipMalloc((void**)&v->d, n * 32));
+  if (n) GM_HIP(dev_malloc((void**)&v->d, n * 32));
   gmh::Fr t = gmh::Fr::from_canonical(tau);
   uint64_t tm[4];
   t.to_limbs(tm);
@@ -599,6 +656,7 @@ int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], si
   if (v->d) (void)hipFree(v->d);
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
+  if ((rc = maybe_auto_tables(C, b.get()))) return rc;
   *handle = put_bases(std::move(b));
   return GM_OK;
 }
@@ -761,7 +819,7 @@ int gm_idx_register(const uint32_t* index, size_t n, uint64_t* handle) {
   for (size_t k = 0; k < n; k++) mx = index[k] > mx ? index[k] : mx;
   I->max_plus_1 = n ? (size_t)mx + 1 : 0;
   if (n) {
-    GM_HIP(hipMalloc((void**)&I->d, n * 4));
+    GM_HIP(dev_malloc((void**)&I->d, n * 4));
     GM_HIP(hipMemcpyAsync(I->d, index, n * 4, hipMemcpyHostToDevice, C->stream));
     GM_HIP(hipStreamSynchronize(C->stream));
   }
@@ -842,11 +900,11 @@ int gm_spm_register(const uint64_t* rowptr, const uint32_t* cols, const uint64_t
   M->nrows = nrows;
   M->ncols = ncols;
   M->nnz = nnz;
-  GM_HIP(hipMalloc((void**)&M->rowptr, (nrows + 1) * 8));
+  GM_HIP(dev_malloc((void**)&M->rowptr, (nrows + 1) * 8));
   GM_HIP(hipMemcpyAsync(M->rowptr, rowptr, (nrows + 1) * 8, hipMemcpyHostToDevice, C->stream));
   if (nnz) {
-    GM_HIP(hipMalloc((void**)&M->cols, nnz * 4));
-    GM_HIP(hipMalloc((void**)&M->vals, nnz * 32));
+    GM_HIP(dev_malloc((void**)&M->cols, nnz * 4));
+    GM_HIP(dev_malloc((void**)&M->vals, nnz * 32));
     GM_HIP(hipMemcpyAsync(M->cols, cols, nnz * 4, hipMemcpyHostToDevice, C->stream));
     GM_HIP(hipMemcpyAsync(M->vals, vals_mont, nnz * 32, hipMemcpyHostToDevice, C->stream));
   }

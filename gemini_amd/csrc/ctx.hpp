@@ -240,10 +240,13 @@ struct Context {
   int msm_split = 0;          // one-call MSMs as two window groups over three streams (gm_set_msm_split)
   int msm_affine_levels = 0;  // affine tree levels in front of the XYZZ accumulation; -1 = automatic
   size_t msm_table_min = (size_t)1 << 17;  // smallest MSM that uses fixed-base tables when present
+  bool auto_tables = true;    // build fixed-base tables when bases are registered, if they fit (gm_set_auto_tables)
+  size_t auto_tables_max = 0;  // byte budget of one key's tables; 0 = 30 % of the device memory
   int cu_count = 256;
 };
 
 Context* context();  // nullptr before gm_init
+hipError_t dev_malloc(void** p, size_t bytes);  // hipMalloc that gives the vector pool's freed blocks back on OOM
 
 Bases* find_bases(uint64_t h);
 FrVec* find_vec(uint64_t h);

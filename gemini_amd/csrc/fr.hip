@@ -686,7 +686,7 @@ int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_
   if ((rc = C->pool.alloc(((nf + 1) / 2) * FR_BYTES, (void**)&S->f[1], &S->fcap[1]))) return rc;
   if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g[0], &S->gcap[0]))) return rc;
   if ((rc = C->pool.alloc(((ng + 1) / 2) * FR_BYTES, (void**)&S->g[1], &S->gcap[1]))) return rc;
-  GM_HIP(hipMalloc((void**)&S->partials, 512 * 2 * FR_BYTES));
+  GM_HIP(dev_malloc((void**)&S->partials, 512 * 2 * FR_BYTES));
   GM_HIP(hipHostMalloc((void**)&S->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
   hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   GM_HIP(hipMemcpyAsync(S->f[0], f_src, nf * FR_BYTES, kind, C->stream));
@@ -893,7 +893,7 @@ int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream,
   int rc;
   if ((rc = C->pool.alloc(nf * FR_BYTES, (void**)&S->f, &S->fcap))) return rc;
   if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g, &S->gcap))) return rc;
-  GM_HIP(hipMalloc((void**)&S->partials, 512 * 2 * FR_BYTES));
+  GM_HIP(dev_malloc((void**)&S->partials, 512 * 2 * FR_BYTES));
   GM_HIP(hipHostMalloc((void**)&S->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
   hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   GM_HIP(hipMemcpyAsync(S->f, f_stream, nf * FR_BYTES, kind, C->stream));
@@ -1027,7 +1027,7 @@ int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle) {
   if (rc) return rc;
   if ((rc = C->pool.alloc(((T->nf + 1) / 2) * FR_BYTES, (void**)&T->f[1], &T->fcap[1]))) return rc;
   if ((rc = C->pool.alloc(((T->ng + 1) / 2) * FR_BYTES, (void**)&T->g[1], &T->gcap[1]))) return rc;
-  GM_HIP(hipMalloc((void**)&T->partials, 512 * 2 * FR_BYTES));
+  GM_HIP(dev_malloc((void**)&T->partials, 512 * 2 * FR_BYTES));
   GM_HIP(hipHostMalloc((void**)&T->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
   memcpy(T->twist, S->twist, 32);
   T->round = S->round;  // "copy other informations such us round(s) and twist"

@@ -437,6 +437,38 @@ GM_DEV void acc30_from_canonical(Acc30& A, const G1Xyzz& c) {
     acc30_set_limb(A, 39 + i, zzz.l[i]);
   }
 }
+GM_DEV void acc30_load(Acc30& A, const void* p) {
+  const gm_u4v* s = reinterpret_cast<const gm_u4v*>(p);
+  const gm_u4v v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3], v4 = s[4], v5 = s[5], v6 = s[6], v7 = s[7], v8 = s[8], v9 = s[9], v10 = s[10], v11 = s[11];
+  A.a0 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+  A.a1 = __builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7);
+  A.a2 = __builtin_shufflevector(v4, v5, 0, 1, 2, 3, 4, 5, 6, 7);
+  A.a3 = __builtin_shufflevector(v6, v7, 0, 1, 2, 3, 4, 5, 6, 7);
+  A.a4 = __builtin_shufflevector(v8, v9, 0, 1, 2, 3, 4, 5, 6, 7);
+  A.a5 = __builtin_shufflevector(v10, v11, 0, 1, 2, 3, 4, 5, 6, 7);
+  A.a6 = s[12];
+}
+GM_DEV bool acc30_is_identity(const Acc30& A) {
+  uint32_t zz = 0;
+#pragma unroll
+  for (int i = 26; i < 39; i++) zz |= acc30_limb(A, i);
+  return zz == 0;
+}
+GM_DEV void acc30_shfl_xor(Acc30& d, const Acc30& s, int m) {
+#pragma unroll
+  for (int i = 0; i < 52; i++) acc30_set_limb(d, i, __shfl_xor(acc30_limb(s, i), m));
+}
+// acc += o, both loose XYZZ (o is consumed).  The statement (gen_madd30.py: gen_add) does everything but p == 0 (mod q) --
+// doubling / cancellation, rare -- where the lanes concerned come back with both operands intact and take the complete
+// canonical addition.
+GM_DEV void acc30_add(Acc30& acc, Acc30& o) {
+  const uint32_t flag = g1_add30_asm(acc, o);
+  if (flag) {
+    G1Xyzz c = acc30_to_canonical(acc);
+    xyzz_add(c, acc30_to_canonical(o));
+    acc30_from_canonical(acc, c);
+  }
+}
 #endif
 
 }  // namespace gm

@@ -10,19 +10,21 @@ bucket accumulator LIVES in the product's own representation across iterations:
     v mod q, Montgomery factor 2^390 (field30.cuh).  A Montgomery product of loose values is < q + ab / 2^390
     with NO conditional subtraction; a - b is a + K q - b with a carry pass (K q's limbs raised so no limb goes
     negative).  Bounds are tracked by the generator (class V below) and asserted.
-  * the base point arrives as the 24 canonical words k_acc0 loads; only IT is unpacked (2 x 24 instructions).
+  * the base point arrives as the 24 canonical words k_acc0 loads, INSIDE two of the temporary elements, and is
+    unpacked in place (2 x 24 instructions); the statement therefore consumes them (in/out operands).
   * 6 products + 2 squares + ONE fused double product: Y3 = R (Q - X3) + (2q - Y1) PPP accumulates both
     13 x 13 products into the same columns in front of a single Montgomery reduction (-182 multiply-adds).
   * every register is physical and statically renamed: no moves between products, no calls.
 
 EFD madd-2008-s; the exceptional cases:
-  * acc == identity (ZZ limbs all zero): the lane runs the arithmetic on garbage and is overwritten at the end
-    with (x, y, 1, 1) -- no divergent branch around 4 000 instructions.
+  * acc == identity (ZZ limbs all zero): the lane is set to (x, y, 1, 1) up front and sits out the arithmetic
+    (EXEC mask) -- no divergent branch around 4 000 instructions in the kernel.
+  * a negative digit adds -P: y is negated on those lanes after the unpack (13-limb q - y), inside the statement.
   * P = x2 ZZ1 - X1 == 0 (mod q) (doubling / cancellation; the reference's elastic benchmark makes EVERY base the
     generator, examples/snark.rs:59-63): PP = P^2 is then exactly q (or 0), so one compare of PP's low limb
-    against q_0 and 0 flags the lane (false positives 2^-29); if any active non-identity lane is flagged the
-    WAVE leaves the statement before acc is modified with flag = 1 and k_acc0 runs the generic (canonical,
-    complete) addition for that iteration.
+    against q_0 and 0 flags the lane (false positives 2^-29); if any lane is flagged, the lanes doing arithmetic
+    leave the statement before acc is modified with flag = 1 and k_acc0 runs the generic (canonical, complete)
+    addition for them in that iteration (identity lanes are already done and keep flag = 0).
 
 The generator INTERPRETS the instruction list it emits against big-integer arithmetic (`--selftest`), bounds
 included (64-bit column accumulators, 32-bit limb sums), so mistakes show up without a GPU.
@@ -37,34 +39,38 @@ from gen_field_mul30 import INV30, M32, MASK30, P30, Q, Q32, Prog
 R390 = 1 << 390
 LIMIT = 1 << 386          # every loose value stays below this (top limb < 2^26)
 
-# ---- register plan ---------------------------------------------------------------------------------
-# v[VB .. VB+51]   acc: X, Y, ZZ, ZZZ (13 limbs each)          in/out
-# v[VB+52 .. +75]  base words: x (12), y (12)                  in
-# v[VB+76 .. ]     four temporary elements, accumulators, scratch, flag
-VB = 104
+# ---- register plan (64-bit and wider VGPR operands must start at an even register on gfx90a+) ---------
+# v[VB .. VB+51]   acc: X, Y, ZZ, ZZZ (13 limbs each)                         in/out
+# E0, E1           two temporary elements; the base's x / y words ARRIVE in E0[1..12] / E1[1..12] and are unpacked in place
+# E2, E3           two more temporary elements; accumulators, scratch, flag, sign
+VB = 48
 ACC_X = [f"v{VB + i}" for i in range(13)]
 ACC_Y = [f"v{VB + 13 + i}" for i in range(13)]
 ACC_ZZ = [f"v{VB + 26 + i}" for i in range(13)]
 ACC_ZZZ = [f"v{VB + 39 + i}" for i in range(13)]
-BXW = [f"v{VB + 52 + i}" for i in range(12)]
-BYW = [f"v{VB + 64 + i}" for i in range(12)]
-TB = VB + 76
-E = [[f"v{TB + 13 * e + i}" for i in range(13)] for e in range(4)]
-ACCUM = TB + 52           # v[ACCUM:ACCUM+1]  column accumulator
-SPL = TB + 54             # v[SPL:SPL+1]      split-off high part of a column
-SPT = TB + 56             # v[SPT:SPT+1]      second split of the same column
-TMP = f"v{TB + 58}"
-CAR = f"v{TB + 59}"
-FLAG = f"v{TB + 60}"
-V_END = TB + 61           # first register NOT used
+CAR = f"v{VB + 52}"
+E0B, E1B, E2B, E3B = VB + 53, VB + 67, VB + 80, VB + 93
+TMP = f"v{VB + 66}"
+E = [[f"v{b + i}" for i in range(13)] for b in (E0B, E1B, E2B, E3B)]
+BXW = E[0][1:]            # 12 words, first register even
+BYW = E[1][1:]
+assert (E0B + 1) % 2 == 0 and (E1B + 1) % 2 == 0
+ACCUM = VB + 106          # v[ACCUM:ACCUM+1]  column accumulator
+SPL = VB + 108            # v[SPL:SPL+1]      split-off high part of a column
+SPT = VB + 110            # v[SPT:SPT+1]      second split of the same column
+FLAG = f"v{VB + 112}"
+SGN = f"v{VB + 113}"      # in: != 0 -> add the NEGATED base
+V_END = VB + 114          # first register NOT used
+assert ACCUM % 2 == 0
 # scalar registers
 SB = 40
 SP = [f"s{SB + i}" for i in range(13)]     # q in radix 2^30
 SINV = f"s{SB + 13}"
 S_IDENT = SB + 14         # s[54:55]: lanes whose accumulator is the identity
-S_SAVE = SB + 16          # s[56:57]
+S_SAVE = SB + 16          # s[56:57]: EXEC at entry
 S_TMP = SB + 18           # s[58:59]
-S_END = SB + 20
+S_TMP2 = SB + 20          # s[60:61]
+S_END = SB + 22
 ONE30 = [(R390 % Q >> (30 * i)) & MASK30 for i in range(13)]
 
 
@@ -103,6 +109,10 @@ class Asm(Prog):
                 out.append(f"s_cbranch_execz {ins[1]}f")
             elif op == "restore_exec":
                 out.append(f"s_mov_b64 exec, s[{ins[1]}:{ins[1] + 1}]")
+            elif op == "exec_andn2":    # exec = s[a] & ~s[b]
+                out.append(f"s_andn2_b64 exec, s[{ins[1]}:{ins[1] + 1}], s[{ins[2]}:{ins[2] + 1}]")
+            elif op == "cmp_ne_s":
+                out.append(f"v_cmp_ne_u32 s[{ins[1]}:{ins[1] + 1}], {o(ins[2])}, {o(ins[3])}")
             elif op == "label":
                 out.append(f"{ins[1]}:")
             else:
@@ -146,6 +156,10 @@ class Asm(Prog):
                     pc = labels[ins[1]]
             elif op == "restore_exec":
                 ex = regs[f"s{ins[1]}"]
+            elif op == "exec_andn2":
+                ex = regs[f"s{ins[1]}"] & ~regs[f"s{ins[2]}"] & 1
+            elif op == "cmp_ne_s":
+                regs[f"s{ins[1]}"] = int(g(ins[2]) != g(ins[3])) if ex else 0
             elif op == "cmp_eq_s":
                 regs[f"s{ins[1]}"] = int(g(ins[2]) == g(ins[3])) if ex else 0
             elif not ex:
@@ -222,14 +236,24 @@ def raised(kq):
     return m
 
 
+class Plan:
+    """scratch registers of the element operations: column accumulator pair, two split pairs, two single temporaries"""
+
+    def __init__(self, accum, spl, spt, tmp, car):
+        self.ACCUM, self.SPL, self.SPT, self.TMP, self.CAR = accum, spl, spt, tmp, car
+
+
 class Gen:
-    def __init__(self):
+    def __init__(self, plan=None):
         self.p = Asm()
+        self.pl = plan or Plan(ACCUM, SPL, SPT, TMP, CAR)
 
     # ---- element ops -----------------------------------------------------------------------------
     def unpack(self, words, dst):
-        """12 canonical 32-bit words -> 13 limbs; dst must not overlap words"""
+        """12 canonical 32-bit words -> 13 limbs; words may be dst[1..12] (in place: limb i is written after its last use as a word)"""
+        assert words == dst[1:] or not set(words) & set(dst)
         p = self.p
+        TMP, CAR, ACCUM, SPL, SPT = self.pl.TMP, self.pl.CAR, self.pl.ACCUM, self.pl.SPL, self.pl.SPT
         p.emit("and", dst[0], MASK30, words[0])
         for i in range(1, 12):
             p.emit("alignbit", dst[i], words[i], words[i - 1], 32 - 2 * i)
@@ -242,6 +266,7 @@ class Gen:
         assert b.bound <= k * Q, "subtrahend may exceed k q"
         m = raised(k * Q)
         p = self.p
+        TMP, CAR, ACCUM, SPL, SPT = self.pl.TMP, self.pl.CAR, self.pl.ACCUM, self.pl.SPL, self.pl.SPT
         dst = dst or a.r
         for i in range(13):
             p.emit("add", TMP, m[i], a.r[i])
@@ -260,6 +285,7 @@ class Gen:
         assert b.bound <= k * Q
         m = raised(k * Q)
         p = self.p
+        TMP, CAR, ACCUM, SPL, SPT = self.pl.TMP, self.pl.CAR, self.pl.ACCUM, self.pl.SPL, self.pl.SPT
         dst = dst or b.r
         for i in range(13):
             p.emit("sub", TMP, m[i], b.r[i])
@@ -274,6 +300,7 @@ class Gen:
 
     def dbl(self, a, dst):
         p = self.p
+        TMP, CAR, ACCUM, SPL, SPT = self.pl.TMP, self.pl.CAR, self.pl.ACCUM, self.pl.SPL, self.pl.SPT
         for i in range(13):
             p.emit("lshl", TMP, 1, a.r[i])
             if i > 0:
@@ -292,6 +319,7 @@ class Gen:
         m_regs: 13 registers for the quotient digits m_k; t_regs: the result (may equal m_regs, or the `a` registers of
         the LAST product: t_j is written in column j + 13, a_j / m_j are last read in column j + 12)."""
         p = self.p
+        TMP, CAR, ACCUM, SPL, SPT = self.pl.TMP, self.pl.CAR, self.pl.ACCUM, self.pl.SPL, self.pl.SPT
         total = 0
         for a, b in prods:
             total += a.bound * (a.bound if b is None else b.bound)
@@ -371,29 +399,49 @@ class Gen:
         # invariant bounds of the accumulator at entry (checked against what leaves, below)
         BX, BY, BZ = 7 * Q, 2 * Q, 2 * Q
         X, Y, ZZ, ZZZ = V(ACC_X, BX), V(ACC_Y, BY), V(ACC_ZZ, BZ), V(ACC_ZZZ, BZ)
-        # identity lanes: ZZ == 0 exactly
+        qx = self.unpack(BXW, E[0])
+        qy = self.unpack(BYW, E[1])
+        # negative digit: y2 = q - y2 on the lanes that ask for it (y2 != 0: the curve has no point of order 2)
+        p.emit("cmp_ne_s", S_TMP, 0, SGN)
+        p.emit("s_nop", 4)
+        p.emit("saveexec_and", S_SAVE, S_TMP)
+        p.emit("cbranch_execz", "1")
+        self.rsub(qy, 1)
+        p.emit("label", "1")
+        p.emit("restore_exec", S_SAVE)
+        qy = V(E[1], Q)
+        # identity lanes (ZZ == 0 exactly): acc = (x2, y2, 1, 1); they sit out the arithmetic below
         p.emit("or3", TMP, ACC_ZZ[0], ACC_ZZ[1], ACC_ZZ[2])
         for i in range(3, 13, 2):
             p.emit("or3", TMP, TMP, ACC_ZZ[i], ACC_ZZ[i + 1])
         p.emit("cmp_eq_s", S_IDENT, 0, TMP)
-        qx = self.unpack(BXW, E[0])
-        qy = self.unpack(BYW, E[1])
+        p.emit("s_nop", 4)
+        p.emit("saveexec_and", S_SAVE, S_IDENT)
+        p.emit("cbranch_execz", "2")
+        for i in range(13):
+            p.emit("mov", ACC_X[i], qx.r[i])
+            p.emit("mov", ACC_Y[i], qy.r[i])
+            p.emit("mov", ACC_ZZ[i], ONE30[i])
+            p.emit("mov", ACC_ZZZ[i], ONE30[i])
+        p.emit("label", "2")
+        p.emit("exec_andn2", S_SAVE, S_IDENT)
+        p.emit("cbranch_execz", "9")
         U = self.mont([(qx, ZZ)], E[2], E[2])                  # u2 = x2 ZZ1
         P = self.sub(U, X, 7)                                  # p = u2 - X1            (E2)
         S = self.mont([(qy, ZZZ)], E[3], E[3])                 # s2 = y2 ZZZ1
         R = self.sub(S, Y, 2)                                  # r = s2 - Y1            (E3)
         PP = self.mont([(P, None)], E[0], E[0], sq_tmp=E[1])   # pp = p^2               (E0)
         assert PP.bound < 2 * Q
-        # p == 0 (mod q)  <=>  pp in {0, q}: compare the low limb, leave before acc changes if any live lane matches
+        # p == 0 (mod q)  <=>  pp in {0, q}: compare the low limb; if any lane matches, the lanes of this statement leave
+        # with flag = 1 before acc changes (identity lanes are done and keep flag = 0)
         p.emit("cmp_eq_s", S_TMP, SP[0], PP.r[0])
-        p.emit("cmp_eq_s", S_SAVE, 0, PP.r[0])
+        p.emit("cmp_eq_s", S_TMP2, 0, PP.r[0])
         p.emit("s_nop", 4)
-        p.emit("s_or", S_TMP, S_TMP, S_SAVE)
-        p.emit("s_andn2", S_TMP, S_TMP, S_IDENT)
-        p.emit("cbranch_s_z", S_TMP, "2")
+        p.emit("s_or", S_TMP, S_TMP, S_TMP2)
+        p.emit("cbranch_s_z", S_TMP, "3")
         p.emit("mov", FLAG, 1)
         p.emit("branch", "9")
-        p.emit("label", "2")
+        p.emit("label", "3")
         ZZn = self.mont([(ZZ, PP)], E[1], ACC_ZZ)              # ZZ3 = ZZ1 pp           (in place)
         PPP = self.mont([(P, PP)], E[1], E[1])                 # ppp = p pp             (E1)
         ZZZn = self.mont([(ZZZ, PPP)], E[2], ACC_ZZZ)          # ZZZ3 = ZZZ1 ppp        (in place; P dead)
@@ -407,17 +455,8 @@ class Gen:
         Y3 = self.mont([(R, T), (PPP, NY)], E[0], ACC_Y)       # Y3 = r (q - X3) - Y1 ppp, ONE reduction (in place on NY)
         assert X3.bound <= BX and Y3.bound <= BY and ZZn.bound <= BZ and ZZZn.bound <= BZ, (X3.bound / Q, Y3.bound / Q, ZZn.bound / Q)
         self.bounds = {"X": X3.bound / Q, "Y": Y3.bound / Q, "ZZ": ZZn.bound / Q, "P": P.bound / Q, "T": T.bound / Q}
-        # identity lanes: acc = (x2, y2, 1, 1)
-        p.emit("saveexec_and", S_SAVE, S_IDENT)
-        p.emit("cbranch_execz", "8")
-        self.unpack(BXW, ACC_X)
-        self.unpack(BYW, ACC_Y)
-        for i in range(13):
-            p.emit("mov", ACC_ZZ[i], ONE30[i])
-            p.emit("mov", ACC_ZZZ[i], ONE30[i])
-        p.emit("label", "8")
-        p.emit("restore_exec", S_SAVE)
         p.emit("label", "9")
+        p.emit("restore_exec", S_SAVE)
         return p
 
 
@@ -453,8 +492,9 @@ def selftest(ncases=400):
     def limbs(v):
         return [(v >> (30 * i)) & MASK30 for i in range(12)] + [v >> 360]
 
-    def run(acc_vals, bx, by):
+    def run(acc_vals, bx, by, sgn=0):
         regs = {f"v{i}": rnd.getrandbits(32) for i in range(V_END + 4)}
+        regs[SGN] = sgn
         regs.update({f"s{i}": rnd.getrandbits(1) for i in range(S_END + 2)})
         for regs_, v in zip((ACC_X, ACC_Y, ACC_ZZ, ACC_ZZZ), acc_vals):
             for r, l in zip(regs_, limbs(v)):
@@ -474,9 +514,11 @@ def selftest(ncases=400):
     for case in range(ncases):
         bx, by = rnd.randrange(Q), rnd.randrange(1, Q)
         kind = case % 8
-        if kind == 0:      # identity accumulator
-            flag, out, _ = run((0, 0, 0, 0), bx, by)
-            assert flag == 0 and out == [bx, by, R390 % Q, R390 % Q], "identity lane"
+        sgn = rnd.choice((0, 0, 1, 0x80000000))
+        by_eff = Q - by if sgn else by
+        if kind == 0:      # identity accumulator (X, Y, ZZZ arbitrary: only ZZ == 0 marks it)
+            flag, out, _ = run((rnd.randrange(7 * Q), rnd.randrange(2 * Q), 0, rnd.randrange(2 * Q)), bx, by, sgn)
+            assert flag == 0 and out == [bx, by_eff, R390 % Q, R390 % Q], "identity lane"
             continue
         # loose representatives at the invariant bounds: residue + j q
         res = [rnd.randrange(Q) for _ in range(4)]
@@ -491,8 +533,8 @@ def selftest(ncases=400):
             Ri = pow(R390, -1, Q)
             res[0] = bx * res[2] * Ri % Q
             vals[0] = res[0] + rnd.randrange(7) * Q
-        exp = model_madd(res, (bx, by))
-        flag, out, untouched = run(vals, bx, by)
+        exp = model_madd(res, (bx, by_eff))
+        flag, out, untouched = run(vals, bx, by, sgn)
         if exp == "flag":
             assert flag == 1 and untouched, "p == 0 must leave with the flag set and acc untouched"
             nflag += 1
@@ -512,13 +554,16 @@ def emit(out):
     out.append("// GENERATED by gen_madd30.py -- do not edit; edit the generator.")
     out.append("// clang-format off")
     out.append(f"// XYZZ mixed addition on 13 x 30-bit loose limbs, one asm statement on physical registers: {len(prog.ins)} instructions,")
-    out.append(f"// {sum(1 for i in prog.ins if i[0] == 'mad64')} v_mad_u64_u32.  acc = v[{VB}:{VB + 51}] (X, Y, ZZ, ZZZ), base words = v[{VB + 52}:{VB + 75}], temporaries up to v{V_END - 1}.")
+    out.append(f"// {sum(1 for i in prog.ins if i[0] == 'mad64')} v_mad_u64_u32.  acc = v[{VB}:{VB + 51}] (X, Y, ZZ, ZZZ); the base words arrive in v[{E0B + 1}:{E0B + 12}] (x) and")
+    out.append(f"// v[{E1B + 1}:{E1B + 12}] (y) and are CONSUMED; every register of the statement is below v{V_END}.")
     out.append(f"constexpr int GM_MADD30_VGPRS = {V_END};")
     out.append("typedef uint32_t gm_u8v __attribute__((ext_vector_type(8)));")
     out.append("typedef uint32_t gm_u4v __attribute__((ext_vector_type(4)));")
-    out.append("// acc: six 8-register groups + one 4-register group (52 limbs); base: three 8-register groups (x words, y words)")
+    out.append("// acc: six 8-register groups + one 4-register group (52 limbs)")
     out.append("struct Acc30 { gm_u8v a0, a1, a2, a3, a4, a5; gm_u4v a6; };")
-    out.append("__device__ __forceinline__ uint32_t g1_madd30_asm(Acc30& A, gm_u8v b0, gm_u8v b1, gm_u8v b2) {")
+    out.append("// x0..x2 / y0..y2: the 12 + 12 canonical words of the affine base (device form); neg != 0 adds -P; returns != 0 on the lanes")
+    out.append("// whose addition was NOT done (p == 0 mod q somewhere in the wave): acc is unchanged there, take the complete addition")
+    out.append("__device__ __forceinline__ uint32_t g1_madd30_asm(Acc30& A, gm_u4v x0, gm_u4v x1, gm_u4v x2, gm_u4v y0, gm_u4v y1, gm_u4v y2, uint32_t neg) {")
     out.append("  uint32_t flag;")
     out.append("  asm volatile(")
     for line in lines:
@@ -531,23 +576,230 @@ def emit(out):
     outs.append(f'"={{v[{VB + 48}:{VB + 51}]}}"(A.a6)')
     ins.append(f'"{{v[{VB + 48}:{VB + 51}]}}"(A.a6)')
     outs.append(f'"={{{FLAG}}}"(flag)')
-    for k in range(3):
-        ins.append(f'"{{v[{VB + 52 + 8 * k}:{VB + 52 + 8 * k + 7}]}}"(b{k})')
+    for k, name in enumerate(("x0", "x1", "x2")):
+        outs.append(f'"={{v[{E0B + 1 + 4 * k}:{E0B + 4 + 4 * k}]}}"({name})')
+        ins.append(f'"{{v[{E0B + 1 + 4 * k}:{E0B + 4 + 4 * k}]}}"({name})')
+    for k, name in enumerate(("y0", "y1", "y2")):
+        outs.append(f'"={{v[{E1B + 1 + 4 * k}:{E1B + 4 + 4 * k}]}}"({name})')
+        ins.append(f'"{{v[{E1B + 1 + 4 * k}:{E1B + 4 + 4 * k}]}}"({name})')
+    ins.append(f'"{{{SGN}}}"(neg)')
     out.append("      : " + ", ".join(outs))
     out.append("      : " + ", ".join(ins))
-    clob = ['"vcc"', '"scc"'] + [f'"s{i}"' for i in range(SB, S_END)] + [f'"v{i}"' for i in range(TB, V_END) if f"v{i}" != FLAG]
+    pinned = set(range(VB, VB + 52)) | set(range(E0B + 1, E0B + 13)) | set(range(E1B + 1, E1B + 13)) | {int(FLAG[1:]), int(SGN[1:])}
+    clob = ['"vcc"', '"scc"'] + [f'"s{i}"' for i in range(SB, S_END)] + [f'"v{i}"' for i in range(VB, V_END) if i not in pinned]
     out.append("      : " + ", ".join(clob) + ");")
     out.append("  return flag;")
     out.append("}")
     out.append("// clang-format on")
 
 
+# ---- register plan of the full addition acc += o (both XYZZ, loose) ------------------------------------
+AQ = VB + 54              # o = (X2, Y2, ZZ2, ZZZ2): v[AQ .. AQ+51], in/out (consumed)
+assert AQ % 2 == 0
+O_X = [f"v{AQ + i}" for i in range(13)]
+O_Y = [f"v{AQ + 13 + i}" for i in range(13)]
+O_ZZ = [f"v{AQ + 26 + i}" for i in range(13)]
+O_ZZZ = [f"v{AQ + 39 + i}" for i in range(13)]
+A_TB = AQ + 52
+AE = [[f"v{A_TB + 13 * e + i}" for i in range(13)] for e in range(4)]
+A_ACCUM = A_TB + 52
+A_SPL, A_SPT = A_ACCUM + 2, A_ACCUM + 4
+A_TMP, A_CAR, A_FLAG = f"v{A_ACCUM + 6}", f"v{VB + 52}", f"v{A_ACCUM + 7}"
+A_V_END = A_ACCUM + 8
+assert A_ACCUM % 2 == 0
+S_OID = SB + 20           # s[60:61]: lanes whose o is the identity
+
+
+def gen_add():
+    """acc += o for two loose XYZZ points (EFD add-2008-s, 11 products + 2 squares + one fused double product, 13 reductions).
+    o == identity: acc stays; acc == identity: acc = o; p == 0 (mod q) on a lane doing arithmetic: those lanes leave with
+    flag = 1 and BOTH operands untouched (the caller takes the complete canonical addition)."""
+    g = Gen(Plan(A_ACCUM, A_SPL, A_SPT, A_TMP, A_CAR))
+    p = g.p
+    for j in range(13):
+        p.emit("smov", SP[j], P30[j])
+    p.emit("smov", SINV, INV30)
+    p.emit("mov", A_FLAG, 0)
+    BX, BY, BZ = 7 * Q, 2 * Q, 2 * Q
+    X1, Y1, ZZ1, ZZZ1 = V(ACC_X, BX), V(ACC_Y, BY), V(ACC_ZZ, BZ), V(ACC_ZZZ, BZ)
+    X2, Y2, ZZ2, ZZZ2 = V(O_X, BX), V(O_Y, BY), V(O_ZZ, BZ), V(O_ZZZ, BZ)
+    # identity masks
+    for regs, sdst in ((ACC_ZZ, S_IDENT), (O_ZZ, S_OID)):
+        p.emit("or3", A_TMP, regs[0], regs[1], regs[2])
+        for i in range(3, 13, 2):
+            p.emit("or3", A_TMP, A_TMP, regs[i], regs[i + 1])
+        p.emit("cmp_eq_s", sdst, 0, A_TMP)
+    p.emit("s_nop", 4)
+    # acc identity (whatever o is): acc = o
+    p.emit("saveexec_and", S_SAVE, S_IDENT)
+    p.emit("cbranch_execz", "1")
+    for a_, o_ in ((ACC_X, O_X), (ACC_Y, O_Y), (ACC_ZZ, O_ZZ), (ACC_ZZZ, O_ZZZ)):
+        for i in range(13):
+            p.emit("mov", a_[i], o_[i])
+    p.emit("label", "1")
+    # arithmetic lanes: neither is the identity
+    p.emit("s_or", S_TMP, S_IDENT, S_OID)
+    p.emit("exec_andn2", S_SAVE, S_TMP)
+    p.emit("cbranch_execz", "9")
+    U1 = g.mont([(X1, ZZ2)], AE[0], AE[0])
+    U2 = g.mont([(X2, ZZ1)], AE[1], AE[1])
+    P = g.sub(U2, U1, 2)                                       # E1
+    PP = g.mont([(P, None)], AE[2], AE[2], sq_tmp=AE[3])       # E2
+    assert PP.bound < 2 * Q
+    p.emit("cmp_eq_s", S_TMP, SP[0], PP.r[0])
+    p.emit("cmp_eq_s", S_TMP2, 0, PP.r[0])
+    p.emit("s_nop", 4)
+    p.emit("s_or", S_TMP, S_TMP, S_TMP2)
+    p.emit("cbranch_s_z", S_TMP, "3")
+    p.emit("mov", A_FLAG, 1)
+    p.emit("branch", "9")
+    p.emit("label", "3")
+    S1 = g.mont([(Y1, ZZZ2)], AE[3], AE[3])                    # E3
+    S2 = g.mont([(Y2, ZZZ1)], ACC_Y, ACC_Y)                    # Y1 dead
+    R = g.sub(S2, S1, 2)                                       # ACC_Y
+    ZZ12 = g.mont([(ZZ1, ZZ2)], O_X, ACC_ZZ)                   # in place; X2 dead: O_X is scratch
+    ZZn = g.mont([(ZZ12, PP)], O_X, ACC_ZZ)
+    PPP = g.mont([(P, PP)], O_X, O_X)                          # ppp in O_X; P dead
+    ZZZ12 = g.mont([(ZZZ1, ZZZ2)], AE[1], ACC_ZZZ)
+    ZZZn = g.mont([(ZZZ12, PPP)], AE[1], ACC_ZZZ)
+    QQ = g.mont([(U1, PP)], AE[1], AE[1])                      # q = u1 pp (E1); U1, pp dead
+    R2 = g.mont([(R, None)], ACC_X, ACC_X, sq_tmp=AE[0])       # X1 dead since U1
+    X3a = g.sub(R2, PPP, 2)
+    D = g.dbl(QQ, AE[0])
+    X3 = g.sub(X3a, D, 3)
+    T = g.sub(QQ, X3, 7)                                       # E1
+    NS = g.rsub(S1, 2)                                         # E3
+    Y3 = g.mont([(R, T), (PPP, NS)], AE[2], ACC_Y)             # in place on R
+    assert X3.bound <= BX and Y3.bound <= BY and ZZn.bound <= BZ and ZZZn.bound <= BZ
+    g.bounds = {"X": X3.bound / Q, "Y": Y3.bound / Q, "ZZ": ZZn.bound / Q, "ZZZ": ZZZn.bound / Q, "P": P.bound / Q, "T": T.bound / Q}
+    p.emit("label", "9")
+    p.emit("restore_exec", S_SAVE)
+    return g
+
+
+def model_add(a, o):
+    Ri = pow(R390, -1, Q)
+    mm = lambda x, y: x * y * Ri % Q
+    X1, Y1, ZZ1, ZZZ1 = a
+    X2, Y2, ZZ2, ZZZ2 = o
+    u1, u2, s1, s2 = mm(X1, ZZ2), mm(X2, ZZ1), mm(Y1, ZZZ2), mm(Y2, ZZZ1)
+    p_, r = (u2 - u1) % Q, (s2 - s1) % Q
+    if p_ == 0:
+        return "flag"
+    pp = mm(p_, p_)
+    ppp = mm(p_, pp)
+    qq = mm(u1, pp)
+    x3 = (mm(r, r) - ppp - 2 * qq) % Q
+    y3 = (mm(r, (qq - x3) % Q) - mm(s1, ppp)) % Q
+    return (x3, y3, mm(mm(ZZ1, ZZ2), pp), mm(mm(ZZZ1, ZZZ2), ppp))
+
+
+def selftest_add(ncases=300):
+    g = gen_add()
+    prog = g.p
+    rnd = random.Random(11)
+    n_mad = sum(1 for i in prog.ins if i[0] == "mad64")
+    print(f"add30: {len(prog.ins)} instructions, {n_mad} v_mad_u64_u32; bounds leaving (units of q): {g.bounds}", file=sys.stderr)
+    groups = (ACC_X, ACC_Y, ACC_ZZ, ACC_ZZZ, O_X, O_Y, O_ZZ, O_ZZZ)
+
+    def limbs(v):
+        return [(v >> (30 * i)) & MASK30 for i in range(12)] + [v >> 360]
+
+    def run(vals):
+        regs = {f"v{i}": rnd.getrandbits(32) for i in range(A_V_END + 4)}
+        regs.update({f"s{i}": rnd.getrandbits(1) for i in range(S_END + 2)})
+        for regs_, v in zip(groups, vals):
+            for r, l in zip(regs_, limbs(v)):
+                regs[r] = l
+        keep = {k: regs[k] for grp in groups for k in grp}
+        prog.run(regs)
+        out = [sum(regs[r] << (30 * i) for i, r in enumerate(regs_)) for regs_ in groups[:4]]
+        for regs_ in groups[:4]:
+            assert all(regs[r] <= MASK30 for r in regs_[:12]), "result limb not normalised"
+        return regs[A_FLAG], out, all(regs[k] == keep[k] for k in keep), all(regs[k] == keep[k] for grp in groups[:4] for k in grp)
+
+    mult = (7, 2, 2, 2)
+    nflag = 0
+    for case in range(ncases):
+        kind = case % 8
+        res = [rnd.randrange(Q) for _ in range(8)]
+        for i in (2, 3, 6, 7):
+            res[i] = res[i] or 1
+        if kind == 1:
+            vals = [r + (m - 1) * Q for r, m in zip(res, mult + mult)]
+        else:
+            vals = [r + rnd.randrange(m) * Q for r, m in zip(res, mult + mult)]
+        if kind == 2:      # acc identity: result = o exactly (limbs copied)
+            vals[2] = 0
+            flag, out, _, _ = run(vals)
+            assert flag == 0 and out == vals[4:], "acc identity"
+            continue
+        if kind == 3:      # o identity: acc unchanged
+            vals[6] = 0
+            flag, out, _, acc_same = run(vals)
+            assert flag == 0 and acc_same, "o identity"
+            continue
+        if kind == 4:      # both identity
+            vals[2] = vals[6] = 0
+            flag, out, _, _ = run(vals)
+            assert flag == 0 and out[2] == 0, "both identity"
+            continue
+        if kind == 5:      # same x: u1 == u2  ->  X2 = X1 ZZ2 / ZZ1
+            res[4] = res[0] * res[6] * pow(res[2], -1, Q) % Q
+            vals[4] = res[4] + rnd.randrange(7) * Q
+        exp = model_add(res[:4], res[4:])
+        flag, out, untouched, _ = run(vals)
+        if exp == "flag":
+            assert flag == 1 and untouched, "p == 0 must leave with the flag set and both operands untouched"
+            nflag += 1
+            continue
+        assert flag == 0
+        for i in range(4):
+            assert out[i] % Q == exp[i], ("coordinate", i)
+    assert nflag > 0
+    print(f"add30: {ncases} cases ok ({nflag} flagged)", file=sys.stderr)
+
+
+def emit_add(out):
+    g = gen_add()
+    prog = g.p
+    out.append(f"// XYZZ + XYZZ on loose limbs (add-2008-s): {len(prog.ins)} instructions, {sum(1 for i in prog.ins if i[0] == 'mad64')} v_mad_u64_u32.")
+    out.append(f"// acc = v[{VB}:{VB + 51}], o = v[{AQ}:{AQ + 51}] (CONSUMED unless the flag is returned); registers below v{A_V_END}.")
+    out.append(f"constexpr int GM_ADD30_VGPRS = {A_V_END};")
+    out.append("// returns != 0 on the lanes whose addition was NOT done (p == 0 mod q: doubling or cancellation); acc and o are intact there")
+    out.append("__device__ __forceinline__ uint32_t g1_add30_asm(Acc30& A, Acc30& O) {")
+    out.append("  uint32_t flag;")
+    out.append("  asm volatile(")
+    for line in prog.text():
+        out.append(f'      "{line}\\n\\t"')
+    outs, ins = [], []
+    for base, name in ((VB, "A"), (AQ, "O")):
+        for k in range(6):
+            outs.append(f'"={{v[{base + 8 * k}:{base + 8 * k + 7}]}}"({name}.a{k})')
+            ins.append(f'"{{v[{base + 8 * k}:{base + 8 * k + 7}]}}"({name}.a{k})')
+        outs.append(f'"={{v[{base + 48}:{base + 51}]}}"({name}.a6)')
+        ins.append(f'"{{v[{base + 48}:{base + 51}]}}"({name}.a6)')
+    outs.append(f'"={{{A_FLAG}}}"(flag)')
+    out.append("      : " + ", ".join(outs))
+    out.append("      : " + ", ".join(ins))
+    pinned = set(range(VB, VB + 52)) | set(range(AQ, AQ + 52)) | {int(A_FLAG[1:])}
+    clob = ['"vcc"', '"scc"'] + [f'"s{i}"' for i in range(SB, S_END)] + [f'"v{i}"' for i in range(VB, A_V_END) if i not in pinned]
+    out.append("      : " + ", ".join(clob) + ");")
+    out.append("  return flag;")
+    out.append("}")
+
+
 def main():
     if "--selftest" in sys.argv:
         selftest(2000 if "--long" in sys.argv else 400)
+        selftest_add(1500 if "--long" in sys.argv else 300)
         return
     out = []
     emit(out)
+    assert out[-1] == "// clang-format on"
+    out.pop()
+    emit_add(out)
+    out.append("// clang-format on")
     sys.stdout.write("\n".join(out) + "\n")
 
 

@@ -947,7 +947,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAV
 // before anything is modified, and that iteration takes the canonical, complete addition of g1.cuh.
 // k_acc0_canon above is the round-2 kernel (canonical 12 x 32-bit accumulator), kept for A/B runs (GM_ACC0=canon).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_acc0(const uint64_t* __restrict__ entries,
+template <int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_acc0(const uint64_t* __restrict__ entries,
                                               const uint32_t* __restrict__ total_ptr,
                                               const uint8_t* __restrict__ bases, long long first, long long step,
                                               long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
@@ -985,8 +986,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       const uint8_t* src = (phi != nullptr && ((e >> ENTRY_HALF_SHIFT) & 1ull)) ? phi : bases;
       const gm_u4v* bp = reinterpret_cast<const gm_u4v*>(src + (size_t)idx * AFF_BYTES);
-      const gm_u4v x0 = bp[0], x1 = bp[1], x2 = bp[2];
-      gm_u4v y0 = bp[3], y1 = bp[4], y2 = bp[5];
+      const gm_u4v x0 = bp[0], x1 = bp[1], x2 = bp[2], y0 = bp[3], y1 = bp[4], y2 = bp[5];
       const uint32_t key = (uint32_t)(e >> 32);
       if (key != cur) {
         if (cur != KEY_INV) {
@@ -1004,24 +1004,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const uint32_t nz = x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w | x2.x | x2.y | x2.z | x2.w | y0.x | y0.y | y0.z | y0.w |
                           y1.x | y1.y | y1.z | y1.w | y2.x | y2.y | y2.z | y2.w;
       if (nz == 0) continue;  // the identity base (0, 0)
-      if ((e >> 31) & 1ull) {
-        Fq y;
-        y.l[0] = y0.x; y.l[1] = y0.y; y.l[2] = y0.z; y.l[3] = y0.w; y.l[4] = y1.x; y.l[5] = y1.y; y.l[6] = y1.z; y.l[7] = y1.w;
-        y.l[8] = y2.x; y.l[9] = y2.y; y.l[10] = y2.z; y.l[11] = y2.w;
-        y = fq_neg_canonical(y);
-        y0 = gm_u4v{y.l[0], y.l[1], y.l[2], y.l[3]};
-        y1 = gm_u4v{y.l[4], y.l[5], y.l[6], y.l[7]};
-        y2 = gm_u4v{y.l[8], y.l[9], y.l[10], y.l[11]};
-      }
-      const uint32_t flag = g1_madd30_asm(acc, __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7),
-                                          __builtin_shufflevector(x2, y0, 0, 1, 2, 3, 4, 5, 6, 7),
-                                          __builtin_shufflevector(y1, y2, 0, 1, 2, 3, 4, 5, 6, 7));
-      if (flag) {  // wave-uniform over the lanes that ran the statement; rare
-        G1Affine p;
-        p.x.l[0] = x0.x; p.x.l[1] = x0.y; p.x.l[2] = x0.z; p.x.l[3] = x0.w; p.x.l[4] = x1.x; p.x.l[5] = x1.y; p.x.l[6] = x1.z; p.x.l[7] = x1.w;
-        p.x.l[8] = x2.x; p.x.l[9] = x2.y; p.x.l[10] = x2.z; p.x.l[11] = x2.w;
-        p.y.l[0] = y0.x; p.y.l[1] = y0.y; p.y.l[2] = y0.z; p.y.l[3] = y0.w; p.y.l[4] = y1.x; p.y.l[5] = y1.y; p.y.l[6] = y1.z; p.y.l[7] = y1.w;
-        p.y.l[8] = y2.x; p.y.l[9] = y2.y; p.y.l[10] = y2.z; p.y.l[11] = y2.w;
+      const uint32_t neg = (uint32_t)(e >> 31) & 1u;
+      const uint32_t flag = g1_madd30_asm(acc, x0, x1, x2, y0, y1, y2, neg);
+      if (flag) {  // rare: p == 0 (mod q) on some lane of the wave -- the complete addition on canonical values
+        // the statement consumed its copy of the base: load it again, through a laundered pointer so that the compiler
+        // does not keep the 24 words of EVERY iteration alive across the statement for this path
+        const uint8_t* again = src + (size_t)idx * AFF_BYTES;
+        asm volatile("" : "+v"(again));
+        G1Affine p = g1_load_affine(again);
+        if (neg) p.y = fq_neg_canonical(p.y);
         G1Xyzz c = acc30_to_canonical(acc);
         xyzz_madd(c, p);
         acc30_from_canonical(acc, c);
@@ -1049,22 +1040,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_in, const uint8_t* __restrict__ pts_in,
                                               uint32_t E, uint32_t* __restrict__ keys_out,
                                               uint8_t* __restrict__ pts_out, uint8_t* __restrict__ buckets,
-                                              int final_level, int in_loose, int bucket_loose) {
-  // in_loose: pts_in holds 208-byte loose records (k_acc0's level-0 partials); bucket_loose: the bucket array does
-  auto load_in = [&](size_t slot) { return in_loose ? g1_load_xyzz30(pts_in + slot * XYZZ30_BYTES) : g1_load_xyzz(pts_in + slot * XYZZ_BYTES); };
-  auto store_bucket = [&](uint32_t key, const G1Xyzz& v) {
-    if (bucket_loose) g1_store_xyzz30(buckets + (size_t)key * XYZZ30_BYTES, v);
-    else g1_store_xyzz(buckets + (size_t)key * XYZZ_BYTES, v);
-  };
-  __shared__ __attribute__((aligned(16))) uint8_t lds[128 * XYZZ_BYTES];
+                                              int final_level) {
+  // every record -- partials of all levels, buckets -- is a 208-byte loose XYZZ record (g1.cuh: Acc30); additions are
+  // the asm statement of gen_madd30.py (acc30_add)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[128 * XYZZ30_BYTES];
   const int lane = threadIdx.x;
   const uint32_t wave = blockIdx.x;
   const uint32_t s0 = wave * 128u + 2u * lane;
   uint32_t hk = s0 < E ? keys_in[s0] : KEY_INV;
   uint32_t tk = s0 + 1 < E ? keys_in[s0 + 1] : KEY_INV;
   uint32_t hs = 2 * lane, ts = 2 * lane + 1;  // LDS slot ids
-  if (hk != KEY_INV) g1_store_xyzz(lds + hs * XYZZ_BYTES, load_in((size_t)s0));
-  if (tk != KEY_INV) g1_store_xyzz(lds + ts * XYZZ_BYTES, load_in((size_t)s0 + 1));
+  auto copy_rec = [](void* dst, const void* src) {
+    const gm_u4v* s = reinterpret_cast<const gm_u4v*>(src);
+    gm_u4v* d = reinterpret_cast<gm_u4v*>(dst);
+#pragma unroll
+    for (int i = 0; i < 13; i++) d[i] = s[i];
+  };
+  auto add_slots = [&](uint32_t dst_slot, uint32_t src_slot, Acc30& a) {  // a = lds[dst] + lds[src]
+    Acc30 o;
+    acc30_load(a, lds + dst_slot * XYZZ30_BYTES);
+    acc30_load(o, lds + src_slot * XYZZ30_BYTES);
+    acc30_add(a, o);
+  };
+  if (hk != KEY_INV) copy_rec(lds + hs * XYZZ30_BYTES, pts_in + (size_t)s0 * XYZZ30_BYTES);
+  if (tk != KEY_INV) copy_rec(lds + ts * XYZZ30_BYTES, pts_in + ((size_t)s0 + 1) * XYZZ30_BYTES);
   // a producer emits (head, INV) or (head, tail) or (INV, INV); normalise (INV, tail) defensively
   if (hk == KEY_INV && tk != KEY_INV) {
     hk = tk;
@@ -1074,9 +1073,9 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
   // equal head/tail keys cannot be produced, but merging them keeps the invariant "hk != tk"
   __syncthreads();
   if (hk != KEY_INV && hk == tk) {
-    G1Xyzz a = g1_load_xyzz(lds + hs * XYZZ_BYTES);
-    xyzz_add(a, g1_load_xyzz(lds + ts * XYZZ_BYTES));
-    g1_store_xyzz(lds + hs * XYZZ_BYTES, a);
+    Acc30 a;
+    add_slots(hs, ts, a);
+    acc30_store(lds + hs * XYZZ30_BYTES, a);
     tk = KEY_INV;
   }
   __syncthreads();
@@ -1092,9 +1091,9 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
     const bool taken = lane > 0 && tk != KEY_INV && ptk != KEY_INV && ptk == hk;   // my head consumed by prev
     if (__any(give)) {
       if (give) {
-        G1Xyzz a = g1_load_xyzz(lds + ts * XYZZ_BYTES);
-        xyzz_add(a, g1_load_xyzz(lds + nhs * XYZZ_BYTES));
-        store_bucket(tk, a);
+        Acc30 a;
+        add_slots(ts, nhs, a);
+        acc30_store(buckets + (size_t)tk * XYZZ30_BYTES, a);
       }
     }
     __syncthreads();
@@ -1134,24 +1133,24 @@ __global__ __launch_bounds__(64) void k_merge(const uint32_t* __restrict__ keys_
     }
     if (__any(do_add)) {
       if (do_add) {
-        G1Xyzz a = g1_load_xyzz(lds + add_dst * XYZZ_BYTES);
-        xyzz_add(a, g1_load_xyzz(lds + add_src * XYZZ_BYTES));
-        g1_store_xyzz(lds + add_dst * XYZZ_BYTES, a);
+        Acc30 a;
+        add_slots(add_dst, add_src, a);
+        acc30_store(lds + add_dst * XYZZ30_BYTES, a);
       }
     }
-    if (f1k != KEY_INV) store_bucket(f1k, g1_load_xyzz(lds + f1s * XYZZ_BYTES));
-    if (f2k != KEY_INV) store_bucket(f2k, g1_load_xyzz(lds + f2s * XYZZ_BYTES));
+    if (f1k != KEY_INV) copy_rec(buckets + (size_t)f1k * XYZZ30_BYTES, lds + f1s * XYZZ30_BYTES);
+    if (f2k != KEY_INV) copy_rec(buckets + (size_t)f2k * XYZZ30_BYTES, lds + f2s * XYZZ30_BYTES);
     __syncthreads();
   }
   if (lane == 0) {
     if (final_level) {
-      if (hk != KEY_INV) store_bucket(hk, g1_load_xyzz(lds + hs * XYZZ_BYTES));
-      if (tk != KEY_INV) store_bucket(tk, g1_load_xyzz(lds + ts * XYZZ_BYTES));
+      if (hk != KEY_INV) copy_rec(buckets + (size_t)hk * XYZZ30_BYTES, lds + hs * XYZZ30_BYTES);
+      if (tk != KEY_INV) copy_rec(buckets + (size_t)tk * XYZZ30_BYTES, lds + ts * XYZZ30_BYTES);
     } else {
       keys_out[2 * (size_t)wave] = hk;
       keys_out[2 * (size_t)wave + 1] = tk;
-      if (hk != KEY_INV) g1_store_xyzz(pts_out + (size_t)(2 * (size_t)wave) * XYZZ_BYTES, g1_load_xyzz(lds + hs * XYZZ_BYTES));
-      if (tk != KEY_INV) g1_store_xyzz(pts_out + (size_t)(2 * (size_t)wave + 1) * XYZZ_BYTES, g1_load_xyzz(lds + ts * XYZZ_BYTES));
+      if (hk != KEY_INV) copy_rec(pts_out + (size_t)(2 * (size_t)wave) * XYZZ30_BYTES, lds + hs * XYZZ30_BYTES);
+      if (tk != KEY_INV) copy_rec(pts_out + (size_t)(2 * (size_t)wave + 1) * XYZZ30_BYTES, lds + ts * XYZZ30_BYTES);
     }
   }
 }
@@ -1180,7 +1179,7 @@ struct GroupSumArgs {
   // GS_PLANE: input length 2^nb per set; r < nb: elements with bit r set; r == nb: all elements
   uint32_t nb;
   uint32_t lpo_shift;   // lanes per output = 2^lpo_shift
-  int in_loose;         // the input is the bucket array in 208-byte loose records (g1.cuh: g1_load_xyzz30)
+  int out_canonical;    // write canonical 192-byte records (the plane sums the host reads) instead of 208-byte loose ones
 };
 struct GroupSumJobs {
   GroupSumArgs j[3];
@@ -1189,20 +1188,9 @@ struct GroupSumJobs {
   uint32_t* err_dst;
 };
 
-GM_DEV G1Xyzz xyzz_shfl_xor(const G1Xyzz& v, int m) {
-  G1Xyzz r;
-#pragma unroll
-  for (int i = 0; i < FQE_LIMBS; i++) {
-    r.x.l[i] = __shfl_xor(v.x.l[i], m);
-    r.y.l[i] = __shfl_xor(v.y.l[i], m);
-    r.zz.l[i] = __shfl_xor(v.zz.l[i], m);
-    r.zzz.l[i] = __shfl_xor(v.zzz.l[i], m);
-  }
-  return r;
-}
-
 // up to three independent jobs per launch so that passes of the same level overlap instead of
-// serialising their (latency-bound) depth
+// serialising their (latency-bound) depth.  Inputs and intermediate arrays are 208-byte loose records, sums run on the asm
+// addition (acc30_add); only the last launch of a call (out_canonical) writes the canonical 192-byte records the host reads.
 __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
   if (J.err_dst && blockIdx.x == 0 && threadIdx.x == 0) *J.err_dst = *J.err_src;
   const int job = blockIdx.x < J.blk_end[0] ? 0 : (blockIdx.x < J.blk_end[1] ? 1 : 2);
@@ -1213,34 +1201,42 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
   const uint32_t gt = (blockIdx.x - blk0) * blockDim.x + threadIdx.x;
   const uint32_t lpo = 1u << a.lpo_shift;
   const uint32_t o = gt >> a.lpo_shift, q = gt & (lpo - 1u);
-  G1Xyzz acc = G1Xyzz::identity();
-  const int in_loose = a.in_loose;
-  auto load = [&](size_t slot) { return in_loose ? g1_load_xyzz30(in + slot * XYZZ30_BYTES) : g1_load_xyzz(in + slot * XYZZ_BYTES); };
+  Acc30 acc;
+  acc30_zero(acc);
+  auto add_rec = [&](size_t slot) {
+    Acc30 v;
+    acc30_load(v, in + slot * XYZZ30_BYTES);
+    acc30_add(acc, v);
+  };
   if (o < a.n_out) {
     const uint32_t w = o / a.per_win, r = o % a.per_win;
     const size_t base = (size_t)w * a.win_stride;
     if (a.mode == GS_STRIDED) {
       const size_t b0 = base + (size_t)(r / a.n_lo) * a.s_hi + (size_t)(r % a.n_lo) * a.s_lo;
-      for (uint32_t e = q; e < a.len; e += lpo) xyzz_add(acc, load(b0 + (size_t)e * a.s_e));
+      for (uint32_t e = q; e < a.len; e += lpo) add_rec(b0 + (size_t)e * a.s_e);
     } else {
       const uint32_t nb = a.nb;
       if (r == nb) {  // total
-        for (uint32_t e = q; e < (1u << nb); e += lpo) xyzz_add(acc, load(base + e));
+        for (uint32_t e = q; e < (1u << nb); e += lpo) add_rec(base + e);
       } else {        // elements whose bit r is set
         const uint32_t half = nb ? (1u << (nb - 1)) : 0u;
         for (uint32_t e = q; e < half; e += lpo) {
           uint32_t v = ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u));
-          xyzz_add(acc, load(base + v));
+          add_rec(base + v);
         }
       }
     }
   }
 #pragma unroll 1
   for (int m = (int)(lpo >> 1); m >= 1; m >>= 1) {
-    G1Xyzz other = xyzz_shfl_xor(acc, m);
-    xyzz_add(acc, other);
+    Acc30 other;
+    acc30_shfl_xor(other, acc, m);
+    acc30_add(acc, other);
   }
-  if (o < a.n_out && q == 0) g1_store_xyzz(out + (size_t)o * XYZZ_BYTES, acc);
+  if (o < a.n_out && q == 0) {
+    if (a.out_canonical) g1_store_xyzz(out + (size_t)o * XYZZ_BYTES, acc30_to_canonical(acc));
+    else acc30_store(out + (size_t)o * XYZZ30_BYTES, acc);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1677,6 +1673,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   // GLV (glv_split): two 128-bit digit strings per scalar over HALF the windows, the second one on phi(P)
   static const bool sort_atomic_env0 = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
   static const bool acc0_canon = getenv("GM_ACC0") && !strcmp(getenv("GM_ACC0"), "canon");  // A/B: the round-2 accumulate kernel
+  static const int acc0_waves = getenv("GM_ACC0_WAVES") ? atoi(getenv("GM_ACC0_WAVES")) : 3;  // waves per SIMD of k_acc0 (2 or 3)
   const int loose = acc0_canon ? 0 : 1;                       // k_acc0 writes 208-byte loose records (buckets, level-0 partials)
   const size_t bucket_bytes = loose ? XYZZ30_BYTES : XYZZ_BYTES;
   const bool use_glv = bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && n <= ((size_t)1 << 26);
@@ -1859,8 +1856,11 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   if (acc0_canon)
     hipLaunchKernelGGL(k_acc0_canon, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
+  else if (acc0_waves == 2)
+    hipLaunchKernelGGL(k_acc0<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
   else
-    hipLaunchKernelGGL(k_acc0, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+    hipLaunchKernelGGL(k_acc0<3>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
   pf.end(part, PROF_ACC0, st);
   if (sts.tail != st) {
@@ -2178,10 +2178,10 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
   auto b = std::make_unique<Bases>();
   b->n = n;
   if (n) {
-    GM_HIP(hipMalloc((void**)&b->d, n * AFF_BYTES));
+    GM_HIP(dev_malloc((void**)&b->d, n * AFF_BYTES));
     {
       uint8_t* stage = nullptr;
-      GM_HIP(hipMalloc((void**)&stage, n * stride));
+      GM_HIP(dev_malloc((void**)&stage, n * stride));
       GM_HIP(hipMemcpyAsync(stage, bases, n * stride, hipMemcpyHostToDevice, C->stream));
       hipLaunchKernelGGL(k_pack_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C->stream, stage, stride, n, b->d);
       GM_HIP(hipStreamSynchronize(C->stream));
@@ -2204,7 +2204,7 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
 int bases_build_phi(Context* C, Bases* b) {
   static const bool glv_env = getenv("GM_GLV") && !strcmp(getenv("GM_GLV"), "1");
   if (!(glv_env || C->msm_glv) || b->n == 0 || b->phi) return GM_OK;
-  GM_HIP(hipMalloc((void**)&b->phi, b->n * AFF_BYTES));
+  GM_HIP(dev_malloc((void**)&b->phi, b->n * AFF_BYTES));
   hipLaunchKernelGGL(k_phi_bases, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, C->stream, b->d, b->n, b->phi);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
@@ -2214,7 +2214,7 @@ int bases_build_phi(Context* C, Bases* b) {
 int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out96) {
   if (n == 0) return GM_OK;
   uint8_t* tmp = nullptr;
-  GM_HIP(hipMalloc((void**)&tmp, n * AFF_BYTES));
+  GM_HIP(dev_malloc((void**)&tmp, n * AFF_BYTES));
   hipLaunchKernelGGL(k_export_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C->stream, b->d + offset * AFF_BYTES, n, tmp);
   GM_HIP(hipGetLastError());
   GM_HIP(hipMemcpyAsync(out96, tmp, n * AFF_BYTES, hipMemcpyDeviceToHost, C->stream));
@@ -2226,12 +2226,12 @@ int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out9
 // fixed-base table (affine, 32 x 256 entries) for `base`
 static int build_fixed_table(Context* C, const uint64_t base_affine[12], uint8_t** table_aff) {
   uint8_t *d_base = nullptr, *t_xyzz = nullptr;
-  GM_HIP(hipMalloc((void**)&d_base, AFF_BYTES));
-  GM_HIP(hipMalloc((void**)&t_xyzz, (size_t)32 * 256 * XYZZ_BYTES));
-  GM_HIP(hipMalloc((void**)table_aff, (size_t)32 * 256 * AFF_BYTES));
+  GM_HIP(dev_malloc((void**)&d_base, AFF_BYTES));
+  GM_HIP(dev_malloc((void**)&t_xyzz, (size_t)32 * 256 * XYZZ_BYTES));
+  GM_HIP(dev_malloc((void**)table_aff, (size_t)32 * 256 * AFF_BYTES));
   {
     uint8_t* stage = nullptr;
-    GM_HIP(hipMalloc((void**)&stage, AFF_BYTES));
+    GM_HIP(dev_malloc((void**)&stage, AFF_BYTES));
     GM_HIP(hipMemcpyAsync(stage, base_affine, AFF_BYTES, hipMemcpyHostToDevice, C->stream));
     hipLaunchKernelGGL(k_pack_bases, dim3(1), dim3(64), 0, C->stream, stage, (size_t)AFF_BYTES, (size_t)1, d_base);
     GM_HIP(hipStreamSynchronize(C->stream));
@@ -2428,7 +2428,7 @@ int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const 
   H->ng = ng;
   H->f[0] = b->d;  // take ownership of the packed copy
   b->d = nullptr;
-  GM_HIP(hipMalloc((void**)&H->f[1], ((nf + 1) / 2) * AFF_BYTES));
+  GM_HIP(dev_malloc((void**)&H->f[1], ((nf + 1) / 2) * AFF_BYTES));
   if ((rc = C->pool.alloc(ng * 32, (void**)&H->g[0], &H->gcap[0]))) return rc;
   if ((rc = C->pool.alloc(((ng + 1) / 2) * 32, (void**)&H->g[1], &H->gcap[1]))) return rc;
   if ((rc = C->pool.alloc(3 * ((((ng + 1) / 2) + 1) * 32), (void**)&H->tmp, &H->tmpcap))) return rc;  // three compacted scalar vectors
@@ -2556,12 +2556,16 @@ int bases_precompute(Context* C, Bases* b, int c) {
     b->table = nullptr;
   }
   uint8_t* t = nullptr;
-  GM_HIP(hipMalloc((void**)&t, (size_t)W * b->n * AFF_BYTES));
+  GM_HIP(dev_malloc((void**)&t, (size_t)W * b->n * AFF_BYTES));
   GM_HIP(hipMemcpyAsync(t, b->d, b->n * AFF_BYTES, hipMemcpyDeviceToDevice, C->stream));
   // one slab of XYZZ results at a time (192 B per point), normalised NORM_K points per inversion
   const size_t slab = std::min<size_t>(b->n, (size_t)1 << 22);
   uint8_t* xy = nullptr;
-  GM_HIP(hipMalloc((void**)&xy, slab * XYZZ_BYTES));
+  {
+    const hipError_t e = dev_malloc((void**)&xy, slab * XYZZ_BYTES);
+    if (e != hipSuccess) (void)hipFree(t);
+    GM_HIP(e);
+  }
   for (int w = 0; w + 1 < W; w++)
     for (size_t off = 0; off < b->n; off += slab) {
       const size_t m = std::min(slab, b->n - off);
@@ -2588,10 +2592,10 @@ int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* 
     uint8_t* table = nullptr;
     int rc = build_fixed_table(C, base_affine, &table);
     if (rc) return rc;
-    GM_HIP(hipMalloc((void**)&b->d, n * AFF_BYTES));
+    GM_HIP(dev_malloc((void**)&b->d, n * AFF_BYTES));
     const size_t slab = std::min<size_t>(n, (size_t)1 << 22);
     uint8_t* xy = nullptr;
-    GM_HIP(hipMalloc((void**)&xy, slab * XYZZ_BYTES));
+    GM_HIP(dev_malloc((void**)&xy, slab * XYZZ_BYTES));
     for (size_t off = 0; off < n; off += slab) {
       const size_t m = std::min(slab, n - off);
       hipLaunchKernelGGL(k_fixed_base_mul, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, C->stream,

@@ -53,6 +53,12 @@ class G1Bases:
                                                   C.c_size_t(n), C.byref(h)))
         return cls(h.value, n)
 
+    def table_info(self):
+        """(window width, bytes) of the fixed-base tables of this handle; (0, 0) without tables"""
+        c, b = C.c_int(0), C.c_size_t(0)
+        capi.check(capi.load().gm_g1_bases_table_info(C.c_uint64(self.handle), C.byref(c), C.byref(b)))
+        return c.value, b.value
+
     def precompute(self, c: int = 0):
         """build the fixed-base window tables (gm_g1_bases_precompute); setup, outside any prover timer"""
         capi.check(capi.load().gm_g1_bases_precompute(C.c_uint64(self.handle), C.c_int(c)))

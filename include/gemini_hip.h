@@ -84,6 +84,17 @@ int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96);
  * paths).  Setup cost is comparable to generating the SRS; like CommitterKey::new it is outside the
  * prover timer.  c = 0 picks the default (20).  No reference counterpart: ark-ec recomputes. */
 int gm_g1_bases_precompute(uint64_t handle, int c);
+/* Tables BY DEFAULT (on = 1 at gm_init): every registration (gm_g1_bases_register, gm_g1_fixed_base_register,
+ * gm_g1_srs_register) of 2^17 .. 2^26 - 1 points builds the tables above when W x n x 96 bytes fit `max_bytes`
+ * (0 = 30 % of the device memory) and the free memory; otherwise, silently, the plain path serves the key.
+ * A committer key is registered once and serves ~3 N pairs of MSMs per proof; the build is setup, like
+ * CommitterKey::new (src/kzg/time.rs:49-72, which builds a window table of its own to generate the key). */
+int gm_set_auto_tables(int on, size_t max_bytes);
+/* Window width (0 = no tables) and size in bytes of the tables of a handle. */
+int gm_g1_bases_table_info(uint64_t handle, int* c, size_t* bytes);
+/* Give the freed blocks of the device-vector pool (up to 55 % of the device memory) back to the driver -- for a host
+ * process that shares the GPU with another allocator (torch, a second rank). */
+int gm_pool_trim(void);
 
 /* MSM against registered bases.  Pair i uses base[offset + i] (reversed = 0) or base[offset - i]
  * (reversed = 1).  reversed/offset express CommitterKey::commit's prefix slice

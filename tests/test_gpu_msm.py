@@ -195,8 +195,8 @@ def test_msm_2_16_vs_oracle(gm, oracle):
 
 
 def test_msm_2_23_vs_oracle(gm, oracle):
-    """the wide-window configuration (c = 19, 14 windows, 3.7 M buckets) at a size where it is the default,
-    against the CPU Pippenger on the same inputs (about 10 s of CPU on the GPU box)"""
+    """2^23 - 3 pairs against the CPU Pippenger on the same inputs (about 10 s of CPU on the GPU box), both ways: the default
+    for a resident key (tables) and the plain wide-window configuration (c = 19, 14 windows, 3.7 M buckets)"""
     import bench
 
     n = (1 << 23) - 3
@@ -204,10 +204,45 @@ def test_msm_2_23_vs_oracle(gm, oracle):
     reg = gm.G1Bases.fixed_base(oracle.g1_generator(), bench.uniform_fr(rng, n))
     try:
         sc = bench.uniform_fr(rng, n)
-        got = reg.msm_bigint(sc)
-        assert_same_point(oracle, got, oracle.msm_pippenger(reg.download(), sc))
+        exp = oracle.msm_pippenger(reg.download(), sc)
+        # the library default for a resident key of this size: fixed-base tables (c = 20, 13 windows, one shared bucket set)
+        assert reg.table_info()[0] == 20  # (22 from 2^23 points on)
+        assert_same_point(oracle, reg.msm_bigint(sc), exp)
+        # and the plain path of the same size
+        gm.capi.check(gm.capi.load().gm_set_msm_table_min(C.c_size_t(1 << 62)))
+        assert_same_point(oracle, reg.msm_bigint(sc), exp)
     finally:
+        gm.capi.check(gm.capi.load().gm_set_msm_table_min(C.c_size_t(1 << 17)))
         reg.free()
+
+
+def test_tables_are_the_default_for_a_resident_key(gm, oracle):
+    """gm_set_auto_tables (on at gm_init): registering 2^17 .. 2^26 - 1 bases builds the fixed-base tables when they fit the
+    budget; smaller keys, a tiny budget or the knob turned off leave the plain path.  Same group element either way."""
+    lib = gm.capi.load()
+    n = (1 << 17) + 3
+    ks = oracle.random_fr(2901, n)
+    sc = oracle.random_fr(2902, n)
+    try:
+        reg = gm.G1Bases.fixed_base(oracle.g1_generator(), ks)
+        assert reg.table_info() == (20, 13 * n * 96)
+        with_tables = reg.msm_bigint(sc)
+        assert_same_point(oracle, with_tables, oracle.msm_pippenger(reg.download(), sc))
+        reg.free()
+        small = gm.G1Bases.fixed_base(oracle.g1_generator(), ks[:5000])
+        assert small.table_info() == (0, 0)
+        small.free()
+        gm.capi.check(lib.gm_set_auto_tables(C.c_int(1), C.c_size_t(1 << 20)))  # a budget the tables do not fit
+        reg = gm.G1Bases.fixed_base(oracle.g1_generator(), ks)
+        assert reg.table_info() == (0, 0)
+        reg.free()
+        gm.capi.check(lib.gm_set_auto_tables(C.c_int(0), C.c_size_t(0)))
+        reg = gm.G1Bases.fixed_base(oracle.g1_generator(), ks)
+        assert reg.table_info() == (0, 0)
+        assert (reg.msm_bigint(sc) == with_tables).all()
+        reg.free()
+    finally:
+        gm.capi.check(lib.gm_set_auto_tables(C.c_int(1), C.c_size_t(0)))
 
 
 def test_msm_2_20_properties(gm, oracle, pyref):

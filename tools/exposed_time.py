@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--primary", default="k_acc0")
     ap.add_argument("--reps", type=int, default=1, help="repetitions in the run; the window is the last one")
     ap.add_argument("--window", default=None, help="t0,t1 in trace nanoseconds")
+    ap.add_argument("--stamps", default=None, help="JSON output of tools/run_snark.py / run_psnark.py of the traced run: the window is its LAST proof "
+                    "(clock readings around every proof; the clock that brackets kernel activity is picked)")
     ap.add_argument("--title", default=None)
     ap.add_argument("--md", default=None)
     ap.add_argument("--json", default=None)
@@ -130,7 +132,20 @@ def main():
     ev = load(a.trace)
     if not ev:
         sys.exit("no kernel dispatches in " + a.trace)
-    if a.window:
+    if a.stamps:
+        with open(a.stamps) as f:
+            txt = f.read()
+        st = json.loads(txt[txt.index("{"):])["stamps"][-1]
+        t0 = t1 = None
+        for clk in ("boottime_ns", "monotonic_ns", "realtime_ns"):
+            c0, c1 = st["t0"][clk], st["t1"][clk]
+            if any(c0 <= s_ <= c1 for s_, _, _ in ev):
+                t0, t1 = c0, c1
+                break
+        if t0 is None:
+            sys.exit("no clock of the stamps brackets any kernel of the trace")
+        # the window is the proof's whole wall time on the host: GPU idle at either end (transcript, set-up of the call) counts
+    elif a.window:
         t0, t1 = (int(x) for x in a.window.split(","))
     else:
         t0, t1 = cut_last_rep(ev, a.reps)

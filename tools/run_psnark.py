@@ -68,7 +68,11 @@ def main():
     index = Proof.index(ck, r1cs)
     t_index = time.perf_counter() - t0
     out = {"logn": args.instance_logsize, "srs_s": round(t_srs, 3), "index_s": round(t_index, 3), "runs": []}
+    stamps = []  # clock readings around every proof, for tools/exposed_time.py --stamps
+    clocks = lambda: {"boottime_ns": time.clock_gettime_ns(time.CLOCK_BOOTTIME), "monotonic_ns": time.clock_gettime_ns(time.CLOCK_MONOTONIC),
+                      "realtime_ns": time.clock_gettime_ns(time.CLOCK_REALTIME)}
     for _ in range(args.repeat):
+        stamps.append({"t0": clocks()})
         if args.elastic:
             from gemini_amd.circuit import R1csStream
             from gemini_amd.kzg import CommitterKeyStream
@@ -78,8 +82,10 @@ def main():
             stream.free()
         else:
             proof = Proof.new_time(ck, r1cs, index)
+        stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         out["proof_size_B"] = proof.compressed_size()
+    out["stamps"] = stamps
     key = "ark_gemini::psnark::elastic_prover" if args.elastic else "ark_gemini::psnark::time_prover"
     out["elastic_prover_s" if args.elastic else "time_prover_s"] = min(r[key] for r in out["runs"])
     import hashlib

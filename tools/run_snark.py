@@ -79,9 +79,13 @@ def main():
         ck.powers_of_g.precompute(0)
         t_tab = time.perf_counter() - t0
     out = {"n_gpus": world, "logn": args.instance_logsize, "instance_s": round(t_inst, 3), "srs_s": round(t_srs, 3), "tables_s": None if t_tab is None else round(t_tab, 3), "runs": []}
+    stamps = []  # per proof: clock readings around it, for tools/exposed_time.py --stamps (rocprofv3 timestamps are one of these clocks)
+    clocks = lambda: {"boottime_ns": time.clock_gettime_ns(time.CLOCK_BOOTTIME), "monotonic_ns": time.clock_gettime_ns(time.CLOCK_MONOTONIC),
+                      "realtime_ns": time.clock_gettime_ns(time.CLOCK_REALTIME)}
     for _ in range(args.repeat):
         if world > 1:
             dist.barrier()
+        stamps.append({"t0": clocks()})
         if args.elastic:
             from gemini_amd.circuit import R1csStream
             from gemini_amd.kzg import CommitterKeyStream
@@ -97,6 +101,7 @@ def main():
             stream.free()
         else:
             proof = Proof.new_time(r1cs, ck, native=args.native)
+        stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         out["proof_size_B"] = proof.compressed_size()  # examples/snark.rs:96 "proof-size {}B"
     key = "ark_gemini::snark::elastic_prover" if args.elastic else "ark_gemini::snark::time_prover"
@@ -111,6 +116,7 @@ def main():
         assert len({d for _, d in allt}) == 1, "ranks produced different proofs"
         dist.destroy_process_group()
     out["proof_sha256"] = __import__("hashlib").sha256(proof.serialize_compressed()).hexdigest()
+    out["stamps"] = stamps
     if rank == 0:
         print(json.dumps(out))
 
