@@ -859,93 +859,16 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict_
 // ------------------------------------------------------------------------------------------
 // level 0: chunk-per-thread accumulation of sorted entries
 // ------------------------------------------------------------------------------------------
-#ifndef GM_ACC0_WAVES
-#define GM_ACC0_WAVES 2
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GM_ACC0_WAVES, GM_ACC0_WAVES))) void k_acc0_canon(const uint64_t* __restrict__ entries,
-                                              const uint32_t* __restrict__ total_ptr,
-                                              const uint8_t* __restrict__ bases, long long first, long long step,
-                                              long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
-                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi) {
-  __shared__ uint64_t ebuf[8][256];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t total = *total_ptr;
-  const uint64_t start = (uint64_t)t * L;
-  uint32_t head_key = KEY_INV, tail_key = KEY_INV;
-  if (start < total) {
-    const uint64_t end = min(start + (uint64_t)L, total);
-    G1Xyzz acc = G1Xyzz::identity();
-    uint32_t cur = KEY_INV;
-    bool first_run = true;
-    // No software prefetch here: hipcc must drain vmcnt before every call of the out-of-line Fq
-    // multiplier, so an early-issued gather cannot overlap the addition inside one wave (measured:
-    // no change).  The second resident wave per SIMD hides the gather latency instead.
-    for (uint64_t i = start; i < end; i++) {
-      // Entries are staged eight at a time through LDS: a lane walks its own chunk, so lane t reads entries[t L + i]
-      // -- 8 bytes out of a different 128-byte line per lane and iteration, and with one addition (~20 k cycles)
-      // between two reads of a line it is long gone from L1 / L2 by then (the PMC pass counted every line ~16 times:
-      // 2.1 GB of the 4.5 GB per launch).  Four 16-byte loads per eight iterations fetch each line twice; the
-      // transposed LDS image [k][lane] is written and read conflict-free and only by its own lane (no barrier).
-      const uint32_t k8 = (uint32_t)(i - start) & 7u;
-      if (k8 == 0) {
-        const uint4* src = reinterpret_cast<const uint4*>(entries + i);  // start = t * L with L even: 16-byte aligned
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint4 v = src[q];  // may run past `end` inside the (padded) entry buffer; those slots are never used
-          ebuf[2 * q][threadIdx.x] = ((uint64_t)v.y << 32) | v.x;
-          ebuf[2 * q + 1][threadIdx.x] = ((uint64_t)v.w << 32) | v.z;
-        }
-      }
-      const uint64_t e = ebuf[k8][threadIdx.x];
-      long long idx;
-      if (tab_stride) {  // fixed-base tables: row = window, column = pair
-        const uint32_t lo = (uint32_t)e & 0x7fffffffu;
-        idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
-      } else {
-        idx = first + step * (long long)(e & 0x3fffffffull);
-      }
-      // GLV calls: bit 30 of the index field selects phi(P) (same addressing, second array)
-      const uint8_t* src = (phi != nullptr && ((e >> ENTRY_HALF_SHIFT) & 1ull)) ? phi : bases;
-      G1Affine p = g1_load_affine(src + (size_t)idx * AFF_BYTES);
-      const uint32_t key = (uint32_t)(e >> 32);
-      if (key != cur) {
-        if (cur != KEY_INV) {
-          if (first_run) {
-            head_key = cur;
-            g1_store_xyzz(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES, acc);
-            first_run = false;
-          } else {
-            g1_store_xyzz(buckets + (size_t)cur * XYZZ_BYTES, acc);  // interior run = whole bucket
-          }
-        }
-        cur = key;
-        acc = G1Xyzz::identity();
-      }
-      if ((e >> 31) & 1ull) p.y = fq_neg_canonical(p.y);
-      xyzz_madd(acc, p);
-    }
-    if (first_run) {
-      head_key = cur;
-      g1_store_xyzz(pp + (size_t)(2 * (size_t)t) * XYZZ_BYTES, acc);
-    } else {
-      tail_key = cur;
-      g1_store_xyzz(pp + (size_t)(2 * (size_t)t + 1) * XYZZ_BYTES, acc);
-    }
-  }
-  pk[2 * (size_t)t] = head_key;
-  pk[2 * (size_t)t + 1] = tail_key;
-}
-
-
 // ------------------------------------------------------------------------------------------
-// k_acc0: the same chunk-per-lane accumulation with the accumulator in the product's own representation
+// k_acc0: chunk-per-lane accumulation of sorted entries with the accumulator in the product's own representation
 // (13 x 30-bit loose limbs, 52 pinned VGPRs) and the whole mixed addition ONE asm statement (gen_madd30.py,
 // g1_madd30_gen.inc): no unpack / repack / conditional subtraction per product, no calls, one reduction for
 // Y3 = R (Q - X3) - Y1 PPP.  Runs are written as 208-byte loose records (buckets, level-0 partials) that the
 // consumers canonicalise on load.  The statement handles an identity accumulator itself; p == 0 (doubling /
 // cancellation: every base equal in the reference's elastic benchmark) makes the wave leave it with flag = 1
 // before anything is modified, and that iteration takes the canonical, complete addition of g1.cuh.
-// k_acc0_canon above is the round-2 kernel (canonical 12 x 32-bit accumulator), kept for A/B runs (GM_ACC0=canon).
+// (Round 2's kernel kept a canonical 12 x 32-bit accumulator and called an out-of-line multiplier: 2.58 ms against 2.13 ms
+// at 2^20 pairs, profiles/r3_ab_acc0_*.json.)
 // ------------------------------------------------------------------------------------------
 template <int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_acc0(const uint64_t* __restrict__ entries,
@@ -965,7 +888,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     uint32_t cur = KEY_INV;
     bool first_run = true;
     for (uint64_t i = start; i < end; i++) {
-      // entries staged eight at a time through a transposed LDS image (see k_acc0_canon)
+      // Entries are staged eight at a time through LDS: a lane walks its own chunk, so lane t reads entries[t L + i]
+      // -- 8 bytes out of a different 128-byte line per lane and iteration, and with one addition (~20 k cycles)
+      // between two reads of a line it is long gone from L1 / L2 by then.  Four 16-byte loads per eight iterations fetch
+      // each line twice; the transposed LDS image [k][lane] is written and read conflict-free and only by its own lane.
       const uint32_t k8 = (uint32_t)(i - start) & 7u;
       if (k8 == 0) {
         const uint4* src = reinterpret_cast<const uint4*>(entries + i);
@@ -1672,10 +1598,10 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
   // GLV (glv_split): two 128-bit digit strings per scalar over HALF the windows, the second one on phi(P)
   static const bool sort_atomic_env0 = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
-  static const bool acc0_canon = getenv("GM_ACC0") && !strcmp(getenv("GM_ACC0"), "canon");  // A/B: the round-2 accumulate kernel
-  static const int acc0_waves = getenv("GM_ACC0_WAVES") ? atoi(getenv("GM_ACC0_WAVES")) : 3;  // waves per SIMD of k_acc0 (2 or 3)
-  const int loose = acc0_canon ? 0 : 1;                       // k_acc0 writes 208-byte loose records (buckets, level-0 partials)
-  const size_t bucket_bytes = loose ? XYZZ30_BYTES : XYZZ_BYTES;
+  // waves per SIMD of k_acc0: 2 (198 VGPRs) and 3 (168) measure the same (2.13 / 2.15 ms at 2^20: the kernel is issue-bound,
+  // not latency-bound); 2 leaves 112 registers per lane of a SIMD for other kernels
+  static const int acc0_waves = getenv("GM_ACC0_WAVES") ? atoi(getenv("GM_ACC0_WAVES")) : 2;
+  const size_t bucket_bytes = XYZZ30_BYTES;  // buckets, partials, row / column sums: 208-byte loose records (g1.cuh: Acc30)
   const bool use_glv = bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && n <= ((size_t)1 << 26);
   const int W = ((use_glv ? 128 : 256) + c - 1) / c;
   GM_CHECK(nparts == 1 || !use_table, GM_EINVAL, "msm: the fixed-base table path is not split into window groups");
@@ -1726,7 +1652,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   if ((rc = ws.pp[0].ensure(E1 * bucket_bytes))) return rc;
   const uint64_t E2 = 2 * ((E1 + 127) / 128);
   if ((rc = ws.pk[1].ensure(E2 * 4))) return rc;
-  if ((rc = ws.pp[1].ensure(E2 * XYZZ_BYTES))) return rc;
+  if ((rc = ws.pp[1].ensure(E2 * bucket_bytes))) return rc;
 
   const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
   GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 2) * 4, st));
@@ -1853,10 +1779,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   }
   st = sts.acc;
   pf.begin(part, PROF_ACC0, st);
-  if (acc0_canon)
-    hipLaunchKernelGGL(k_acc0_canon, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
-                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
-  else if (acc0_waves == 2)
+  if (acc0_waves == 2)
     hipLaunchKernelGGL(k_acc0<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
   else
@@ -1872,12 +1795,12 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   {
     uint64_t E = E1;
     int src = 0;
-    for (int lvl = 0;; lvl++) {
+    for (;;) {
       uint32_t waves = (uint32_t)((E + 127) / 128);
       int final_level = waves == 1;
       hipLaunchKernelGGL(k_merge, dim3(waves), dim3(64), 0, st, ws.pk[src].as<uint32_t>(), ws.pp[src].as<uint8_t>(),
                          (uint32_t)E, ws.pk[src ^ 1].as<uint32_t>(), ws.pp[src ^ 1].as<uint8_t>(),
-                         ws.buckets.as<uint8_t>(), final_level, (loose && lvl == 0) ? 1 : 0, loose);
+                         ws.buckets.as<uint8_t>(), final_level);
       if (final_level) break;
       E = 2ull * waves;
       src ^= 1;
@@ -1920,14 +1843,14 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   auto strided = [&](const uint8_t* in, uint8_t* out, uint32_t win_in, uint32_t n_hi, uint32_t n_lo, uint32_t s_hi, uint32_t s_lo,
                      uint32_t s_e, uint32_t len) {
     GroupSumArgs g{};
-    g.in = in; g.out = out; g.mode = GS_STRIDED; g.in_loose = (loose && in == ws.buckets.as<uint8_t>()) ? 1 : 0;
+    g.in = in; g.out = out; g.mode = GS_STRIDED;
     g.per_win = n_hi * n_lo; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = win_in;
     g.n_lo = n_lo; g.s_hi = s_hi; g.s_lo = s_lo; g.s_e = s_e; g.len = len; g.lpo_shift = lpo_for(len, g.n_out);
     return g;
   };
   auto plane = [&](const uint8_t* in, uint8_t* out, uint32_t nb) {
     GroupSumArgs g{};
-    g.in = in; g.out = out; g.mode = GS_PLANE; g.in_loose = (loose && in == ws.buckets.as<uint8_t>()) ? 1 : 0;
+    g.in = in; g.out = out; g.mode = GS_PLANE; g.out_canonical = 1;  // what the host reads
     g.per_win = nb + 1; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = 1u << nb; g.nb = nb;
     g.lpo_shift = lpo_for(nb ? (1u << (nb - 1)) : 1u, g.n_out);
     return g;
@@ -1966,21 +1889,21 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     launch({plane(X, planes, wf[0])}, true);
   } else if (m == 2) {
     // Y1[d1] = sum_{d0} X (rows), Y0[d0] = sum_{d1} X (columns)
-    if ((rc = ws.rows.ensure((size_t)Wb * (n0 + n1) * XYZZ_BYTES))) return rc;
+    if ((rc = ws.rows.ensure((size_t)Wb * (n0 + n1) * XYZZ30_BYTES))) return rc;
     uint8_t* Y0 = ws.rows.as<uint8_t>();
-    uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ_BYTES;
+    uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ30_BYTES;
     lpo_jobs = 2;
     launch({strided(X, Y1, B, 1, n1, 0, n0, 1, n0), strided(X, Y0, B, 1, n0, 0, 1, n0, n1)});
     launch({plane(Y0, planes + plane_off[0] * XYZZ_BYTES, wf[0]), plane(Y1, planes + plane_off[1] * XYZZ_BYTES, wf[1])}, true);
   } else {
     // level 1: A[d2][d1] = sum_{d0} X, Bm[d2][d0] = sum_{d1} X
-    if ((rc = ws.rows.ensure((size_t)Wb * ((size_t)n2 * n1 + (size_t)n2 * n0) * XYZZ_BYTES))) return rc;
-    if ((rc = ws.cols.ensure((size_t)Wb * (n0 + n1 + n2) * XYZZ_BYTES))) return rc;
+    if ((rc = ws.rows.ensure((size_t)Wb * ((size_t)n2 * n1 + (size_t)n2 * n0) * XYZZ30_BYTES))) return rc;
+    if ((rc = ws.cols.ensure((size_t)Wb * (n0 + n1 + n2) * XYZZ30_BYTES))) return rc;
     uint8_t* A = ws.rows.as<uint8_t>();
-    uint8_t* Bm = A + (size_t)Wb * n2 * n1 * XYZZ_BYTES;
+    uint8_t* Bm = A + (size_t)Wb * n2 * n1 * XYZZ30_BYTES;
     uint8_t* Y0 = ws.cols.as<uint8_t>();
-    uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ_BYTES;
-    uint8_t* Y2 = Y1 + (size_t)Wb * n1 * XYZZ_BYTES;
+    uint8_t* Y1 = Y0 + (size_t)Wb * n0 * XYZZ30_BYTES;
+    uint8_t* Y2 = Y1 + (size_t)Wb * n1 * XYZZ30_BYTES;
     lpo_jobs = 2;
     launch({strided(X, A, B, n2, n1, n1 * n0, n0, 1, n0), strided(X, Bm, B, n2, n0, n1 * n0, 1, n0, n1)});
     // level 2: Y2[d2] = sum_{d1} A, Y1[d1] = sum_{d2} A, Y0[d0] = sum_{d2} Bm
