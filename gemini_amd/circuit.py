@@ -65,6 +65,11 @@ class R1cs:
         self.z, self.w, self.x = z, w, x
 
     def free(self):
+        for v in getattr(self, "_device_cache", {}).values():  # instance-only vectors of the preprocessing prover (psnark.py)
+            for x in (v if isinstance(v, (list, tuple)) else [v]):
+                if hasattr(x, "free"):
+                    x.free()
+        self._device_cache = {}
         seen = set()
         for m in (self.a, self.b, self.c, self.at, self.bt, self.ct):
             if id(m) not in seen:

@@ -209,6 +209,7 @@ int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out);
 int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out);
 int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]);
 int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results);
+int fr_eval_le_batch(Context* C, FrVec* const* ps, size_t k, const uint64_t* xs, size_t npoints, uint64_t* results);
 int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out);
 int fr_fill(Context* C, FrVec* v, const uint64_t val[4]);
 int fr_reverse(Context* C, FrVec* in, FrVec* out);
@@ -309,6 +310,7 @@ void gm_shutdown(void) {
     if (C->small_stream[k]) (void)hipStreamDestroy(C->small_stream[k]);
   }
   if (C->host_small) (void)hipHostFree(C->host_small);
+  if (C->host_batch) (void)hipHostFree(C->host_batch);
   (void)hipStreamDestroy(C->stream);
   delete C;
   g_ctx = nullptr;
@@ -791,6 +793,16 @@ int gm_fr_eval_le(uint64_t poly, const uint64_t* xs_mont, size_t npoints, uint64
   GM_CTX();
   GM_VEC(vp, poly, "fr_eval_le");
   return fr_eval_le(C, vp, xs_mont, npoints, results_mont);
+}
+int gm_fr_eval_le_batch(const uint64_t* polys, size_t k, const uint64_t* xs_mont, size_t npoints, uint64_t* results_mont) {
+  GM_CTX();
+  GM_CHECK((polys && results_mont && xs_mont) || k == 0, GM_EINVAL, "fr_eval_le_batch: null pointer");
+  std::vector<FrVec*> ps(k);
+  for (size_t j = 0; j < k; j++) {
+    ps[j] = find_vec(polys[j]);
+    GM_CHECK(ps[j] != nullptr, GM_EHANDLE, "fr_eval_le_batch: unknown vector handle %llu", (unsigned long long)polys[j]);
+  }
+  return fr_eval_le_batch(C, ps.data(), k, xs_mont, npoints, results_mont);
 }
 int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, uint64_t out) {
   GM_CTX();

@@ -235,6 +235,8 @@ struct Context {
   bool have_start_ev = false;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
+  uint64_t* host_batch = nullptr;  // pinned, grow-only: partial sums of a batch of evaluations (fr_eval_le_batch)
+  size_t host_batch_cap = 0;
   int msm_c_override = 0;
   int msm_glv = 0;            // build phi(P) at registration and split scalars by the GLV endomorphism (gm_set_msm_glv)
   int msm_split = 0;          // one-call MSMs as two window groups over three streams (gm_set_msm_split)

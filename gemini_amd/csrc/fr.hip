@@ -1165,6 +1165,50 @@ int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_
   return GM_OK;
 }
 
+// k polynomials at the SAME <= 3 points: all kernels and one copy are enqueued before the single wait (the foldings of
+// the tensor check are evaluated at +-beta one after the other in the reference, tensorcheck/mod.rs:228-247; 23 waits
+// per proof at 2^24).  results: k x npoints x 4 limbs.
+int fr_eval_le_batch(Context* C, FrVec* const* ps, size_t k, const uint64_t* xs, size_t npoints, uint64_t* results) {
+  GM_FR_LOCK(C);
+  GM_CHECK(npoints >= 1 && npoints <= 3, GM_EINVAL, "eval_le_batch: 1..3 points per pass (got %zu)", npoints);
+  if (k == 0) return GM_OK;
+  EvalArgs A;
+  memset(&A, 0, sizeof A);
+  for (size_t j = 0; j < npoints; j++) make_pow_table(gmh::Fr::from_limbs(xs + 4 * j), A.xt[j]);
+  A.npoints = (uint32_t)npoints;
+  const size_t slot = (size_t)512 * 3 * FR_BYTES;  // per polynomial: <= 2^17 threads = 512 blocks
+  int rc = C->fr_scratch.ensure(k * slot);
+  if (rc) return rc;
+  if (C->host_batch_cap < k * slot) {
+    if (C->host_batch) (void)hipHostFree(C->host_batch);
+    C->host_batch = nullptr;
+    C->host_batch_cap = 0;
+    GM_HIP(hipHostMalloc((void**)&C->host_batch, k * slot, hipHostMallocDefault));
+    C->host_batch_cap = k * slot;
+  }
+  std::vector<unsigned> nblocks(k);
+  for (size_t j = 0; j < k; j++) {
+    uint32_t lt = 8;
+    while (lt < 17 && ((size_t)1 << lt) < ps[j]->len) lt++;
+    A.log_threads = lt;
+    nblocks[j] = (unsigned)(((size_t)1 << lt) / 256);
+    hipLaunchKernelGGL(k_eval_le, dim3(nblocks[j]), dim3(256), 0, C->stream, ps[j]->d, ps[j]->len, A, C->fr_scratch.as<uint8_t>() + j * slot);
+    GM_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(C->host_batch) + j * slot, C->fr_scratch.as<uint8_t>() + j * slot,
+                          (size_t)nblocks[j] * 3 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  }
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  for (size_t j = 0; j < k; j++) {
+    const uint64_t* h = C->host_batch + j * (slot / 8);
+    for (size_t q = 0; q < npoints; q++) {
+      gmh::Fr s = gmh::Fr::zero();
+      for (unsigned i = 0; i < nblocks[j]; i++) s = s + gmh::Fr::from_limbs(h + ((size_t)i * 3 + q) * 4);
+      s.to_limbs(results + (j * npoints + q) * 4);
+    }
+  }
+  return GM_OK;
+}
+
 int fr_trim(Context* C, FrVec* v) {
   GM_FR_LOCK(C);
   // DensePolynomial::from_coefficients_vec strips high zero coefficients

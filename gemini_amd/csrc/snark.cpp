@@ -181,7 +181,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
     beta.neg().to_limbs(pts + 8);
   }
   RC(gm_fr_eval_le(w, pts, 3, P->base_evaluations));
-  for (size_t k = 0; k < P->nfold; k++) RC(gm_fr_eval_le(foldings[k], pts + 4, 2, P->fold_evaluations + 8 * k));
+  RC(gm_fr_eval_le_batch(foldings.data(), P->nfold, pts + 4, 2, P->fold_evaluations));  // one wait for all levels
   RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->base_evaluations, 1));
   RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->base_evaluations + 4, 1));
   RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->base_evaluations + 8, 1));

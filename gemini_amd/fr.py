@@ -194,6 +194,16 @@ def evaluate_le(poly, xs_mont) -> np.ndarray:
     return out
 
 
+def evaluate_le_batch(polys, xs_mont) -> np.ndarray:
+    """evaluate_le of k device vectors at the same 1..3 points with one wait for all; returns (k, npoints, 4)"""
+    xs = capi.u64(xs_mont).reshape(-1, 4)
+    out = np.empty((len(polys), len(xs), 4), dtype=np.uint64)
+    if len(polys):
+        h = np.array([p.handle for p in polys], dtype=np.uint64)
+        capi.check(capi.load().gm_fr_eval_le_batch(capi.ptr(h), C.c_size_t(len(polys)), capi.ptr(xs), C.c_size_t(len(xs)), capi.ptr(out)))
+    return out
+
+
 def linear_combination(polys, challenges_mont) -> FrVec:
     """src/misc.rs:37-48 (zip of polynomials and challenges; trailing zeros trimmed)"""
     ch = capi.u64(challenges_mont).reshape(-1, 4)

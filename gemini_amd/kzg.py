@@ -304,26 +304,41 @@ class CommitterKeyStream:
         first.free()
         return out
 
-    def commit_folding(self, polynomials: FoldedPolynomialTree, max_msm_buffer: int) -> list:
-        """:192-223: one ChunkedPippenger of size max_msm_buffer / depth per folding level"""
+    def commit_folding(self, polynomials: FoldedPolynomialTree, max_msm_buffer: int, levels=None) -> list:
+        """:192-223: one ChunkedPippenger of size max_msm_buffer / depth per folding level.  `levels` (optional): the
+        little-endian folding levels when the caller holds them already (they are left alone then).  When no level is
+        cut -- every level fits the effective flush size -- the depth MSMs go through ONE pipelined batch call
+        (gm_g1_msm_v_batch, like CommitterKey.batch_commit): the commitment of level j is sum_i level_j[i] * tau^i g
+        whichever way the pairs are walked."""
         n = polynomials.depth()
-        levels = self._foldings_le(polynomials)
-        out = []
-        for lvl in levels:
-            s = reverse(lvl)
-            out.append(self._msm_stream(s, self._n() - len(s), max(1, max_msm_buffer // n)))
-            s.free()
-            lvl.free()
-        return out
+        own = levels is None
+        if own:
+            levels = self._foldings_le(polynomials)
+        chunk = max(max(1, max_msm_buffer // n), self.min_device_chunk)
+        try:
+            if type(self) is CommitterKeyStream and levels and all(len(l) <= chunk for l in levels):
+                assert self._n() >= max(len(l) for l in levels)
+                return list(self.powers_of_g.msm_vec_batch(levels, [len(l) for l in levels], offset=0, reversed_=False))
+            out = []
+            for lvl in levels:
+                s = reverse(lvl)
+                out.append(self._msm_stream(s, self._n() - len(s), max(1, max_msm_buffer // n)))
+                s.free()
+            return out
+        finally:
+            if own:
+                for lvl in levels:
+                    lvl.free()
 
-    def open_folding(self, polynomials: FoldedPolynomialTree, points_mont, etas_mont, max_msm_buffer: int):
+    def open_folding(self, polynomials: FoldedPolynomialTree, points_mont, etas_mont, max_msm_buffer: int, levels=None):
         """:229-285 -> (remainders per level (big-endian), proof = sum_i etas[i-1] * commit(quotient_i)).
         The reference merges equal bases in a HashMapPippenger; on the device that is the linear
-        combination of the quotients followed by one (chunked) MSM."""
+        combination of the quotients followed by one (chunked) MSM.  `levels`: as in commit_folding (consumed here)."""
         pts = capi.u64(points_mont).reshape(-1, 4)
         etas = capi.u64(etas_mont).reshape(-1, 4)
         pts_int = [fr_to_int(p) for p in pts]
-        levels = self._foldings_le(polynomials)
+        if levels is None:
+            levels = self._foldings_le(polynomials)
         quotients, remainders = [], []
         for lvl in levels:
             if len(lvl) > len(pts):

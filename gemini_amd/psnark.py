@@ -9,7 +9,7 @@ import time
 import numpy as np
 
 from .circuit import R1cs
-from .fr import (FrVec, IdxVec, R_MOD, accumulated_product_monic, alg_hash, element, evaluate_le, fr_from_int, fr_to_int, hadamard, ip,
+from .fr import (FrVec, IdxVec, R_MOD, accumulated_product_monic, alg_hash, element, evaluate_le, evaluate_le_batch, fr_from_int, fr_to_int, hadamard, ip,
                  linear_combination, lookup, plookup_set, plookup_subset, powers, shift_monic, tensor)
 from .kzg import CommitterKey
 from .sumcheck import Sumcheck, TimeProver
@@ -63,6 +63,46 @@ def _joint(r1cs: R1cs):
         j = joint_matrices(r1cs.a, r1cs.b, r1cs.c, r1cs.a.nrows, len(r1cs.z))
         r1cs._joint_matrices = j
     return j
+
+
+class _JointDevice:
+    """the joint-matrix vectors of an instance resident in HBM: a function of the matrices only (what `index` commits to,
+    src/psnark/time_prover.rs:49-64), so they are uploaded ONCE per R1cs object and live with it -- like its CSR matrices,
+    they are part of the instance that is resident before the prover starts.  (The reference recomputes joint_matrices on the
+    CPU inside new_time, :99-110; re-uploading 5 vectors per proof kept the GPU idle for 4 % of psnark -i 22.)"""
+
+    def __init__(self, r1cs: R1cs):
+        row_index_h, col_index_h, val_a_h, val_b_h, val_c_h = _joint(r1cs)
+        self.row_index_h, self.col_index_h = row_index_h, col_index_h
+        self.row_index, self.col_index = IdxVec.from_host(row_index_h), IdxVec.from_host(col_index_h)
+        self.row, self.col = _field_of_index(self.row_index), _field_of_index(self.col_index)
+        self.val_a, self.val_b, self.val_c = FrVec.from_host(val_a_h), FrVec.from_host(val_b_h), FrVec.from_host(val_c_h)
+        self.ext_fre = {}
+
+    def extended_frequencies(self, len_r: int, len_z: int):
+        """[extend_frequency(compute_frequency(..)) for the row and the column index] as device index vectors
+        (plookup/time_prover.rs:66-79; src/psnark/time_prover.rs:165-178): instance-only as well -- the bincount / repeat over
+        the index arrays kept the GPU idle for 44 ms of a 480 ms proof at 2^22 when done per proof"""
+        key = (len_r, len_z)
+        if key not in self.ext_fre:
+            self.ext_fre[key] = [IdxVec.from_host(extend_frequency(compute_frequency(len_r, self.row_index_h))),
+                                 IdxVec.from_host(extend_frequency(compute_frequency(len_z, self.col_index_h)))]
+        return self.ext_fre[key]
+
+    def free(self):
+        for v in (self.row_index, self.col_index, self.row, self.col, self.val_a, self.val_b, self.val_c):
+            v.free()
+        for pair in self.ext_fre.values():
+            for v in pair:
+                v.free()
+        self.ext_fre = {}
+
+
+def _joint_device(r1cs: R1cs) -> "_JointDevice":
+    cache = r1cs.__dict__.setdefault("_device_cache", {})
+    if "joint" not in cache:
+        cache["joint"] = _JointDevice(r1cs)
+    return cache["joint"]
 
 
 def _field_of_index(index: IdxVec) -> FrVec:
@@ -135,8 +175,9 @@ class EntryProduct:
         ci = fr_to_int(chal)
         provers = [TimeProver(acc_v, rrot_v, chal) for rrot_v, acc_v in zip(rrot_vs, acc_vs)]
         claimed_sumchecks = []
-        for cp, acc_v in zip(claimed_products, acc_vs):
-            acc_v_chal = fr_to_int(evaluate_le(acc_v, chal.reshape(1, 4))[0])
+        acc_v_chals = evaluate_le_batch(list(acc_vs), chal.reshape(1, 4))
+        for cp, acc_v, av in zip(claimed_products, acc_vs, acc_v_chals):
+            acc_v_chal = fr_to_int(av[0])
             chal_n = pow(ci, len(acc_v), R_MOD)
             claimed_sumchecks.append(fr_from_int((acc_v_chal * ci + fr_to_int(cp) - chal_n) % R_MOD))
         for v in rrot_vs + (acc_vs if own else []):
@@ -185,13 +226,8 @@ class Proof:
     @staticmethod
     def index(ck: CommitterKey, r1cs: R1cs) -> list:
         """src/psnark/time_prover.rs:49-64"""
-        row_index, col_index, val_a, val_b, val_c = _joint(r1cs)
-        ri, cidx = IdxVec.from_host(row_index), IdxVec.from_host(col_index)
-        row, col = _field_of_index(ri), _field_of_index(cidx)
-        out = ck.batch_commit([row, col, val_a, val_b, val_c])
-        for v in (row, col, ri, cidx):
-            v.free()
-        return out
+        jd = _joint_device(r1cs)
+        return ck.batch_commit([jd.row, jd.col, jd.val_a, jd.val_b, jd.val_c])
 
     @staticmethod
     def new_time(ck: CommitterKey, r1cs: R1cs, index: list) -> "Proof":
@@ -229,10 +265,9 @@ class Proof:
         c_challenges = K(powers(alpha, len(b_challenges)))
         a_challenges = K(hadamard(b_challenges, c_challenges))
 
-        row_index_h, col_index_h, val_a_h, val_b_h, val_c_h = _joint(r1cs)  # :99-110
-        row_index, col_index = K(IdxVec.from_host(row_index_h)), K(IdxVec.from_host(col_index_h))
-        row, col = K(_field_of_index(row_index)), K(_field_of_index(col_index))
-        val_a, val_b, val_c = K(FrVec.from_host(val_a_h)), K(FrVec.from_host(val_b_h)), K(FrVec.from_host(val_c_h))
+        jd = _joint_device(r1cs)  # :99-110, resident with the instance
+        row_index, col_index, row, col = jd.row_index, jd.col_index, jd.row, jd.col
+        val_a, val_b, val_c = jd.val_a, jd.val_b, jd.val_c
         num_non_zero = len(row_index)
         spans["joint matrices"] = time.perf_counter() - t0
 
@@ -276,8 +311,7 @@ class Proof:
 
         t0 = time.perf_counter()
         alg_hash_poly = [K(alg_hash(b_challenges, None, zeta)), K(alg_hash(c_challenges, None, zeta)), K(alg_hash(r1cs.z, None, zeta))]  # :160-164
-        frequency = [compute_frequency(len(alg_hash_poly[0]), row_index_h), compute_frequency(len(alg_hash_poly[2]), col_index_h)]  # :165-168
-        ext_fre = [K(IdxVec.from_host(extend_frequency(frequency[0]))), K(IdxVec.from_host(extend_frequency(frequency[1])))]  # :175-178
+        ext_fre = jd.extended_frequencies(len(alg_hash_poly[0]), len(alg_hash_poly[2]))  # :165-168, :175-178
         sorted_polynomials = [K(lookup(alg_hash_poly[0], ext_fre[0])), K(lookup(alg_hash_poly[1], ext_fre[0])),
                               K(lookup(alg_hash_poly[2], ext_fre[1]))]  # :169-173
         # :179-183: ck.index_by(ext_fre).commit(alg_hash_poly) = commitment to the sorted vector under ck (:183)
@@ -319,7 +353,7 @@ class Proof:
         t0 = time.perf_counter()
         polynomials = [ralpha_star] + accumulated_vec  # :244-251
         ralpha_star_acc_mu_proof = ck.batch_open_multi_points(polynomials, psi.reshape(1, 4), open_chal)
-        ralpha_star_acc_mu_evals = [evaluate_le(p, psi.reshape(1, 4))[0] for p in polynomials]
+        ralpha_star_acc_mu_evals = [e[0] for e in evaluate_le_batch(polynomials, psi.reshape(1, 4))]
         spans["Opening at psi"] = time.perf_counter() - t0
 
         h_a, h_b = hadamard(ralpha_star, val_a), hadamard(r_star, val_b)  # :253-254
@@ -418,10 +452,9 @@ class Proof:
         spans["sumcheck1"] = time.perf_counter() - t0
 
         # the Joint{Row,Col,Val} streams (:100-146) walk the joint support; here its index / value vectors
-        row_index_h, col_index_h, val_a_h, val_b_h, val_c_h = _joint(r1cs)
-        row_index, col_index = K(IdxVec.from_host(row_index_h)), K(IdxVec.from_host(col_index_h))
-        row, col = K(_field_of_index(row_index)), K(_field_of_index(col_index))
-        val_a, val_b, val_c = K(FrVec.from_host(val_a_h)), K(FrVec.from_host(val_b_h)), K(FrVec.from_host(val_c_h))
+        jd = _joint_device(r1cs)
+        row_index, col_index, row, col = jd.row_index, jd.col_index, jd.row, jd.col
+        val_a, val_b, val_c = jd.val_a, jd.val_b, jd.val_c
         num_non_zero = len(row_index)
         z_le = K(reverse(r1cs_stream.z))
         w_le = K(reverse(r1cs_stream.witness))
@@ -452,8 +485,7 @@ class Proof:
 
         zeta = transcript.get_challenge(b"zeta")  # :199
         hashed_r, hashed_alpha, hashed_z = K(alg_hash(rs, None, zeta)), K(alg_hash(alphas, None, zeta)), K(alg_hash(z_le, None, zeta))  # :205-210
-        frequency = [compute_frequency(len(rs), row_index_h), compute_frequency(len(z_le), col_index_h)]
-        ext_fre = [K(IdxVec.from_host(extend_frequency(frequency[0]))), K(IdxVec.from_host(extend_frequency(frequency[1])))]
+        ext_fre = jd.extended_frequencies(len(rs), len(z_le))
         sorted_r, sorted_alpha, sorted_z = K(lookup(hashed_r, ext_fre[0])), K(lookup(hashed_alpha, ext_fre[0])), K(lookup(hashed_z, ext_fre[1]))  # :212-214
         t0 = time.perf_counter()
         sorted_r_commitment, sorted_alpha_commitment, sorted_z_commitment = ck.commit(S(sorted_r)), ck.commit(S(sorted_alpha)), ck.commit(S(sorted_z))
@@ -505,7 +537,7 @@ class Proof:
         polynomial = K(linear_combination([ralpha_star] + accs, oc10.to_host()))
         oc10.free()
         ralpha_star_acc_mu_proof = ck.open(S(polynomial), psi, max_msm_buffer)[1]
-        ralpha_star_acc_mu_evals = [evaluate_le(p, psi.reshape(1, 4))[0] for p in [ralpha_star] + accs]  # :332-343
+        ralpha_star_acc_mu_evals = [e[0] for e in evaluate_le_batch([ralpha_star] + accs, psi.reshape(1, 4))]  # :332-343
         lhs = [K(hadamard(v, ep_r)) for v in (ralpha_star, r_star, alpha_star)]
         r_val_chal_a, r_val_chal_b = ip(lhs[0], val_a), ip(lhs[1], val_b)  # :348-349
         for e in ralpha_star_acc_mu_evals:

@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 from .circuit import R1cs
-from .fr import FrVec, evaluate_le, fold_polynomial, fr_from_int, fr_to_int, hadamard, linear_combination, powers, reverse, tensor, R_MOD
+from .fr import FrVec, evaluate_le, evaluate_le_batch, fold_polynomial, fr_from_int, fr_to_int, hadamard, linear_combination, powers, reverse, tensor, R_MOD
 from .kzg import CommitterKey
 from .sumcheck import Sumcheck
 from .tensorcheck import TensorcheckProof
@@ -182,22 +182,17 @@ def elastic_tensorcheck(transcript, ck, base_polynomial: FrVec, body_stream: FrV
 
     tc_challenges = list(challenges)[:-1]  # strip_last
     tree = FoldedPolynomialTree(body_stream, tc_challenges)
-    commitments = ck.commit_folding(tree, max_msm_buffer)
+    # The reference re-streams the folded polynomial tree for the commitments, the evaluations and the opening
+    # (O(log n) memory); with the streams resident in HBM the levels (n / 2 + n / 4 + ... elements) are folded ONCE.
+    levels = ck._foldings_le(tree)
+    commitments = ck.commit_folding(tree, max_msm_buffer, levels=levels)
     for c in commitments:
         transcript.append_g1(b"commitment", c)
     eval_chal = transcript.get_challenge(b"evaluation-chal")
     ec = fr_to_int(eval_chal)
     pts = np.stack([fr_from_int(ec * ec % R_MOD), eval_chal, fr_from_int((-ec) % R_MOD)])
-    # evaluate_folding (tensorcheck/mod.rs:73-88): f^(j)(x) for every folding level
-    fold_evals = []
-    cur = reverse(body_stream)
-    first = cur
-    for ch in tc_challenges:
-        cur = fold_polynomial(cur, ch)
-        fold_evals.append(evaluate_le(cur, pts[1:]))
-        if cur is not first:
-            pass
-    # (levels are freed below; kept simple: the tree is shallow)
+    # evaluate_folding (tensorcheck/mod.rs:73-88): f^(j)(x) for every folding level, one wait for all of them
+    fold_evals = list(evaluate_le_batch(levels, pts[1:]))
     evaluations_w = _evaluate_be(base_polynomial, pts)
     for e in evaluations_w:
         transcript.append_fr(b"eval", e)
@@ -209,9 +204,8 @@ def elastic_tensorcheck(transcript, ck, base_polynomial: FrVec, body_stream: FrV
     oc = open_chals.to_host()
     open_chals.free()
     _, proof_w = ck.open_multi_points(base_polynomial, pts, max_msm_buffer)
-    _, proof = ck.open_folding(tree, pts, oc[1:], max_msm_buffer)
+    _, proof = ck.open_folding(tree, pts, oc[1:], max_msm_buffer, levels=levels)  # frees the levels
     evaluation_proof = g1_sum(np.stack([proof_w, proof]))
-    first.free()
     return TensorcheckProof(commitments, fold_evals, evaluation_proof, [evaluations_w])
 
 

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .fr import FrVec, evaluate_le, fold_polynomial, fr_from_int, fr_to_int, linear_combination, powers, R_MOD
+from .fr import FrVec, evaluate_le, evaluate_le_batch, fold_polynomial, fr_from_int, fr_to_int, linear_combination, powers, R_MOD
 from .kzg import CommitterKey
 
 
@@ -47,8 +47,10 @@ class TensorcheckProof:
         minus_eval_chal = fr_from_int((-ec) % R_MOD)
         eval_chal2 = fr_from_int(ec * ec % R_MOD)
         pts3 = np.stack([eval_chal2, eval_chal, minus_eval_chal])
-        base_evals = [evaluate_le(p, pts3) for p in base_polynomials]
-        fold_evals = [evaluate_le(p, pts3[1:]) for p in foldings]
+        # :228-247, one wait per group instead of one per polynomial (22 base polynomials + ~90 foldings in the preprocessing prover)
+        base_evals = list(evaluate_le_batch(list(base_polynomials), pts3)) if all(isinstance(p, FrVec) for p in base_polynomials) \
+            else [evaluate_le(p, pts3) for p in base_polynomials]
+        fold_evals = list(evaluate_le_batch(foldings, pts3[1:]))
         for e3 in base_evals:
             for e in e3:
                 transcript.append_fr(b"eval", e)

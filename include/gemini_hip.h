@@ -223,6 +223,9 @@ int gm_fr_ip(uint64_t a, uint64_t b, uint64_t result_mont[4]);
 /* results[j] = sum_i p_i x_j^i for up to 3 points in one pass      src/misc.rs:194-199
  * (tensorcheck evaluates every polynomial at beta^2, beta, -beta: tensorcheck/mod.rs:228-247) */
 int gm_fr_eval_le(uint64_t poly, const uint64_t* xs_mont, size_t npoints, uint64_t* results_mont);
+/* The same for k polynomials at the same points, one wait for all (results: k x npoints x 4 limbs) -- the foldings of a
+ * tensor check at +-beta                                            tensorcheck/mod.rs:236-247 */
+int gm_fr_eval_le_batch(const uint64_t* polys, size_t k, const uint64_t* xs_mont, size_t npoints, uint64_t* results_mont);
 /* out = sum_j c_j p_j padded to the longest; logical length trimmed of high zeros
  *                                                                  src/misc.rs:37-48 */
 int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, uint64_t out);

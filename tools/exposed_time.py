@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--window", default=None, help="t0,t1 in trace nanoseconds")
     ap.add_argument("--stamps", default=None, help="JSON output of tools/run_snark.py / run_psnark.py of the traced run: the window is its LAST proof "
                     "(clock readings around every proof; the clock that brackets kernel activity is picked)")
+    ap.add_argument("--gaps", type=int, default=0, help="also list the N largest GPU-idle gaps of the window with the kernels around them")
     ap.add_argument("--title", default=None)
     ap.add_argument("--md", default=None)
     ap.add_argument("--json", default=None)
@@ -152,6 +153,21 @@ def main():
     r = analyse(ev, t0, t1, a.primary)
     md = to_md(r, a.title or a.trace)
     print(md)
+    if a.gaps:
+        win = sorted((s_, e_, n_) for s_, e_, n_ in ev if e_ > t0 and s_ < t1)
+        gaps = []
+        cover, last = t0, "(window start)"
+        for s_, e_, n_ in win:
+            if s_ > cover:
+                gaps.append((s_ - cover, cover - t0, last, n_))
+            if e_ > cover:
+                cover, last = e_, n_
+        if t1 > cover:
+            gaps.append((t1 - cover, cover - t0, last, "(window end)"))
+        gaps.sort(reverse=True)
+        print(f"largest {a.gaps} idle gaps (ms, at ms into the window, kernel before -> kernel after); {len(gaps)} gaps in all")
+        for g_, at, b_, n_ in gaps[: a.gaps]:
+            print(f"  {g_ / 1e6:8.3f}  @{at / 1e6:9.3f}  {b_} -> {n_}")
     if a.md:
         with open(a.md, "a") as f:
             f.write(md + "\n")
