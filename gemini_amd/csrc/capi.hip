@@ -77,6 +77,7 @@ int DevPool::alloc(size_t bytes, void** p, size_t* cap) {
   size_t want = (bytes + 4095) & ~(size_t)4095;
   hipError_t e = hipMalloc(p, want);
   if (e == hipErrorOutOfMemory) {  // give cached blocks back and retry once
+    (void)hipGetLastError();  // the failed attempt must not surface later as a stale hipGetLastError() of an unrelated launch
     release_all();
     e = hipMalloc(p, want);
   }
@@ -538,6 +539,22 @@ int gm_g1_msm_v_batch(uint64_t bases_handle, size_t offset, int reversed, const 
     ptrs[j] = v->d;
   }
   return msm_run_batch(C, b, (int64_t)offset, reversed ? -1 : 1, ptrs.data(), 1, ns, k, true, out_jac);
+}
+
+int gm_g1_msm_v_batch_partial(uint64_t bases_handle, size_t offset, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
+                              uint64_t* out_jac) {
+  GM_CTX();
+  Bases* b = find_bases(bases_handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "msm_v_batch_partial: unknown bases handle %llu", (unsigned long long)bases_handle);
+  GM_CHECK(k == 0 || (vec_handles && ns && out_jac), GM_EINVAL, "msm_v_batch_partial: null pointer");
+  std::vector<const void*> ptrs(k);
+  for (size_t j = 0; j < k; j++) {
+    FrVec* v = find_vec(vec_handles[j]);
+    GM_CHECK(v != nullptr, GM_EHANDLE, "msm_v_batch_partial: unknown vector handle %llu", (unsigned long long)vec_handles[j]);
+    GM_CHECK(ns[j] <= v->len, GM_EINVAL, "msm_v_batch_partial: %zu pairs from a vector of length %zu", ns[j], v->len);
+    ptrs[j] = v->d;
+  }
+  return msm_run_batch(C, b, (int64_t)offset, reversed ? -1 : 1, ptrs.data(), 1, ns, k, false, out_jac);
 }
 
 int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,

@@ -31,16 +31,38 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device()) if _dist().get_backend() == "nccl" else torch.device("cpu")
 
 
+_GATHER_BUFS = {}  # (device, words) -> (pinned in, device in, device out, pinned out): ~100 collectives per proof reuse them
+
+
 def all_gather_u64(local: np.ndarray) -> np.ndarray:
-    """all-gather a small uint64 array; returns (world, *local.shape)."""
+    """all-gather a small uint64 array; returns (world, *local.shape).  The payloads are host results (an MSM partial
+    is finished by the host Horner), so on RCCL every collective is H2D -> all_gather -> D2H: the staging tensors are
+    allocated once per size (pinned on the host side), the copies are asynchronous on the current stream and there is
+    ONE wait, after the copy back."""
     import torch
 
     dist = _dist()
     world = dist.get_world_size()
-    loc = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint64).view(np.int64).reshape(-1)).to(_device())
-    out = torch.empty(world * loc.numel(), dtype=torch.int64, device=loc.device)
-    dist.all_gather_into_tensor(out, loc)
-    return out.cpu().numpy().view(np.uint64).reshape((world,) + tuple(np.shape(local)))
+    loc_np = np.ascontiguousarray(local, dtype=np.uint64).view(np.int64).reshape(-1)
+    dev = _device()
+    if dev.type == "cpu":
+        loc = torch.from_numpy(loc_np)
+        out = torch.empty(world * loc.numel(), dtype=torch.int64)
+        dist.all_gather_into_tensor(out, loc)
+        return out.numpy().view(np.uint64).reshape((world,) + tuple(np.shape(local)))
+    key = (str(dev), loc_np.size, world)
+    bufs = _GATHER_BUFS.get(key)
+    if bufs is None:
+        bufs = (torch.empty(loc_np.size, dtype=torch.int64).pin_memory(), torch.empty(loc_np.size, dtype=torch.int64, device=dev),
+                torch.empty(world * loc_np.size, dtype=torch.int64, device=dev), torch.empty(world * loc_np.size, dtype=torch.int64).pin_memory())
+        _GATHER_BUFS[key] = bufs
+    h_in, d_in, d_out, h_out = bufs
+    h_in.numpy()[:] = loc_np
+    d_in.copy_(h_in, non_blocking=True)
+    dist.all_gather_into_tensor(d_out, d_in)
+    h_out.copy_(d_out, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h_out.numpy().view(np.uint64).reshape((world,) + tuple(np.shape(local))).copy()
 
 
 def shard_range(n: int, rank: int, world: int, align: int = 1):
@@ -230,12 +252,44 @@ class ShardedCommitterKey:
     def commit(self, polynomial) -> np.ndarray:
         return g1_sum(all_gather_u64(self.partial(polynomial)))
 
+    def batch_partials(self, polys) -> np.ndarray:
+        """this rank's UN-NORMALISED shares of commit(p) for every p: the strided gathers of the rank's scalars, then ONE
+        pipelined batch call (gm_g1_msm_v_batch_partial: two big lanes + four small ones, host tails under the next
+        call's kernels) -- what CommitterKey.batch_commit does on one GPU.  (k, 18)"""
+        from .fr import _as_vec, stride
+        from .msm import g1_zero
+
+        if self._local_msm != self._hip_msm:  # injected local compute (CPU tests)
+            return np.stack([self.partial(p) for p in polys])
+        out = np.tile(g1_zero(), (len(polys), 1))
+        vecs, cnts, idx, tmps = [], [], [], []
+        try:
+            for j, p in enumerate(polys):
+                cnt = cyclic_count(min(len(p), self.n_global), self.rank, self.world)
+                if cnt == 0:
+                    continue
+                v, tmp = _as_vec(p)
+                if tmp:
+                    tmps.append(v)
+                if self.world != 1:
+                    v = stride(v, self.rank, self.world, cnt)
+                    tmps.append(v)
+                vecs.append(v)
+                cnts.append(cnt)
+                idx.append(j)
+            if vecs:
+                out[idx] = self.powers_of_g.msm_vec_batch(vecs, cnts, partial=True)
+        finally:
+            for v in tmps:
+                v.free()
+        return out
+
     def batch_commit(self, polynomials) -> list:
-        """one all-gather for the whole batch (k x 144 bytes)"""
+        """one batch of local MSMs, ONE all-gather for the whole batch (k x 144 bytes), one normalisation per commitment"""
         polys = list(polynomials)
         if not polys:
             return []
-        parts = all_gather_u64(np.stack([self.partial(p) for p in polys]))  # (world, k, 18)
+        parts = all_gather_u64(self.batch_partials(polys))  # (world, k, 18)
         return [g1_sum(parts[:, k]) for k in range(len(polys))]
 
     # the openings are commitments to quotients computed (replicated) on every rank: same code as the

@@ -91,15 +91,17 @@ class G1Bases:
                                            C.c_size_t(voffset), C.c_size_t(n), capi.ptr(out)))
         return out
 
-    def msm_vec_batch(self, vecs, ns, offset: int = 0, reversed_: bool = False) -> np.ndarray:
-        """k MSMs, vector j's first ns[j] elements against bases[offset ...]; returns (k, 18)"""
+    def msm_vec_batch(self, vecs, ns, offset: int = 0, reversed_: bool = False, partial: bool = False) -> np.ndarray:
+        """k MSMs, vector j's first ns[j] elements against bases[offset ...]; returns (k, 18).  partial: un-normalised
+        results (the per-rank shares of a sharded batch_commit)"""
         k = len(vecs)
         out = np.empty((k, 18), dtype=np.uint64)
         if k == 0:
             return out
         handles = np.array([v.handle for v in vecs], dtype=np.uint64)
         nn = np.array(ns, dtype=np.uintp)
-        capi.check(capi.load().gm_g1_msm_v_batch(C.c_uint64(self.handle), C.c_size_t(offset), C.c_int(int(reversed_)), capi.ptr(handles),
+        fn = capi.load().gm_g1_msm_v_batch_partial if partial else capi.load().gm_g1_msm_v_batch
+        capi.check(fn(C.c_uint64(self.handle), C.c_size_t(offset), C.c_int(int(reversed_)), capi.ptr(handles),
                                                  nn.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(k), capi.ptr(out)))
         return out
 

@@ -112,6 +112,10 @@ int gm_g1_msm_v(uint64_t bases_handle, size_t offset, int reversed, uint64_t vec
  * host tail of call j overlaps the kernels of call j+1.  out_jac: k x 18 limbs. */
 int gm_g1_msm_v_batch(uint64_t bases_handle, size_t offset, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
                       uint64_t* out_jac);
+/* The same with UN-NORMALISED results (any Jacobian representative, no field inversion): the per-rank partials of a
+ * sharded batch_commit -- all-gathered k x 144 bytes at a time, summed and normalised once per commitment (gm_g1_sum). */
+int gm_g1_msm_v_batch_partial(uint64_t bases_handle, size_t offset, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
+                              uint64_t* out_jac);
 
 /* Same, raw device pointer to n x 32-byte scalars already in HBM (mont != 0: Montgomery form).
  * This is the entry bench.py times: inputs resident, result = 144 bytes. */

@@ -299,7 +299,7 @@ def test_evaluate_index_poly(gm, oracle, pyref, n):
     vec.free()
 
 
-@pytest.mark.parametrize("logn", [18, 20])
+@pytest.mark.parametrize("logn", [18, 20, 22])
 def test_psnark_config5_shape_time_equals_elastic(gm, oracle, pyref, logn):
     """BASELINE configs[4] (`examples/psnark -i 26`) in its own shape at a suite-sized instance: dummy_r1cs(2^logn) and
     the recipe of examples/psnark.rs:70-81 (key of num_constraints + num_variables powers, index from the key).  The
@@ -396,9 +396,10 @@ def test_device_proofs_are_accepted_by_the_reference_verifier(gm, oracle, pyref,
     ck.powers_of_g.free()
 
 
-@pytest.mark.parametrize("logn", [20, 22, 24])
+@pytest.mark.parametrize("logn", [20, 22, 24, 26])
 def test_full_size_device_proof_is_accepted_by_the_reference_verifier(gm, oracle, pyref, logn):
-    """examples/psnark.rs:70-81 at 2^20 / 2^22 / 2^24 constraints (BASELINE configs[4] shape, smaller): the preprocessing
+    """examples/psnark.rs:70-81 at 2^20 / 2^22 / 2^24 constraints and at 2^26 -- BASELINE configs[4] ITSELF (`psnark -i 26`,
+    sumcheck + MSM both on the GPU; ~5 s of device time, a 13 GB key).  The preprocessing
     verifier is O(log n) -- it never touches the matrices -- so the device proof of a full-size instance is checked
     against the reference's acceptance predicate directly (three sumcheck subclaims, plookup / entry-product relations,
     two pairing checks over ~25 commitments each)."""

@@ -537,6 +537,47 @@ def test_snark_elastic_config4_shape_at_logn_22(gm, oracle, pyref):
     ck.powers_of_g.free()
 
 
+def test_snark_elastic_config4_at_logn_26_closed_forms(gm, oracle, pyref):
+    """BASELINE configs[3] two powers short of its own size (`examples/snark -i 28` needs the 8 GPUs of the config; one GPU
+    proves it in 3 s, see profiles/): the elastic prover on dummy_r1cs_stream(2^26) over the GENERATOR-COPIES key of
+    examples/snark.rs:59-63, max_msm_buffer = 2^20 (:57), default flush merging.  Checked through what the instance fixes in
+    closed form -- every base is g and w = [e; n - 1], so commitment(w) = e (n - 1) g; z_c = [1; n], so
+    zc(alpha) = (alpha^n - 1) / (alpha - 1) with alpha re-derived by the oracle's Merlin from that commitment; the first
+    sumcheck message on all-ones vectors -- and the space -> time hand-off after 4 rounds (SPACE_TIME_THRESHOLD = 22)."""
+    from gemini_amd.circuit import R1csStream, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream, g1_generator_mont
+    from gemini_amd.msm import G1Bases
+    from gemini_amd.snark import Proof
+
+    R = pyref.R_MOD
+    logn = 26
+    n = 1 << logn
+    e = 0x0F1E2D3C4B5A69788796A5B4C3D2E1F00112233445566778 % R
+    ones = np.zeros((n + 1, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    ck = CommitterKey(G1Bases.fixed_base(g1_generator_mont(), ones), 3)
+    del ones
+    r1cs = dummy_r1cs(e, n)
+    stream = R1csStream(r1cs)
+    proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << 20)
+    inv = lambda v: pow(v % R, -1, R)
+    want_cm = pyref.g1_mul(pyref.G1_GEN, e * (n - 1) % R)
+    assert jac_to_affine_ints(oracle, proof.witness_commitment) == want_cm
+    tr = pyref.GeminiTranscript(pyref.PROTOCOL_NAME)
+    tr.append_message(b"witness", pyref.g1_serialize_uncompressed(want_cm))
+    alpha = tr.get_challenge(b"alpha")
+    I = gm.fr.fr_to_int
+    assert I(proof.zc_alpha) == (pow(alpha, n, R) - 1) * inv(alpha - 1) % R
+    a0 = (pow(alpha, n, R) - 1) * inv(alpha * alpha - 1) % R
+    msgs = proof.first_sumcheck_msgs[0]
+    assert len(msgs) == logn
+    assert I(msgs[0][0]) == a0 and I(msgs[0][1]) == a0 * (1 + alpha) % R
+    assert len(proof.tensorcheck_proof.folded_polynomials_commitments) == logn - 1
+    stream.free()
+    r1cs.free()
+    ck.powers_of_g.free()
+
+
 def test_stream_commit_crosses_the_merge_floor(gm, oracle):
     """a CommitterKeyStream that merges flushes shorter than 2^22 pairs (the default floor is 2^26) on a stream longer
     than the floor: 2^22 + 5 coefficients cross one chunk boundary of _msm_stream; time == stream (src/kzg/tests.rs:16-29)"""
