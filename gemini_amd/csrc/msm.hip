@@ -864,9 +864,8 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict_
 // (13 x 30-bit loose limbs, 52 pinned VGPRs) and the whole mixed addition ONE asm statement (gen_madd30.py,
 // g1_madd30_gen.inc): no unpack / repack / conditional subtraction per product, no calls, one reduction for
 // Y3 = R (Q - X3) - Y1 PPP.  Runs are written as 208-byte loose records (buckets, level-0 partials) that the
-// consumers canonicalise on load.  The statement handles an identity accumulator itself; p == 0 (doubling /
-// cancellation: every base equal in the reference's elastic benchmark) makes the wave leave it with flag = 1
-// before anything is modified, and that iteration takes the canonical, complete addition of g1.cuh.
+// consumers add in the same representation.  The statement is COMPLETE: an identity accumulator, a negated base,
+// doubling and cancellation (every base is equal in the reference's elastic benchmark) are handled inside it.
 // (Round 2's kernel kept a canonical 12 x 32-bit accumulator and called an out-of-line multiplier: 2.58 ms against 2.13 ms
 // at 2^20 pairs, profiles/r3_ab_acc0_*.json.)
 // ------------------------------------------------------------------------------------------
@@ -931,18 +930,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
                           y1.x | y1.y | y1.z | y1.w | y2.x | y2.y | y2.z | y2.w;
       if (nz == 0) continue;  // the identity base (0, 0)
       const uint32_t neg = (uint32_t)(e >> 31) & 1u;
-      const uint32_t flag = g1_madd30_asm(acc, x0, x1, x2, y0, y1, y2, neg);
-      if (flag) {  // rare: p == 0 (mod q) on some lane of the wave -- the complete addition on canonical values
-        // the statement consumed its copy of the base: load it again, through a laundered pointer so that the compiler
-        // does not keep the 24 words of EVERY iteration alive across the statement for this path
-        const uint8_t* again = src + (size_t)idx * AFF_BYTES;
-        asm volatile("" : "+v"(again));
-        G1Affine p = g1_load_affine(again);
-        if (neg) p.y = fq_neg_canonical(p.y);
-        G1Xyzz c = acc30_to_canonical(acc);
-        xyzz_madd(c, p);
-        acc30_from_canonical(acc, c);
-      }
+      // complete: identity accumulator, doubling and cancellation are handled inside the statement (gen_madd30.py)
+      (void)g1_madd30_asm(acc, x0, x1, x2, y0, y1, y2, neg);
     }
     if (first_run) {
       head_key = cur;

@@ -17,6 +17,14 @@ G = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 P = os.path.join(ROOT, "profiles")
 
 
+def kname(full):
+    """`void gm::k_acc0<2>(unsigned long const*, ...)` -> `gm::k_acc0`"""
+    n = full.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
+
+
 def find(sub, pattern):
     hits = glob.glob(os.path.join(G, sub, "**", pattern), recursive=True)
     assert hits, (sub, pattern)
@@ -27,7 +35,7 @@ def stats_md(csv_path, title, note, out_name, top=40):
     rows = list(csv.DictReader(open(csv_path)))
     out = [f"# {title}", "", note, "", "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---:|---:|---:|---:|---:|---:|"]
     for r in rows[:top]:
-        out.append("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (r["Name"].split("(")[0], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+        out.append("| `%s` | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (kname(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
                                                                   float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
     open(os.path.join(P, out_name + ".md"), "w").write("\n".join(out) + "\n")
     shutil.copy(csv_path, os.path.join(P, out_name + ".csv"))
@@ -48,7 +56,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(find(f"pmc_{c}", "*counter_collection.csv"))):
         if r["Counter_Name"] == c:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     res[c] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 pm = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 3 --warmup 1 --headline-only`, "
                 f"MI355X, {DESC}; averages over all dispatches of a kernel in that command (four one-call 2^20-pair MSMs)",
@@ -64,4 +72,4 @@ for k, (f, n) in sorted(res["FETCH_SIZE"].items()):
                         "hbm_bytes_corrected": int((2 * f + w) * 1024)}
 json.dump(pm, open(os.path.join(P, f"{TAG}_pmc_msm20.json"), "w"), indent=1)
 print("k_acc0 PMC:", pm["kernels"].get("gm::k_acc0"))
-print("k_acc0 rocprof avg us:", [float(r["AverageNs"]) / 1e3 for r in rows if r["Name"].startswith("gm::k_acc0")])
+print("k_acc0 rocprof avg us:", [float(r["AverageNs"]) / 1e3 for r in rows if kname(r["Name"]) == "gm::k_acc0"])
