@@ -458,17 +458,9 @@ GM_DEV void acc30_shfl_xor(Acc30& d, const Acc30& s, int m) {
 #pragma unroll
   for (int i = 0; i < 52; i++) acc30_set_limb(d, i, __shfl_xor(acc30_limb(s, i), m));
 }
-// acc += o, both loose XYZZ (o is consumed).  The statement (gen_madd30.py: gen_add) does everything but p == 0 (mod q) --
-// doubling / cancellation, rare -- where the lanes concerned come back with both operands intact and take the complete
-// canonical addition.
-GM_DEV void acc30_add(Acc30& acc, Acc30& o) {
-  const uint32_t flag = g1_add30_asm(acc, o);
-  if (flag) {
-    G1Xyzz c = acc30_to_canonical(acc);
-    xyzz_add(c, acc30_to_canonical(o));
-    acc30_from_canonical(acc, c);
-  }
-}
+// acc += o, both loose XYZZ (o is consumed).  The statement (gen_madd30.py: gen_add) is complete: identity operands,
+// doubling and cancellation are handled inside it.
+GM_DEV void acc30_add(Acc30& acc, Acc30& o) { (void)g1_add30_asm(acc, o); }
 #endif
 
 }  // namespace gm

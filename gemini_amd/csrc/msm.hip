@@ -1768,8 +1768,10 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   }
   st = sts.acc;
   pf.begin(part, PROF_ACC0, st);
+  // dynamic LDS padding caps the blocks per CU: the kernel needs 162 VGPRs, so three waves per SIMD WOULD fit
+  static const size_t acc0_lds_pad = getenv("GM_ACC0_LDS_PAD") ? (size_t)strtoull(getenv("GM_ACC0_LDS_PAD"), nullptr, 10) : 0;
   if (acc0_waves == 2)
-    hipLaunchKernelGGL(k_acc0<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+    hipLaunchKernelGGL(k_acc0<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), acc0_lds_pad, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
   else
     hipLaunchKernelGGL(k_acc0<3>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
