@@ -108,6 +108,15 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
     import hashlib
 
     digest = hashlib.sha256(runs[-1][1].serialize_compressed()).hexdigest()
+    per_rank = None
+    if world > 1:
+        # every rank's own stage breakdown of its median run (the field arithmetic is replicated, the MSMs are sharded: the
+        # spread between the ranks and the share of the commitment spans say what N GPUs bought)
+        import torch.distributed as dist
+
+        mine = sorted((dict(r[1].spans) for r in runs), key=lambda sp: sp[SPAN])[len(runs) // 2]
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {k: round(v, 4) for k, v in mine.items()})
 
     # roofline of the sumcheck kernel (k_sc_round, fused fold + next message): 192 * N algorithmic bytes per
     # sumcheck, two sumchecks per proof, against the sum of its launch durations (HIP events
@@ -228,6 +237,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         "runs_s": [round(sp[SPAN], 4) for sp in spans_sorted],
         "higher_is_better": False,
         "spans_s": {k: round(v, 4) for k, v in med.items()},
+        "per_rank_spans_s": per_rank,
         "setup_s": {"dummy_r1cs_to_hbm": round(t_inst, 3), "srs_generation_on_device": round(t_srs, 3)},
         "sumcheck_roofline": sc,
         "fixed_base_tables": tables,

@@ -769,12 +769,15 @@ int gm_fr_stride(uint64_t in, size_t start, size_t stride, size_t count, uint64_
   GM_VEC(vi, in, "fr_stride");
   GM_VEC(vo, out, "fr_stride");
   GM_CHECK(vi != vo, GM_EINVAL, "fr_stride: output must not alias the input");
-  GM_CHECK(stride >= 1 && (count == 0 || start + (count - 1) * stride < vi->len), GM_EINVAL,
+  // overflow-safe form of start + (count - 1) * stride < len
+  GM_CHECK(stride >= 1 && (count == 0 || (start < vi->len && count - 1 <= (vi->len - 1 - start) / stride)), GM_EINVAL,
            "fr_stride: elements %zu + k * %zu, k < %zu, outside a vector of length %zu", start, stride, count, vi->len);
   GM_CHECK(vo->cap >= count, GM_EINVAL, "fr_stride: output capacity %zu < %zu", vo->cap, count);
   int rc = fr_stride_raw(C, vi->d, start, stride, count, vo->d);
   if (rc) return rc;
   vo->len = count;
+  // entry points return with their work done: the input may be freed (and its pool block reused on another stream) right away
+  GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
 int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out) {

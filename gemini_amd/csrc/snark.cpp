@@ -73,6 +73,12 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   RC(vec_len(w, &nw));
   RC(gm_g1_bases_len(ck_bases, &nck));
   // z_a, z_b, z_c (:32-34)
+  // shapes: A, B, C have |z| columns and their transposes |z| rows -- abc_tensored below is exposed over all |z| entries
+  for (int k = 0; k < 6; k++) {
+    size_t rows = 0, cols = 0;
+    RC(gm_spm_shape(matrices[k], &rows, &cols, nullptr));
+    if ((k < 3 ? cols : rows) != nz) return GM_EINVAL;
+  }
   uint64_t z_abc[3];
   for (int k = 0; k < 3; k++) {
     size_t rows = 0;
