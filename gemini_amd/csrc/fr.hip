@@ -223,6 +223,10 @@ struct EvalArgs {
   PowTable xt[3];
   uint32_t npoints;
   uint32_t log_threads;
+  // neg_of[k] = j + 1: point k is MINUS point j.  A thread owns coefficients t, t + T, ... with T even, all of the parity of t,
+  // and (-x)^T = x^T, so its share of p(-x) is (-1)^t times its share of p(x): no second Horner chain.  The tensor check
+  // evaluates every polynomial at beta^2, beta, -beta and every folding at beta, -beta (tensorcheck/mod.rs:228-247).
+  uint32_t neg_of[3];
 };
 __global__ __launch_bounds__(256) void k_eval_le(const uint8_t* __restrict__ p, size_t n, EvalArgs A,
                                                  uint8_t* __restrict__ partials) {
@@ -239,9 +243,13 @@ __global__ __launch_bounds__(256) void k_eval_le(const uint8_t* __restrict__ p, 
     size_t cnt = (n - t + T - 1) / T;
     for (size_t c = cnt; c-- > 0;) {
       Fr coef = fp_load<FrParams>(p + (t + c * T) * FR_BYTES);
-      for (uint32_t k = 0; k < A.npoints; k++) acc[k] = fr_add(fr_mul(acc[k], step[k]), coef);
+      for (uint32_t k = 0; k < A.npoints; k++)
+        if (!A.neg_of[k]) acc[k] = fr_add(fr_mul(acc[k], step[k]), coef);
     }
-    for (uint32_t k = 0; k < A.npoints; k++) acc[k] = fr_mul(acc[k], pow_from_table(A.xt[k], t));
+    for (uint32_t k = 0; k < A.npoints; k++)
+      if (!A.neg_of[k]) acc[k] = fr_mul(acc[k], pow_from_table(A.xt[k], t));
+    for (uint32_t k = 0; k < A.npoints; k++)
+      if (A.neg_of[k]) acc[k] = (t & 1) ? fp_neg<FrParams>(acc[A.neg_of[k] - 1]) : acc[A.neg_of[k] - 1];
   }
   block_sum<3>(acc, lds);
   if (threadIdx.x == 0)
@@ -1140,6 +1148,19 @@ int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]) {
   return GM_OK;
 }
 
+// point k == -point j (j < k) as field elements
+static void eval_mark_negations(EvalArgs& A, const uint64_t* xs, size_t npoints) {
+  for (size_t k = 1; k < npoints; k++)
+    for (size_t j = 0; j < k; j++) {
+      if (A.neg_of[j]) continue;
+      const gmh::Fr s = gmh::Fr::from_limbs(xs + 4 * k) + gmh::Fr::from_limbs(xs + 4 * j);
+      if (s.is_zero()) {
+        A.neg_of[k] = (uint32_t)j + 1;
+        break;
+      }
+    }
+}
+
 int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results) {
   GM_FR_LOCK(C);
   GM_CHECK(npoints >= 1 && npoints <= 3, GM_EINVAL, "eval_le: 1..3 points per pass (got %zu)", npoints);
@@ -1147,6 +1168,7 @@ int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_
   memset(&A, 0, sizeof A);
   for (size_t k = 0; k < npoints; k++) make_pow_table(gmh::Fr::from_limbs(xs + 4 * k), A.xt[k]);
   A.npoints = (uint32_t)npoints;
+  eval_mark_negations(A, xs, npoints);
   uint32_t lt = 8;
   while (lt < 17 && ((size_t)1 << lt) < p->len) lt++;
   A.log_threads = lt;
@@ -1176,6 +1198,7 @@ int fr_eval_le_batch(Context* C, FrVec* const* ps, size_t k, const uint64_t* xs,
   memset(&A, 0, sizeof A);
   for (size_t j = 0; j < npoints; j++) make_pow_table(gmh::Fr::from_limbs(xs + 4 * j), A.xt[j]);
   A.npoints = (uint32_t)npoints;
+  eval_mark_negations(A, xs, npoints);
   const size_t slot = (size_t)512 * 3 * FR_BYTES;  // per polynomial: <= 2^17 threads = 512 blocks
   int rc = C->fr_scratch.ensure(k * slot);
   if (rc) return rc;

@@ -224,3 +224,297 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   P->spans[6] = since(t_all);
   return GM_OK;
 }
+
+// =====================================================================================================================
+// snark::Proof::new_elastic (src/snark/elastic_prover.rs:174-266) with its `tensorcheck` (:105-168),
+// CommitterKeyStream::{commit, commit_folding, open_multi_points, open_folding} (src/kzg/space.rs:95-285) and
+// Sumcheck::new_elastic (sumcheck/proof.rs:145-154, elastic_prover.rs:44-57) as ONE entry point.
+//
+// The streams of the reference (`Reverse(..)` views, big-endian) are device-resident reversed vectors; the key stays in
+// time order in HBM and the stream view `Reverse(powers_of_g)` + advance_by is the reversed / offset addressing of the MSM
+// entry points.  `max_msm_buffer` bounds HOST buffering in the reference; here every flush shorter than
+// `min_device_chunk` pairs is merged into one device MSM (gemini_amd/kzg.py::CommitterKeyStream, same rule).  The
+// reference re-streams the folded polynomial tree three times to stay in O(log n) memory; with the streams resident
+// the levels are folded once.  gemini_amd/snark.py::new_elastic is the same sequence in Python; the tests hold the two
+// -- and the time prover, `assert_eq!(time_proof, space_proof)` src/snark/tests.rs:56 -- byte for byte equal.
+// =====================================================================================================================
+namespace {
+
+constexpr size_t SPACE_TIME_THRESHOLD = 22;  // src/lib.rs:76
+
+// sum over stream positions k < len: stream[k] * power[top - k], flushed every max(chunk, min_chunk) pairs
+// (msm_chunks / ChunkedPippenger composition, src/kzg/space.rs:22-55)
+int stream_msm(uint64_t bases, uint64_t stream, size_t len, size_t top, size_t chunk, uint64_t out[18]) {
+  if (len == 0) return gm_g1_sum(nullptr, 0, out);
+  if (chunk == 0) chunk = 1;
+  if (len <= chunk) return gm_g1_msm_v(bases, top, 1, stream, 0, len, out);
+  std::vector<uint64_t> parts;
+  for (size_t off = 0; off < len; off += chunk) {
+    const size_t m = len - off < chunk ? len - off : chunk;
+    parts.resize(parts.size() + 18);
+    RC(gm_g1_msm_v(bases, top - off, 1, stream, off, m, parts.data() + parts.size() - 18));
+  }
+  return gm_g1_sum(parts.data(), parts.size() / 18, out);
+}
+
+// Sumcheck::prove over an ElasticProver: a SpaceProver that becomes a TimeProver when fewer than
+// SPACE_TIME_THRESHOLD rounds remain (elastic_prover.rs:44-57); Prover::next_message folds first.
+int sumcheck_new_elastic(uint64_t transcript, uint64_t f_stream, uint64_t g_stream, const uint64_t twist[4], uint64_t* messages,
+                         std::vector<uint64_t>& challenges, size_t cap_rounds, uint64_t final_foldings[8], size_t* rounds) {
+  uint64_t space = 0, time = 0;
+  RC(gm_sp_new_v(f_stream, g_stream, twist, &space));
+  struct Guard {
+    uint64_t &s, &t;
+    ~Guard() {
+      if (t) (void)gm_sc_free(t);
+      if (s) (void)gm_sp_free(s);
+    }
+  } guard{space, time};
+  challenges.assign(cap_rounds * 4, 0);
+  size_t k = 0;
+  const uint64_t* vm = nullptr;
+  for (;;) {
+    if (vm && !time) {  // ElasticProver::fold
+      size_t tot = 0, rnd = 0;
+      RC(gm_sp_rounds(space, &tot, &rnd));
+      if (tot - rnd < SPACE_TIME_THRESHOLD) {
+        RC(gm_sp_to_time(space, &time));
+        RC(gm_sc_fold(time, vm));
+        (void)gm_sp_free(space);
+        space = 0;
+      } else {
+        RC(gm_sp_fold(space, vm));
+      }
+      vm = nullptr;
+    }
+    uint64_t a[4], b[4];
+    int has = 0;
+    if (time) RC(gm_sc_round(time, vm, a, b, &has));
+    else RC(gm_sp_round(space, vm, a, b, &has));
+    if (!has) break;
+    if (k >= cap_rounds) return GM_EINVAL;
+    memcpy(messages + 8 * k, a, 32);
+    memcpy(messages + 8 * k + 4, b, 32);
+    RC(gm_transcript_append_fr(transcript, L("evaluations"), 11, messages + 8 * k, 2));
+    RC(gm_transcript_challenge_fr(transcript, L("challenge"), 9, challenges.data() + 4 * k));
+    vm = challenges.data() + 4 * k;
+    k++;
+  }
+  int has = 0;
+  if (time) RC(gm_sc_final(time, final_foldings, final_foldings + 4, &has));
+  else RC(gm_sp_final(space, final_foldings, final_foldings + 4, &has));
+  if (!has) return GM_ESTATE;
+  RC(gm_transcript_append_fr(transcript, L("final-folding"), 13, final_foldings, 1));
+  RC(gm_transcript_append_fr(transcript, L("final-folding"), 13, final_foldings + 4, 1));
+  *rounds = k;
+  challenges.resize(k * 4);
+  return GM_OK;
+}
+
+}  // namespace
+
+extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_stream, uint64_t w_stream, uint64_t za_stream, uint64_t zb_stream,
+                                    uint64_t zc_stream, uint64_t ck_bases, size_t max_msm_buffer, size_t min_device_chunk, int g1_encoding,
+                                    size_t cap_rounds, gm_snark_proof* P) {
+  if (!matrices_t || !P || !P->messages[0] || !P->messages[1] || !P->fold_commitments || !P->fold_evaluations) return GM_EINVAL;
+  const auto t_all = Clock::now();
+  Vecs V;
+  size_t nz = 0, nw = 0, nck = 0, nzc = 0;
+  RC(vec_len(z_stream, &nz));
+  RC(vec_len(w_stream, &nw));
+  RC(vec_len(zc_stream, &nzc));
+  RC(gm_g1_bases_len(ck_bases, &nck));
+  if (nw > nck || nz > nck) return GM_EINVAL;  // the streaming committer insists on a key as long as every stream (space.rs:169-175)
+  for (int k = 0; k < 3; k++) {
+    size_t rows = 0;
+    RC(gm_spm_shape(matrices_t[k], &rows, nullptr, nullptr));
+    if (rows != nz) return GM_EINVAL;
+  }
+  const size_t flush = max_msm_buffer > min_device_chunk ? max_msm_buffer : min_device_chunk;
+  TranscriptGuard T;
+  static const char protocol[] = "GEMINI-v0";
+  RC(gm_transcript_new(L(protocol), sizeof protocol - 1, &T.h));
+  if (g1_encoding) RC(gm_transcript_set_g1_encoding(T.h, g1_encoding));
+  P->spans[0] = 0.0;  // the matrix products z_a, z_b, z_c belong to the stream construction (R1csStream), not to the prover
+
+  auto t0 = Clock::now();
+  RC(stream_msm(ck_bases, w_stream, nw, nw - 1, (size_t)1 << 20 > min_device_chunk ? (size_t)1 << 20 : min_device_chunk,
+                P->witness_commitment));  // ck.commit(witness): msm_chunks of 2^20 (:209, space.rs:169-177)
+  P->spans[1] = since(t0);
+  RC(gm_transcript_append_g1(T.h, L("witness"), 7, P->witness_commitment, 1, 0));
+  uint64_t alpha[4];
+  RC(gm_transcript_challenge_fr(T.h, L("alpha"), 5, alpha));
+  {
+    uint64_t zc_le;
+    RC(V.alloc(nzc, &zc_le));
+    RC(gm_fr_reverse(zc_stream, zc_le));
+    RC(gm_fr_eval_le(zc_le, alpha, 1, P->zc_alpha));  // evaluate_be(z_c, alpha) :216
+  }
+  RC(gm_transcript_append_fr(T.h, L("zc(alpha)"), 9, P->zc_alpha, 1));
+
+  t0 = Clock::now();
+  std::vector<uint64_t> ch1, ch2;
+  RC(sumcheck_new_elastic(T.h, za_stream, zb_stream, alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));  // :222
+  P->spans[2] = since(t0);
+
+  t0 = Clock::now();
+  uint64_t eta[4];
+  RC(gm_transcript_challenge_fr(T.h, L("eta"), 3, eta));
+  const size_t nt = (size_t)1 << P->rounds[0];
+  uint64_t a_ch, b_ch, c_ch;
+  RC(V.alloc(nt, &b_ch));
+  RC(gm_fr_tensor(ch1.data(), P->rounds[0], b_ch));  // MatrixTensor streams (:233-238) on the transposed matrices
+  RC(V.alloc(nt, &c_ch));
+  RC(gm_fr_powers(alpha, nt, c_ch));
+  RC(V.alloc(nt, &a_ch));
+  RC(gm_fr_hadamard(b_ch, c_ch, a_ch));
+  uint64_t coeffs[12];
+  Fr::one().to_limbs(coeffs);
+  memcpy(coeffs + 4, eta, 32);
+  (Fr::from_limbs(eta) * Fr::from_limbs(eta)).to_limbs(coeffs + 8);
+  uint64_t t_abc[3];
+  const uint64_t rand_vecs[3] = {a_ch, b_ch, c_ch};
+  for (int k = 0; k < 3; k++) {
+    RC(V.alloc(nz, &t_abc[k]));
+    RC(gm_spm_mul(matrices_t[k], rand_vecs[k], t_abc[k]));
+  }
+  uint64_t lhs_le, lhs;
+  RC(V.alloc(nz, &lhs_le));
+  RC(gm_fr_lincomb(t_abc, coeffs, 3, lhs_le));
+  RC(gm_fr_vec_set_len(lhs_le, nz));
+  RC(V.alloc(nz, &lhs));
+  RC(gm_fr_reverse(lhs_le, lhs));
+  P->spans[3] = since(t0);
+
+  t0 = Clock::now();
+  uint64_t one[4];
+  Fr::one().to_limbs(one);
+  RC(sumcheck_new_elastic(T.h, lhs, z_stream, one, P->messages[1], ch2, cap_rounds, P->final_foldings[1], &P->rounds[1]));  // :241
+  P->spans[4] = since(t0);
+
+  // ---- tensorcheck (:105-168) over the folded polynomial tree of body = lhs + batch_challenge * z
+  t0 = Clock::now();
+  uint64_t batch_challenge[4];
+  RC(gm_transcript_challenge_fr(T.h, L("batch_challenge"), 15, batch_challenge));
+  uint64_t z_le, body_le;
+  RC(V.alloc(nz, &z_le));
+  RC(gm_fr_reverse(z_stream, z_le));
+  uint64_t lc_coeffs[8];
+  Fr::one().to_limbs(lc_coeffs);
+  memcpy(lc_coeffs + 4, batch_challenge, 32);
+  const uint64_t body[2] = {lhs_le, z_le};
+  RC(V.alloc(nz, &body_le));
+  RC(gm_fr_lincomb(body, lc_coeffs, 2, body_le));
+  std::vector<uint64_t> levels;
+  std::vector<size_t> level_len;
+  {
+    uint64_t cur = body_le;
+    size_t len = 0;
+    RC(vec_len(cur, &len));
+    for (size_t k = 0; k + 1 < P->rounds[1]; k++) {  // strip_last
+      uint64_t nxt;
+      len = (len + 1) / 2;
+      RC(V.alloc(len, &nxt));
+      RC(gm_fr_fold(cur, ch2.data() + 4 * k, nxt));
+      levels.push_back(nxt);
+      level_len.push_back(len);
+      cur = nxt;
+    }
+  }
+  P->nfold = levels.size();
+  if (P->nfold > cap_rounds) return GM_EINVAL;
+  if (P->nfold) {  // commit_folding (space.rs:192-223): one ChunkedPippenger of max_msm_buffer / depth per level
+    const size_t per = max_msm_buffer / P->nfold ? max_msm_buffer / P->nfold : 1;
+    const size_t lvl_flush = per > min_device_chunk ? per : min_device_chunk;
+    bool cut = false;
+    for (size_t l : level_len) cut = cut || l > lvl_flush;
+    if (!cut) {  // no level is cut: the commitments are sum_i level[i] * tau^i g whichever way the pairs are walked
+      RC(gm_g1_msm_v_batch(ck_bases, 0, 0, levels.data(), level_len.data(), P->nfold, P->fold_commitments));
+    } else {
+      for (size_t k = 0; k < P->nfold; k++) {
+        uint64_t s;
+        RC(V.alloc(level_len[k], &s));
+        RC(gm_fr_reverse(levels[k], s));
+        RC(stream_msm(ck_bases, s, level_len[k], level_len[k] - 1, lvl_flush, P->fold_commitments + 18 * k));
+      }
+    }
+  }
+  for (size_t k = 0; k < P->nfold; k++) RC(gm_transcript_append_g1(T.h, L("commitment"), 10, P->fold_commitments + 18 * k, 1, 0));
+  uint64_t pts[12];  // beta^2, beta, -beta
+  RC(gm_transcript_challenge_fr(T.h, L("evaluation-chal"), 15, pts + 4));
+  {
+    const Fr beta = Fr::from_limbs(pts + 4);
+    beta.sqr().to_limbs(pts);
+    beta.neg().to_limbs(pts + 8);
+  }
+  RC(gm_fr_eval_le_batch(levels.data(), P->nfold, pts + 4, 2, P->fold_evaluations));  // evaluate_folding, tensorcheck/mod.rs:73-88
+  uint64_t w_le;
+  RC(V.alloc(nw, &w_le));
+  RC(gm_fr_reverse(w_stream, w_le));
+  RC(gm_fr_eval_le(w_le, pts, 3, P->base_evaluations));
+  RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->base_evaluations, 1));
+  RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->base_evaluations + 4, 1));
+  RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->base_evaluations + 8, 1));
+  for (size_t k = 0; k < 2 * P->nfold; k++) RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->fold_evaluations + 4 * k, 1));
+  uint64_t open_chal[4];
+  RC(gm_transcript_challenge_fr(T.h, L("open-chal"), 9, open_chal));
+  uint64_t proof_w[18], proof_f[18];
+  {  // open_multi_points(w) (space.rs:128-166): quotient of w by (x - beta^2)(x - beta)(x + beta), committed as a stream
+    uint64_t q, qs, rem[12];
+    RC(V.alloc(nw ? nw - 1 : 0, &q));
+    RC(gm_fr_div_vanishing(w_le, pts, 3, q, rem));
+    size_t lq = 0;
+    RC(vec_len(q, &lq));
+    RC(V.alloc(lq, &qs));
+    RC(gm_fr_reverse(q, qs));
+    RC(stream_msm(ck_bases, qs, lq, lq ? lq - 1 : 0, flush, proof_w));
+  }
+  {  // open_folding (space.rs:229-285): sum_i open_chal^(i + 1) * commit(quotient of level i); HashMapPippenger merges the
+     // equal bases, i.e. the scalars are the linear combination of the quotients
+    std::vector<uint64_t> quots, etas;
+    Fr acc = Fr::from_limbs(open_chal);
+    const Fr oc = acc;
+    for (size_t k = 0; k < P->nfold; k++) {
+      if (level_len[k] > 3) {
+        uint64_t q, rem[12];
+        RC(V.alloc(level_len[k] - 1, &q));
+        RC(gm_fr_div_vanishing(levels[k], pts, 3, q, rem));
+        quots.push_back(q);
+        etas.resize(etas.size() + 4);
+        acc.to_limbs(etas.data() + etas.size() - 4);
+      }
+      acc = acc * oc;
+    }
+    if (quots.empty()) {
+      RC(gm_g1_sum(nullptr, 0, proof_f));
+    } else {
+      size_t longest = 0;
+      for (uint64_t q : quots) {
+        size_t l = 0;
+        RC(vec_len(q, &l));
+        longest = l > longest ? l : longest;
+      }
+      uint64_t batched, bs;
+      RC(V.alloc(longest, &batched));
+      RC(gm_fr_lincomb(quots.data(), etas.data(), quots.size(), batched));
+      size_t lb = 0;
+      RC(vec_len(batched, &lb));
+      if (lb == 0) {
+        RC(gm_g1_sum(nullptr, 0, proof_f));
+      } else {
+        RC(V.alloc(lb, &bs));
+        RC(gm_fr_reverse(batched, bs));
+        RC(stream_msm(ck_bases, bs, lb, lb - 1, flush, proof_f));
+      }
+    }
+  }
+  {
+    uint64_t both[36];
+    memcpy(both, proof_w, sizeof proof_w);
+    memcpy(both + 18, proof_f, sizeof proof_f);
+    RC(gm_g1_sum(both, 2, P->evaluation_proof));
+  }
+  P->spans[5] = since(t0);
+  P->spans[6] = since(t_all);
+  return GM_OK;
+}

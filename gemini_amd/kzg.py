@@ -314,7 +314,7 @@ class CommitterKeyStream:
         own = levels is None
         if own:
             levels = self._foldings_le(polynomials)
-        chunk = max(max(1, max_msm_buffer // n), self.min_device_chunk)
+        chunk = max(max(1, max_msm_buffer // max(n, 1)), self.min_device_chunk)
         try:
             if type(self) is CommitterKeyStream and levels and all(len(l) <= chunk for l in levels):
                 assert self._n() >= max(len(l) for l in levels)
@@ -322,7 +322,7 @@ class CommitterKeyStream:
             out = []
             for lvl in levels:
                 s = reverse(lvl)
-                out.append(self._msm_stream(s, self._n() - len(s), max(1, max_msm_buffer // n)))
+                out.append(self._msm_stream(s, self._n() - len(s), max(1, max_msm_buffer // max(n, 1))))
                 s.free()
             return out
         finally:

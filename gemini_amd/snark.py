@@ -122,6 +122,10 @@ def _new_time_native(r1cs: R1cs, ck: CommitterKey) -> "Proof":
     mats = (C.c_uint64 * 6)(*[x.handle for x in (r1cs.a, r1cs.b, r1cs.c, r1cs.at, r1cs.bt, r1cs.ct)])
     capi.check(capi.load().gm_snark_new_time(mats, C.c_uint64(r1cs.z.handle), C.c_uint64(r1cs.w.handle), C.c_uint64(ck.powers_of_g.handle),
                                              C.c_int(int(default_group_encoding())), C.c_size_t(cap), C.byref(P)))
+    return _unpack_native(P, m, fc, fe, _SPAN_NAMES)
+
+
+def _unpack_native(P, m, fc, fe, span_names) -> "Proof":
     A = lambda a: np.array(a, dtype=np.uint64)  # noqa: E731
     msgs = []
     for k in range(2):
@@ -132,8 +136,37 @@ def _new_time_native(r1cs: R1cs, ck: CommitterKey) -> "Proof":
     be = A(P.base_evaluations).reshape(3, 4)
     tc = TensorcheckProof([fc[i].copy() for i in range(nf)], [fe[i].reshape(2, 4).copy() for i in range(nf)], A(P.evaluation_proof), [be])
     proof = Proof(A(P.witness_commitment), A(P.zc_alpha), msgs[0], msgs[1], tc)
-    proof.spans = {name: P.spans[i] for i, name in enumerate(_SPAN_NAMES)}
+    proof.spans = {name: P.spans[i] for i, name in enumerate(span_names) if name}
     return proof
+
+
+_ELASTIC_SPAN_NAMES = [None, "Commitment to w", "First sumcheck", "MatrixTensor streams", "Second sumcheck", "Tensorcheck",
+                       "ark_gemini::snark::elastic_prover"]
+
+
+def _new_elastic_native(r1cs_stream, ck_stream, max_msm_buffer: int) -> "Proof":
+    """gm_snark_new_elastic: the elastic prover's orchestration compiled into the library (gemini_amd/csrc/snark.cpp), one call"""
+    import ctypes as C
+
+    from . import capi
+    from .transcript import default_group_encoding
+
+    cap = max(len(r1cs_stream.z), 2).bit_length() + 2
+    m = [np.zeros((cap, 8), dtype=np.uint64) for _ in range(2)]
+    fc = np.zeros((cap, 18), dtype=np.uint64)
+    fe = np.zeros((cap, 8), dtype=np.uint64)
+    P = _GmSnarkProof()
+    U = C.POINTER(C.c_uint64)
+    for k in range(2):
+        P.messages[k] = m[k].ctypes.data_as(U)
+    P.fold_commitments = fc.ctypes.data_as(U)
+    P.fold_evaluations = fe.ctypes.data_as(U)
+    mats = (C.c_uint64 * 3)(*[x.handle for x in (r1cs_stream.at, r1cs_stream.bt, r1cs_stream.ct)])
+    h = lambda v: C.c_uint64(v.handle)  # noqa: E731
+    capi.check(capi.load().gm_snark_new_elastic(mats, h(r1cs_stream.z), h(r1cs_stream.witness), h(r1cs_stream.z_a), h(r1cs_stream.z_b), h(r1cs_stream.z_c),
+                                                C.c_uint64(ck_stream.powers_of_g.handle), C.c_size_t(max_msm_buffer), C.c_size_t(ck_stream.min_device_chunk),
+                                                C.c_int(int(default_group_encoding())), C.c_size_t(cap), C.byref(P)))
+    return _unpack_native(P, m, fc, fe, _ELASTIC_SPAN_NAMES)
 
 
 # ---- CanonicalSerialize of the proof (src/snark/mod.rs:75-82): gemini_amd/wire.py holds the formats ------------
@@ -209,8 +242,13 @@ def elastic_tensorcheck(transcript, ck, base_polynomial: FrVec, body_stream: FrV
     return TensorcheckProof(commitments, fold_evals, evaluation_proof, [evaluations_w])
 
 
-def new_elastic(r1cs_stream, ck_stream, max_msm_buffer: int) -> Proof:
-    """src/snark/elastic_prover.rs:174-266 over device-resident streams"""
+def new_elastic(r1cs_stream, ck_stream, max_msm_buffer: int, native: bool = False) -> Proof:
+    """src/snark/elastic_prover.rs:174-266 over device-resident streams.  native: the same sequence compiled into the library
+    (gm_snark_new_elastic, one call per proof) -- for a key whose stream view is the resident key itself (CommitterKeyStream)."""
+    from .kzg import CommitterKeyStream
+
+    if native and type(ck_stream) is CommitterKeyStream:
+        return _new_elastic_native(r1cs_stream, ck_stream, max_msm_buffer)
     spans = {}
     t_all = time.perf_counter()
     transcript = Transcript(PROTOCOL_NAME)

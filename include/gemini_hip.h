@@ -393,6 +393,18 @@ typedef struct gm_snark_proof {
 int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_t w, uint64_t ck_bases, int g1_encoding, size_t cap_rounds,
                       gm_snark_proof* proof);
 
+/* snark::Proof::new_elastic(r1cs_stream, ck_stream, max_msm_buffer) (src/snark/elastic_prover.rs:174-266) as one call.
+ * matrices_t: gm_spm handles of A^T, B^T, C^T (the MatrixTensor streams, :233-238); z_stream, w_stream, za/zb/zc_stream:
+ * the BIG-ENDIAN streams of R1csStream (`Reverse(..)`, src/snark/tests.rs:38-52) as device vectors; ck_bases: the key in time
+ * order (its stream view Reverse(powers_of_g) is the reversed addressing of the MSMs), at least as long as every stream.
+ * Sumchecks run on the space prover until fewer than SPACE_TIME_THRESHOLD = 22 rounds remain; every flush of a streaming
+ * MSM shorter than `min_device_chunk` pairs is merged (max_msm_buffer bounds host buffering in the reference).
+ * Same proof bytes as gm_snark_new_time on the same instance and key (src/snark/tests.rs:56).  spans[0] is 0: the matrix
+ * products belong to the construction of the streams. */
+int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_stream, uint64_t w_stream, uint64_t za_stream, uint64_t zb_stream,
+                         uint64_t zc_stream, uint64_t ck_bases, size_t max_msm_buffer, size_t min_device_chunk, int g1_encoding,
+                         size_t cap_rounds, gm_snark_proof* proof);
+
 #ifdef __cplusplus
 }
 #endif

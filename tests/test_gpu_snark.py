@@ -426,6 +426,7 @@ def test_snark_time_prover_full_size_closed_forms(gm, oracle, pyref):
     assert len(proof.tensorcheck_proof.folded_polynomials_commitments) == logn - 1
     assert proof.compressed_size() == 6056  # the size DESIGN.md derives for logN 24
     r1cs.free()
+    ck.powers_of_g.free()  # 3.2 GB of powers + 38.7 GB of fixed-base tables
 
 
 def test_matrix_tensor_known_answers(gm, oracle, pyref):
@@ -781,5 +782,49 @@ def test_native_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
         g = R1cs(*mats, gm.FrVec.from_host(_M(oracle, inst["z"])), gm.FrVec.from_host(_M(oracle, inst["w"])), gm.FrVec.from_host(_M(oracle, inst["x"])))
         p1, p2 = Proof.new_time(g, ck), Proof.new_time(g, ck, native=True)
         assert p1 == p2 and p2.serialize(True, 0) == W.snark_proof(sr.snark_new_time(inst, sr.srs(tau, 2 * n + 1)), True, "arkworks")
+        g.free()
+    ck.powers_of_g.free()
+
+
+@pytest.mark.parametrize("logn", [1, 3, 6, 9, 14, 20, 23])
+def test_native_elastic_prover_equals_the_stepwise_one_and_the_time_prover(gm, oracle, pyref, logn):
+    """gm_snark_new_elastic (src/snark/elastic_prover.rs:174-266 compiled into the library, gemini_amd/csrc/snark.cpp) against
+    the step-by-step elastic driver of gemini_amd/snark.py and against Proof::new_time on the same key
+    (`assert_eq!(time_proof, space_proof)`, src/snark/tests.rs:14-57), byte for byte: on the dummy instance, on a general
+    sparse one, with merged flushes and with max_msm_buffer cut literally (min_device_chunk = 1), below and above
+    SPACE_TIME_THRESHOLD = 22 rounds (2^23: the space prover runs the first two rounds, then hands over)."""
+    from gemini_amd.circuit import R1cs, R1csStream, SparseMatrix, dummy_r1cs
+    from gemini_amd.kzg import CommitterKey, CommitterKeyStream
+    from gemini_amd.snark import Proof
+    from oracle import snark_ref as sr
+    from tests.util import random_r1cs_instance
+
+    n = 1 << logn
+    e = oracle.limbs_to_ints(oracle.random_fr(6400 + logn, 1))[0]
+    tau = oracle.limbs_to_ints(oracle.random_fr(6500 + logn, 1))[0]
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
+    r1cs = dummy_r1cs(e, n)
+    want = Proof.new_time(r1cs, ck, native=True).serialize_compressed()
+    stream = R1csStream(r1cs)
+    merged = CommitterKeyStream.from_committer_key(ck)
+    native = Proof.new_elastic(stream, merged, 1 << 20, native=True)
+    assert native.serialize_compressed() == want
+    assert len(native.first_sumcheck_msgs[0]) == logn
+    if logn <= 20:
+        stepwise = Proof.new_elastic(stream, merged, 1 << 20)
+        assert native == stepwise and native.serialize_uncompressed() == stepwise.serialize_uncompressed()
+        literal = CommitterKeyStream.from_committer_key(ck, min_device_chunk=1)
+        assert Proof.new_elastic(stream, literal, 1 << (10 if logn > 10 else 2), native=True).serialize_compressed() == want
+    stream.free()
+    r1cs.free()
+    if 3 <= logn <= 6:  # a general instance (distinct sparse A, B, C; public input of two elements)
+        inst, _ = random_r1cs_instance(pyref, sr, n, 6600 + logn, nx=2)
+        M = lambda v: gm.fr.fr_from_int(v)  # noqa: E731
+        dev = lambda rows: [[(M(v), col) for v, col in row] for row in rows]  # noqa: E731
+        mats = [SparseMatrix.from_rows(dev(inst[k]), n) for k in "abc"] + [SparseMatrix.from_rows(dev(inst[k]), n, transpose=True) for k in "abc"]
+        g = R1cs(*mats, gm.FrVec.from_host(_M(oracle, inst["z"])), gm.FrVec.from_host(_M(oracle, inst["w"])), gm.FrVec.from_host(_M(oracle, inst["x"])))
+        gs = R1csStream(g)
+        assert Proof.new_elastic(gs, merged, 1 << 20, native=True).serialize_compressed() == Proof.new_time(g, ck).serialize_compressed()
+        gs.free()
         g.free()
     ck.powers_of_g.free()

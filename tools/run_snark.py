@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--max-msm-buffer-log", type=int, default=20, help="max_msm_buffer of the elastic prover (examples/snark.rs:57: 2^20)")
     ap.add_argument("--tables", action="store_true", help="gm_g1_bases_precompute on the committer key before proving (13 x the key in HBM)")
     ap.add_argument("--min-device-chunk-log", type=int, default=None, help="CommitterKeyStream.min_device_chunk = 2^k (default: the class default)")
-    ap.add_argument("--native", action="store_true", help="gm_snark_new_time: the prover's orchestration compiled into the library (one call per proof)")
+    ap.add_argument("--native", action="store_true", help="gm_snark_new_time / gm_snark_new_elastic: the prover's orchestration compiled into the library (one call per proof)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/snark.rs elastic_snark_main) instead of --time-prover")
     args = ap.parse_args()
@@ -97,7 +97,7 @@ def main():
                 cks = ShardedCommitterKeyStream.from_sharded_key(ck)
             else:
                 cks = CommitterKeyStream.from_committer_key(ck, min_device_chunk=None if args.min_device_chunk_log is None else 1 << args.min_device_chunk_log)
-            proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log)
+            proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log, native=args.native)
             stream.free()
         else:
             proof = Proof.new_time(r1cs, ck, native=args.native)
