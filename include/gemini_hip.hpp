@@ -10,7 +10,7 @@
 //   gm::TimeProver (trait Prover)                           src/subprotocols/sumcheck/prover.rs:30-45
 //   gm::Transcript (GeminiTranscript over merlin)           src/transcript.rs:8-34
 //   gm::Sumcheck::{prove, new_time}                         src/subprotocols/sumcheck/proof.rs:36-66,125-130
-//   gm::R1cs, gm::SnarkProof::new_time                      src/circuit.rs, src/snark/time_prover.rs:19-117
+//   gm::R1cs, gm::SnarkProof::{new_time, new_elastic}       src/circuit.rs, src/snark/time_prover.rs:19-117, elastic_prover.rs:174-266
 #pragma once
 #include <array>
 #include <cstdint>
@@ -437,44 +437,89 @@ struct SnarkProof {
   TensorcheckProof tensorcheck_proof;
 
   static SnarkProof new_time(const R1cs& r1cs, const CommitterKey& ck, int g1_encoding = 0) {
-    size_t cap = 2;
-    for (size_t n = r1cs.nz_; n > 1; n = (n + 1) / 2) cap++;
-    std::vector<uint64_t> m0(cap * 8), m1(cap * 8), fc(cap * 18), fe(cap * 8);
-    gm_snark_proof p;
-    memset(&p, 0, sizeof p);
-    p.messages[0] = m0.data();
-    p.messages[1] = m1.data();
-    p.fold_commitments = fc.data();
-    p.fold_evaluations = fe.data();
+    Buffers b(r1cs.nz_);
     const uint64_t mats[6] = {r1cs.a_.handle(), r1cs.b_.handle(), r1cs.c_.handle(), r1cs.at_.handle(), r1cs.bt_.handle(), r1cs.ct_.handle()};
-    check(gm_snark_new_time(mats, r1cs.z_, r1cs.w_, ck.handle(), g1_encoding, cap, &p));
-    SnarkProof out;
-    memcpy(out.witness_commitment.data(), p.witness_commitment, 144);
-    memcpy(out.zc_alpha.data(), p.zc_alpha, 32);
-    auto msgs = [](const uint64_t* m, size_t rounds) {
-      std::vector<RoundMsg> v(rounds);
-      for (size_t i = 0; i < rounds; i++) {
-        memcpy(v[i].a.data(), m + 8 * i, 32);
-        memcpy(v[i].b.data(), m + 8 * i + 4, 32);
-      }
-      return v;
-    };
-    out.first_sumcheck_msgs = msgs(m0.data(), p.rounds[0]);
-    out.second_sumcheck_msgs = msgs(m1.data(), p.rounds[1]);
-    memcpy(out.first_final_foldings.data(), p.final_foldings[0], 64);
-    memcpy(out.second_final_foldings.data(), p.final_foldings[1], 64);
-    auto& tc = out.tensorcheck_proof;
-    tc.folded_polynomials_commitments.resize(p.nfold);
-    tc.folded_polynomials_evaluations.resize(p.nfold);
-    for (size_t i = 0; i < p.nfold; i++) {
-      memcpy(tc.folded_polynomials_commitments[i].data(), fc.data() + 18 * i, 144);
-      memcpy(tc.folded_polynomials_evaluations[i].data(), fe.data() + 8 * i, 64);
-    }
-    memcpy(tc.evaluation_proof.data(), p.evaluation_proof, 144);
-    tc.base_polynomials_evaluations.resize(1);
-    memcpy(tc.base_polynomials_evaluations[0].data(), p.base_evaluations, 96);
-    return out;
+    check(gm_snark_new_time(mats, r1cs.z_, r1cs.w_, ck.handle(), g1_encoding, b.cap, &b.p));
+    return b.unpack();
   }
+
+  // Proof::new_elastic(r1cs_stream, ck_stream, max_msm_buffer) (src/snark/elastic_prover.rs:174-266): the streams of
+  // R1csStream (`Reverse(..)` of z, w, A z, B z, C z: src/snark/tests.rs:38-52) are built here as reversed device vectors,
+  // outside the prover like the reference's stream construction; the proof equals new_time's (src/snark/tests.rs:56)
+  static SnarkProof new_elastic(const R1cs& r1cs, const CommitterKey& ck, size_t max_msm_buffer = (size_t)1 << 20,
+                                size_t min_device_chunk = (size_t)1 << 26, int g1_encoding = 0) {
+    struct Vec {
+      uint64_t h = 0;
+      explicit Vec(size_t n) { check(gm_fr_vec_alloc(n, &h)); }
+      ~Vec() {
+        if (h) gm_fr_vec_free(h);
+      }
+    };
+    const size_t nz = r1cs.nz_;
+    size_t nw = 0;
+    check(gm_fr_vec_len(r1cs.w_, &nw));
+    Vec z_be(nz), w_be(nw), tmp(nz), za(nz), zb(nz), zc(nz);
+    check(gm_fr_reverse(r1cs.z_, z_be.h));
+    check(gm_fr_reverse(r1cs.w_, w_be.h));
+    const DeviceMatrix* m[3] = {&r1cs.a_, &r1cs.b_, &r1cs.c_};
+    Vec* out[3] = {&za, &zb, &zc};
+    for (int k = 0; k < 3; k++) {
+      check(gm_spm_mul(m[k]->handle(), r1cs.z_, tmp.h));
+      check(gm_fr_reverse(tmp.h, out[k]->h));
+    }
+    Buffers b(nz);
+    const uint64_t mats_t[3] = {r1cs.at_.handle(), r1cs.bt_.handle(), r1cs.ct_.handle()};
+    check(gm_snark_new_elastic(mats_t, z_be.h, w_be.h, za.h, zb.h, zc.h, ck.handle(), max_msm_buffer, min_device_chunk, g1_encoding, b.cap, &b.p));
+    return b.unpack();
+  }
+
+ private:
+  // the plain-C proof record of the library and its caller-owned arrays
+  struct Buffers {
+    size_t cap = 2;
+    std::vector<uint64_t> m0, m1, fc, fe;
+    gm_snark_proof p;
+    explicit Buffers(size_t nz) {
+      for (size_t n = nz; n > 1; n = (n + 1) / 2) cap++;
+      m0.resize(cap * 8);
+      m1.resize(cap * 8);
+      fc.resize(cap * 18);
+      fe.resize(cap * 8);
+      memset(&p, 0, sizeof p);
+      p.messages[0] = m0.data();
+      p.messages[1] = m1.data();
+      p.fold_commitments = fc.data();
+      p.fold_evaluations = fe.data();
+    }
+    SnarkProof unpack() const {
+      SnarkProof out;
+      memcpy(out.witness_commitment.data(), p.witness_commitment, 144);
+      memcpy(out.zc_alpha.data(), p.zc_alpha, 32);
+      auto msgs = [](const uint64_t* m, size_t rounds) {
+        std::vector<RoundMsg> v(rounds);
+        for (size_t i = 0; i < rounds; i++) {
+          memcpy(v[i].a.data(), m + 8 * i, 32);
+          memcpy(v[i].b.data(), m + 8 * i + 4, 32);
+        }
+        return v;
+      };
+      out.first_sumcheck_msgs = msgs(m0.data(), p.rounds[0]);
+      out.second_sumcheck_msgs = msgs(m1.data(), p.rounds[1]);
+      memcpy(out.first_final_foldings.data(), p.final_foldings[0], 64);
+      memcpy(out.second_final_foldings.data(), p.final_foldings[1], 64);
+      auto& tc = out.tensorcheck_proof;
+      tc.folded_polynomials_commitments.resize(p.nfold);
+      tc.folded_polynomials_evaluations.resize(p.nfold);
+      for (size_t i = 0; i < p.nfold; i++) {
+        memcpy(tc.folded_polynomials_commitments[i].data(), fc.data() + 18 * i, 144);
+        memcpy(tc.folded_polynomials_evaluations[i].data(), fe.data() + 8 * i, 64);
+      }
+      memcpy(tc.evaluation_proof.data(), p.evaluation_proof, 144);
+      tc.base_polynomials_evaluations.resize(1);
+      memcpy(tc.base_polynomials_evaluations[0].data(), p.base_evaluations, 96);
+      return out;
+    }
+  };
 };
 
 }  // namespace gm

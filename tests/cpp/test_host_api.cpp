@@ -94,6 +94,24 @@ int main(int argc, char** argv) {
       }
       print("snark_open", proof.tensorcheck_proof.evaluation_proof);
       for (auto& e : proof.tensorcheck_proof.base_polynomials_evaluations[0]) print("snark_be", e);
+      // Proof::new_elastic on the same instance and key: assert_eq!(time_proof, space_proof) (src/snark/tests.rs:56);
+      // max_msm_buffer cut literally (min_device_chunk = 1) and merged
+      for (size_t floor : {(size_t)1, (size_t)1 << 26}) {
+        auto el = gm::SnarkProof::new_elastic(r1cs, key, 4, floor);
+        const bool same = el.witness_commitment == proof.witness_commitment && el.zc_alpha == proof.zc_alpha &&
+                          el.first_final_foldings == proof.first_final_foldings && el.second_final_foldings == proof.second_final_foldings &&
+                          el.tensorcheck_proof.folded_polynomials_commitments == proof.tensorcheck_proof.folded_polynomials_commitments &&
+                          el.tensorcheck_proof.folded_polynomials_evaluations == proof.tensorcheck_proof.folded_polynomials_evaluations &&
+                          el.tensorcheck_proof.evaluation_proof == proof.tensorcheck_proof.evaluation_proof &&
+                          el.tensorcheck_proof.base_polynomials_evaluations == proof.tensorcheck_proof.base_polynomials_evaluations &&
+                          el.first_sumcheck_msgs.size() == proof.first_sumcheck_msgs.size() && el.second_sumcheck_msgs.size() == proof.second_sumcheck_msgs.size();
+        bool msgs_same = same;
+        for (size_t i = 0; msgs_same && i < el.first_sumcheck_msgs.size(); i++)
+          msgs_same = el.first_sumcheck_msgs[i].a == proof.first_sumcheck_msgs[i].a && el.first_sumcheck_msgs[i].b == proof.first_sumcheck_msgs[i].b;
+        for (size_t i = 0; msgs_same && i < el.second_sumcheck_msgs.size(); i++)
+          msgs_same = el.second_sumcheck_msgs[i].a == proof.second_sumcheck_msgs[i].a && el.second_sumcheck_msgs[i].b == proof.second_sumcheck_msgs[i].b;
+        printf("snark_elastic_equals_time %d\n", (int)msgs_same);
+      }
     }
     // error behaviour: hadamard-style length mismatch surfaces as gm::Error, not a crash
     try {

@@ -89,3 +89,5 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
     assert [[F("snark_fe", 2 * k), F("snark_fe", 2 * k + 1)] for k in range(len(vals["snark_fe"]) // 2)] == tc["folded_polynomials_evaluations"]
     assert A("snark_open") == tc["evaluation_proof"]
     assert [[F("snark_be", k) for k in range(3)]] == tc["base_polynomials_evaluations"]
+    # gm::SnarkProof::new_elastic (gm_snark_new_elastic), flushes cut literally and merged: the time prover's proof
+    assert vals["snark_elastic_equals_time"] == [["1"], ["1"]]
