@@ -1,0 +1,431 @@
+// psnark::Proof::new_time (src/psnark/time_prover.rs:69-384) with EntryProduct::new_time_batch
+// (src/subprotocols/entryproduct/time_prover.rs:53-114), the plookup vector builders
+// (src/subprotocols/plookup/time_prover.rs:89-112), Sumcheck::{new_time, prove_batch} (sumcheck/proof.rs:69-130),
+// TensorcheckProof::new_time (tensorcheck/mod.rs:190-275) and CommitterKey::{commit, batch_commit,
+// batch_open_multi_points} (src/kzg/time.rs:81-159) as ONE entry point of the library.
+//
+// Pure orchestration over the library's own C ABI, like snark.cpp: every O(n) step is a gm_* call, the sequence is the
+// one of gemini_amd/psnark.py::Proof.new_time (the tests hold the two byte for byte equal).  Driven from Python the
+// prover makes ~1000 FFI round trips per proof, most of which wait for the device; here the GPU is fed from one thread
+// that never leaves the library.
+#include "prover_common.hpp"
+
+namespace {
+
+using namespace gmprover;
+
+Fr fr_pow(Fr base, size_t e) {
+  Fr acc = Fr::one();
+  while (e) {
+    if (e & 1) acc = acc * base;
+    base = base.sqr();
+    e >>= 1;
+  }
+  return acc;
+}
+
+// ck.commit(v): msm_unchecked truncates to the shorter side (src/kzg/time.rs:82)
+int commit(uint64_t ck, size_t nck, uint64_t v, uint64_t out[18]) {
+  size_t n = 0;
+  RC(vec_len(v, &n));
+  return gm_g1_msm_v(ck, 0, 0, v, 0, n < nck ? n : nck, out);
+}
+int batch_commit(uint64_t ck, size_t nck, const std::vector<uint64_t>& vs, uint64_t* out) {
+  std::vector<size_t> ns(vs.size());
+  for (size_t k = 0; k < vs.size(); k++) {
+    RC(vec_len(vs[k], &ns[k]));
+    if (ns[k] > nck) ns[k] = nck;
+  }
+  return gm_g1_msm_v_batch(ck, 0, 0, vs.data(), ns.data(), vs.size(), out);
+}
+
+// batch_open_multi_points (src/kzg/time.rs:149-159): commit((sum_i chal^i p_i) / prod (x - point_j))
+int batch_open(Vecs& V, uint64_t ck, size_t nck, const std::vector<uint64_t>& polys, const uint64_t* pts, size_t npts, const uint64_t chal[4],
+               uint64_t out[18]) {
+  std::vector<uint64_t> etas(4 * polys.size());
+  Fr acc = Fr::one();
+  const Fr c = Fr::from_limbs(chal);
+  size_t longest = 0;
+  for (size_t k = 0; k < polys.size(); k++) {
+    acc.to_limbs(etas.data() + 4 * k);
+    acc = acc * c;
+    size_t l = 0;
+    RC(vec_len(polys[k], &l));
+    longest = l > longest ? l : longest;
+  }
+  uint64_t combined, quotient;
+  RC(V.alloc(longest, &combined));
+  RC(gm_fr_lincomb(polys.data(), etas.data(), polys.size(), combined));
+  size_t lc = 0;
+  RC(vec_len(combined, &lc));
+  RC(V.alloc(lc ? lc - 1 : 0, &quotient));
+  uint64_t rem[12];
+  RC(gm_fr_div_vanishing(combined, pts, npts, quotient, rem));
+  V.release(combined);
+  const int rc = commit(ck, nck, quotient, out);
+  V.release(quotient);
+  return rc;
+}
+
+// plookup (plookup/time_prover.rs:89-112) -> lookup_set, lookup_subset, lookup_sorted
+int plookup(Vecs& V, uint64_t subset, uint64_t set_, uint64_t index, size_t index_len, uint64_t ext_fre, size_t ext_len, const uint64_t y[4],
+            const uint64_t z[4], const uint64_t zeta[4], uint64_t out[3]) {
+  size_t nset = 0, nsub = 0;
+  RC(vec_len(set_, &nset));
+  RC(vec_len(subset, &nsub));
+  uint64_t set_h = set_, subset_h = subset;
+  if (!Fr::from_limbs(zeta).is_zero()) {
+    RC(V.alloc(nset, &set_h));
+    RC(gm_fr_alg_hash(set_, 0, zeta, set_h));
+    const size_t n = nsub < index_len ? nsub : index_len;
+    RC(V.alloc(n, &subset_h));
+    RC(gm_fr_alg_hash(subset, index, zeta, subset_h));
+    nsub = n;
+  }
+  RC(V.alloc(nset ? nset + 1 : 0, &out[0]));
+  RC(gm_fr_plookup_set(set_h, y, z, out[0]));
+  RC(V.alloc(nsub, &out[1]));
+  RC(gm_fr_add_scalar(subset_h, y, out[1]));
+  uint64_t srt;
+  RC(V.alloc(ext_len, &srt));
+  RC(gm_fr_gather(set_h, ext_fre, srt));
+  RC(V.alloc(ext_len ? ext_len + 1 : 0, &out[2]));
+  RC(gm_fr_plookup_set(srt, y, z, out[2]));
+  V.release(srt);
+  if (set_h != set_) V.release(set_h);
+  if (subset_h != subset) V.release(subset_h);
+  return GM_OK;
+}
+
+}  // namespace
+
+extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases, int g1_encoding, size_t cap_rounds, gm_psnark_proof* P) {
+  if (!I || !P || !I->index_commitments || !P->messages[0] || !P->messages[1] || !P->messages[2] || !P->fold_commitments || !P->fold_evaluations)
+    return GM_EINVAL;
+  const auto t_all = Clock::now();
+  Vecs V;
+  size_t nz = 0, nck = 0;
+  RC(vec_len(I->z, &nz));
+  RC(gm_g1_bases_len(ck_bases, &nck));
+  const size_t nnz = I->nnz;
+  if (nck < nnz || nck < I->ext_fre_row_len || nck < I->ext_fre_col_len) return GM_EINVAL;  // index_by zips need as many powers as indices (:119-127,179-183)
+  uint64_t one[4];
+  Fr::one().to_limbs(one);
+
+  // z_a, z_b, z_c (:74-76)
+  uint64_t z_abc[3];
+  const uint64_t mats[3] = {I->a, I->b, I->c};
+  for (int k = 0; k < 3; k++) {
+    size_t rows = 0, cols = 0;
+    RC(gm_spm_shape(mats[k], &rows, &cols, nullptr));
+    if (cols != nz) return GM_EINVAL;
+    RC(V.alloc(rows, &z_abc[k]));
+    RC(gm_spm_mul(mats[k], I->z, z_abc[k]));
+  }
+  TranscriptGuard T;
+  static const char protocol[] = "GEMINI-v0";
+  RC(gm_transcript_new(L(protocol), sizeof protocol - 1, &T.h));
+  if (g1_encoding) RC(gm_transcript_set_g1_encoding(T.h, g1_encoding));
+
+  auto t0 = Clock::now();
+  RC(commit(ck_bases, nck, I->w, P->witness_commitment));  // :79
+  P->spans[0] = since(t0);
+  RC(gm_transcript_append_g1(T.h, L("witness"), 7, P->witness_commitment, 1, 0));  // :82-86
+  RC(gm_transcript_append_message(T.h, L("ck"), 2, I->ck_g2_bytes, I->ck_g2_len));
+  RC(gm_transcript_append_g1(T.h, L("instance"), 8, I->index_commitments, 5, 1));
+  uint64_t alpha[4];
+  RC(gm_transcript_challenge_fr(T.h, L("alpha"), 5, alpha));
+  RC(gm_fr_eval_le(z_abc[2], alpha, 1, P->zc_alpha));  // :88-89
+  RC(gm_transcript_append_fr(T.h, L("zc(alpha)"), 9, P->zc_alpha, 1));
+
+  t0 = Clock::now();
+  std::vector<uint64_t> ch1, ch2;
+  RC(sumcheck_new_time(T.h, z_abc[0], z_abc[1], alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));  // :92
+  P->spans[1] = since(t0);
+
+  t0 = Clock::now();
+  const size_t nt = (size_t)1 << P->rounds[0];
+  // extend_frequency(compute_frequency(set_len, index)) has set_len + |index| entries (plookup/time_prover.rs:66-79)
+  if (I->ext_fre_row_len != nt + nnz || I->ext_fre_col_len != nz + nnz) return GM_EINVAL;
+  uint64_t a_ch, b_ch, c_ch;
+  RC(V.alloc(nt, &b_ch));
+  RC(gm_fr_tensor(ch1.data(), P->rounds[0], b_ch));  // :95-97
+  RC(V.alloc(nt, &c_ch));
+  RC(gm_fr_powers(alpha, nt, c_ch));
+  RC(V.alloc(nt, &a_ch));
+  RC(gm_fr_hadamard(b_ch, c_ch, a_ch));
+  P->spans[2] = since(t0);  // "joint matrices": resident with the instance
+
+  uint64_t ralpha_star, r_star, alpha_star, z_star;  // :114-117
+  RC(V.alloc(nnz, &ralpha_star));
+  RC(gm_fr_gather(a_ch, I->row_index, ralpha_star));
+  RC(V.alloc(nnz, &r_star));
+  RC(gm_fr_gather(b_ch, I->row_index, r_star));
+  RC(V.alloc(nnz, &alpha_star));
+  RC(gm_fr_gather(c_ch, I->row_index, alpha_star));
+  RC(V.alloc(nnz, &z_star));
+  RC(gm_fr_gather(I->z, I->col_index, z_star));
+
+  t0 = Clock::now();
+  RC(batch_commit(ck_bases, nck, {ralpha_star, r_star, alpha_star}, &P->r_star_commitments[0][0]));  // :119-127
+  RC(commit(ck_bases, nck, z_star, P->z_star_commitment));
+  P->spans[3] = since(t0);
+  RC(gm_transcript_append_g1(T.h, L("ra*"), 3, P->r_star_commitments[0], 1, 0));  // :129-132
+  RC(gm_transcript_append_g1(T.h, L("rb*"), 3, P->r_star_commitments[1], 1, 0));
+  RC(gm_transcript_append_g1(T.h, L("rc*"), 3, P->r_star_commitments[2], 1, 0));
+  RC(gm_transcript_append_g1(T.h, L("z*"), 2, P->z_star_commitment, 1, 0));
+  uint64_t eta3[12];  // 1, eta, eta^2   :134-135
+  memcpy(eta3, one, 32);
+  RC(gm_transcript_challenge_fr(T.h, L("chal"), 4, eta3 + 4));
+  Fr::from_limbs(eta3 + 4).sqr().to_limbs(eta3 + 8);
+  uint64_t r_star_val;
+  {
+    uint64_t h[3];
+    const uint64_t lhs[3] = {ralpha_star, r_star, alpha_star}, rhs[3] = {I->val_a, I->val_b, I->val_c};
+    for (int k = 0; k < 3; k++) {
+      RC(V.alloc(nnz, &h[k]));
+      RC(gm_fr_hadamard(lhs[k], rhs[k], h[k]));
+    }
+    RC(V.alloc(nnz, &r_star_val));
+    RC(gm_fr_lincomb(h, eta3, 3, r_star_val));  // :137-144
+    for (int k = 0; k < 3; k++) V.release(h[k]);
+  }
+
+  t0 = Clock::now();
+  RC(sumcheck_new_time(T.h, z_star, r_star_val, one, P->messages[1], ch2, cap_rounds, P->final_foldings[1], &P->rounds[1]));  // :147-152
+  uint64_t second_challenges;
+  RC(V.alloc((size_t)1 << P->rounds[1], &second_challenges));
+  RC(gm_fr_tensor(ch2.data(), P->rounds[1], second_challenges));
+  if (((size_t)1 << P->rounds[1]) < nnz) return GM_EINVAL;
+  RC(gm_fr_vec_set_len(second_challenges, nnz));  // &second_challenges[..num_non_zero]
+  P->spans[4] = since(t0);
+
+  uint64_t zeta[4];
+  RC(gm_transcript_challenge_fr(T.h, L("zeta"), 4, zeta));  // :157
+
+  t0 = Clock::now();
+  uint64_t ahp[3];  // alg_hash of b_challenges, c_challenges, z   :160-164
+  RC(V.alloc(nt, &ahp[0]));
+  RC(gm_fr_alg_hash(b_ch, 0, zeta, ahp[0]));
+  RC(V.alloc(nt, &ahp[1]));
+  RC(gm_fr_alg_hash(c_ch, 0, zeta, ahp[1]));
+  RC(V.alloc(nz, &ahp[2]));
+  RC(gm_fr_alg_hash(I->z, 0, zeta, ahp[2]));
+  uint64_t sorted[3];  // :169-173
+  RC(V.alloc(I->ext_fre_row_len, &sorted[0]));
+  RC(gm_fr_gather(ahp[0], I->ext_fre_row, sorted[0]));
+  RC(V.alloc(I->ext_fre_row_len, &sorted[1]));
+  RC(gm_fr_gather(ahp[1], I->ext_fre_row, sorted[1]));
+  RC(V.alloc(I->ext_fre_col_len, &sorted[2]));
+  RC(gm_fr_gather(ahp[2], I->ext_fre_col, sorted[2]));
+  RC(batch_commit(ck_bases, nck, {sorted[0], sorted[1], sorted[2]}, &P->sorted_commitments[0][0]));  // :179-183
+  P->spans[5] = since(t0);
+  RC(gm_transcript_append_g1(T.h, L("sorted_alpha_commitment"), 23, P->sorted_commitments[1], 1, 0));  // :186-188
+  RC(gm_transcript_append_g1(T.h, L("sorted_r_commitment"), 19, P->sorted_commitments[0], 1, 0));
+  RC(gm_transcript_append_g1(T.h, L("sorted_z_commitment"), 19, P->sorted_commitments[2], 1, 0));
+  uint64_t gamma[4], chi[4];
+  RC(gm_transcript_challenge_fr(T.h, L("gamma"), 5, gamma));  // :190-191
+  RC(gm_transcript_challenge_fr(T.h, L("chi"), 3, chi));
+
+  t0 = Clock::now();
+  uint64_t lookup_vec[9];  // r: set, subset, sorted; alpha: ..; z: ..   :194-209
+  RC(plookup(V, r_star, b_ch, I->row_index, nnz, I->ext_fre_row, I->ext_fre_row_len, gamma, chi, zeta, lookup_vec));
+  RC(plookup(V, alpha_star, c_ch, I->row_index, nnz, I->ext_fre_row, I->ext_fre_row_len, gamma, chi, zeta, lookup_vec + 3));
+  RC(plookup(V, z_star, I->z, I->col_index, nnz, I->ext_fre_col, I->ext_fre_col_len, gamma, chi, zeta, lookup_vec + 6));
+  uint64_t acc_vec[9];  // accumulated_product(monic(v))   :211-214
+  for (int k = 0; k < 9; k++) {
+    size_t l = 0;
+    RC(vec_len(lookup_vec[k], &l));
+    RC(V.alloc(l + 1, &acc_vec[k]));
+    RC(gm_fr_acc_product(lookup_vec[k], acc_vec[k]));
+    RC(gm_fr_vec_download(acc_vec[k], 0, P->products[k], 1));  // the full product is the first accumulated entry
+  }
+  P->spans[6] = since(t0);
+  RC(gm_transcript_append_fr(T.h, L("set_r_ep"), 8, P->products[3], 1));  // :216-221 (labels as in the reference)
+  RC(gm_transcript_append_fr(T.h, L("subset_r_ep"), 11, P->products[4], 1));
+  RC(gm_transcript_append_fr(T.h, L("set_r_ep"), 8, P->products[0], 1));
+  RC(gm_transcript_append_fr(T.h, L("subset_r_ep"), 11, P->products[1], 1));
+  RC(gm_transcript_append_fr(T.h, L("set_z_ep"), 8, P->products[6], 1));
+  RC(gm_transcript_append_fr(T.h, L("subset_z_ep"), 11, P->products[7], 1));
+
+  // EntryProduct::new_time_batch (entryproduct/time_prover.rs:53-114)   :223-239
+  t0 = Clock::now();
+  std::vector<uint64_t> provers;
+  struct ProverGuard {
+    std::vector<uint64_t>& p;
+    ~ProverGuard() {
+      for (uint64_t h : p) (void)gm_sc_free(h);
+    }
+  } prover_guard{provers};
+  uint64_t psi[4];
+  {
+    uint64_t rrot[9];
+    for (int k = 0; k < 9; k++) {
+      size_t l = 0;
+      RC(vec_len(lookup_vec[k], &l));
+      RC(V.alloc(l + 1, &rrot[k]));
+      RC(gm_fr_shift_monic(lookup_vec[k], rrot[k]));
+    }
+    RC(batch_commit(ck_bases, nck, std::vector<uint64_t>(acc_vec, acc_vec + 9), &P->acc_v_commitments[0][0]));
+    for (int k = 0; k < 9; k++) RC(gm_transcript_append_g1(T.h, L("acc_v"), 5, P->acc_v_commitments[k], 1, 0));
+    RC(gm_transcript_challenge_fr(T.h, L("ep-chal"), 7, psi));
+    for (int k = 0; k < 9; k++) {
+      uint64_t h = 0;
+      RC(gm_sc_new_v(acc_vec[k], rrot[k], psi, &h));  // the prover copies its vectors
+      provers.push_back(h);
+      V.release(rrot[k]);
+    }
+    uint64_t acc_chal[9][4];
+    RC(gm_fr_eval_le_batch(acc_vec, 9, psi, 1, &acc_chal[0][0]));
+    const Fr ci = Fr::from_limbs(psi);
+    for (int k = 0; k < 9; k++) {
+      size_t l = 0;
+      RC(vec_len(acc_vec[k], &l));
+      (Fr::from_limbs(acc_chal[k]) * ci + Fr::from_limbs(P->products[k]) - fr_pow(ci, l)).to_limbs(P->claimed_sumchecks[k]);
+    }
+  }
+  P->spans[7] = since(t0);
+
+  uint64_t open_chal[4];
+  RC(gm_transcript_challenge_fr(T.h, L("open-chal"), 9, open_chal));  // :241-242
+  t0 = Clock::now();
+  std::vector<uint64_t> polys = {ralpha_star};  // :244-251
+  polys.insert(polys.end(), acc_vec, acc_vec + 9);
+  RC(batch_open(V, ck_bases, nck, polys, psi, 1, open_chal, P->ralpha_star_acc_mu_proof));
+  RC(gm_fr_eval_le_batch(polys.data(), 10, psi, 1, &P->ralpha_star_acc_mu_evals[0][0]));
+  P->spans[8] = since(t0);
+  {
+    uint64_t h_a, h_b;  // :253-254
+    RC(V.alloc(nnz, &h_a));
+    RC(gm_fr_hadamard(ralpha_star, I->val_a, h_a));
+    RC(V.alloc(nnz, &h_b));
+    RC(gm_fr_hadamard(r_star, I->val_b, h_b));
+    RC(gm_fr_ip(h_a, second_challenges, P->rstars_vals[0]));
+    RC(gm_fr_ip(h_b, second_challenges, P->rstars_vals[1]));
+    V.release(h_a);
+    V.release(h_b);
+  }
+  for (int k = 0; k < 10; k++) RC(gm_transcript_append_fr(T.h, L("ralpha_star_acc_mu"), 18, P->ralpha_star_acc_mu_evals[k], 1));  // :258-261
+  RC(gm_transcript_append_g1(T.h, L("ralpha_star_mu_proof"), 20, P->ralpha_star_acc_mu_proof, 1, 0));
+  {
+    const uint64_t lhs[3] = {ralpha_star, r_star, alpha_star}, rhs[3] = {I->val_a, I->val_b, I->val_c};  // :263-290
+    for (int k = 0; k < 3; k++) {
+      uint64_t h, pr = 0;
+      RC(V.alloc(nnz, &h));
+      RC(gm_fr_hadamard(lhs[k], second_challenges, h));
+      RC(gm_sc_new_v(h, rhs[k], one, &pr));
+      provers.push_back(pr);
+      V.release(h);
+    }
+    uint64_t pr = 0;
+    RC(gm_sc_new_v(r_star, alpha_star, psi, &pr));
+    provers.push_back(pr);
+  }
+  t0 = Clock::now();
+  std::vector<uint64_t> ch3(cap_rounds * 4, 0);
+  RC(gm_sumcheck_prove_batch(T.h, provers.data(), provers.size(), P->messages[2], ch3.data(), cap_rounds, &P->third_final_foldings[0][0], &P->rounds[2]));  // :293
+  for (uint64_t h : provers) (void)gm_sc_free(h);
+  provers.clear();
+  P->spans[9] = since(t0);
+  for (uint64_t v : {second_challenges, r_star_val, a_ch, b_ch, c_ch, ahp[0], ahp[1], ahp[2], z_abc[0], z_abc[1], z_abc[2]}) V.release(v);
+
+  // ---- TensorcheckProof::new_time(transcript, ck, 22 base polynomials, 4 bodies)   :296-367, tensorcheck/mod.rs:190-275
+  t0 = Clock::now();
+  std::vector<uint64_t> base = {I->w, ralpha_star, r_star, alpha_star, z_star, I->row, I->col, I->val_a, I->val_b, I->val_c, sorted[0], sorted[1], sorted[2]};
+  base.insert(base.end(), acc_vec, acc_vec + 9);
+  const size_t n3 = P->rounds[2], n2 = P->rounds[1];
+  std::vector<uint64_t> shift_lookup(9);  // :323-326
+  for (int k = 0; k < 9; k++) {
+    size_t l = 0;
+    RC(vec_len(lookup_vec[k], &l));
+    RC(V.alloc(l + 1, &shift_lookup[k]));
+    RC(gm_fr_shift_monic(lookup_vec[k], shift_lookup[k]));
+  }
+  struct Body {
+    std::vector<uint64_t> polys;
+    std::vector<uint64_t> challenges;  // 4 limbs each
+  };
+  std::vector<Body> bodies(4);
+  {
+    bodies[0].polys.assign(acc_vec, acc_vec + 9);  // accumulated_vec + [r_star], challenges third_ch[j] * psi^(2^j)   :334-349
+    bodies[0].polys.push_back(r_star);
+    bodies[0].challenges.resize(4 * n3);
+    Fr tw = Fr::from_limbs(psi);
+    for (size_t j = 0; j < n3; j++) {
+      (Fr::from_limbs(ch3.data() + 4 * j) * tw).to_limbs(bodies[0].challenges.data() + 4 * j);
+      tw = tw.sqr();
+    }
+    bodies[1].polys = shift_lookup;  // shift_monic_lookup_vec + [val_a, val_b, val_c, alpha_star], challenges third_ch
+    bodies[1].polys.insert(bodies[1].polys.end(), {I->val_a, I->val_b, I->val_c, alpha_star});
+    bodies[1].challenges.assign(ch3.begin(), ch3.begin() + 4 * n3);
+    bodies[2].polys = {z_star};  // challenges second_ch
+    bodies[2].challenges.assign(ch2.begin(), ch2.begin() + 4 * n2);
+    bodies[3].polys = {ralpha_star, r_star, alpha_star};  // challenges second_ch[j] * third_ch[j]
+    const size_t nh = n2 < n3 ? n2 : n3;
+    bodies[3].challenges.resize(4 * nh);
+    for (size_t j = 0; j < nh; j++)
+      (Fr::from_limbs(ch2.data() + 4 * j) * Fr::from_limbs(ch3.data() + 4 * j)).to_limbs(bodies[3].challenges.data() + 4 * j);
+  }
+  uint64_t batch_challenge[4];
+  RC(gm_transcript_challenge_fr(T.h, L("batch_challenge"), 15, batch_challenge));
+  size_t max_group = 0;
+  for (auto& b : bodies) max_group = b.polys.size() > max_group ? b.polys.size() : max_group;
+  std::vector<uint64_t> bc(4 * max_group);  // powers(batch_challenge, max_len)
+  {
+    Fr acc = Fr::one();
+    const Fr c = Fr::from_limbs(batch_challenge);
+    for (size_t k = 0; k < max_group; k++) {
+      acc.to_limbs(bc.data() + 4 * k);
+      acc = acc * c;
+    }
+  }
+  std::vector<uint64_t> foldings;
+  for (auto& b : bodies) {
+    size_t longest = 0;
+    for (uint64_t p : b.polys) {
+      size_t l = 0;
+      RC(vec_len(p, &l));
+      longest = l > longest ? l : longest;
+    }
+    uint64_t batched;
+    RC(V.alloc(longest, &batched));
+    RC(gm_fr_lincomb(b.polys.data(), bc.data(), b.polys.size(), batched));
+    uint64_t cur = batched;
+    size_t len = 0;
+    RC(vec_len(cur, &len));
+    const size_t nch = b.challenges.size() / 4;
+    for (size_t k = 0; k + 1 < nch; k++) {  // foldings_polynomial: all challenges but the last (:124-133)
+      uint64_t nxt;
+      len = (len + 1) / 2;
+      RC(V.alloc(len, &nxt));
+      RC(gm_fr_fold(cur, b.challenges.data() + 4 * k, nxt));
+      foldings.push_back(nxt);
+      cur = nxt;
+    }
+  }
+  P->nfold = foldings.size();
+  if (P->nfold > P->cap_folds) return GM_EINVAL;
+  if (P->nfold) RC(batch_commit(ck_bases, nck, foldings, P->fold_commitments));
+  for (size_t k = 0; k < P->nfold; k++) RC(gm_transcript_append_g1(T.h, L("commitment"), 10, P->fold_commitments + 18 * k, 1, 0));
+  uint64_t pts[12];  // beta^2, beta, -beta
+  RC(gm_transcript_challenge_fr(T.h, L("evaluation-chal"), 15, pts + 4));
+  {
+    const Fr beta = Fr::from_limbs(pts + 4);
+    beta.sqr().to_limbs(pts);
+    beta.neg().to_limbs(pts + 8);
+  }
+  RC(gm_fr_eval_le_batch(base.data(), base.size(), pts, 3, &P->base_evaluations[0][0]));
+  RC(gm_fr_eval_le_batch(foldings.data(), P->nfold, pts + 4, 2, P->fold_evaluations));
+  for (size_t k = 0; k < 3 * base.size(); k++) RC(gm_transcript_append_fr(T.h, L("eval"), 4, &P->base_evaluations[0][0] + 4 * k, 1));
+  for (size_t k = 0; k < 2 * P->nfold; k++) RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->fold_evaluations + 4 * k, 1));
+  uint64_t open_chal2[4];
+  RC(gm_transcript_challenge_fr(T.h, L("open-chal"), 9, open_chal2));
+  {
+    std::vector<uint64_t> all = base;
+    all.insert(all.end(), foldings.begin(), foldings.end());
+    RC(batch_open(V, ck_bases, nck, all, pts, 3, open_chal2, P->evaluation_proof));
+  }
+  P->spans[10] = since(t0);
+  P->spans[11] = since(t_all);
+  return GM_OK;
+}

@@ -6,60 +6,11 @@
 // this: pure orchestration over the library's own C ABI (every O(n) step below is a gm_* call that a Rust / C++
 // embedder could make itself -- gemini_amd/snark.py is the same sequence in Python and the tests hold the two byte for
 // byte equal).  What a shim gains is one FFI call per proof: `Proof::new_time(&r1cs, &ck)` -> gm_snark_new_time.
-#include <chrono>
-#include <cstring>
-#include <vector>
-
-#include "../../include/gemini_hip.h"
-#include "host_field.hpp"
+#include "prover_common.hpp"
 
 namespace {
 
-using gmh::Fr;
-using Clock = std::chrono::steady_clock;
-
-double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
-
-// device vectors owned by one proof: freed on every exit path
-struct Vecs {
-  std::vector<uint64_t> h;
-  ~Vecs() {
-    for (uint64_t v : h) (void)gm_fr_vec_free(v);
-  }
-  int alloc(size_t n, uint64_t* out) {
-    int rc = gm_fr_vec_alloc(n, out);
-    if (!rc) h.push_back(*out);
-    return rc;
-  }
-};
-struct TranscriptGuard {
-  uint64_t h = 0;
-  ~TranscriptGuard() {
-    if (h) (void)gm_transcript_free(h);
-  }
-};
-
-#define RC(x)            \
-  do {                   \
-    int rc_ = (x);       \
-    if (rc_) return rc_; \
-  } while (0)
-
-const uint8_t* L(const char* s) { return reinterpret_cast<const uint8_t*>(s); }
-
-int vec_len(uint64_t v, size_t* n) { return gm_fr_vec_len(v, n); }
-
-// Sumcheck::new_time (proof.rs:125-130): prover over copies of f and g, round loop inside the library
-int sumcheck_new_time(uint64_t transcript, uint64_t f, uint64_t g, const uint64_t twist[4], uint64_t* messages, std::vector<uint64_t>& challenges,
-                      size_t cap_rounds, uint64_t final_foldings[8], size_t* rounds) {
-  uint64_t prover = 0;
-  RC(gm_sc_new_v(f, g, twist, &prover));
-  challenges.assign(cap_rounds * 4, 0);
-  int rc = gm_sumcheck_prove(transcript, prover, messages, challenges.data(), cap_rounds, final_foldings, rounds);
-  (void)gm_sc_free(prover);
-  if (!rc) challenges.resize(*rounds * 4);
-  return rc;
-}
+using namespace gmprover;
 
 }  // namespace
 

@@ -230,8 +230,11 @@ class Proof:
         return ck.batch_commit([jd.row, jd.col, jd.val_a, jd.val_b, jd.val_c])
 
     @staticmethod
-    def new_time(ck: CommitterKey, r1cs: R1cs, index: list) -> "Proof":
-        """src/psnark/time_prover.rs:69-384"""
+    def new_time(ck: CommitterKey, r1cs: R1cs, index: list, native: bool = False) -> "Proof":
+        """src/psnark/time_prover.rs:69-384.  native: the same sequence compiled into the library (gm_psnark_new_time, one call
+        per proof) -- for a single-GPU CommitterKey."""
+        if native and type(ck) is CommitterKey:
+            return _new_time_native(ck, r1cs, index)
         spans = {}
         keep = []  # device vectors freed at the end
 
@@ -657,3 +660,91 @@ class Proof:
 
     def compressed_size(self) -> int:
         return len(self.serialize_compressed())
+
+
+# ---- gm_psnark_new_time: the orchestration above compiled into the library (gemini_amd/csrc/psnark.cpp) -------------------
+_PSNARK_SPANS = ["Commitment to w", "First sumcheck", "joint matrices", "Commitments to z* and r*", "Second sumcheck",
+                 "Commitments to sorted vectors", "plookup vectors + accumulated products", "Entry products", "Opening at psi", "Third sumcheck",
+                 "Tensorcheck", "ark_gemini::psnark::time_prover"]
+
+
+def _psnark_ctypes():
+    import ctypes as C
+
+    U64P = C.POINTER(C.c_uint64)
+
+    class Instance(C.Structure):
+        _fields_ = [("a", C.c_uint64), ("b", C.c_uint64), ("c", C.c_uint64), ("z", C.c_uint64), ("w", C.c_uint64), ("row_index", C.c_uint64),
+                    ("col_index", C.c_uint64), ("nnz", C.c_size_t), ("row", C.c_uint64), ("col", C.c_uint64), ("val_a", C.c_uint64),
+                    ("val_b", C.c_uint64), ("val_c", C.c_uint64), ("ext_fre_row", C.c_uint64), ("ext_fre_col", C.c_uint64),
+                    ("ext_fre_row_len", C.c_size_t), ("ext_fre_col_len", C.c_size_t), ("index_commitments", U64P),
+                    ("ck_g2_bytes", C.POINTER(C.c_uint8)), ("ck_g2_len", C.c_size_t)]
+
+    class ProofRec(C.Structure):
+        _fields_ = [("witness_commitment", C.c_uint64 * 18), ("zc_alpha", C.c_uint64 * 4), ("rounds", C.c_size_t * 3), ("messages", U64P * 3),
+                    ("final_foldings", (C.c_uint64 * 8) * 2), ("third_final_foldings", (C.c_uint64 * 8) * 13),
+                    ("r_star_commitments", (C.c_uint64 * 18) * 3), ("z_star_commitment", C.c_uint64 * 18),
+                    ("sorted_commitments", (C.c_uint64 * 18) * 3), ("products", (C.c_uint64 * 4) * 9),
+                    ("acc_v_commitments", (C.c_uint64 * 18) * 9), ("claimed_sumchecks", (C.c_uint64 * 4) * 9),
+                    ("ralpha_star_acc_mu_evals", (C.c_uint64 * 4) * 10), ("ralpha_star_acc_mu_proof", C.c_uint64 * 18),
+                    ("rstars_vals", (C.c_uint64 * 4) * 2), ("nfold", C.c_size_t), ("cap_folds", C.c_size_t), ("fold_commitments", U64P),
+                    ("fold_evaluations", U64P), ("evaluation_proof", C.c_uint64 * 18), ("base_evaluations", (C.c_uint64 * 12) * 22),
+                    ("spans", C.c_double * 12)]
+
+    return Instance, ProofRec
+
+
+def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list) -> "Proof":
+    import ctypes as C
+
+    from . import capi
+    from .transcript import default_group_encoding
+
+    Instance, ProofRec = _psnark_ctypes()
+    jd = _joint_device(r1cs)
+    nrows = max(r1cs.a.nrows, r1cs.b.nrows)
+    len_r = 1 << max(nrows - 1, 0).bit_length()  # the first sumcheck's tensor: 2^rounds, rounds = ceil(log2 max(|A z|, |B z|))
+    ext = jd.extended_frequencies(len_r, len(r1cs.z))
+    U = C.POINTER(C.c_uint64)
+    idx = np.ascontiguousarray(np.stack(index), dtype=np.uint64)
+    g2 = ck.powers_of_g2_bytes()
+    g2buf = (C.c_uint8 * len(g2)).from_buffer_copy(g2)
+    I = Instance(r1cs.a.handle, r1cs.b.handle, r1cs.c.handle, r1cs.z.handle, r1cs.w.handle, jd.row_index.handle, jd.col_index.handle, len(jd.row_index),
+                 jd.row.handle, jd.col.handle, jd.val_a.handle, jd.val_b.handle, jd.val_c.handle, ext[0].handle, ext[1].handle, len(ext[0]), len(ext[1]),
+                 idx.ctypes.data_as(U), C.cast(g2buf, C.POINTER(C.c_uint8)), len(g2))
+    cap = max(2 * max(len(r1cs.z), len(jd.row_index)) + 4, 4).bit_length() + 3
+    m = [np.zeros((cap, 8), dtype=np.uint64) for _ in range(3)]
+    cap_folds = 4 * cap
+    fc = np.zeros((cap_folds, 18), dtype=np.uint64)
+    fe = np.zeros((cap_folds, 8), dtype=np.uint64)
+    P = ProofRec()
+    for k in range(3):
+        P.messages[k] = m[k].ctypes.data_as(U)
+    P.cap_folds = cap_folds
+    P.fold_commitments = fc.ctypes.data_as(U)
+    P.fold_evaluations = fe.ctypes.data_as(U)
+    capi.check(capi.load().gm_psnark_new_time(C.byref(I), C.c_uint64(ck.powers_of_g.handle), C.c_int(int(default_group_encoding())), C.c_size_t(cap),
+                                              C.byref(P)))
+    A = lambda a: np.array(a, dtype=np.uint64)  # noqa: E731
+    msgs = lambda k: [(m[k][i, :4].copy(), m[k][i, 4:].copy()) for i in range(P.rounds[k])]  # noqa: E731
+    ff = lambda rec: [(A(rec)[:4].copy(), A(rec)[4:].copy())]  # noqa: E731
+    prods = [A(P.products[k]) for k in range(9)]
+    nf = P.nfold
+    tc = TensorcheckProof([fc[i].copy() for i in range(nf)], [fe[i].reshape(2, 4).copy() for i in range(nf)], A(P.evaluation_proof),
+                          [A(P.base_evaluations[k]).reshape(3, 4) for k in range(22)])
+    ep = EntryProductMsgs([A(P.acc_v_commitments[k]) for k in range(9)], [A(P.claimed_sumchecks[k]) for k in range(9)])
+    third_ff = []
+    for j in range(13):
+        r = A(P.third_final_foldings[j])
+        third_ff.append((r[:4].copy(), r[4:].copy()))
+    sc = [A(P.sorted_commitments[k]) for k in range(3)]
+    proof = Proof(
+        witness_commitment=A(P.witness_commitment), zc_alpha=A(P.zc_alpha), first_sumcheck_msgs=(msgs(0), ff(P.final_foldings[0])),
+        r_star_commitments=[A(P.r_star_commitments[k]) for k in range(3)], z_star_commitment=A(P.z_star_commitment),
+        second_sumcheck_msgs=(msgs(1), ff(P.final_foldings[1])),
+        set_r_ep=prods[0], subset_r_ep=prods[1], sorted_r_commitment=sc[0], set_alpha_ep=prods[3], subset_alpha_ep=prods[4],
+        sorted_alpha_commitment=sc[1], set_z_ep=prods[6], subset_z_ep=prods[7], sorted_z_commitment=sc[2], ep_msgs=ep,
+        ralpha_star_acc_mu_evals=[A(P.ralpha_star_acc_mu_evals[k]) for k in range(10)], ralpha_star_acc_mu_proof=A(P.ralpha_star_acc_mu_proof),
+        rstars_vals=[A(P.rstars_vals[0]), A(P.rstars_vals[1])], third_sumcheck_msgs=(msgs(2), third_ff), tensorcheck_proof=tc)
+    proof.spans = {name: P.spans[i] for i, name in enumerate(_PSNARK_SPANS)}
+    return proof

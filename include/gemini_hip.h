@@ -405,6 +405,54 @@ int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_stream, uint64
                          uint64_t zc_stream, uint64_t ck_bases, size_t max_msm_buffer, size_t min_device_chunk, int g1_encoding,
                          size_t cap_rounds, gm_snark_proof* proof);
 
+/* psnark::Proof::new_time(&ck, &r1cs, &index) (src/psnark/time_prover.rs:69-384) as one call: the preprocessing prover's
+ * orchestration -- three sumchecks (the third a 13-prover batch), three lookups with their nine entry products, ~25
+ * commitments, the 22-polynomial tensor check -- compiled into the library (gemini_amd/csrc/psnark.cpp).
+ * The instance record holds what depends on the R1CS only and is resident before the prover starts: the matrices, z and w,
+ * the joint support of A, B, C walked column-major (src/misc.rs:269-366) as index vectors (gm_idx_register) and as field
+ * vectors, the three value vectors over it, the extended-frequency index vectors of the row / column lookups
+ * (plookup/time_prover.rs:66-79), the five index commitments of Proof::index (:49-64) and the bytes the reference absorbs as
+ * b"ck" (the serialised G2 powers of the key).  All caller-owned arrays: messages (cap_rounds x 8 limbs each),
+ * fold_commitments (cap_folds x 18), fold_evaluations (cap_folds x 8).  products: the full products of the nine lookup
+ * vectors in the order r (set, subset, sorted), alpha (..), z (..).  Same bytes as gemini_amd/psnark.py (tests). */
+typedef struct gm_psnark_instance {
+  uint64_t a, b, c;                 /* gm_spm handles */
+  uint64_t z, w;                    /* vectors */
+  uint64_t row_index, col_index;    /* gm_idx handles over the joint support */
+  size_t nnz;
+  uint64_t row, col, val_a, val_b, val_c; /* vectors of length nnz */
+  uint64_t ext_fre_row, ext_fre_col;      /* gm_idx handles */
+  size_t ext_fre_row_len, ext_fre_col_len;
+  const uint64_t* index_commitments;      /* 5 x 18 limbs */
+  const uint8_t* ck_g2_bytes;
+  size_t ck_g2_len;
+} gm_psnark_instance;
+typedef struct gm_psnark_proof {
+  uint64_t witness_commitment[18];
+  uint64_t zc_alpha[4];
+  size_t rounds[3];
+  uint64_t* messages[3];
+  uint64_t final_foldings[2][8];        /* first and second sumcheck */
+  uint64_t third_final_foldings[13][8]; /* one (lhs, rhs) per prover of the batch */
+  uint64_t r_star_commitments[3][18];
+  uint64_t z_star_commitment[18];
+  uint64_t sorted_commitments[3][18];   /* r, alpha, z */
+  uint64_t products[9][4];
+  uint64_t acc_v_commitments[9][18];
+  uint64_t claimed_sumchecks[9][4];
+  uint64_t ralpha_star_acc_mu_evals[10][4];
+  uint64_t ralpha_star_acc_mu_proof[18];
+  uint64_t rstars_vals[2][4];
+  size_t nfold;
+  size_t cap_folds;
+  uint64_t* fold_commitments;
+  uint64_t* fold_evaluations;
+  uint64_t evaluation_proof[18];
+  uint64_t base_evaluations[22][12];
+  double spans[12];
+} gm_psnark_proof;
+int gm_psnark_new_time(const gm_psnark_instance* instance, uint64_t ck_bases, int g1_encoding, size_t cap_rounds, gm_psnark_proof* proof);
+
 #ifdef __cplusplus
 }
 #endif

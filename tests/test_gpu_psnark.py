@@ -134,6 +134,8 @@ def test_psnark_time_prover_random_r1cs(gm, oracle, pyref, n, seed):
     assert [jac_to_affine_ints(oracle, c) for c in index] == exp_index
     proof = Proof.new_time(ck, r1cs, index)
     _check_proof(gm, oracle, proof, exp)
+    native = Proof.new_time(ck, r1cs, index, native=True)  # gm_psnark_new_time: the same sequence compiled into the library
+    assert native == proof and native.serialize_uncompressed() == proof.serialize_uncompressed()
     # serialized size: fixed-size fields + the vectors (src/psnark/mod.rs:29-51)
     blob = proof.serialize_compressed()
     n_msgs = sum(len(getattr(proof, k)[0]) for k in ("first_sumcheck_msgs", "second_sumcheck_msgs", "third_sumcheck_msgs"))
@@ -423,5 +425,31 @@ def test_full_size_device_proof_is_accepted_by_the_reference_verifier(gm, oracle
     vk = V.VerifierKey.from_trapdoor(tau, 5)
     stub = {"x": [e], "z": range(n)}  # the verifier reads the public input and the number of variables only
     V.psnark_verify(psnark_proof_to_ints(gm, oracle, proof), stub, vk, [jac_to_affine_ints(oracle, c) for c in index], n)
+    r1cs.free()
+    ck.powers_of_g.free()
+
+
+@pytest.mark.parametrize("logn", [3, 6, 10, 16, 20])
+def test_native_psnark_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
+    """gm_psnark_new_time (src/psnark/time_prover.rs:69-384 compiled into the library, gemini_amd/csrc/psnark.cpp) against the
+    step-by-step driver of gemini_amd/psnark.py on dummy_r1cs(2^logn) with the example's key recipe plus one power
+    (examples/psnark.rs:70-81): the same proof, byte for byte, in both serialisation modes; same span names."""
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.psnark import Proof
+
+    n = 1 << logn
+    e = oracle.limbs_to_ints(oracle.random_fr(7100 + logn, 1))[0]
+    tau = oracle.limbs_to_ints(oracle.random_fr(7200 + logn, 1))[0]
+    r1cs = dummy_r1cs(e, n)
+    ck = CommitterKey.new(2 * n + 1, 5, oracle.ints_to_limbs([tau], 4)[0])
+    index = Proof.index(ck, r1cs)
+    stepwise = Proof.new_time(ck, r1cs, index)
+    native = Proof.new_time(ck, r1cs, index, native=True)
+    assert native == stepwise
+    for compress in (True, False):
+        assert native.serialize(compress, 0) == stepwise.serialize(compress, 0)
+    assert set(native.spans) == set(stepwise.spans)
+    assert Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() == native.serialize_compressed()  # no state left behind
     r1cs.free()
     ck.powers_of_g.free()

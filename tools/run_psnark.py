@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-i", "--instance-logsize", type=int, default=16)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--native", action="store_true", help="gm_psnark_new_time: the prover's orchestration compiled into the library (one call per proof)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/psnark.rs elastic_snark_main) instead of --time-prover")
     ap.add_argument("--verifiable-key", action="store_true", help="one more power than examples/psnark.rs:76 asks for: the reference's "
@@ -81,7 +82,7 @@ def main():
             proof = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20)
             stream.free()
         else:
-            proof = Proof.new_time(ck, r1cs, index)
+            proof = Proof.new_time(ck, r1cs, index, native=args.native)
         stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         out["proof_size_B"] = proof.compressed_size()
