@@ -42,6 +42,8 @@ def all_gather_u64(local: np.ndarray) -> np.ndarray:
     import torch
 
     dist = _dist()
+    if not dist.is_initialized():  # a single process: the "gather" of one rank
+        return np.ascontiguousarray(local, dtype=np.uint64)[None].copy()
     world = dist.get_world_size()
     loc_np = np.ascontiguousarray(local, dtype=np.uint64).view(np.int64).reshape(-1)
     dev = _device()
@@ -105,7 +107,7 @@ class ShardedTimeProver:
     def __init__(self, make_prover, f_local, g_local, twist_mont, lo: int, n_global: int):
         dist = _dist()
         self.make_prover = make_prover
-        self.world = dist.get_world_size()
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.n = n_global
         assert lo % 2 == 0
         self.local = make_prover(f_local, g_local, twist_mont)

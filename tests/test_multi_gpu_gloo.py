@@ -174,3 +174,28 @@ def test_cyclic_key_balance():
                 p0 = (n - 1 - first - r) % world
                 per.append(cyclic_count(total, p0, world))
             assert sum(per) == total and max(per) - min(per) <= 1
+
+
+def test_block_sharded_prover_field_work_scales_with_the_ranks():
+    """gemini_amd/dist_prover.py shards the FIELD arithmetic of `snark --time-prover` too.  Its device passes account the
+    field elements they read + write as they run, and the GPU suite holds that count equal to the pure model fr_work /
+    fr_work_sumcheck on 1, 2 and 4 ranks (tests/test_gpu_world2.py); here the model is evaluated where the metric is quoted:
+    at 2^24 constraints every rank of 2, 4, 8 does at most 1.1 x (the unsharded total / ranks), phase by phase within 1.25 x
+    (the gathered tails are the only replicated work)."""
+    from gemini_amd.dist_prover import BlockLayout, fr_work, fr_work_sumcheck
+
+    n = 1 << 24
+    single = fr_work(n, 1)
+    total = sum(single.values()) + 2 * fr_work_sumcheck(n, 1)
+    for g in (2, 4, 8):
+        per_rank = fr_work(n, g)
+        mine = sum(per_rank.values()) + 2 * fr_work_sumcheck(n, g)
+        assert mine <= 1.1 * total / g, (g, mine, total / g)
+        for phase, v in per_rank.items():
+            assert v <= 1.25 * single[phase] / g + 64, (g, phase, v, single[phase] / g)
+        L = BlockLayout(n, g - 1, g)
+        assert L.m == n // g and L.jmax == (L.m >> 10).bit_length() - 1  # levels with blocks of >= 2^10 elements stay sharded
+    # the key: 2 m powers per rank in per-level slices + the replicated prefix for the gathered levels
+    L = BlockLayout(n, 3, 8)
+    slices = sum(L.block_len(j) for j in range(L.jmax + 1)) + (n >> (L.jmax + 1))
+    assert slices <= 2 * L.m + 8 * 1024

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--tables", action="store_true", help="gm_g1_bases_precompute on the committer key before proving (13 x the key in HBM)")
     ap.add_argument("--min-device-chunk-log", type=int, default=None, help="CommitterKeyStream.min_device_chunk = 2^k (default: the class default)")
     ap.add_argument("--native", action="store_true", help="gm_snark_new_time / gm_snark_new_elastic: the prover's orchestration compiled into the library (one call per proof)")
+    ap.add_argument("--block-sharded", action="store_true", help="N ranks, field arithmetic sharded as well: every vector and the key in blocks "
+                    "(gemini_amd/dist_prover.py); the world size must be a power of two")
+    ap.add_argument("--tail-log", type=int, default=10, help="--block-sharded: blocks shorter than 2^k elements are gathered")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/snark.rs elastic_snark_main) instead of --time-prover")
     args = ap.parse_args()
@@ -54,11 +57,20 @@ def main():
     rng = np.random.default_rng(2022420)
     rnd = lambda: int.from_bytes(rng.bytes(40), "little") % gm.fr.R_MOD
     t0 = time.perf_counter()
-    r1cs = dummy_r1cs(rnd(), n)
+    e_inst = rnd()
+    if args.block_sharded:
+        from gemini_amd.dist_prover import BlockLayout, BlockShardedKey, R1csBlock
+
+        layout = BlockLayout(n, rank, world, args.tail_log)
+        r1cs = R1csBlock.dummy(e_inst, layout)
+    else:
+        r1cs = dummy_r1cs(e_inst, n)
     t_inst = time.perf_counter() - t0
     t0 = time.perf_counter()
     tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
-    if world > 1:
+    if args.block_sharded:
+        ck = BlockShardedKey.new(n, 5, tau, rank, world, args.tail_log)
+    elif world > 1:
         from gemini_amd.dist import ShardedCommitterKey
 
         ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
@@ -99,10 +111,16 @@ def main():
                 cks = CommitterKeyStream.from_committer_key(ck, min_device_chunk=None if args.min_device_chunk_log is None else 1 << args.min_device_chunk_log)
             proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log, native=args.native)
             stream.free()
+        elif args.block_sharded:
+            from gemini_amd.dist_prover import new_time_block_sharded
+
+            proof = new_time_block_sharded(r1cs, ck)
         else:
             proof = Proof.new_time(r1cs, ck, native=args.native)
         stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
+        if getattr(proof, "fr_work", None):
+            out["fr_work"] = proof.fr_work  # field elements this rank's device passes read + wrote (gemini_amd/dist_prover.py)
         out["proof_size_B"] = proof.compressed_size()  # examples/snark.rs:96 "proof-size {}B"
     key = "ark_gemini::snark::elastic_prover" if args.elastic else "ark_gemini::snark::time_prover"
     out["elastic_prover_s" if args.elastic else "time_prover_s"] = min(r[key] for r in out["runs"])
