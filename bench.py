@@ -76,7 +76,16 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
     t0 = time.perf_counter()
     tau_i = rnd()
     tau = np.array([(tau_i >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
-    if world > 1:
+    block_sharded = world > 1 and world & (world - 1) == 0 and n // world >= 1 << 12 and os.environ.get("GM_BENCH_SHARDING", "block") == "block"
+    if block_sharded:
+        # N ranks, a power of two: every vector of the prover and the key in blocks (gemini_amd/dist_prover.py) -- the field
+        # arithmetic is sharded as well as the MSMs
+        from gemini_amd.dist_prover import BlockLayout, BlockShardedKey, R1csBlock, new_time_block_sharded
+
+        r1cs.free()
+        r1cs = R1csBlock.dummy(e, BlockLayout(n, rank, world))
+        ck = BlockShardedKey.new(n, 5, tau, rank, world)
+    elif world > 1:
         from gemini_amd.dist import ShardedCommitterKey
 
         ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
@@ -92,7 +101,10 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         for _ in range(k):
             if world > 1:
                 dist.barrier()
-            p = Proof.new_time(r1cs, ck, native=(world == 1))  # one rank: gm_snark_new_time, the orchestration inside the library
+            if block_sharded:
+                p = new_time_block_sharded(r1cs, ck)
+            else:
+                p = Proof.new_time(r1cs, ck, native=(world == 1))  # one rank: gm_snark_new_time, the orchestration inside the library
             sp = dict(p.spans)
             if world > 1:  # the span of the slowest rank
                 t = torch.tensor([sp[SPAN]], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -145,7 +157,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
 
     # The key was registered with the library's default: fixed-base window tables when they fit (gm_set_auto_tables), so the
     # runs above ARE the default configuration.  The same prover on the plain path (no tables) beside it.
-    tab_c, tab_bytes = ck.powers_of_g.table_info() if world == 1 else (0, 0)
+    tab_c, tab_bytes = ck.powers_of_g.table_info() if world == 1 else (ck.level_keys[0].table_info() if block_sharded else (0, 0))
     tables = {"window_bits": tab_c, "table_bytes": tab_bytes, "built_at": "key registration (CommitterKey::new, outside the prover span)"}
     plain = None
     if world == 1 and tab_c:
@@ -156,7 +168,10 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         same = hashlib.sha256(pruns[-1][1].serialize_compressed()).hexdigest() == digest
         plain = {"value": round(pv[1], 4), "unit": "s", "runs_s": [round(v, 4) for v in pv], "same_proof_bytes": same}
     r1cs.free()
-    ck.powers_of_g.free()
+    if block_sharded:
+        ck.free()
+    else:
+        ck.powers_of_g.free()
 
     # CPU baseline of the SAME span: the C restatement of the reference's algorithm end to end (oracle/snark_c.py:
     # MSMs one OpenMP task per window like ark-ec, field passes and sumchecks single-threaded like the reference),
@@ -246,7 +261,9 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         "verifier": verdict,
         "proof_sha256": digest,
         "driver": "gm_snark_new_time (prover orchestration compiled into the library, gemini_amd/csrc/snark.cpp)" if world == 1
-                  else "gemini_amd/snark.py step by step over the sharded key",
+                  else ("gemini_amd/dist_prover.py: field arithmetic and key block-sharded over the ranks" if block_sharded
+                        else "gemini_amd/snark.py step by step over the element-cyclic sharded key (field arithmetic replicated)"),
+        "fr_work_rank0": getattr(runs[-1][1], "fr_work", None),
         "note": "median of 3 after one warm-up; instance (diagonal CSR) and SRS resident in HBM before the timer; proof elements equal the CPU "
                 "restatement at logn 3/6/9 (tests/test_gpu_snark.py)",
     }
