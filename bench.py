@@ -157,7 +157,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
 
     # The key was registered with the library's default: fixed-base window tables when they fit (gm_set_auto_tables), so the
     # runs above ARE the default configuration.  The same prover on the plain path (no tables) beside it.
-    tab_c, tab_bytes = ck.powers_of_g.table_info() if world == 1 else (ck.level_keys[0].table_info() if block_sharded else (0, 0))
+    tab_c, tab_bytes = ck.powers_of_g.table_info() if world == 1 else (ck.bases.table_info() if block_sharded else (0, 0))
     tables = {"window_bits": tab_c, "table_bytes": tab_bytes, "built_at": "key registration (CommitterKey::new, outside the prover span)"}
     plain = None
     if world == 1 and tab_c:

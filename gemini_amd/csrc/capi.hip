@@ -206,6 +206,7 @@ int msm_stream_add(Context* C, MsmStream* S, const void* bases_host, const void*
 int msm_stream_finalize(Context* C, MsmStream* S, uint64_t out_jac[18], size_t* pairs);
 int fr_fold(Context* C, FrVec* f, const uint64_t r[4], FrVec* out);
 int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out);
+int fr_powers_at(Context* C, const uint64_t x[4], size_t start, size_t n, uint8_t* out);
 int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out);
 int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out);
 int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]);
@@ -557,6 +558,23 @@ int gm_g1_msm_v_batch_partial(uint64_t bases_handle, size_t offset, int reversed
   return msm_run_batch(C, b, (int64_t)offset, reversed ? -1 : 1, ptrs.data(), 1, ns, k, false, out_jac);
 }
 
+int gm_g1_msm_v_batch_at(uint64_t bases_handle, const size_t* offsets, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
+                         int partial, uint64_t* out_jac) {
+  GM_CTX();
+  Bases* b = find_bases(bases_handle);
+  GM_CHECK(b != nullptr, GM_EHANDLE, "msm_v_batch_at: unknown bases handle %llu", (unsigned long long)bases_handle);
+  GM_CHECK(k == 0 || (offsets && vec_handles && ns && out_jac), GM_EINVAL, "msm_v_batch_at: null pointer");
+  std::vector<const void*> ptrs(k);
+  for (size_t j = 0; j < k; j++) {
+    FrVec* v = find_vec(vec_handles[j]);
+    GM_CHECK(v != nullptr, GM_EHANDLE, "msm_v_batch_at: unknown vector handle %llu", (unsigned long long)vec_handles[j]);
+    GM_CHECK(ns[j] <= v->len, GM_EINVAL, "msm_v_batch_at: %zu pairs from a vector of length %zu", ns[j], v->len);
+    GM_CHECK(offsets[j] <= ((size_t)1 << 62), GM_EINVAL, "msm_v_batch_at: offset %zu", offsets[j]);
+    ptrs[j] = v->d;
+  }
+  return msm_run_batch_offsets(C, b, offsets, reversed ? -1 : 1, ptrs.data(), 1, ns, k, partial == 0, out_jac);
+}
+
 int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
                 uint64_t out_jac[18]) {
   GM_CTX();
@@ -673,6 +691,39 @@ int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], si
   std::unique_ptr<Bases> b;
   if (!rc) rc = fixed_base_generate(C, base_affine, v->d, 1, n, b);
   if (v->d) (void)hipFree(v->d);
+  if (rc) return rc;
+  if ((rc = bases_build_phi(C, b.get()))) return rc;
+  if ((rc = maybe_auto_tables(C, b.get()))) return rc;
+  *handle = put_bases(std::move(b));
+  return GM_OK;
+}
+
+int gm_g1_srs_register_segments(const uint64_t base_affine[12], const uint64_t tau[4], const size_t* starts, const size_t* counts, size_t nseg,
+                                uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(base_affine && tau && handle && (nseg == 0 || (starts && counts)), GM_EINVAL, "srs_register_segments: null pointer");
+  size_t n = 0;
+  for (size_t s = 0; s < nseg; s++) {
+    GM_CHECK(counts[s] <= ((size_t)1 << 40) && n + counts[s] >= n, GM_EINVAL, "srs_register_segments: segment %zu has %zu powers", s, counts[s]);
+    n += counts[s];
+  }
+  // the exponents' images on device: segment s = tau^starts[s] * (1, tau, tau^2, ...), then one fixed-base pass over all of them
+  auto v = std::make_unique<FrVec>();
+  v->cap = n;
+  if (n) GM_HIP(dev_malloc((void**)&v->d, n * 32));
+  gmh::Fr t = gmh::Fr::from_canonical(tau);
+  uint64_t tm[4];
+  t.to_limbs(tm);
+  int rc = GM_OK;
+  size_t at = 0;
+  for (size_t s = 0; s < nseg && !rc; s++) {
+    rc = fr_powers_at(C, tm, starts[s], counts[s], v->d + at * 32);
+    at += counts[s];
+  }
+  std::unique_ptr<Bases> b;
+  if (!rc) rc = fixed_base_generate(C, base_affine, v->d, 1, n, b);
+  if (v->d) (void)hipFree(v->d);
+  v->d = nullptr;
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
   if ((rc = maybe_auto_tables(C, b.get()))) return rc;

@@ -269,5 +269,8 @@ int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const v
             bool normalize, uint64_t out_jac[18]);
 int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, const void* const* d_scalars, int mont, const size_t* ns,
                   size_t k, bool normalize, uint64_t* out_jac);
+// call j walks the bases from index pair_offsets[j] (step +1) or DOWN from it (step -1)
+int msm_run_batch_offsets(Context* C, const Bases* bases, const size_t* pair_offsets, int64_t step, const void* const* d_scalars, int mont,
+                          const size_t* ns, size_t k, bool normalize, uint64_t* out_jac);
 
 }  // namespace gm

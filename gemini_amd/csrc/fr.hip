@@ -167,11 +167,11 @@ __global__ __launch_bounds__(256) void k_fold(const uint8_t* __restrict__ f, siz
 }
 
 // out[i] = x^i: wave tiles of 64 * K elements, lane-strided inside the tile      misc.rs:59-65
-__global__ __launch_bounds__(256) void k_powers(PowTable xt, size_t n, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_powers(PowTable xt, size_t start, size_t n, uint8_t* __restrict__ out) {
   const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  Fr cur = pow_from_table(xt, t);
+  Fr cur = pow_from_table(xt, start + t);
   Fr step = pow_from_table(xt, T);
   for (size_t i = t; i < n; i += T) {
     fp_store<FrParams>(out + i * FR_BYTES, cur);
@@ -1092,10 +1092,22 @@ int fr_powers(Context* C, const uint64_t x[4], size_t n, FrVec* out) {
   GM_CHECK(out->cap >= n, GM_EINVAL, "powers: output capacity %zu < %zu", out->cap, n);
   PowTable t;
   make_pow_table(gmh::Fr::from_limbs(x), t);
-  if (n) hipLaunchKernelGGL(k_powers, dim3(grid_for(n, 512)), dim3(256), 0, C->stream, t, n, out->d);
+  if (n) hipLaunchKernelGGL(k_powers, dim3(grid_for(n, 512)), dim3(256), 0, C->stream, t, (size_t)0, n, out->d);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
   out->len = n;
+  return GM_OK;
+}
+
+// out[i] = x^(start + i), i < n, into raw device memory (the segments of a block-sharded key); start + n < 2^40
+int fr_powers_at(Context* C, const uint64_t x[4], size_t start, size_t n, uint8_t* out) {
+  GM_FR_LOCK(C);
+  GM_CHECK(start < ((size_t)1 << 39) && n < ((size_t)1 << 39), GM_EINVAL, "powers_at: exponent range [%zu, %zu + %zu)", start, start, n);
+  PowTable t;
+  make_pow_table(gmh::Fr::from_limbs(x), t);
+  if (n) hipLaunchKernelGGL(k_powers, dim3(grid_for(n, 512)), dim3(256), 0, C->stream, t, start, n, out);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
 

@@ -1485,6 +1485,10 @@ int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, c
                   size_t k, bool normalize, uint64_t* out_jac) {
   return msm_run_batch_at(C, bases, first, step, nullptr, d_scalars, mont, ns, k, normalize, out_jac);
 }
+int msm_run_batch_offsets(Context* C, const Bases* bases, const size_t* pair_offsets, int64_t step, const void* const* d_scalars, int mont,
+                          const size_t* ns, size_t k, bool normalize, uint64_t* out_jac) {
+  return msm_run_batch_at(C, bases, 0, step, pair_offsets, d_scalars, mont, ns, k, normalize, out_jac);
+}
 // pair_offsets[j] (optional): call j starts at base first + step * pair_offsets[j]
 // firsts[j] (optional): call j starts at base firsts[j] instead of `first` (herring: even / odd halves of one array)
 static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64_t step, const size_t* pair_offsets, const void* const* d_scalars,

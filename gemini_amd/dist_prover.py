@@ -57,11 +57,14 @@ class BlockLayout:
 
 
 class BlockShardedKey:
-    """`CommitterKey` (src/kzg/time.rs:24-27) in per-level block slices: level_keys[j] holds powers [lo_j, lo_j + m / 2^j) of this
-    rank for j = 0 .. jmax, `prefix` the first n / 2^(jmax + 1) powers on every rank (the gathered levels)."""
+    """`CommitterKey` (src/kzg/time.rs:24-27) in per-level block slices, all in ONE registered key: segment j holds powers
+    [lo_j, lo_j + m / 2^j) of this rank for j = 0 .. jmax, the last segment the first n / 2^(jmax + 1) powers (the gathered levels,
+    the same on every rank).  One handle means one pipelined batch call serves MSMs of several levels (`commit`)."""
 
-    def __init__(self, layout: BlockLayout, level_keys, prefix, max_eval_points: int):
-        self.layout, self.level_keys, self.prefix = layout, level_keys, prefix
+    PREFIX = -1
+
+    def __init__(self, layout: BlockLayout, bases, offsets, counts, max_eval_points: int):
+        self.layout, self.bases, self.offsets, self.counts = layout, bases, offsets, counts
         self._max_eval_points = max_eval_points
 
     @classmethod
@@ -72,22 +75,20 @@ class BlockShardedKey:
         L = BlockLayout(n_poly, rank, world, tail_log)
         g = g1_generator_mont() if g_affine is None else g_affine
         tau_l = np.asarray(tau_canonical, dtype=np.uint64).reshape(4)
-        tau = sum(int(v) << (64 * i) for i, v in enumerate(tau_l))
-        lim = lambda v: np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)  # noqa: E731
+        starts = [L.lo(j) for j in range(L.jmax + 1)] + [0]
+        counts = [L.block_len(j) for j in range(L.jmax + 1)] + [max(L.n >> (L.jmax + 1), 1)]
+        offsets = [int(v) for v in np.concatenate([[0], np.cumsum(counts)[:-1]])]
+        return cls(L, G1Bases.srs_segments(g, tau_l, starts, counts), offsets, counts, max_eval_points)
 
-        def slice_key(start: int, count: int):
-            first = G1Bases.fixed_base(g, np.array([lim(pow(tau, start, R_MOD))], dtype=np.uint64))
-            base = first.download()[0]
-            first.free()
-            return G1Bases.srs(base, tau_l, count)
-
-        levels = [slice_key(L.lo(j), L.block_len(j)) for j in range(L.jmax + 1)]
-        prefix = slice_key(0, max(L.n >> (L.jmax + 1), 1))
-        return cls(L, levels, prefix, max_eval_points)
+    def commit(self, levels, vecs, partial: bool = True) -> np.ndarray:
+        """MSMs of vecs[i] against the slice of level levels[i] (PREFIX: the replicated prefix), one pipelined batch; (k, 18).
+        A vector longer than its slice is cut (the quotient of a block with its carry appended never is)."""
+        offs = [self.offsets[lv] for lv in levels]
+        ns = [min(len(v), self.counts[lv]) for lv, v in zip(levels, vecs)]
+        return self.bases.msm_vec_batch_at(vecs, ns, offs, partial=partial)
 
     def free(self):
-        for k in self.level_keys + [self.prefix]:
-            k.free()
+        self.bases.free()
 
 
 class R1csBlock:
@@ -259,7 +260,7 @@ def new_time_block_sharded(r1cs: R1csBlock, key: BlockShardedKey):
     spans["product_matrix_vector x3"] = time.perf_counter() - t0
     transcript = Transcript(PROTOCOL_NAME)
     t0 = time.perf_counter()
-    part = key.level_keys[0].msm_vec_batch([r1cs.w], [len(r1cs.w)], partial=True)[0]  # ck.commit(&r1cs.w) :42
+    part = key.commit([0], [r1cs.w])[0]  # ck.commit(&r1cs.w) :42
     witness_commitment = g1_sum(all_gather_u64(part))
     spans["Commitment to w"] = time.perf_counter() - t0
     transcript.append_g1(b"witness", witness_commitment)
@@ -329,13 +330,14 @@ def new_time_block_sharded(r1cs: R1csBlock, key: BlockShardedKey):
         else:
             small.append(nxt)
         cur = nxt
-    # commitments: the sharded levels against their key slices (un-normalised partials, one all-gather), the small ones replicated
-    parts = np.stack([key.level_keys[j].msm_vec_batch([blk], [len(blk)], partial=True)[0] for j, blk in enumerate(sharded, start=1)]) \
-        if sharded else np.empty((0, 18), dtype=np.uint64)
-    gathered = all_gather_u64(parts) if len(parts) else None
-    commitments = [g1_sum(gathered[:, i]) for i in range(len(sharded))]
-    if small:
-        commitments += list(key.prefix.msm_vec_batch(small, [min(len(v), len(key.prefix)) for v in small]))
+    # commitments: one pipelined batch over the sharded levels (against their key slices) and the small ones (against the
+    # replicated prefix), un-normalised; one all-gather for the sharded ones
+    parts = key.commit(list(range(1, len(sharded) + 1)) + [key.PREFIX] * len(small), sharded + small)
+    commitments = []
+    if sharded:
+        gathered = all_gather_u64(parts[: len(sharded)])
+        commitments = [g1_sum(gathered[:, i]) for i in range(len(sharded))]
+    commitments += [g1_sum(parts[len(sharded) + i].reshape(1, 18)) for i in range(len(small))]
     for cm in commitments:
         transcript.append_g1(b"commitment", cm)
     eval_chal = transcript.get_challenge(b"evaluation-chal")
@@ -368,7 +370,7 @@ def new_time_block_sharded(r1cs: R1csBlock, key: BlockShardedKey):
     oi = I(open_chal)
     # the opening: sum_i eta_i commit(p_i div Z), p_0 = w, p_i = level i.  Per polynomial: the carry, one division, one MSM against the
     # level's key slice; the eta_i are applied to the (normalised) partial points in one tiny MSM, not to the vectors
-    my_points, my_etas = [], []
+    quots, q_levels, q_idx = [], [], []
     for i, blk in enumerate(blocks):
         Lb = m >> i
         if r < g - 1:  # the carry from the blocks above: the degree < 3 polynomial with S_r's values at the roots
@@ -377,13 +379,12 @@ def new_time_block_sharded(r1cs: R1csBlock, key: BlockShardedKey):
         q, _ = div_vanishing(blk, pts)
         acct.add("opening", 3 * len(blk), len(q))
         if len(q):
-            pt = g1_sum(key.level_keys[i].msm_vec_batch([q], [len(q)], partial=True))  # normalised: Z = 1 or the identity
-            if any(pt[12:]):  # not the identity
-                my_points.append(pt[:12])
-                my_etas.append(np.array([(pow(oi, i, R_MOD) >> (64 * t)) & (2**64 - 1) for t in range(4)], dtype=np.uint64))
-        q.free()
-    mine = VariableBaseMSM.msm_bigint(np.stack(my_points), np.stack(my_etas)) if my_points else g1_zero()
-    pieces = [all_gather_u64(mine)]
+            quots.append(q)
+            q_levels.append(i)
+            q_idx.append(i)
+        else:
+            q.free()
+    comb_at = None
     if small:
         etas = np.stack([F(pow(oi, len(blocks) + i, R_MOD)) for i in range(len(small))])
         comb = linear_combination(small, etas)
@@ -391,9 +392,24 @@ def new_time_block_sharded(r1cs: R1csBlock, key: BlockShardedKey):
         if len(comb) > 3:
             q, _ = div_vanishing(comb, pts)
             acct.add("opening", 3 * len(comb), len(q))
-            pieces.append(key.prefix.msm_vec(q, n=min(len(q), len(key.prefix))).reshape(1, 18))
-            q.free()
+            comb_at = len(quots)
+            quots.append(q)
+            q_levels.append(key.PREFIX)
         comb.free()
+    # every quotient through one pipelined batch; normalised one by one (Z = 1 or the identity) for the tiny eta-MSM
+    qparts = key.commit(q_levels, quots) if quots else np.empty((0, 18), dtype=np.uint64)
+    for q in quots:
+        q.free()
+    my_points, my_etas = [], []
+    for t, i in enumerate(q_idx):
+        pt = g1_sum(qparts[t].reshape(1, 18))
+        if any(pt[12:]):  # not the identity
+            my_points.append(pt[:12])
+            my_etas.append(np.array([(pow(oi, i, R_MOD) >> (64 * w_)) & (2**64 - 1) for w_ in range(4)], dtype=np.uint64))
+    mine = VariableBaseMSM.msm_bigint(np.stack(my_points), np.stack(my_etas)) if my_points else g1_zero()
+    pieces = [all_gather_u64(mine)]
+    if comb_at is not None:
+        pieces.append(qparts[comb_at].reshape(1, 18))
     evaluation_proof = g1_sum(np.concatenate([p.reshape(-1, 18) for p in pieces]))
     for v in blocks + small + [body, abc, z_a, z_b, z_c]:
         v.free()

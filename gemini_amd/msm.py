@@ -53,6 +53,18 @@ class G1Bases:
                                                   C.c_size_t(n), C.byref(h)))
         return cls(h.value, n)
 
+    @classmethod
+    def srs_segments(cls, base_affine: np.ndarray, tau_canonical: np.ndarray, starts, counts) -> "G1Bases":
+        """segment s = tau^(starts[s] + i) * g, i < counts[s], back to back in one handle (gm_g1_srs_register_segments)"""
+        capi.ensure_init()
+        st = np.array(starts, dtype=np.uintp)
+        ct = np.array(counts, dtype=np.uintp)
+        h = C.c_uint64()
+        capi.check(capi.load().gm_g1_srs_register_segments(capi.ptr(capi.u64(base_affine).reshape(12)), capi.ptr(capi.u64(tau_canonical).reshape(4)),
+                                                           st.ctypes.data_as(C.POINTER(C.c_size_t)), ct.ctypes.data_as(C.POINTER(C.c_size_t)),
+                                                           C.c_size_t(len(st)), C.byref(h)))
+        return cls(h.value, int(ct.sum()))
+
     def table_info(self):
         """(window width, bytes) of the fixed-base tables of this handle; (0, 0) without tables"""
         c, b = C.c_int(0), C.c_size_t(0)
@@ -103,6 +115,20 @@ class G1Bases:
         fn = capi.load().gm_g1_msm_v_batch_partial if partial else capi.load().gm_g1_msm_v_batch
         capi.check(fn(C.c_uint64(self.handle), C.c_size_t(offset), C.c_int(int(reversed_)), capi.ptr(handles),
                                                  nn.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(k), capi.ptr(out)))
+        return out
+
+    def msm_vec_batch_at(self, vecs, ns, offsets, reversed_: bool = False, partial: bool = False) -> np.ndarray:
+        """k MSMs, vector j's first ns[j] elements against bases[offsets[j] ...] (gm_g1_msm_v_batch_at); returns (k, 18)"""
+        k = len(vecs)
+        out = np.empty((k, 18), dtype=np.uint64)
+        if k == 0:
+            return out
+        handles = np.array([v.handle for v in vecs], dtype=np.uint64)
+        nn = np.array(ns, dtype=np.uintp)
+        off = np.array(offsets, dtype=np.uintp)
+        capi.check(capi.load().gm_g1_msm_v_batch_at(C.c_uint64(self.handle), off.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_int(int(reversed_)),
+                                                    capi.ptr(handles), nn.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(k),
+                                                    C.c_int(int(partial)), capi.ptr(out)))
         return out
 
     def free(self):

@@ -117,6 +117,12 @@ int gm_g1_msm_v_batch(uint64_t bases_handle, size_t offset, int reversed, const 
 int gm_g1_msm_v_batch_partial(uint64_t bases_handle, size_t offset, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
                               uint64_t* out_jac);
 
+/* The same with a base offset PER CALL: call j pairs vector j with bases[offsets[j] ...] (reversed: walking down from it).
+ * One key that holds several ranges of powers back to back -- the per-level slices of a block-sharded key
+ * (gm_g1_srs_register_segments) -- serves every level through one pipelined batch.  partial != 0: un-normalised results. */
+int gm_g1_msm_v_batch_at(uint64_t bases_handle, const size_t* offsets, int reversed, const uint64_t* vec_handles, const size_t* ns, size_t k,
+                         int partial, uint64_t* out_jac);
+
 /* Same, raw device pointer to n x 32-byte scalars already in HBM (mont != 0: Montgomery form).
  * This is the entry bench.py times: inputs resident, result = 144 bytes. */
 int gm_g1_msm_d(uint64_t bases_handle, size_t offset, int reversed, const void* d_scalars, int mont, size_t n,
@@ -165,6 +171,11 @@ int gm_host_free(void* p);
 int gm_g1_fixed_base_register(const uint64_t base_affine[12], const uint64_t* scalars, size_t n, uint64_t* handle);
 /* powers_of_g[i] = tau^i * g for i < n, entirely on device (tau canonical). */
 int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], size_t n, uint64_t* handle);
+/* Several ranges of the same powers back to back in ONE handle: segment s = tau^(starts[s] + i) * g, i < counts[s]
+ * (exponents below 2^39).  What a rank of a block-sharded prover holds of CommitterKey::powers_of_g (src/kzg/time.rs:24-27):
+ * its block of every folding level, addressed by gm_g1_msm_v_batch_at. */
+int gm_g1_srs_register_segments(const uint64_t base_affine[12], const uint64_t tau[4], const size_t* starts, const size_t* counts, size_t nseg,
+                                uint64_t* handle);
 
 /* Tuning knob (0 = automatic): window width c of the bucket method.  The result does not depend
  * on it (tests sweep it). */

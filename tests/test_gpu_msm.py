@@ -355,6 +355,44 @@ def test_batch_msm_equals_single_calls(gm, oracle):
     b.free()
 
 
+def test_segmented_srs_and_batch_with_offsets(gm, oracle, pyref):
+    """gm_g1_srs_register_segments: ranges of tau^i g back to back in one handle (a rank's slices of
+    CommitterKey::powers_of_g, src/kzg/time.rs:24-27) == the same ranges of the plain key;
+    gm_g1_msm_v_batch_at: call j against bases[offsets[j] ...] == single calls with that offset, normalised or not"""
+    from gemini_amd.fr import FrVec
+
+    g = oracle.g1_generator()
+    tau = oracle.random_fr(71, 1)[0]
+    plain = gm.G1Bases.srs(g, tau, 1200)
+    starts, counts = [512, 0, 1000, 7, 256], [300, 0, 200, 1, 128]
+    seg = gm.G1Bases.srs_segments(g, tau, starts, counts)
+    try:
+        assert len(seg) == sum(counts)
+        whole = plain.download()
+        got = seg.download()
+        at = 0
+        for s0, c0 in zip(starts, counts):
+            assert (got[at:at + c0] == whole[s0:s0 + c0]).all()
+            at += c0
+        offs = [0, 300, 500, 501, 300]
+        ns = [300, 200, 1, 128, 57]
+        vecs = [FrVec.from_host(oracle.fr_to_mont(oracle.random_fr(80 + j, m))) for j, m in enumerate(ns)]
+        single = [seg.msm_vec(v, n=m, offset=o) for v, m, o in zip(vecs, ns, offs)]
+        norm = seg.msm_vec_batch_at(vecs, ns, offs)
+        assert all((norm[j] == single[j]).all() for j in range(len(ns)))
+        part = seg.msm_vec_batch_at(vecs, ns, offs, partial=True)
+        assert all(oracle.g1_jac_eq(part[j], single[j]) for j in range(len(ns)))
+        # and against the plain key's own range: segment 2 = powers 1000 .. 1199
+        assert (plain.msm_vec(vecs[1], n=200, offset=1000) == single[1]).all()
+        with pytest.raises(gm.capi.GeminiHipError):
+            seg.msm_vec_batch_at(vecs[:1], [300], [400])  # runs past the end of the key
+        for v in vecs:
+            v.free()
+    finally:
+        seg.free()
+        plain.free()
+
+
 def _set_levels(gm, k):
     import ctypes as C
 
