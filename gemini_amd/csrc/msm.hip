@@ -1123,22 +1123,25 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
     acc30_load(v, in + slot * XYZZ30_BYTES);
     acc30_add(acc, v);
   };
+  // the first element of a lane is LOADED, not added to the identity: one addition less on the dependent chain of the
+  // latency-bound levels (6 -> 5 and 5 -> 4 additions of a lone wave, ~20 us each)
   if (o < a.n_out) {
     const uint32_t w = o / a.per_win, r = o % a.per_win;
     const size_t base = (size_t)w * a.win_stride;
     if (a.mode == GS_STRIDED) {
       const size_t b0 = base + (size_t)(r / a.n_lo) * a.s_hi + (size_t)(r % a.n_lo) * a.s_lo;
-      for (uint32_t e = q; e < a.len; e += lpo) add_rec(b0 + (size_t)e * a.s_e);
+      if (q < a.len) acc30_load(acc, in + (b0 + (size_t)q * a.s_e) * XYZZ30_BYTES);
+      for (uint32_t e = q + lpo; e < a.len; e += lpo) add_rec(b0 + (size_t)e * a.s_e);
     } else {
       const uint32_t nb = a.nb;
       if (r == nb) {  // total
-        for (uint32_t e = q; e < (1u << nb); e += lpo) add_rec(base + e);
+        if (q < (1u << nb)) acc30_load(acc, in + (base + q) * XYZZ30_BYTES);
+        for (uint32_t e = q + lpo; e < (1u << nb); e += lpo) add_rec(base + e);
       } else {        // elements whose bit r is set
         const uint32_t half = nb ? (1u << (nb - 1)) : 0u;
-        for (uint32_t e = q; e < half; e += lpo) {
-          uint32_t v = ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u));
-          add_rec(base + v);
-        }
+        auto slot_of = [&](uint32_t e) { return ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u)); };
+        if (q < half) acc30_load(acc, in + (base + slot_of(q)) * XYZZ30_BYTES);
+        for (uint32_t e = q + lpo; e < half; e += lpo) add_rec(base + slot_of(e));
       }
     }
   }
