@@ -2291,8 +2291,11 @@ int msm_stream_add(Context* C, MsmStream* S, const void* bases_host, const void*
   while (n && !rc) {
     MsmStreamSlot& sl = S->s[S->cur];
     if ((rc = msm_stream_drain(C, S, sl))) break;  // the MSM that reads this slot's buffers
+    // a failing runtime call must not return from inside the loop: the drain + reset below are what keeps the invariant
+    // "nothing of this stream stays on the shared lanes" when an MSM of an earlier slot is still in flight
+    auto hip_rc = [&](hipError_t e, const char* what) { return e == hipSuccess ? GM_OK : hip_fail(e, what, __FILE__, __LINE__); };
     if (!sl.have_ev) {
-      GM_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+      if ((rc = hip_rc(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreateWithFlags(stream slot)"))) break;
       sl.have_ev = true;
     }
     if (!sl.scalars) {
@@ -2303,8 +2306,10 @@ int msm_stream_add(Context* C, MsmStream* S, const void* bases_host, const void*
       }
     }
     const size_t take = std::min(n, S->chunk - S->fill);
-    if (own_bases) GM_HIP(hipMemcpyAsync(sl.raw + S->fill * S->stride, bp, take * S->stride, hipMemcpyHostToDevice, S->copy));
-    GM_HIP(hipMemcpyAsync(sl.scalars + S->fill * 32, sp, take * 32, hipMemcpyHostToDevice, S->copy));
+    if (own_bases &&
+        (rc = hip_rc(hipMemcpyAsync(sl.raw + S->fill * S->stride, bp, take * S->stride, hipMemcpyHostToDevice, S->copy), "hipMemcpyAsync(stream bases)")))
+      break;
+    if ((rc = hip_rc(hipMemcpyAsync(sl.scalars + S->fill * 32, sp, take * 32, hipMemcpyHostToDevice, S->copy), "hipMemcpyAsync(stream scalars)"))) break;
     S->fill += take;
     n -= take;
     if (own_bases) bp += take * S->stride;
@@ -2338,6 +2343,7 @@ int msm_stream_finalize(Context* C, MsmStream* S, uint64_t out_jac[18], size_t* 
   return rc;
 }
 
+void hg1_destroy(Context* C, HerringG1* H);
 int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const uint64_t* g_mont, size_t ng, const uint64_t twist[4],
                uint64_t* handle) {
   GM_CHECK(nf >= 1 && ng >= 1, GM_EINVAL, "herring G1 prover: empty vectors");
@@ -2349,12 +2355,22 @@ int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const 
   H->ng = ng;
   H->f[0] = b->d;  // take ownership of the packed copy
   b->d = nullptr;
-  GM_HIP(dev_malloc((void**)&H->f[1], ((nf + 1) / 2) * AFF_BYTES));
-  if ((rc = C->pool.alloc(ng * 32, (void**)&H->g[0], &H->gcap[0]))) return rc;
-  if ((rc = C->pool.alloc(((ng + 1) / 2) * 32, (void**)&H->g[1], &H->gcap[1]))) return rc;
-  if ((rc = C->pool.alloc(3 * ((((ng + 1) / 2) + 1) * 32), (void**)&H->tmp, &H->tmpcap))) return rc;  // three compacted scalar vectors
-  GM_HIP(hipMemcpyAsync(H->g[0], g_mont, ng * 32, hipMemcpyHostToDevice, C->stream));
-  GM_HIP(hipStreamSynchronize(C->stream));
+  auto fail = [&](int code) {  // what has been allocated so far goes back
+    hg1_destroy(C, H.get());
+    return code;
+  };
+  {
+    hipError_t e = dev_malloc((void**)&H->f[1], ((nf + 1) / 2) * AFF_BYTES);
+    if (e != hipSuccess) return fail(hip_fail(e, "dev_malloc(herring G1 fold buffer)", __FILE__, __LINE__));
+  }
+  if ((rc = C->pool.alloc(ng * 32, (void**)&H->g[0], &H->gcap[0]))) return fail(rc);
+  if ((rc = C->pool.alloc(((ng + 1) / 2) * 32, (void**)&H->g[1], &H->gcap[1]))) return fail(rc);
+  if ((rc = C->pool.alloc(3 * ((((ng + 1) / 2) + 1) * 32), (void**)&H->tmp, &H->tmpcap))) return fail(rc);  // three compacted scalar vectors
+  {
+    hipError_t e = hipMemcpyAsync(H->g[0], g_mont, ng * 32, hipMemcpyHostToDevice, C->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync(herring G1 scalars)", __FILE__, __LINE__));
+  }
   memcpy(H->twist, twist, 32);
   size_t mn = nf < ng ? nf : ng;
   H->tot_rounds = (size_t)ceil_log2_sz(mn);  // Witness::required_rounds: log2(min(len)) (time_prover.rs:36-39)

@@ -175,7 +175,10 @@ def g1_serialize(jac, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS) -> 
     return bytes(out)
 
 
-def g1_deserialize(buf: bytes, pos: int, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS, validate: bool = True):
+def g1_deserialize(buf: bytes, pos: int, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS, validate: bool = True, strict: bool = False):
+    """strict = False accepts what ark-ec 0.4's `Affine::deserialize_with_mode` accepts (recalled, like the layouts: the crate is
+    not in /root/reference): the infinity flag wins over whatever the coordinate bytes hold, and the y-sign flag of an
+    UNCOMPRESSED point is not compared with y.  strict = True rejects both (the canonical encoding only)."""
     n = g1_size(compress)
     if pos + n > len(buf):
         raise WireError("not enough bytes for a G1 point")
@@ -198,7 +201,7 @@ def g1_deserialize(buf: bytes, pos: int, compress: bool, enc: G1Encoding = G1Enc
         x = int.from_bytes(raw[:48], "big")
         y = None if compress else int.from_bytes(raw[48:], "big")
     if inf:
-        if x or y:
+        if strict and (x or y):
             raise WireError("G1 point at infinity with non-zero coordinates")
         return g1_from_affine_ints(None), pos + n
     if compress:
@@ -209,7 +212,7 @@ def g1_deserialize(buf: bytes, pos: int, compress: bool, enc: G1Encoding = G1Enc
             raise WireError("G1 x coordinate is not on the curve")
         if _y_is_larger(y) != larger:
             y = (Q_MOD - y) % Q_MOD
-    elif enc == G1Encoding.ARKWORKS and validate and _y_is_larger(y) != larger:
+    elif enc == G1Encoding.ARKWORKS and strict and _y_is_larger(y) != larger:
         raise WireError("G1 y-sign flag does not match y")
     _check_point(x, y, validate)
     return g1_from_affine_ints((x, y)), pos + n
