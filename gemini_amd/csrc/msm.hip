@@ -945,6 +945,109 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   pk[2 * (size_t)t + 1] = tail_key;
 }
 
+// The same accumulation with the gather of entry i + 1 IN FLIGHT during the addition of entry i (24 more registers).  On the
+// plain path the 96 B x n bases sit in the Infinity Cache and the wait is short; the fixed-base tables are 13 x that (1.3 GB
+// at 2^20 points, 38 GB at 2^25) and every gather is a random HBM access of ~1-2 us, a tenth of the addition it feeds.
+template <int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_acc0_pf(const uint64_t* __restrict__ entries,
+                                              const uint32_t* __restrict__ total_ptr,
+                                              const uint8_t* __restrict__ bases, long long first, long long step,
+                                              long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
+                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi) {
+  __shared__ uint64_t ebuf[8][256];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t total = *total_ptr;
+  const uint64_t start = (uint64_t)t * L;
+  uint32_t head_key = KEY_INV, tail_key = KEY_INV;
+  if (start < total) {
+    const uint64_t end = min(start + (uint64_t)L, total);
+    Acc30 acc;
+    acc30_zero(acc);
+    uint32_t cur = KEY_INV;
+    bool first_run = true;
+    // entry i of this lane (staged eight at a time through the transposed LDS image, as in k_acc0)
+    auto entry_at = [&](uint64_t i) {
+      const uint32_t k8 = (uint32_t)(i - start) & 7u;
+      if (k8 == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(entries + i);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const uint4 v = src[q];
+          ebuf[2 * q][threadIdx.x] = ((uint64_t)v.y << 32) | v.x;
+          ebuf[2 * q + 1][threadIdx.x] = ((uint64_t)v.w << 32) | v.z;
+        }
+      }
+      return ebuf[k8][threadIdx.x];
+    };
+    auto base_of = [&](uint64_t e) {
+      long long idx;
+      if (tab_stride) {
+        const uint32_t lo = (uint32_t)e & 0x7fffffffu;
+        idx = (long long)(lo >> ENTRY_W_SHIFT) * tab_stride + first + step * (long long)(lo & ((1u << ENTRY_W_SHIFT) - 1u));
+      } else {
+        idx = first + step * (long long)(e & 0x3fffffffull);
+      }
+      const uint8_t* src = (phi != nullptr && ((e >> ENTRY_HALF_SHIFT) & 1ull)) ? phi : bases;
+      return reinterpret_cast<const gm_u4v*>(src + (size_t)idx * AFF_BYTES);
+    };
+    uint64_t e = entry_at(start);
+    const gm_u4v* bp = base_of(e);
+    gm_u4v x0 = bp[0], x1 = bp[1], x2 = bp[2], y0 = bp[3], y1 = bp[4], y2 = bp[5];
+    for (uint64_t i = start; i < end; i++) {
+      uint64_t en = 0;
+      gm_u4v n0 = x0, n1 = x1, n2 = x2, n3 = y0, n4 = y1, n5 = y2;
+      if (i + 1 < end) {
+        // issued here, waited for after the addition.  The loads are asm so that the compiler can neither sink them below the
+        // statement nor wait for them in front of it; its own s_waitcnt bookkeeping stays safe (extra outstanding loads only
+        // make a vmcnt(k) wait longer, never shorter)
+        en = entry_at(i + 1);
+        const gm_u4v* np = base_of(en);
+        asm volatile(
+            "global_load_dwordx4 %0, %6, off\n\t"
+            "global_load_dwordx4 %1, %6, off offset:16\n\t"
+            "global_load_dwordx4 %2, %6, off offset:32\n\t"
+            "global_load_dwordx4 %3, %6, off offset:48\n\t"
+            "global_load_dwordx4 %4, %6, off offset:64\n\t"
+            "global_load_dwordx4 %5, %6, off offset:80"
+            : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(n4), "=&v"(n5)
+            : "v"(np));
+      }
+      const uint32_t key = (uint32_t)(e >> 32);
+      if (key != cur) {
+        if (cur != KEY_INV) {
+          if (first_run) {
+            head_key = cur;
+            acc30_store(pp + (size_t)(2 * (size_t)t) * XYZZ30_BYTES, acc);
+            first_run = false;
+          } else {
+            acc30_store(buckets + (size_t)cur * XYZZ30_BYTES, acc);  // interior run = whole bucket
+          }
+        }
+        cur = key;
+        acc30_set_identity(acc);
+      }
+      const uint32_t nz = x0.x | x0.y | x0.z | x0.w | x1.x | x1.y | x1.z | x1.w | x2.x | x2.y | x2.z | x2.w | y0.x | y0.y | y0.z | y0.w |
+                          y1.x | y1.y | y1.z | y1.w | y2.x | y2.y | y2.z | y2.w;
+      if (nz != 0) {  // not the identity base (0, 0)
+        const uint32_t neg = (uint32_t)(e >> 31) & 1u;
+        (void)g1_madd30_asm(acc, x0, x1, x2, y0, y1, y2, neg);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5));
+      e = en;
+      x0 = n0; x1 = n1; x2 = n2; y0 = n3; y1 = n4; y2 = n5;
+    }
+    if (first_run) {
+      head_key = cur;
+      acc30_store(pp + (size_t)(2 * (size_t)t) * XYZZ30_BYTES, acc);
+    } else {
+      tail_key = cur;
+      acc30_store(pp + (size_t)(2 * (size_t)t + 1) * XYZZ30_BYTES, acc);
+    }
+  }
+  pk[2 * (size_t)t] = head_key;
+  pk[2 * (size_t)t + 1] = tail_key;
+}
+
 #ifdef GM_EXPERIMENTS
 #include "msm_levels.inc"
 #endif
@@ -1777,7 +1880,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   pf.begin(part, PROF_ACC0, st);
   // dynamic LDS padding caps the blocks per CU: the kernel needs 162 VGPRs, so three waves per SIMD WOULD fit
   static const size_t acc0_lds_pad = getenv("GM_ACC0_LDS_PAD") ? (size_t)strtoull(getenv("GM_ACC0_LDS_PAD"), nullptr, 10) : 0;
-  if (acc0_waves == 2)
+  // gather of the next entry under the addition of this one: GM_ACC0_PREFETCH = 0 / 1 forces, default = on the table path
+  static const int acc0_pf_env = getenv("GM_ACC0_PREFETCH") ? atoi(getenv("GM_ACC0_PREFETCH")) : -1;
+  const bool acc0_pf = acc0_pf_env >= 0 ? acc0_pf_env != 0 : use_table;
+  if (acc0_pf)
+    hipLaunchKernelGGL(k_acc0_pf<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
+  else if (acc0_waves == 2)
     hipLaunchKernelGGL(k_acc0<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), acc0_lds_pad, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
                        acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
   else
