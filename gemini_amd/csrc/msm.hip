@@ -869,6 +869,9 @@ __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict_
 // (Round 2's kernel kept a canonical 12 x 32-bit accumulator and called an out-of-line multiplier: 2.58 ms against 2.13 ms
 // at 2^20 pairs, profiles/r3_ab_acc0_*.json.)
 // ------------------------------------------------------------------------------------------
+#ifdef GM_ACC0_CYCLES
+__device__ unsigned long long gm_acc0_dbg[4];
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_acc0(const uint64_t* __restrict__ entries,
                                               const uint32_t* __restrict__ total_ptr,
@@ -880,6 +883,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   const uint64_t total = *total_ptr;
   const uint64_t start = (uint64_t)t * L;
   uint32_t head_key = KEY_INV, tail_key = KEY_INV;
+#ifdef GM_ACC0_CYCLES
+  const uint64_t dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
   if (start < total) {
     const uint64_t end = min(start + (uint64_t)L, total);
     Acc30 acc;
@@ -943,6 +949,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   }
   pk[2 * (size_t)t] = head_key;
   pk[2 * (size_t)t + 1] = tail_key;
+#ifdef GM_ACC0_CYCLES
+  if ((threadIdx.x & 63) == 0) {  // per wave: shader cycles, 100 MHz ticks, waves (make EXTRA=-DGM_ACC0_CYCLES; tools/acc0_cycles.py)
+    atomicAdd(&gm_acc0_dbg[0], (unsigned long long)(clock64() - dbg_c0));
+    atomicAdd(&gm_acc0_dbg[1], (unsigned long long)(wall_clock64() - dbg_w0));
+    atomicAdd(&gm_acc0_dbg[2], 1ull);
+  }
+#endif
 }
 
 // The same accumulation with the gather of entry i + 1 IN FLIGHT during the addition of entry i (24 more registers).  On the
@@ -2659,3 +2672,20 @@ int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* 
 }
 
 }  // namespace gm
+
+#ifdef GM_ACC0_CYCLES
+// development build only (make EXTRA=-DGM_ACC0_CYCLES): shader cycles / 100 MHz ticks / waves summed over the k_acc0 launches
+// since the last reset -- tools/acc0_cycles.py turns them into the clock and the cycles per entry of the kernel itself
+extern "C" int gm_debug_acc0_cycles(uint64_t out[3], int reset) {
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(gm::gm_acc0_dbg), sizeof h) != hipSuccess) return 1;
+  out[0] = h[0];
+  out[1] = h[1];
+  out[2] = h[2];
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gm::gm_acc0_dbg), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
