@@ -371,6 +371,9 @@ def main():
     ms = (C.c_double * 7)()
     cnt = (C.c_uint64 * 7)()
     gm.capi.check(lib.gm_prof_read(ms, cnt, C.c_int(7)))
+    acc0_mhz = C.c_double(0.0)
+    gm.capi.check(lib.gm_prof_read_clock(C.byref(acc0_mhz)))  # clock64() / wall_clock64() inside k_acc0, over the timed steps
+    acc0_mhz = acc0_mhz.value
     gm.capi.check(lib.gm_prof_enable(C.c_int(0)))
 
     # extra (not the headline): the same MSM with fixed-base window tables for the resident SRS
@@ -545,6 +548,11 @@ def main():
                 "madd_per_s": round(16 * n / (acc0_ms * 1e-3)) if acc0_ms and args.logn == LOG_N else None,
                 "madd_issue_bound": MADD_ISSUE_BOUND,
                 "alu_frac": round(16 * n / (acc0_ms * 1e-3) / MADD_ISSUE_BOUND, 4) if acc0_ms and args.logn == LOG_N else None,
+                # the bound above is priced at the nominal 2.4 GHz; this is the clock the kernel actually ran at in the timed steps
+                # (read inside k_acc0: shader cycles against the constant 100 MHz counter) and the fraction at THAT clock
+                "shader_clock_mhz_in_kernel": round(acc0_mhz, 1) if acc0_mhz else None,
+                "alu_frac_at_measured_clock": round(16 * n / (acc0_ms * 1e-3) / (MADD_ISSUE_BOUND * acc0_mhz / 2400.0), 4)
+                if acc0_ms and acc0_mhz and args.logn == LOG_N else None,
             },
             "stage_ms": {k: (round(v, 4) if v is not None else None) for k, v in stages.items()},
         }

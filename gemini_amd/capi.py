@@ -24,7 +24,7 @@ SYMBOLS = [
     "gm_g1_msm", "gm_g1_bases_register", "gm_g1_bases_free", "gm_g1_bases_len", "gm_g1_bases_download", "gm_g1_bases_precompute", "gm_set_auto_tables", "gm_g1_bases_table_info", "gm_pool_trim",
     "gm_g1_msm_h", "gm_g1_msm_v", "gm_g1_msm_v_batch", "gm_g1_msm_v_batch_partial", "gm_g1_msm_v_batch_at", "gm_g1_msm_d", "gm_g1_msm_d_partial", "gm_g1_sum",
     "gm_g1_msm_stream_new", "gm_g1_msm_stream_new_h", "gm_g1_msm_stream_add", "gm_g1_msm_stream_finalize", "gm_g1_msm_stream_free", "gm_host_alloc", "gm_host_free",
-    "gm_g1_fixed_base_register", "gm_g1_srs_register", "gm_g1_srs_register_segments", "gm_set_msm_window", "gm_set_msm_table_min", "gm_set_msm_affine_levels", "gm_set_msm_split", "gm_set_msm_glv", "gm_prof_enable", "gm_prof_read",
+    "gm_g1_fixed_base_register", "gm_g1_srs_register", "gm_g1_srs_register_segments", "gm_set_msm_window", "gm_set_msm_table_min", "gm_set_msm_affine_levels", "gm_set_msm_split", "gm_set_msm_glv", "gm_prof_enable", "gm_prof_read", "gm_prof_read_clock",
     "gm_idx_register", "gm_idx_free", "gm_fr_gather", "gm_fr_alg_hash", "gm_fr_plookup_set", "gm_fr_add_scalar", "gm_fr_shift_monic",
     "gm_fr_acc_product",
     "gm_fr_vec_alloc", "gm_fr_vec_free", "gm_fr_vec_len", "gm_fr_vec_upload", "gm_fr_vec_download",

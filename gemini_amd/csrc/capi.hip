@@ -326,6 +326,13 @@ int gm_prof_enable(int on) {
     C->prof.count[s] = 0;
     C->prof.pending[0][s] = C->prof.pending[1][s] = false;
   }
+  C->prof.acc0_cycles = C->prof.acc0_ticks = 0;
+  return GM_OK;
+}
+int gm_prof_read_clock(double* acc0_mhz) {
+  GM_CTX();
+  GM_CHECK(acc0_mhz != nullptr, GM_EINVAL, "prof_read_clock: null pointer");
+  *acc0_mhz = C->prof.acc0_ticks > 0 ? C->prof.acc0_cycles / C->prof.acc0_ticks * 100.0 : 0.0;
   return GM_OK;
 }
 int gm_prof_read(double* ms_out, uint64_t* count_out, int n) {

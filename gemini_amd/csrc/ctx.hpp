@@ -166,6 +166,7 @@ struct MsmStream {
 constexpr int MSM_SMALL_LANES = 4;
 struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
+  DevBuf clk;  // {shader cycles, 100 MHz ticks} of the first wave of the last k_acc0 (read only while profiling: gm_prof_read_clock)
   DevBuf lvl_cnt, lvl_pos, lvl_pts[2], lvl_keys[2], lvl_prefix, lvl_lane, lvl_entries, lvl_n;  // affine tree levels
   uint64_t* host_planes[2] = {nullptr, nullptr};  // pinned staging for the D2H of window bit-planes (two calls in flight)
   size_t host_planes_cap[2] = {0, 0};
@@ -183,6 +184,7 @@ struct Profiler {
   bool pending[2][PROF_NSTAGES] = {};
   double ms[PROF_NSTAGES] = {};     // summed over calls AND over the window groups of a call
   uint64_t count[PROF_NSTAGES] = {};  // launches of the stage (a split call counts two)
+  double acc0_cycles = 0, acc0_ticks = 0;  // clock64() / wall_clock64() spans of k_acc0's first wave, summed over calls
   void begin(int part, int stage, hipStream_t st);
   void end(int part, int stage, hipStream_t st);
   void begin(int stage, hipStream_t st) { begin(0, stage, st); }

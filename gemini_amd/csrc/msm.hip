@@ -877,9 +877,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
                                               const uint32_t* __restrict__ total_ptr,
                                               const uint8_t* __restrict__ bases, long long first, long long step,
                                               long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
-                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi) {
+                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi,
+                                              unsigned long long* __restrict__ clk) {
   __shared__ uint64_t ebuf[8][256];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t clk_c0 = clock64(), clk_w0 = wall_clock64();  // the shader clock this launch ran at (lane 0 reports it)
   const uint64_t total = *total_ptr;
   const uint64_t start = (uint64_t)t * L;
   uint32_t head_key = KEY_INV, tail_key = KEY_INV;
@@ -949,6 +951,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   }
   pk[2 * (size_t)t] = head_key;
   pk[2 * (size_t)t + 1] = tail_key;
+  if (t == 0 && clk != nullptr) {
+    clk[0] = (unsigned long long)(clock64() - clk_c0);
+    clk[1] = (unsigned long long)(wall_clock64() - clk_w0);
+  }
 #ifdef GM_ACC0_CYCLES
   if ((threadIdx.x & 63) == 0) {  // per wave: shader cycles, 100 MHz ticks, waves (make EXTRA=-DGM_ACC0_CYCLES; tools/acc0_cycles.py)
     atomicAdd(&gm_acc0_dbg[0], (unsigned long long)(clock64() - dbg_c0));
@@ -966,9 +972,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
                                               const uint32_t* __restrict__ total_ptr,
                                               const uint8_t* __restrict__ bases, long long first, long long step,
                                               long long tab_stride, uint32_t L, uint32_t* __restrict__ pk,
-                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi) {
+                                              uint8_t* __restrict__ pp, uint8_t* __restrict__ buckets, const uint8_t* __restrict__ phi,
+                                              unsigned long long* __restrict__ clk) {
   __shared__ uint64_t ebuf[8][256];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t clk_c0 = clock64(), clk_w0 = wall_clock64();  // the shader clock this launch ran at (lane 0 reports it)
   const uint64_t total = *total_ptr;
   const uint64_t start = (uint64_t)t * L;
   uint32_t head_key = KEY_INV, tail_key = KEY_INV;
@@ -1059,6 +1067,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   }
   pk[2 * (size_t)t] = head_key;
   pk[2 * (size_t)t + 1] = tail_key;
+  if (t == 0 && clk != nullptr) {
+    clk[0] = (unsigned long long)(clock64() - clk_c0);
+    clk[1] = (unsigned long long)(wall_clock64() - clk_w0);
+  }
 }
 
 #ifdef GM_EXPERIMENTS
@@ -1216,14 +1228,22 @@ struct GroupSumJobs {
   GroupSumArgs j[3];
   uint32_t blk_end[3];  // cumulative block counts
   const uint32_t* err_src;  // last launch of a call: forward the scalar-range flag behind the plane sums
-  uint32_t* err_dst;
+  uint32_t* err_dst;         // ... and the clock readings of the call's k_acc0 (two 64-bit words at err_dst + 2)
+  const unsigned long long* clk_src;
 };
 
 // up to three independent jobs per launch so that passes of the same level overlap instead of
 // serialising their (latency-bound) depth.  Inputs and intermediate arrays are 208-byte loose records, sums run on the asm
 // addition (acc30_add); only the last launch of a call (out_canonical) writes the canonical 192-byte records the host reads.
 __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
-  if (J.err_dst && blockIdx.x == 0 && threadIdx.x == 0) *J.err_dst = *J.err_src;
+  if (J.err_dst && blockIdx.x == 0 && threadIdx.x == 0) {
+    *J.err_dst = *J.err_src;
+    if (J.clk_src) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(J.err_dst + 2);
+      d[0] = J.clk_src[0];
+      d[1] = J.clk_src[1];
+    }
+  }
   const int job = blockIdx.x < J.blk_end[0] ? 0 : (blockIdx.x < J.blk_end[1] ? 1 : 2);
   const GroupSumArgs& a = J.j[job];
   const uint32_t blk0 = job == 0 ? 0u : J.blk_end[job - 1];
@@ -1893,18 +1913,20 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   pf.begin(part, PROF_ACC0, st);
   // dynamic LDS padding caps the blocks per CU: the kernel needs 162 VGPRs, so three waves per SIMD WOULD fit
   static const size_t acc0_lds_pad = getenv("GM_ACC0_LDS_PAD") ? (size_t)strtoull(getenv("GM_ACC0_LDS_PAD"), nullptr, 10) : 0;
+  if ((rc = ws.clk.ensure(16))) return rc;
+  unsigned long long* acc_clk = ws.clk.as<unsigned long long>();
   // gather of the next entry under the addition of this one: GM_ACC0_PREFETCH = 0 / 1 forces, default = on the table path
   static const int acc0_pf_env = getenv("GM_ACC0_PREFETCH") ? atoi(getenv("GM_ACC0_PREFETCH")) : -1;
   const bool acc0_pf = acc0_pf_env >= 0 ? acc0_pf_env != 0 : use_table;
   if (acc0_pf)
     hipLaunchKernelGGL(k_acc0_pf<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
-                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr, acc_clk);
   else if (acc0_waves == 2)
     hipLaunchKernelGGL(k_acc0<2>, dim3((uint32_t)(T0pad / 256)), dim3(256), acc0_lds_pad, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
-                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr, acc_clk);
   else
     hipLaunchKernelGGL(k_acc0<3>, dim3((uint32_t)(T0pad / 256)), dim3(256), 0, st, acc_entries, acc_total, acc_bases, acc_first, acc_step,
-                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr);
+                       acc_tab, L, ws.pk[0].as<uint32_t>(), ws.pp[0].as<uint8_t>(), ws.buckets.as<uint8_t>(), use_glv ? bases->phi : (const uint8_t*)nullptr, acc_clk);
   pf.end(part, PROF_ACC0, st);
   if (sts.tail != st) {
     GM_HIP(hipEventRecord(ws.acc_ev, st));
@@ -1982,6 +2004,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     if (last) {
       J.err_src = d_err;
       J.err_dst = reinterpret_cast<uint32_t*>(planes + plane_count * XYZZ_BYTES);
+      J.clk_src = ws.clk.as<unsigned long long>();
     }
     uint32_t tot = 0;
     int k = 0;
@@ -2035,7 +2058,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   }
   pf.end(part, PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
-  const size_t plane_bytes = plane_count * XYZZ_BYTES + 8;  // + the scalar-range flag
+  const size_t plane_bytes = plane_count * XYZZ_BYTES + 24;  // + the scalar-range flag + k_acc0's clock readings
   if (ws.host_planes_cap[slot] < plane_bytes) {
     if (ws.host_planes[slot]) (void)hipHostFree(ws.host_planes[slot]);
     ws.host_planes[slot] = nullptr;
@@ -2209,6 +2232,13 @@ static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, boo
     }
   }
   C->prof.collect();
+  if (C->prof.on)  // the clock readings of the call's k_acc0 travelled with the plane sums
+    for (int p = 0; p < nparts; p++)
+      if (!parts[p].empty) {
+        const uint64_t* hp = parts[p].ws->host_planes[parts[p].slot] + parts[p].plane_count * 24;
+        C->prof.acc0_cycles += (double)hp[1];
+        C->prof.acc0_ticks += (double)hp[2];
+      }
   if (rc) return rc;
   if (normalize) result = result.normalized();
   result.to_limbs(out_jac);

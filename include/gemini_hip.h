@@ -205,6 +205,10 @@ int gm_set_msm_affine_levels(int levels);
 #define GM_PROF_NSTAGES 7
 int gm_prof_enable(int on);
 int gm_prof_read(double* ms_out, uint64_t* count_out, int n);
+/* The shader clock (MHz) the bucket accumulation ran at while profiling was on: clock64() against the constant 100 MHz
+ * wall_clock64() inside the kernel, summed over the calls since gm_prof_enable(1).  The issue bound of the accumulation is
+ * proportional to it, and it is NOT the nominal clock (1.9 .. 2.3 GHz under this load). 0 if none ran. */
+int gm_prof_read_clock(double* acc0_mhz);
 
 /* ---- device-resident Fr vectors ------------------------------------------------------------ */
 /* Stand in for the `Vec<F>` values the time prover keeps in RAM (src/snark/time_prover.rs:32-106). */
