@@ -23,7 +23,8 @@ from collections import defaultdict
 
 def short_name(full):
     m = re.match(r"(?:void\s+)?(?:gm::)?([A-Za-z_0-9]+)", full)
-    return m.group(1) if m else full
+    n = m.group(1) if m else full
+    return "k_acc0" if n == "k_acc0_pf" else n  # the same accumulation with the next gather in flight (table path)
 
 
 def load(path):
