@@ -49,12 +49,12 @@ def test_two_ranks_one_gpu_same_proof(extra):
 @pytest.mark.parametrize("tail_log", [4, 6])
 def test_block_sharded_prover_same_proof(tail_log):
     """gemini_amd/dist_prover.py: the field arithmetic sharded as well (block-sharded vectors, per-level key slices, sumchecks
-    through ShardedTimeProver, the opening through per-block carries): 1, 2 and 4 ranks on the one GPU of the test box must
+    through ShardedTimeProver, the opening through per-block carries): 1, 2, 4 (and 8) ranks on the one GPU of the test box must
     produce the single-GPU proof byte for byte.  tail_log 4 / 6 at 2^12 constraints: 6 / 4 sharded levels at 4 ranks."""
     from gemini_amd.dist_prover import fr_work
 
     one = _run(1, [])
-    for world in (1, 2, 4):
+    for world in ((1, 2, 4, 8) if tail_log == 4 else (1, 2, 4)):  # 8 ranks: blocks of 512 constraints, 5 sharded levels
         many = _run(world, ["--block-sharded", "--tail-log", str(tail_log)])
         assert many["n_gpus"] == world
         assert many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
