@@ -9,6 +9,8 @@
 #include <cstdint>
 #include <cstring>
 
+#include "host_fq_adx.hpp"
+
 namespace gmh {
 
 typedef uint64_t u64;
@@ -77,15 +79,22 @@ struct Field {
   bool is_zero() const { return gmh::is_zero<N>(l); }
   bool operator==(const Field& o) const { return memcmp(l, o.l, sizeof l) == 0; }
 
+  // branch-free: the comparisons of a compare-then-subtract form are data-dependent branches that mispredict every other
+  // call, and the window Horner of every MSM is a chain of ~2000 dependent field operations
   Field operator+(const Field& o) const {
-    Field r;
-    u64 c = add_n<N>(r.l, l, o.l);
-    if (c || geq<N>(r.l, P::MOD)) sub_n<N>(r.l, r.l, P::MOD);
+    Field r, s;
+    const u64 c = add_n<N>(r.l, l, o.l);
+    const u64 bw = sub_n<N>(s.l, r.l, P::MOD);
+    const u64 keep = (u64)0 - (u64)((bw != 0) & (c == 0));  // all ones: r < MOD, keep r
+    for (int i = 0; i < N; i++) r.l[i] = (r.l[i] & keep) | (s.l[i] & ~keep);
     return r;
   }
   Field operator-(const Field& o) const {
-    Field r;
-    if (sub_n<N>(r.l, l, o.l)) add_n<N>(r.l, r.l, P::MOD);
+    Field r, s;
+    const u64 bw = sub_n<N>(r.l, l, o.l);
+    add_n<N>(s.l, r.l, P::MOD);
+    const u64 fix = (u64)0 - (u64)(bw != 0);  // all ones: went negative, take r + MOD
+    for (int i = 0; i < N; i++) r.l[i] = (s.l[i] & fix) | (r.l[i] & ~fix);
     return r;
   }
   Field neg() const {
@@ -96,6 +105,16 @@ struct Field {
   }
   Field dbl() const { return *this + *this; }
   Field operator*(const Field& o) const {
+#ifdef GM_HAVE_FQ_ADX
+    if constexpr (P::USE_ADX) if (fq_adx_usable()) {  // x86-64 with BMI2 + ADX: host_fq_adx.hpp (Fq only)
+      Field r;
+      fq_mul_adx(r.l, l, o.l, P::MOD, P::INV);
+      return r;
+    }
+#endif
+    return mul_generic(o);
+  }
+  Field mul_generic(const Field& o) const {
     u64 t[N + 2];
     for (int i = 0; i < N + 2; i++) t[i] = 0;
     for (int i = 0; i < N; i++) {
@@ -155,6 +174,7 @@ struct Field {
 };
 
 struct FqP {
+  static constexpr bool USE_ADX = true;
   static constexpr u64 MOD[6] = {0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
                                  0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL};
   static constexpr u64 INV = 0x89f3fffcfffcfffdULL;
@@ -164,6 +184,7 @@ struct FqP {
                                 0x67eb88a9939d83c0ULL, 0x9a793e85b519952dULL, 0x11988fe592cae3aaULL};
 };
 struct FrP {
+  static constexpr bool USE_ADX = false;
   static constexpr u64 MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL,
                                  0x73eda753299d7d48ULL};
   static constexpr u64 INV = 0xfffffffeffffffffULL;
