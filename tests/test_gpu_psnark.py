@@ -453,3 +453,24 @@ def test_native_psnark_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
     assert Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() == native.serialize_compressed()  # no state left behind
     r1cs.free()
     ck.powers_of_g.free()
+
+
+@pytest.mark.parametrize("n", [8, 64, 512])
+def test_native_psnark_prover_on_general_instances(gm, oracle, pyref, n):
+    """gm_psnark_new_time on GENERAL sparse instances (distinct A, B, a diagonal C; joint support of several entries per row,
+    so the lookup vectors and the three entry products are not the degenerate ones of the dummy instance): byte-equal to the
+    step-by-step driver (tests/soak_psnark.py runs the same over a thousand random instances)"""
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.psnark import Proof
+    from oracle import psnark_ref as pr
+    from oracle import snark_ref as sr
+
+    inst, tau = _random_instance(pyref, sr, n, 7300 + n)
+    r1cs = _device_instance(gm, oracle, inst, n)
+    jm = pr.sum_matrices(inst["a"], inst["b"], inst["c"], n)
+    nnz = len(pr.joint_matrices(jm, inst["a"], inst["b"], inst["c"])[0])
+    ck = CommitterKey.new(nnz + 2 * n, 3, oracle.ints_to_limbs([tau], 4)[0])
+    index = Proof.index(ck, r1cs)
+    assert Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() == Proof.new_time(ck, r1cs, index).serialize_compressed()
+    r1cs.free()
+    ck.powers_of_g.free()
