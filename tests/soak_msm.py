@@ -75,7 +75,8 @@ def test_soak_msm(gm, oracle, pyref):
     gm.capi.check(lib.gm_set_auto_tables(C.c_int(0), C.c_size_t(0)))
     gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1)))
     t_end = time.time() + budget
-    NB = 1 << 17
+    max_log = float(os.environ.get("SOAK_MAX_LOG", "17.2"))  # SOAK_MAX_LOG=20.3: up to 2^20 pairs per case (the CPU side takes ~1 s there)
+    NB = 1 << int(max_log)
     pool = rand_bases(oracle, 4242, NB)
     stats = {"cases": 0, "pairs": 0, "by_key": {}, "by_scalars": {}, "by_path": {}, "max_n": 0, "failures": []}
     case = 0
@@ -87,7 +88,7 @@ def test_soak_msm(gm, oracle, pyref):
                     break
                 continue
             rng = np.random.default_rng(seed0 + case)
-            n = int(min(NB, max(1, round(2 ** rng.uniform(0, 17.2)))))
+            n = int(min(NB, max(1, round(2 ** rng.uniform(0 if max_log < 18 else 12, max_log)))))
             key_kind = ["random", "random", "few_points", "plus_minus", "with_identities"][int(rng.integers(0, 5))]
             nb = int(min(NB, n + int(rng.integers(0, 300))))
             if key_kind == "random":
