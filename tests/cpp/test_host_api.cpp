@@ -52,6 +52,13 @@ int main(int argc, char** argv) {
     print("hashmap", hp.finalize());
     gm::CommitterKey ck(bases);
     print("commit", ck.commit(scalars));
+    {  // CommitterKey::batch_commit (src/kzg/time.rs:98-107): one pipelined call, mixed lengths incl. an empty polynomial
+      std::vector<std::vector<gm::Fr>> polys = {scalars, tail, std::vector<gm::Fr>(), std::vector<gm::Fr>(scalars.begin(), scalars.begin() + 1)};
+      auto batch = ck.batch_commit(polys);
+      bool same = batch.size() == polys.size();
+      for (size_t j = 0; same && j < polys.size(); j++) same = batch[j] == ck.commit(polys[j]);
+      printf("batch_commit_equals_commits %d\n", same ? 1 : 0);
+    }
     gm::Transcript t;
     auto sc = gm::Sumcheck::new_time(t, f, g, tw[0]);
     for (size_t k = 0; k < sc.messages.size(); k++) {

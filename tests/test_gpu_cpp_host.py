@@ -62,6 +62,7 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
     # msm_chunks aligns the streams: the last 100 bases with the 100 scalars (src/kzg/space.rs:36-40)
     assert jac_to_affine_ints(oracle, J("msm_chunks")) == jac_to_affine_ints(oracle, oracle.msm_pippenger(bases[n - 100:], sc[:100]))
     assert vals["msm_err"][0] == ["1", str(n - 5)]
+    assert vals["batch_commit_equals_commits"][0] == ["1"]
     dup = bases[np.arange(n) % 20]
     assert jac_to_affine_ints(oracle, J("hashmap")) == jac_to_affine_ints(oracle, oracle.hashmap_pippenger(dup, mont, 16))
     # sumcheck + transcript vs the restatements
