@@ -1033,6 +1033,24 @@ int gm_spm_shape(uint64_t handle, size_t* nrows, size_t* ncols, size_t* nnz) {
   if (nnz) *nnz = M->nnz;
   return GM_OK;
 }
+// the CSR arrays back on the host (any pointer may be null): what the preprocessing of the indexed SNARK reads
+// (gm_psnark_preprocess: joint support of A, B, C)
+int gm_spm_download(uint64_t handle, uint64_t* rowptr, uint32_t* cols, uint64_t* vals_mont) {
+  GM_CTX();
+  SparseMatrix* M = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    auto it = C->matrices.find(handle);
+    if (it != C->matrices.end()) M = it->second.get();
+  }
+  GM_CHECK(M != nullptr, GM_EHANDLE, "spm_download: unknown matrix handle %llu", (unsigned long long)handle);
+  GM_FR_LOCK(C);
+  if (rowptr) GM_HIP(hipMemcpyAsync(rowptr, M->rowptr, (M->nrows + 1) * 8, hipMemcpyDeviceToHost, C->stream));
+  if (cols && M->nnz) GM_HIP(hipMemcpyAsync(cols, M->cols, M->nnz * 4, hipMemcpyDeviceToHost, C->stream));
+  if (vals_mont && M->nnz) GM_HIP(hipMemcpyAsync(vals_mont, M->vals, M->nnz * 32, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
 int gm_spm_mul(uint64_t matrix, uint64_t x, uint64_t y) {
   GM_CTX();
   SparseMatrix* M;

@@ -8,6 +8,8 @@
 // one of gemini_amd/psnark.py::Proof.new_time (the tests hold the two byte for byte equal).  Driven from Python the
 // prover makes ~1000 FFI round trips per proof, most of which wait for the device; here the GPU is fed from one thread
 // that never leaves the library.
+#include <algorithm>
+
 #include "prover_common.hpp"
 
 namespace {
@@ -428,4 +430,138 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   P->spans[10] = since(t0);
   P->spans[11] = since(t_all);
   return GM_OK;
+}
+
+// ---- preprocessing: the matrix-only part of the instance (gemini_amd/psnark.py::joint_matrices, _JointDevice) -------------
+extern "C" int gm_psnark_preprocess(uint64_t a, uint64_t b, uint64_t c, size_t num_variables, gm_psnark_instance* I) {
+  if (!I) return GM_EINVAL;
+  const uint64_t mats[3] = {a, b, c};
+  size_t nrows[3], ncols[3], nnzs[3];
+  for (int k = 0; k < 3; k++) RC(gm_spm_shape(mats[k], &nrows[k], &ncols[k], &nnzs[k]));
+  const size_t num_constraints = std::max(nrows[0], std::max(nrows[1], nrows[2]));
+  for (int k = 0; k < 3; k++)
+    if (ncols[k] > num_variables) return GM_EINVAL;
+  // keys col * num_constraints + row of every entry, per DISTINCT matrix (dummy_r1cs registers one matrix three times)
+  struct Host {
+    std::vector<uint64_t> rowptr, keys, vals;
+    std::vector<uint32_t> cols;
+    std::vector<size_t> order;  // entries sorted by key, the LAST of equal keys kept
+  };
+  Host H[3];
+  int src_of[3] = {0, 1, 2};
+  if (b == a) src_of[1] = 0;
+  if (c == a) src_of[2] = 0;
+  else if (c == b) src_of[2] = src_of[1];
+  std::vector<uint64_t> all;
+  for (int k = 0; k < 3; k++) {
+    if (src_of[k] != k) continue;
+    Host& h = H[k];
+    h.rowptr.resize(nrows[k] + 1);
+    h.cols.resize(nnzs[k]);
+    h.vals.resize(4 * nnzs[k]);
+    RC(gm_spm_download(mats[k], h.rowptr.data(), h.cols.data(), h.vals.data()));
+    h.keys.resize(nnzs[k]);
+    for (size_t r = 0; r < nrows[k]; r++)
+      for (uint64_t e = h.rowptr[r]; e < h.rowptr[r + 1]; e++) h.keys[e] = (uint64_t)h.cols[e] * num_constraints + r;
+    std::vector<size_t> ord(nnzs[k]);
+    for (size_t e = 0; e < nnzs[k]; e++) ord[e] = e;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return h.keys[x] < h.keys[y]; });
+    for (size_t t = 0; t < ord.size(); t++)
+      if (t + 1 == ord.size() || h.keys[ord[t + 1]] != h.keys[ord[t]]) h.order.push_back(ord[t]);
+    all.insert(all.end(), h.keys.begin(), h.keys.end());
+  }
+  std::sort(all.begin(), all.end());
+  all.erase(std::unique(all.begin(), all.end()), all.end());
+  const size_t nnz = all.size();
+  std::vector<uint32_t> row_index(nnz), col_index(nnz);
+  for (size_t t = 0; t < nnz; t++) {
+    row_index[t] = (uint32_t)(all[t] % num_constraints);
+    col_index[t] = (uint32_t)(all[t] / num_constraints);
+  }
+  memset(I, 0, sizeof *I);
+  I->a = a;
+  I->b = b;
+  I->c = c;
+  I->nnz = nnz;
+  int rc = GM_OK;
+  auto fail = [&](int code) {
+    (void)gm_psnark_preprocess_free(I);
+    return code;
+  };
+  if ((rc = gm_idx_register(row_index.data(), nnz, &I->row_index))) return fail(rc);
+  if ((rc = gm_idx_register(col_index.data(), nnz, &I->col_index))) return fail(rc);
+  // row / col as field vectors: F::from(index) = 0 + 1 * index (the device's own builder, as gemini_amd/psnark.py does)
+  {
+    const Fr one = Fr::one(), zero = Fr::zero();
+    uint64_t zeros = 0;
+    if ((rc = gm_fr_vec_alloc(nnz, &zeros))) return fail(rc);
+    rc = gm_fr_vec_fill(zeros, zero.l);
+    uint64_t* outs[2] = {&I->row, &I->col};
+    const uint64_t idx[2] = {I->row_index, I->col_index};
+    for (int k = 0; k < 2 && !rc; k++) {
+      rc = gm_fr_vec_alloc(nnz, outs[k]);
+      if (!rc) rc = gm_fr_alg_hash(zeros, idx[k], one.l, *outs[k]);
+    }
+    (void)gm_fr_vec_free(zeros);
+    if (rc) return fail(rc);
+  }
+  // the three value vectors over the joint support
+  {
+    uint64_t* outs[3] = {&I->val_a, &I->val_b, &I->val_c};
+    std::vector<uint64_t> dense;
+    for (int k = 0; k < 3; k++) {
+      const Host& h = H[src_of[k]];
+      dense.assign(4 * nnz, 0);
+      size_t pos = 0;  // both sides ascend
+      for (size_t e : h.order) {
+        while (all[pos] != h.keys[e]) pos++;
+        memcpy(&dense[4 * pos], &h.vals[4 * e], 32);
+      }
+      if ((rc = gm_fr_vec_alloc(nnz, outs[k]))) return fail(rc);
+      if (nnz && (rc = gm_fr_vec_upload(*outs[k], 0, dense.data(), nnz))) return fail(rc);
+    }
+  }
+  // extend_frequency(compute_frequency(set_len, index)): value v repeated 1 + #{j : index[j] = v} times
+  {
+    const size_t len_r = num_constraints <= 1 ? 1 : (size_t)1 << (64 - __builtin_clzll((unsigned long long)(num_constraints - 1)));
+    const size_t set_len[2] = {len_r, num_variables};
+    const std::vector<uint32_t>* index[2] = {&row_index, &col_index};
+    uint64_t* outs[2] = {&I->ext_fre_row, &I->ext_fre_col};
+    size_t* lens[2] = {&I->ext_fre_row_len, &I->ext_fre_col_len};
+    for (int k = 0; k < 2; k++) {
+      std::vector<uint32_t> freq(set_len[k], 1);
+      for (uint32_t v : *index[k]) {
+        if (v >= set_len[k]) return fail(GM_EINVAL);
+        freq[v]++;
+      }
+      std::vector<uint32_t> ext;
+      ext.reserve(set_len[k] + nnz);
+      for (size_t v = 0; v < set_len[k]; v++) ext.insert(ext.end(), freq[v], (uint32_t)v);
+      if ((rc = gm_idx_register(ext.data(), ext.size(), outs[k]))) return fail(rc);
+      *lens[k] = ext.size();
+    }
+  }
+  return GM_OK;
+}
+
+extern "C" int gm_psnark_preprocess_free(gm_psnark_instance* I) {
+  if (!I) return GM_EINVAL;
+  for (uint64_t* h : {&I->row_index, &I->col_index, &I->ext_fre_row, &I->ext_fre_col})
+    if (*h) {
+      (void)gm_idx_free(*h);
+      *h = 0;
+    }
+  for (uint64_t* h : {&I->row, &I->col, &I->val_a, &I->val_b, &I->val_c})
+    if (*h) {
+      (void)gm_fr_vec_free(*h);
+      *h = 0;
+    }
+  return GM_OK;
+}
+
+extern "C" int gm_psnark_index(const gm_psnark_instance* I, uint64_t ck_bases, uint64_t* out_jac) {
+  if (!I || !out_jac) return GM_EINVAL;
+  size_t nck = 0;
+  RC(gm_g1_bases_len(ck_bases, &nck));
+  return batch_commit(ck_bases, nck, {I->row, I->col, I->val_a, I->val_b, I->val_c}, out_jac);
 }

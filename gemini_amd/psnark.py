@@ -105,6 +105,45 @@ def _joint_device(r1cs: R1cs) -> "_JointDevice":
     return cache["joint"]
 
 
+class _JointNative:
+    """the same matrix-only part of the instance built INSIDE the library (gm_psnark_preprocess: joint support, value vectors,
+    row / col, extended frequencies; gemini_amd/csrc/psnark.cpp) -- what a Rust / C++ integrator calls instead of restating
+    src/misc.rs:269-366 in the shim.  Kept with the R1cs object like _JointDevice and freed with it."""
+
+    def __init__(self, r1cs: R1cs):
+        import ctypes as C
+
+        from . import capi
+
+        Instance, _ = _psnark_ctypes()
+        self.rec = Instance()
+        capi.check(capi.load().gm_psnark_preprocess(C.c_uint64(r1cs.a.handle), C.c_uint64(r1cs.b.handle), C.c_uint64(r1cs.c.handle),
+                                                    C.c_size_t(len(r1cs.z)), C.byref(self.rec)))
+
+    def index(self, ck: CommitterKey) -> list:
+        import ctypes as C
+
+        from . import capi
+
+        out = np.zeros((5, 18), dtype=np.uint64)
+        capi.check(capi.load().gm_psnark_index(C.byref(self.rec), C.c_uint64(ck.powers_of_g.handle), capi.ptr(out)))
+        return [out[k].copy() for k in range(5)]
+
+    def free(self):
+        import ctypes as C
+
+        from . import capi
+
+        capi.check(capi.load().gm_psnark_preprocess_free(C.byref(self.rec)))
+
+
+def _joint_native(r1cs: R1cs) -> "_JointNative":
+    cache = r1cs.__dict__.setdefault("_device_cache", {})
+    if "joint_native" not in cache:
+        cache["joint_native"] = _JointNative(r1cs)
+    return cache["joint_native"]
+
+
 def _field_of_index(index: IdxVec) -> FrVec:
     """[F::from(i) for i in index] (the `row` / `col` vectors, src/misc.rs:343-349)"""
     zeros = FrVec.alloc(len(index))
@@ -224,17 +263,21 @@ class Proof:
         self.spans = {}
 
     @staticmethod
-    def index(ck: CommitterKey, r1cs: R1cs) -> list:
-        """src/psnark/time_prover.rs:49-64"""
+    def index(ck: CommitterKey, r1cs: R1cs, native: bool = False) -> list:
+        """src/psnark/time_prover.rs:49-64.  native: joint matrices and commitments inside the library (gm_psnark_preprocess +
+        gm_psnark_index)"""
+        if native:
+            return _joint_native(r1cs).index(ck)
         jd = _joint_device(r1cs)
         return ck.batch_commit([jd.row, jd.col, jd.val_a, jd.val_b, jd.val_c])
 
     @staticmethod
     def new_time(ck: CommitterKey, r1cs: R1cs, index: list, native: bool = False) -> "Proof":
         """src/psnark/time_prover.rs:69-384.  native: the same sequence compiled into the library (gm_psnark_new_time, one call
-        per proof) -- for a single-GPU CommitterKey."""
+        per proof) -- for a single-GPU CommitterKey; native = "preprocess": the matrix-only part of the instance record comes from
+        gm_psnark_preprocess as well (nothing of src/misc.rs:269-366 is left to the caller)."""
         if native and type(ck) is CommitterKey:
-            return _new_time_native(ck, r1cs, index)
+            return _new_time_native(ck, r1cs, index, preprocess_in_library=native == "preprocess")
         spans = {}
         keep = []  # device vectors freed at the end
 
@@ -694,25 +737,33 @@ def _psnark_ctypes():
     return Instance, ProofRec
 
 
-def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list) -> "Proof":
+def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_library: bool = False) -> "Proof":
     import ctypes as C
 
     from . import capi
     from .transcript import default_group_encoding
 
     Instance, ProofRec = _psnark_ctypes()
-    jd = _joint_device(r1cs)
-    nrows = max(r1cs.a.nrows, r1cs.b.nrows)
-    len_r = 1 << max(nrows - 1, 0).bit_length()  # the first sumcheck's tensor: 2^rounds, rounds = ceil(log2 max(|A z|, |B z|))
-    ext = jd.extended_frequencies(len_r, len(r1cs.z))
     U = C.POINTER(C.c_uint64)
     idx = np.ascontiguousarray(np.stack(index), dtype=np.uint64)
     g2 = ck.powers_of_g2_bytes()
     g2buf = (C.c_uint8 * len(g2)).from_buffer_copy(g2)
-    I = Instance(r1cs.a.handle, r1cs.b.handle, r1cs.c.handle, r1cs.z.handle, r1cs.w.handle, jd.row_index.handle, jd.col_index.handle, len(jd.row_index),
-                 jd.row.handle, jd.col.handle, jd.val_a.handle, jd.val_b.handle, jd.val_c.handle, ext[0].handle, ext[1].handle, len(ext[0]), len(ext[1]),
-                 idx.ctypes.data_as(U), C.cast(g2buf, C.POINTER(C.c_uint8)), len(g2))
-    cap = max(2 * max(len(r1cs.z), len(jd.row_index)) + 4, 4).bit_length() + 3
+    if preprocess_in_library:  # the matrix-only part of the record comes from gm_psnark_preprocess; z, w, index, G2 bytes are ours
+        I = Instance.from_buffer_copy(_joint_native(r1cs).rec)
+        I.z, I.w = r1cs.z.handle, r1cs.w.handle
+        I.index_commitments = idx.ctypes.data_as(U)
+        I.ck_g2_bytes, I.ck_g2_len = C.cast(g2buf, C.POINTER(C.c_uint8)), len(g2)
+        nnz = I.nnz
+    else:
+        jd = _joint_device(r1cs)
+        nrows = max(r1cs.a.nrows, r1cs.b.nrows)
+        len_r = 1 << max(nrows - 1, 0).bit_length()  # the first sumcheck's tensor: 2^rounds, rounds = ceil(log2 max(|A z|, |B z|))
+        ext = jd.extended_frequencies(len_r, len(r1cs.z))
+        I = Instance(r1cs.a.handle, r1cs.b.handle, r1cs.c.handle, r1cs.z.handle, r1cs.w.handle, jd.row_index.handle, jd.col_index.handle,
+                     len(jd.row_index), jd.row.handle, jd.col.handle, jd.val_a.handle, jd.val_b.handle, jd.val_c.handle, ext[0].handle, ext[1].handle,
+                     len(ext[0]), len(ext[1]), idx.ctypes.data_as(U), C.cast(g2buf, C.POINTER(C.c_uint8)), len(g2))
+        nnz = len(jd.row_index)
+    cap = max(2 * max(len(r1cs.z), nnz) + 4, 4).bit_length() + 3
     m = [np.zeros((cap, 8), dtype=np.uint64) for _ in range(3)]
     cap_folds = 4 * cap
     fc = np.zeros((cap_folds, 18), dtype=np.uint64)

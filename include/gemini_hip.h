@@ -279,6 +279,8 @@ int gm_spm_register(const uint64_t* rowptr, const uint32_t* cols, const uint64_t
 int gm_spm_free(uint64_t handle);
 int gm_spm_mul(uint64_t matrix, uint64_t x, uint64_t y);
 int gm_spm_shape(uint64_t matrix, size_t* nrows_or_null, size_t* ncols_or_null, size_t* nnz_or_null);
+/* The CSR arrays back on the host (rowptr: nrows + 1, cols: nnz, vals: nnz x 4 Montgomery limbs; any pointer may be NULL). */
+int gm_spm_download(uint64_t matrix, uint64_t* rowptr, uint32_t* cols, uint64_t* vals_mont);
 
 /* Split-phase round for callers that drive MANY provers in lock-step (Sumcheck::prove_batch maps its provers over
  * rayon, src/subprotocols/sumcheck/proof.rs:85): _begin does what gm_sc_round does up to the launch of the kernel
@@ -467,6 +469,18 @@ typedef struct gm_psnark_proof {
   double spans[12];
 } gm_psnark_proof;
 int gm_psnark_new_time(const gm_psnark_instance* instance, uint64_t ck_bases, int g1_encoding, size_t cap_rounds, gm_psnark_proof* proof);
+
+/* Everything of `instance` that depends on the MATRICES only, built inside the library from the three registered matrices
+ * (`sum_matrices` + `joint_matrices`, src/misc.rs:269-366: the union of the supports of A, B, C walked column-major, the three value
+ * vectors with zeros where a matrix has no entry, the last of repeated (row, column) entries kept as BTreeMap::collect does; `row` /
+ * `col` as field vectors; the extended frequencies of the two lookups, plookup/time_prover.rs:66-79) and left resident in HBM:
+ * fills a, b, c, row_index, col_index, nnz, row, col, val_a, val_b, val_c, ext_fre_row, ext_fre_col and their lengths.  z, w,
+ * index_commitments and the G2 bytes stay the caller's.  Setup like `Proof::index` (src/psnark/time_prover.rs:49-64), once per
+ * circuit; gm_psnark_preprocess_free releases what it created (not the matrices). */
+int gm_psnark_preprocess(uint64_t a, uint64_t b, uint64_t c, size_t num_variables, gm_psnark_instance* instance);
+int gm_psnark_preprocess_free(gm_psnark_instance* instance);
+/* psnark::Proof::index (src/psnark/time_prover.rs:49-64): commitments to row, col, val_a, val_b, val_c; out = 5 x 18 limbs */
+int gm_psnark_index(const gm_psnark_instance* instance, uint64_t ck_bases, uint64_t* out_jac);
 
 #ifdef __cplusplus
 }

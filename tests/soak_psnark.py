@@ -5,7 +5,8 @@ default (the file name); on the GPU box:
 
 Per case: a satisfied random instance of 2^2 .. 2^10 constraints (distinct sparse A, B, a diagonal C), a fresh key of
 nnz + 2 n powers (examples/psnark.rs:62 plus what a verifiable proof needs) and its index commitments; `Proof::new_time` step by
-step from Python, `gm_psnark_new_time` (compiled driver) and, below 2^7, `Proof::new_elastic` over the stream form must produce
+step from Python, `gm_psnark_new_time` (compiled driver; also on the instance record that `gm_psnark_preprocess` builds inside the
+library, with the index commitments of `gm_psnark_index`) and, below 2^7, `Proof::new_elastic` over the stream form must produce
 the same bytes (src/psnark/tests.rs:56-124), and every fourth proof must be ACCEPTED by the restated reference verifier (three
 sumcheck subclaims, plookup / entry-product relations, two pairing checks: oracle/verifier_ref.py, src/psnark/verifier.rs)."""
 import json
@@ -62,6 +63,11 @@ def test_soak_psnark(gm, oracle, pyref):
             want = stepwise.serialize_compressed()
             if Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() != want:
                 bad.append("native time != stepwise time")
+            index_lib = Proof.index(ck, r1cs, native=True)  # gm_psnark_preprocess + gm_psnark_index
+            if not all((x == y).all() for x, y in zip(index_lib, index)):
+                bad.append("library index != index")
+            if Proof.new_time(ck, r1cs, index_lib, native="preprocess").serialize_compressed() != want:
+                bad.append("native time on the library-preprocessed instance != stepwise time")
             if logn < 7:
                 stream = R1csStream(r1cs)
                 ck_stream = CommitterKeyStream.from_committer_key(ck)

@@ -451,6 +451,8 @@ def test_native_psnark_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
         assert native.serialize(compress, 0) == stepwise.serialize(compress, 0)
     assert set(native.spans) == set(stepwise.spans)
     assert Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() == native.serialize_compressed()  # no state left behind
+    assert all((x == y).all() for x, y in zip(Proof.index(ck, r1cs, native=True), index))  # gm_psnark_preprocess on A = B = C
+    assert Proof.new_time(ck, r1cs, index, native="preprocess").serialize_compressed() == native.serialize_compressed()
     r1cs.free()
     ck.powers_of_g.free()
 
@@ -471,6 +473,16 @@ def test_native_psnark_prover_on_general_instances(gm, oracle, pyref, n):
     nnz = len(pr.joint_matrices(jm, inst["a"], inst["b"], inst["c"])[0])
     ck = CommitterKey.new(nnz + 2 * n, 3, oracle.ints_to_limbs([tau], 4)[0])
     index = Proof.index(ck, r1cs)
-    assert Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() == Proof.new_time(ck, r1cs, index).serialize_compressed()
+    want = Proof.new_time(ck, r1cs, index).serialize_compressed()
+    assert Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() == want
+    # the matrix-only part of the instance built inside the library (gm_psnark_preprocess / gm_psnark_index) instead of by
+    # gemini_amd/psnark.py::joint_matrices: the same joint support, value vectors, frequencies -> the same index and proof
+    from gemini_amd.psnark import _joint_device, _joint_native
+
+    jn, jd = _joint_native(r1cs), _joint_device(r1cs)
+    assert jn.rec.nnz == nnz == len(jd.row_index)
+    index_native = Proof.index(ck, r1cs, native=True)
+    assert all((x == y).all() for x, y in zip(index_native, index))
+    assert Proof.new_time(ck, r1cs, index_native, native="preprocess").serialize_compressed() == want
     r1cs.free()
     ck.powers_of_g.free()
