@@ -429,6 +429,8 @@ class R1cs {
 
  private:
   friend struct SnarkProof;
+  friend class PsnarkInstance;
+  friend struct PsnarkProof;
   DeviceMatrix a_, b_, c_, at_, bt_, ct_;
   uint64_t z_ = 0, w_ = 0;
   size_t nz_;
@@ -534,6 +536,111 @@ struct SnarkProof {
       return out;
     }
   };
+};
+
+// The preprocessing SNARK (src/psnark/mod.rs:29-51): the matrix-only part of the instance (`sum_matrices`, `joint_matrices`, the
+// lookup frequencies; src/misc.rs:269-366) is built inside the library once per circuit and stays in HBM; `index` and `new_time`
+// are one call each (src/psnark/time_prover.rs:49-64, 69-384).
+class PsnarkInstance {
+ public:
+  explicit PsnarkInstance(const R1cs& r1cs) : r1cs_(r1cs) {
+    memset(&rec_, 0, sizeof rec_);
+    check(gm_psnark_preprocess(r1cs.a_.handle(), r1cs.b_.handle(), r1cs.c_.handle(), r1cs.nz_, &rec_));
+    rec_.z = r1cs.z_;
+    rec_.w = r1cs.w_;
+  }
+  ~PsnarkInstance() { gm_psnark_preprocess_free(&rec_); }
+  PsnarkInstance(const PsnarkInstance&) = delete;
+  PsnarkInstance& operator=(const PsnarkInstance&) = delete;
+  size_t num_non_zero() const { return rec_.nnz; }
+  // Proof::index: commitments to row, col, val_a, val_b, val_c
+  std::array<G1Projective, 5> index(const CommitterKey& ck) const {
+    std::array<G1Projective, 5> out;
+    check(gm_psnark_index(&rec_, ck.handle(), out[0].data()));
+    return out;
+  }
+
+ private:
+  friend struct PsnarkProof;
+  const R1cs& r1cs_;
+  gm_psnark_instance rec_;
+};
+
+struct PsnarkProof {
+  G1Projective witness_commitment;
+  Fr zc_alpha;
+  std::vector<RoundMsg> first_sumcheck_msgs, second_sumcheck_msgs, third_sumcheck_msgs;
+  std::array<Fr, 2> first_final_foldings, second_final_foldings;
+  std::array<std::array<Fr, 2>, 13> third_final_foldings;
+  std::array<G1Projective, 3> r_star_commitments;
+  G1Projective z_star_commitment;
+  std::array<G1Projective, 3> sorted_commitments;  // r, alpha, z
+  std::array<Fr, 9> products;                      // r (set, subset, sorted), alpha (..), z (..)
+  std::array<G1Projective, 9> acc_v_commitments;
+  std::array<Fr, 9> claimed_sumchecks;
+  std::array<Fr, 10> ralpha_star_acc_mu_evals;
+  G1Projective ralpha_star_acc_mu_proof;
+  std::array<Fr, 2> rstars_vals;
+  TensorcheckProof tensorcheck_proof;
+
+  // `ck_g2_bytes`: the serialised G2 powers of the key as the transcript absorbs them (src/psnark/time_prover.rs:86-88)
+  static PsnarkProof new_time(const CommitterKey& ck, const PsnarkInstance& inst, const std::array<G1Projective, 5>& index,
+                              const std::vector<uint8_t>& ck_g2_bytes, int g1_encoding = 0) {
+    gm_psnark_instance I = inst.rec_;
+    I.index_commitments = index[0].data();
+    I.ck_g2_bytes = ck_g2_bytes.data();
+    I.ck_g2_len = ck_g2_bytes.size();
+    size_t cap = 4;
+    for (size_t n = 2 * (inst.r1cs_.nz_ > I.nnz ? inst.r1cs_.nz_ : I.nnz) + 4; n > 1; n = (n + 1) / 2) cap++;
+    std::vector<uint64_t> m[3], fc(4 * cap * 18), fe(4 * cap * 8);
+    gm_psnark_proof p;
+    memset(&p, 0, sizeof p);
+    for (int k = 0; k < 3; k++) {
+      m[k].resize(cap * 8);
+      p.messages[k] = m[k].data();
+    }
+    p.cap_folds = 4 * cap;
+    p.fold_commitments = fc.data();
+    p.fold_evaluations = fe.data();
+    check(gm_psnark_new_time(&I, ck.handle(), g1_encoding, cap, &p));
+    PsnarkProof out;
+    auto msgs = [](const std::vector<uint64_t>& mm, size_t rounds) {
+      std::vector<RoundMsg> v(rounds);
+      for (size_t i = 0; i < rounds; i++) {
+        memcpy(v[i].a.data(), mm.data() + 8 * i, 32);
+        memcpy(v[i].b.data(), mm.data() + 8 * i + 4, 32);
+      }
+      return v;
+    };
+    memcpy(out.witness_commitment.data(), p.witness_commitment, 144);
+    memcpy(out.zc_alpha.data(), p.zc_alpha, 32);
+    out.first_sumcheck_msgs = msgs(m[0], p.rounds[0]);
+    out.second_sumcheck_msgs = msgs(m[1], p.rounds[1]);
+    out.third_sumcheck_msgs = msgs(m[2], p.rounds[2]);
+    memcpy(out.first_final_foldings.data(), p.final_foldings[0], 64);
+    memcpy(out.second_final_foldings.data(), p.final_foldings[1], 64);
+    memcpy(out.third_final_foldings.data(), p.third_final_foldings, sizeof p.third_final_foldings);
+    memcpy(out.r_star_commitments.data(), p.r_star_commitments, sizeof p.r_star_commitments);
+    memcpy(out.z_star_commitment.data(), p.z_star_commitment, 144);
+    memcpy(out.sorted_commitments.data(), p.sorted_commitments, sizeof p.sorted_commitments);
+    memcpy(out.products.data(), p.products, sizeof p.products);
+    memcpy(out.acc_v_commitments.data(), p.acc_v_commitments, sizeof p.acc_v_commitments);
+    memcpy(out.claimed_sumchecks.data(), p.claimed_sumchecks, sizeof p.claimed_sumchecks);
+    memcpy(out.ralpha_star_acc_mu_evals.data(), p.ralpha_star_acc_mu_evals, sizeof p.ralpha_star_acc_mu_evals);
+    memcpy(out.ralpha_star_acc_mu_proof.data(), p.ralpha_star_acc_mu_proof, 144);
+    memcpy(out.rstars_vals.data(), p.rstars_vals, sizeof p.rstars_vals);
+    TensorcheckProof& tc = out.tensorcheck_proof;
+    tc.folded_polynomials_commitments.resize(p.nfold);
+    tc.folded_polynomials_evaluations.resize(p.nfold);
+    for (size_t i = 0; i < p.nfold; i++) {
+      memcpy(tc.folded_polynomials_commitments[i].data(), fc.data() + 18 * i, 144);
+      memcpy(tc.folded_polynomials_evaluations[i].data(), fe.data() + 8 * i, 64);
+    }
+    memcpy(tc.evaluation_proof.data(), p.evaluation_proof, 144);
+    tc.base_polynomials_evaluations.resize(22);
+    memcpy(tc.base_polynomials_evaluations[0].data(), p.base_evaluations, sizeof p.base_evaluations);
+    return out;
+  }
 };
 
 }  // namespace gm

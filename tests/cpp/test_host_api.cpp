@@ -120,6 +120,42 @@ int main(int argc, char** argv) {
         printf("snark_elastic_equals_time %d\n", (int)msgs_same);
       }
     }
+    // psnark::Proof::{index, new_time} on a general sparse instance: matrices in the Rust layout (rows of (value, column)), the key
+    // and its serialised G2 powers from the Python side
+    if (in.peek() != EOF) {
+      auto dims = read_vec<uint64_t>(in);  // n, then per matrix: nnz entries follow as (row, col) pairs + values
+      const size_t n = dims[0];
+      gm::Matrix M[3];
+      for (int k = 0; k < 3; k++) {
+        auto rc = read_vec<uint64_t>(in);  // row, col interleaved
+        auto vals = read_vec<gm::Fr>(in);
+        M[k].assign(n, {});
+        for (size_t e = 0; e < vals.size(); e++) M[k][rc[2 * e]].push_back({vals[e], (size_t)rc[2 * e + 1]});
+      }
+      auto z = read_vec<gm::Fr>(in);
+      auto w = read_vec<gm::Fr>(in);
+      auto srs = read_vec<gm::G1Affine>(in);
+      auto g2 = read_vec<uint8_t>(in);
+      gm::R1cs r1cs(M[0], M[1], M[2], z, w);
+      gm::CommitterKey key(srs);
+      gm::PsnarkInstance inst(r1cs);
+      printf("psnark_nnz %zu\n", inst.num_non_zero());
+      auto index = inst.index(key);
+      for (auto& c : index) print("psnark_index", c);
+      auto proof = gm::PsnarkProof::new_time(key, inst, index, g2);
+      print("psnark_witness", proof.witness_commitment);
+      print("psnark_zc_alpha", proof.zc_alpha);
+      for (auto& c : proof.r_star_commitments) print("psnark_rstar", c);
+      print("psnark_zstar", proof.z_star_commitment);
+      for (auto& c : proof.sorted_commitments) print("psnark_sorted", c);
+      for (auto& v : proof.products) print("psnark_product", v);
+      for (auto& c : proof.acc_v_commitments) print("psnark_accv", c);
+      for (auto& v : proof.rstars_vals) print("psnark_rstars_val", v);
+      print("psnark_mu_proof", proof.ralpha_star_acc_mu_proof);
+      print("psnark_open", proof.tensorcheck_proof.evaluation_proof);
+      printf("psnark_rounds %zu %zu %zu %zu\n", proof.first_sumcheck_msgs.size(), proof.second_sumcheck_msgs.size(), proof.third_sumcheck_msgs.size(),
+             proof.tensorcheck_proof.folded_polynomials_commitments.size());
+    }
     // error behaviour: hadamard-style length mismatch surfaces as gm::Error, not a crash
     try {
       gm::check(gm_g1_bases_free(0xdeadbeef));

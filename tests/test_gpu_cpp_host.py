@@ -46,9 +46,44 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
     srs = sr.srs(tau_i, 2 * ns + 1)
     srs_rust = np.zeros((2 * ns + 1, 13), dtype=np.uint64)
     srs_rust[:, :12] = srs
+    # psnark::Proof::{index, new_time} through the C++ mirror on a general sparse instance (gm::PsnarkInstance: the joint matrices
+    # are built inside the library); expected: the Python mirror's own proof of the same instance on the same key
+    import gemini_amd as gm
+    from gemini_amd.circuit import R1cs, SparseMatrix
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.psnark import Proof as PsnarkProof
+    from oracle import psnark_ref as pr
+    from tests.util import random_r1cs_instance
+
+    gm.capi.init()
+    np_ = 32
+    inst, ptau = random_r1cs_instance(pyref, sr, np_, 7400)
+    M = lambda v: gm.fr.fr_from_int(v)  # noqa: E731
+    dev = lambda rows: [[(M(v), col) for v, col in row] for row in rows]  # noqa: E731
+    mont_of = lambda ints: oracle.fr_to_mont(oracle.ints_to_limbs(ints, 4))  # noqa: E731
+    mats = [SparseMatrix.from_rows(dev(inst[k]), np_) for k in "abc"] + [SparseMatrix.from_rows(dev(inst[k]), np_, transpose=True) for k in "abc"]
+    pr1cs = R1cs(*mats, gm.FrVec.from_host(mont_of(inst["z"])), gm.FrVec.from_host(mont_of(inst["w"])), gm.FrVec.from_host(mont_of(inst["x"])))
+    jm = pr.sum_matrices(inst["a"], inst["b"], inst["c"], np_)
+    nnz = len(pr.joint_matrices(jm, inst["a"], inst["b"], inst["c"])[0])
+    pck = CommitterKey.new(nnz + 2 * np_, 3, oracle.ints_to_limbs([ptau], 4)[0])
+    pindex = PsnarkProof.index(pck, pr1cs)
+    pexp = PsnarkProof.new_time(pck, pr1cs, pindex)
+    psrs = pck.powers_of_g.download()
+    psrs_rust = np.zeros((len(psrs), 13), dtype=np.uint64)
+    psrs_rust[:, :12] = psrs
+    g2_bytes = np.frombuffer(pck.powers_of_g2_bytes(), dtype=np.uint8)
     with open(inp, "wb") as fh:
         for a in (rust, sc, mont, f, g, tw, ev, srs_rust):
             _wvec(fh, a)
+        _wvec(fh, np.array([np_], dtype=np.uint64))
+        for k in "abc":
+            rc = np.array([[r, col] for r, row in enumerate(inst[k]) for _, col in row], dtype=np.uint64).reshape(-1)
+            _wvec(fh, rc)
+            _wvec(fh, mont_of([v for row in inst[k] for v, _ in row]))
+        _wvec(fh, mont_of(inst["z"]))
+        _wvec(fh, mont_of(inst["w"]))
+        _wvec(fh, psrs_rust)
+        _wvec(fh, g2_bytes)
     out = subprocess.check_output([exe, inp], text=True)
     vals = {}
     for line in out.splitlines():
@@ -92,3 +127,20 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
     assert [[F("snark_be", k) for k in range(3)]] == tc["base_polynomials_evaluations"]
     # gm::SnarkProof::new_elastic (gm_snark_new_elastic), flushes cut literally and merged: the time prover's proof
     assert vals["snark_elastic_equals_time"] == [["1"], ["1"]]
+    # gm::PsnarkInstance / gm::PsnarkProof: the Python mirror's index and proof of the same instance
+    same = lambda key, k, want: jac_to_affine_ints(oracle, J(key, k)) == jac_to_affine_ints(oracle, want)  # noqa: E731
+    assert vals["psnark_nnz"][0] == [str(nnz)]
+    assert all(same("psnark_index", k, pindex[k]) for k in range(5))
+    assert same("psnark_witness", 0, pexp.witness_commitment) and (J("psnark_zc_alpha") == pexp.zc_alpha).all()
+    assert all(same("psnark_rstar", k, pexp.r_star_commitments[k]) for k in range(3)) and same("psnark_zstar", 0, pexp.z_star_commitment)
+    for k, c in enumerate((pexp.sorted_r_commitment, pexp.sorted_alpha_commitment, pexp.sorted_z_commitment)):
+        assert same("psnark_sorted", k, c)
+    for k, v in ((0, pexp.set_r_ep), (1, pexp.subset_r_ep), (3, pexp.set_alpha_ep), (4, pexp.subset_alpha_ep), (6, pexp.set_z_ep), (7, pexp.subset_z_ep)):
+        assert (J("psnark_product", k) == v).all(), k
+    assert all(same("psnark_accv", k, pexp.ep_msgs.acc_v_commitments[k]) for k in range(9))
+    assert all((J("psnark_rstars_val", k) == pexp.rstars_vals[k]).all() for k in range(2))
+    assert same("psnark_mu_proof", 0, pexp.ralpha_star_acc_mu_proof) and same("psnark_open", 0, pexp.tensorcheck_proof.evaluation_proof)
+    assert [int(x) for x in vals["psnark_rounds"][0]] == [len(pexp.first_sumcheck_msgs[0]), len(pexp.second_sumcheck_msgs[0]), len(pexp.third_sumcheck_msgs[0]),
+                                                          len(pexp.tensorcheck_proof.folded_polynomials_commitments)]
+    pr1cs.free()
+    pck.powers_of_g.free()
