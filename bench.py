@@ -497,8 +497,16 @@ def main():
     if args.snark_logn > 0:
         bases.free()  # the prover's key (2^25 + 1 points) and its vectors want the memory
         gm.capi.check(lib.gm_set_auto_tables(C.c_int(0 if args.no_tables else 1), C.c_size_t(0)))  # the library default
-        tp = snark_time_prover(gm, args.snark_logn, with_tables=not args.no_tables, world=world, rank=rank,
-                               cpu_logn=0 if args.no_cpu_baseline else args.cpu_snark_logn)
+        try:
+            tp = snark_time_prover(gm, args.snark_logn, with_tables=not args.no_tables, world=world, rank=rank,
+                                   cpu_logn=0 if args.no_cpu_baseline else args.cpu_snark_logn)
+        except Exception as exc:  # noqa: BLE001 -- N > 1 has only ever run with gloo on one shared GPU (no multi-GPU node was available
+            # to the builder): a failure of the second metric there must not take the headline line with it.  On one GPU it is a bug.
+            if world == 1:
+                raise
+            import traceback
+
+            tp = {"metric": "snark time_prover", "error": repr(exc), "traceback": traceback.format_exc()[-1500:]}
     if rank == 0:
         pairs = world * n * args.steps
         value = pairs / elapsed / 1e6
