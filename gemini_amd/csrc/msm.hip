@@ -1223,6 +1223,7 @@ struct GroupSumArgs {
   uint32_t nb;
   uint32_t lpo_shift;   // lanes per output = 2^lpo_shift
   int out_canonical;    // write canonical 192-byte records (the plane sums the host reads) instead of 208-byte loose ones
+  const uint32_t* in_cnt;  // input = the bucket array: entries per bucket; a bucket without entries was never written and counts as the identity
 };
 struct GroupSumJobs {
   GroupSumArgs j[3];
@@ -1254,10 +1255,16 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
   const uint32_t o = gt >> a.lpo_shift, q = gt & (lpo - 1u);
   Acc30 acc;
   acc30_zero(acc);
+  const uint32_t* __restrict__ in_cnt = a.in_cnt;
+  auto filled = [&](size_t slot) { return in_cnt == nullptr || in_cnt[slot] != 0u; };
   auto add_rec = [&](size_t slot) {
+    if (!filled(slot)) return;  // an empty bucket: nothing was stored there by this call (the array is not cleared between calls)
     Acc30 v;
     acc30_load(v, in + slot * XYZZ30_BYTES);
     acc30_add(acc, v);
+  };
+  auto load_first = [&](size_t slot) {
+    if (filled(slot)) acc30_load(acc, in + slot * XYZZ30_BYTES);
   };
   // the first element of a lane is LOADED, not added to the identity: one addition less on the dependent chain of the
   // latency-bound levels (6 -> 5 and 5 -> 4 additions of a lone wave, ~20 us each)
@@ -1266,17 +1273,17 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
     const size_t base = (size_t)w * a.win_stride;
     if (a.mode == GS_STRIDED) {
       const size_t b0 = base + (size_t)(r / a.n_lo) * a.s_hi + (size_t)(r % a.n_lo) * a.s_lo;
-      if (q < a.len) acc30_load(acc, in + (b0 + (size_t)q * a.s_e) * XYZZ30_BYTES);
+      if (q < a.len) load_first(b0 + (size_t)q * a.s_e);
       for (uint32_t e = q + lpo; e < a.len; e += lpo) add_rec(b0 + (size_t)e * a.s_e);
     } else {
       const uint32_t nb = a.nb;
       if (r == nb) {  // total
-        if (q < (1u << nb)) acc30_load(acc, in + (base + q) * XYZZ30_BYTES);
+        if (q < (1u << nb)) load_first(base + q);
         for (uint32_t e = q + lpo; e < (1u << nb); e += lpo) add_rec(base + e);
       } else {        // elements whose bit r is set
         const uint32_t half = nb ? (1u << (nb - 1)) : 0u;
         auto slot_of = [&](uint32_t e) { return ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u)); };
-        if (q < half) acc30_load(acc, in + (base + slot_of(q)) * XYZZ30_BYTES);
+        if (q < half) load_first(base + slot_of(q));
         for (uint32_t e = q + lpo; e < half; e += lpo) add_rec(base + slot_of(e));
       }
     }
@@ -1789,7 +1796,9 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
   GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 2) * 4, st));
   uint32_t* d_err = ws.counts.as<uint32_t>() + nbuckets + 1;
-  GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * bucket_bytes, st));
+  // levels (an experiment build) rewrite the entry lists, so the counts no longer say which buckets get written: clear there
+  const bool bucket_counts_valid = levels == 0;
+  if (!bucket_counts_valid) GM_HIP(hipMemsetAsync(ws.buckets.p, 0, nbuckets * bucket_bytes, st));
   const uint32_t dblocks = (uint32_t)((n + 255) / 256);
   Profiler& pf = C->prof;
   auto run_scan = [&]() {
@@ -1982,10 +1991,13 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     while (s < 5 && (1u << s) < len && ((uint64_t)n_out << s) * lpo_jobs < (1ull << lpo_target_log)) s++;
     return s;
   };
+  // the bucket array is NOT cleared per call (109 MB at 2^20 pairs): the first level skips buckets whose entry count is zero
+  const uint8_t* bucket_in = ws.buckets.as<uint8_t>();
+  const uint32_t* bucket_cnt = bucket_counts_valid ? ws.counts.as<uint32_t>() : nullptr;
   auto strided = [&](const uint8_t* in, uint8_t* out, uint32_t win_in, uint32_t n_hi, uint32_t n_lo, uint32_t s_hi, uint32_t s_lo,
                      uint32_t s_e, uint32_t len) {
     GroupSumArgs g{};
-    g.in = in; g.out = out; g.mode = GS_STRIDED;
+    g.in = in; g.out = out; g.mode = GS_STRIDED; g.in_cnt = in == bucket_in ? bucket_cnt : nullptr;
     g.per_win = n_hi * n_lo; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = win_in;
     g.n_lo = n_lo; g.s_hi = s_hi; g.s_lo = s_lo; g.s_e = s_e; g.len = len; g.lpo_shift = lpo_for(len, g.n_out);
     return g;
@@ -1993,6 +2005,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   auto plane = [&](const uint8_t* in, uint8_t* out, uint32_t nb) {
     GroupSumArgs g{};
     g.in = in; g.out = out; g.mode = GS_PLANE; g.out_canonical = 1;  // what the host reads
+    g.in_cnt = in == bucket_in ? bucket_cnt : nullptr;
     g.per_win = nb + 1; g.n_out = (uint32_t)Wb * g.per_win; g.win_stride = 1u << nb; g.nb = nb;
     g.lpo_shift = lpo_for(nb ? (1u << (nb - 1)) : 1u, g.n_out);
     return g;
