@@ -105,7 +105,7 @@ void DevPool::release_all() {
 }
 
 void Profiler::begin(int part, int stage, hipStream_t st) {
-  if (!on) return;
+  if (!on || (only_stage >= 0 && stage != only_stage)) return;
   if (!have_events) {
     for (auto& set : ev)
       for (auto& e : set) (void)hipEventCreate(&e);
@@ -114,7 +114,7 @@ void Profiler::begin(int part, int stage, hipStream_t st) {
   (void)hipEventRecord(ev[part][2 * stage], st);
 }
 void Profiler::end(int part, int stage, hipStream_t st) {
-  if (!on) return;
+  if (!on || (only_stage >= 0 && stage != only_stage)) return;
   (void)hipEventRecord(ev[part][2 * stage + 1], st);
   pending[part][stage] = true;
 }
@@ -321,6 +321,7 @@ void gm_shutdown(void) {
 int gm_prof_enable(int on) {
   GM_CTX();
   C->prof.on = on != 0;
+  C->prof.only_stage = on == 2 ? (int)PROF_ACC0 : -1;
   for (int s = 0; s < PROF_NSTAGES; s++) {
     C->prof.ms[s] = 0;
     C->prof.count[s] = 0;

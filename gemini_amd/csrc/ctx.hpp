@@ -179,6 +179,7 @@ struct MsmWorkspace {
 enum ProfStage { PROF_DIGITS = 0, PROF_SCAN, PROF_SCATTER, PROF_ACC0, PROF_MERGE, PROF_REDUCE, PROF_SC_ROUND, PROF_NSTAGES };
 struct Profiler {
   bool on = false;
+  int only_stage = -1;  // >= 0: events around that stage only (gm_prof_enable(2): the accumulation; every event record is a ~10 us bubble)
   hipEvent_t ev[2][2 * PROF_NSTAGES];  // [window group of a split MSM call][stage begin / end]
   bool have_events = false;
   bool pending[2][PROF_NSTAGES] = {};

@@ -199,7 +199,8 @@ int gm_set_msm_affine_levels(int levels);
 
 /* Per-stage device timing (HIP events on the library's stream).  Stages, in order:
  * 0 digits+histogram, 1 scan, 2 scatter, 3 bucket accumulate (k_acc0), 4 partial merge,
- * 5 bucket reduce, 6 sumcheck round.  gm_prof_enable(1) resets and starts accumulating;
+ * 5 bucket reduce, 6 sumcheck round.  gm_prof_enable(1) resets and starts accumulating; gm_prof_enable(2): stage 3 only (every
+ * event record between two kernels of a call is a ~10 us bubble on the stream: five stages cost an MSM ~60 us, one ~20 us);
  * gm_prof_read returns total milliseconds and launch-group counts per stage.  No reference
  * counterpart (the reference only has start_timer!/end_timer! spans, src/snark/time_prover.rs:23). */
 #define GM_PROF_NSTAGES 7
