@@ -327,13 +327,14 @@ def main():
     mont = lambda v: [(((v << 384) % q) >> (64 * i)) & (2**64 - 1) for i in range(6)]
     g_aff = np.array(mont(gx) + mont(gy), dtype=np.uint64)
     ks = uniform_fr(rng, n)
+    # scalars: two resident sets, alternated, so no step can reuse anything from the previous one.  All host-side generation
+    # comes BEFORE the device-side set-up, so that the device does not sit idle (and clock down) between its set-up work and
+    # the first warm-up step
+    host_scalars = [uniform_fr(rng, n) for _ in range(2)]
     # the headline is the PLAIN one-call MSM: no fixed-base tables for these bases (the library builds them by default at
     # registration; the table path is reported beside it as `with_fixed_base_tables`)
     gm.capi.check(lib.gm_set_auto_tables(C.c_int(0), C.c_size_t(0)))
     bases = gm.G1Bases.fixed_base(g_aff, ks)
-
-    # scalars: two resident sets, alternated, so no step can reuse anything from the previous one
-    host_scalars = [uniform_fr(rng, n) for _ in range(2)]
     dev_scalars = [torch.from_numpy(s.view(np.int64)).cuda() for s in host_scalars]
     torch.cuda.synchronize()
     gather = torch.empty((world, 18), dtype=torch.int64, device=coll_dev) if world > 1 else None
