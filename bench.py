@@ -32,6 +32,46 @@ HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_PAIR = 128  # 32 B scalar + 96 B affine base
 
 
+def host_cpus() -> dict:
+    """CPUs this process may really use: logical count, affinity mask, cgroup quota (`cpu.max` = "1600000 100000" on a 256-thread
+    host means 16) -- the CPU baselines run on THESE, and host threads beyond the quota get the whole process throttled"""
+    logical = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = logical
+    quota = None
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max" and float(b) > 0:
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            quota = None
+    eff = min(logical, aff, int(quota + 0.5) if quota else logical)
+    return {"logical": logical, "affinity": aff, "cgroup_quota": quota, "effective": max(eff, 1)}
+
+
+def cpu_throttled_usec() -> int:
+    """cumulative time the cgroup of this process has been throttled by its CPU quota (0 when unknown)"""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for line in open(path):
+                k, v = line.split()[:2]
+                if k == "throttled_usec":
+                    return int(v)
+                if k == "throttled_time":  # cgroup v1: nanoseconds
+                    return int(v) // 1000
+        except (OSError, ValueError):
+            continue
+    return 0
+
+
 def uniform_fr(rng: np.random.Generator, n: int) -> np.ndarray:
     """n uniform canonical Fr scalars (255-bit draws, rejection above r), shape (n, 4) uint64."""
     r_l = np.array([(R_MOD >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
@@ -208,7 +248,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         top = lgs[-1]
         ratio = measured[top]["cpu_s"] / measured[lgs[0]]["cpu_s"] if len(lgs) > 1 else None  # per factor 4 in n
         steps = (logn - top) / 2.0
-        cpu = {"value": measured[top]["cpu_s"], "unit": "s", "logn": top, "cores": os.cpu_count() or 1,
+        cpu = {"value": measured[top]["cpu_s"], "unit": "s", "logn": top, "cores": host_cpus()["effective"],
                "threads_busy": "<= 17 in the MSMs (one task per window, c = 15 at 2^20), 1 elsewhere", "kind": "port",
                "sample": f"Proof::new_time on dummy_r1cs(2^{lgs[0]}) and dummy_r1cs(2^{top}), one run each "
                          f"({sum(v['cpu_run_incl_setup_s'] for v in measured.values()):.0f} s of CPU incl. setup)",
@@ -361,12 +401,14 @@ def main():
     # untimed pass after the loop
     gm.capi.check(lib.gm_prof_enable(C.c_int(2)))
     barrier()
+    throttled0 = cpu_throttled_usec()
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = step(i)
         assert (r == results.setdefault(i & 1, r)).all(), "non-deterministic MSM result"
     barrier()
     elapsed = time.perf_counter() - t0
+    throttled_in_loop = cpu_throttled_usec() - throttled0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -575,6 +617,9 @@ def main():
                 if acc0_ms and acc0_mhz and args.logn == LOG_N else None,
             },
             "stage_ms": {k: (round(v, 4) if v is not None else None) for k, v in stages.items()},
+            # the host side of a one-call MSM (helper threads, window Horner) runs on the CPUs the container may use; a quota
+            # exhausted by pollers or by other tenants throttles the whole process for the rest of a 100 ms period
+            "host": dict(host_cpus(), cpu_throttled_usec_in_timed_steps=int(throttled_in_loop)),
         }
         if world == 1 and not args.no_cpu_baseline:
             # the CPU restatement of the reference algorithm (arkworks window rule, signed digits,
@@ -583,7 +628,7 @@ def main():
 
             orc.build()
             hb = hb_for_cpu
-            cores = os.cpu_count() or 1
+            cores = host_cpus()["effective"]
             t1 = time.perf_counter()
             exp = orc.msm_pippenger(hb, host_scalars[0], threads=0)
             cpu_s = time.perf_counter() - t1
