@@ -310,6 +310,9 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
 
 
 def main():
+    # the CPU baselines' OpenMP workers sleep when idle instead of spinning: the container's CPU quota (16 of 256 hardware threads on
+    # the pool's boxes) is shared with the host side of the device path that is timed next
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 0.4 s of timed steps behind 75 ms of warm-up -- one 75 ms window of 20 steps was seen to catch a clock
