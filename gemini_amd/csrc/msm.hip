@@ -1976,7 +1976,10 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     wf[1] = nbits - wf[0];
   } else {
     m = 3;
-    wf[0] = nbits / 3;
+    // an odd bit goes to the LOW field (19 bits of the c = 20 tables: 7 + 6 + 6): level 1 sums over it anyway (throughput-bound),
+    // and the latency-bound level 2 then sums 64 instead of 128 elements per output -- two dependent additions less
+    static const bool odd_low = !(getenv("GM_MSM_ODD_BIT") && !strcmp(getenv("GM_MSM_ODD_BIT"), "high"));  // A/B knob
+    wf[0] = odd_low ? (nbits + 2) / 3 : nbits / 3;
     wf[1] = (nbits - wf[0]) / 2;
     wf[2] = nbits - wf[0] - wf[1];
   }
