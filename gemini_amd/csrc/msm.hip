@@ -1221,7 +1221,7 @@ struct GroupSumArgs {
   uint32_t win_stride;  // input elements per bucket set
   // GS_STRIDED: out[w][r] = sum_{e < len} in[w*win_stride + (r / n_lo)*s_hi + (r % n_lo)*s_lo + e*s_e]
   uint32_t n_lo, s_hi, s_lo, s_e, len;
-  // GS_PLANE: input length 2^nb per set; r < nb: elements with bit r set; r == nb: all elements
+  // GS_PLANE: input length 2^nb per set; r < nb: elements with bit r set; r == nb: elements with bit 0 clear (total = that + plane 0)
   uint32_t nb;
   uint32_t lpo_shift;   // lanes per output = 2^lpo_shift
   int out_canonical;    // write canonical 192-byte records (the plane sums the host reads) instead of 208-byte loose ones
@@ -1279,9 +1279,11 @@ __global__ __launch_bounds__(256) void k_group_sum(GroupSumJobs J) {
       for (uint32_t e = q + lpo; e < a.len; e += lpo) add_rec(b0 + (size_t)e * a.s_e);
     } else {
       const uint32_t nb = a.nb;
-      if (r == nb) {  // total
-        if (q < (1u << nb)) load_first(base + q);
-        for (uint32_t e = q + lpo; e < (1u << nb); e += lpo) add_rec(base + e);
+      if (r == nb) {  // the elements whose bit 0 is CLEAR: total = this + plane 0 on the host (one addition per bucket set there);
+                      // summing all 2^nb here made this output twice as deep as every other one of the launch
+        const uint32_t cnt0 = nb ? (1u << (nb - 1)) : 1u;
+        if (q < cnt0) load_first(base + 2u * q);
+        for (uint32_t e = q + lpo; e < cnt0; e += lpo) add_rec(base + 2u * e);
       } else {        // elements whose bit r is set
         const uint32_t half = nb ? (1u << (nb - 1)) : 0u;
         auto slot_of = [&](uint32_t e) { return ((e >> r) << (r + 1)) | (1u << r) | (e & ((1u << r) - 1u)); };
@@ -2279,7 +2281,9 @@ static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, boo
         s = s.dbl();
         s = s.add(plane_at(w, field, jj));
       }
-      S[(size_t)w] = s.add(plane_at(w, 0, P.wf[0]));  // Tot_w
+      gmh::G1 tot = plane_at(w, 0, P.wf[0]);  // the low field's elements with bit 0 clear ...
+      if (P.wf[0] >= 1) tot = tot.add(plane_at(w, 0, 0));  // ... + those with bit 0 set = Tot_w
+      S[(size_t)w] = s.add(tot);
     });
     for (int w = P.Wb - 1; w >= 0; w--) {
       for (int j = 0; j < P.c; j++) result = result.dbl();
