@@ -44,7 +44,7 @@ def stats_md(csv_path, title, note, out_name, top=40):
 
 rows = stats_md(find("msm20", "*kernel_stats.csv"),
                 f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --headline-only (MI355X, {DESC})",
-                "23 one-call 2^20-pair MSMs (3 warm-up + 20 timed), nothing else in the command.", f"{TAG}_msm20_kernel_stats")
+                "33 one-call 2^20-pair MSMs (3 warm-up + 20 timed + 10 untimed ones with every stage timer on), nothing else in the command.", f"{TAG}_msm20_kernel_stats")
 shutil.copy(os.path.join(G, "msm20_bench.json"), os.path.join(P, f"{TAG}_msm20_bench_under_rocprof.json"))
 stats_md(find("snark24", "*kernel_stats.csv"),
          f"rocprofv3 --kernel-trace --stats -- python tools/run_snark.py -i 24 --repeat 3 (MI355X, {DESC})",
@@ -59,7 +59,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     res[c] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 pm = {"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 3 --warmup 1 --headline-only`, "
-                f"MI355X, {DESC}; averages over all dispatches of a kernel in that command (four one-call 2^20-pair MSMs)",
+                f"MI355X, {DESC}; averages over all dispatches of a kernel in that command (seven one-call 2^20-pair MSMs: 1 warm-up + 3 timed + 3 with every stage timer on)",
       "units": "counter values are KiB per dispatch; bytes = value * 1024; gfx950 correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE tallies 128-B requests "
                "at 64 B for 16-B/lane loads, so read bytes = 2 * FETCH_SIZE * 1024 (calibrated there on streaming reads, uncalibrated for this gather pattern; "
                "Infinity-Cache hits are included); WRITE_SIZE as reported",
