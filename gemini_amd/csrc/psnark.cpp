@@ -438,7 +438,10 @@ extern "C" int gm_psnark_preprocess(uint64_t a, uint64_t b, uint64_t c, size_t n
   const uint64_t mats[3] = {a, b, c};
   size_t nrows[3], ncols[3], nnzs[3];
   for (int k = 0; k < 3; k++) RC(gm_spm_shape(mats[k], &nrows[k], &ncols[k], &nnzs[k]));
-  const size_t num_constraints = std::max(nrows[0], std::max(nrows[1], nrows[2]));
+  // as the reference and the Python mirror: keys are col * |rows of A| + row (src/misc.rs:269-366 takes num_constraints from the
+  // instance; the three matrices of an R1CS have the same number of rows -- anything else is rejected here)
+  if (nrows[1] != nrows[0] || nrows[2] != nrows[0]) return GM_EINVAL;
+  const size_t num_constraints = nrows[0];
   for (int k = 0; k < 3; k++)
     if (ncols[k] > num_variables) return GM_EINVAL;
   // keys col * num_constraints + row of every entry, per DISTINCT matrix (dummy_r1cs registers one matrix three times)
