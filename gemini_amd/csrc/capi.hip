@@ -388,7 +388,8 @@ int gm_set_msm_affine_levels(int levels) {
   GM_CTX();
   GM_CHECK(levels >= -1 && levels <= 8, GM_EINVAL, "gm_set_msm_affine_levels: %d not in [-1, 8]", levels);
 #ifndef GM_EXPERIMENTS
-  GM_CHECK(levels == 0, GM_ESTATE, "gm_set_msm_affine_levels: the affine-level experiment is not in this build (make EXTRA=-DGM_EXPERIMENTS; DESIGN.md section 8)");
+  if (levels == -1) levels = 0;  // automatic = no affine levels in a build without the experiment
+  GM_CHECK(levels == 0, GM_EINVAL, "gm_set_msm_affine_levels: the affine-level experiment is not in this build (make EXTRA=-DGM_EXPERIMENTS; DESIGN.md section 8)");
 #endif
   C->msm_affine_levels = levels;
   return GM_OK;
@@ -423,7 +424,9 @@ int gm_g1_bases_register(const void* bases, size_t base_stride, size_t n, uint64
   int rc = bases_from_host(C, bases, base_stride, n, b);
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
-  if ((rc = maybe_auto_tables(C, b.get()))) return rc;
+  // no tables here: a plain registration may be one-shot (VariableBaseMSM::msm = register, one MSM, free) and a table build
+  // costs ~240 doublings per point; the key constructors (gm_g1_srs_register*, gm_g1_fixed_base_register) build them,
+  // and gm_g1_bases_precompute(handle, -1) does for a key uploaded from the host.
   *handle = put_bases(std::move(b));
   return GM_OK;
 }
@@ -448,6 +451,7 @@ int gm_g1_bases_precompute(uint64_t handle, int c) {
   GM_CTX();
   Bases* b = find_bases(handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "bases_precompute: unknown handle %llu", (unsigned long long)handle);
+  if (c == -1) return b->table ? GM_OK : maybe_auto_tables(C, b);  // automatic: the rule of the key constructors (size range, budget, free memory)
   return bases_precompute(C, b, c);
 }
 

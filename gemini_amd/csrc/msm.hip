@@ -1639,7 +1639,7 @@ int msm_run_batch_offsets(Context* C, const Bases* bases, const size_t* pair_off
                           const size_t* ns, size_t k, bool normalize, uint64_t* out_jac) {
   return msm_run_batch_at(C, bases, 0, step, pair_offsets, d_scalars, mont, ns, k, normalize, out_jac);
 }
-// pair_offsets[j] (optional): call j starts at base first + step * pair_offsets[j]
+// pair_offsets[j] (optional): call j starts at base pair_offsets[j] (absolute, whatever the step) and walks step from there
 // firsts[j] (optional): call j starts at base firsts[j] instead of `first` (herring: even / odd halves of one array)
 static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64_t step, const size_t* pair_offsets, const void* const* d_scalars,
                             int mont, const size_t* ns, size_t k, bool normalize, uint64_t* out_jac, const int64_t* firsts) {
@@ -1648,7 +1648,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
   for (size_t j = 0; j < k; j++) pipelined = pipelined && ns[j] <= CH;
   if (!pipelined) {
     for (size_t j = 0; j < k; j++) {
-      int rc = msm_run(C, bases, (firsts ? firsts[j] : first) + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont, ns[j], normalize,
+      int rc = msm_run(C, bases, (pair_offsets ? (int64_t)pair_offsets[j] : (firsts ? firsts[j] : first)), step, d_scalars[j], mont, ns[j], normalize,
                        out_jac + 18 * j);
       if (rc) return rc;
     }
@@ -1706,7 +1706,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     MsmWorkspace& ws = lane > 0 ? C->msm_small[lane - 1] : (lane < 0 ? C->msm_b : C->msm);
     hipStream_t st = lane > 0 ? C->small_stream[lane - 1] : (lane < 0 ? C->stream_b : C->stream);
     if (st != C->stream) GM_HIP(hipStreamWaitEvent(st, C->start_ev, 0));  // scalars produced on the main stream
-    int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, (firsts ? firsts[j] : first) + step * (int64_t)(pair_offsets ? pair_offsets[j] : 0), step, d_scalars[j], mont,
+    int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, (pair_offsets ? (int64_t)pair_offsets[j] : (firsts ? firsts[j] : first)), step, d_scalars[j], mont,
                          ns[j], hslot, &e.P);
     if (rc) return fail(rc);
     q.push_back(e);

@@ -444,6 +444,10 @@ extern "C" int gm_psnark_preprocess(uint64_t a, uint64_t b, uint64_t c, size_t n
   const size_t num_constraints = nrows[0];
   for (int k = 0; k < 3; k++)
     if (ncols[k] > num_variables) return GM_EINVAL;
+  // row / column indices are 32-bit index vectors (gm_idx_*), keys col * num_constraints + row are 64-bit words: an instance
+  // past either limit is refused, not truncated into a wrong joint support
+  if (num_constraints > 0xffffffffull || num_variables > 0xffffffffull) return GM_EINVAL;
+  if (num_constraints && num_variables > UINT64_MAX / num_constraints) return GM_EINVAL;
   // keys col * num_constraints + row of every entry, per DISTINCT matrix (dummy_r1cs registers one matrix three times)
   struct Host {
     std::vector<uint64_t> rowptr, keys, vals;

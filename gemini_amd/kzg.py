@@ -54,6 +54,15 @@ class CommitterKey:
         powers_of_g2 = [G2.mul(g2, pow(tau, i, R_MOD)) for i in range(max_eval_points + 1)]  # :60-67
         return cls(G1Bases.srs(g, tau_canonical, max_degree + 1), max_eval_points, powers_of_g2)
 
+    @classmethod
+    def from_powers(cls, powers_of_g: np.ndarray, max_eval_points: int, powers_of_g2=None) -> "CommitterKey":
+        """a key whose G1 powers come from the host (a deserialised `CommitterKey`, src/kzg/time.rs:24-27): uploaded once,
+        and -- a key stays resident -- given its fixed-base tables when they fit (gm_g1_bases_precompute(handle, -1); a plain
+        `G1Bases.register` builds none, it may serve one MSM only)"""
+        reg = G1Bases.register(powers_of_g)
+        reg.precompute(-1)
+        return cls(reg, max_eval_points, powers_of_g2)
+
     def powers_of_g2_bytes(self) -> bytes:
         """serialize_uncompressed(&self.powers_of_g2), what `append_serializable(b"ck", ..)` absorbs"""
         from . import g2 as G2

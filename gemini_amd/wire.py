@@ -175,10 +175,12 @@ def g1_serialize(jac, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS) -> 
     return bytes(out)
 
 
-def g1_deserialize(buf: bytes, pos: int, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS, validate: bool = True, strict: bool = False):
-    """strict = False accepts what ark-ec 0.4's `Affine::deserialize_with_mode` accepts (recalled, like the layouts: the crate is
-    not in /root/reference): the infinity flag wins over whatever the coordinate bytes hold, and the y-sign flag of an
-    UNCOMPRESSED point is not compared with y.  strict = True rejects both (the canonical encoding only)."""
+def g1_deserialize(buf: bytes, pos: int, compress: bool, enc: G1Encoding = G1Encoding.ARKWORKS, validate: bool = True, strict: bool = True):
+    """strict = True (the default of every proof / verifier parser here) accepts the canonical encoding only, so a proof has
+    ONE byte string.  strict = False additionally accepts what ark-ec 0.4's `Affine::deserialize_with_mode` is RECALLED to accept
+    (the crate is not in /root/reference and no vector of the real crate pins it): the infinity flag wins over whatever the
+    coordinate bytes hold, and the y-sign flag of an UNCOMPRESSED point is not compared with y -- for byte-compatibility
+    experiments only, it makes encodings malleable."""
     n = g1_size(compress)
     if pos + n > len(buf):
         raise WireError("not enough bytes for a G1 point")

@@ -69,7 +69,9 @@ int gm_abi_version(void);
 int gm_g1_msm(const void* bases, size_t base_stride, const uint64_t* scalars, size_t n, uint64_t out_jac[18]);
 
 /* SRS resident in HBM: replaces the `powers_of_g: Vec<G1Affine>` field of CommitterKey
- * (src/kzg/time.rs:24-27) as the MSM operand.  The bases are copied; `handle` is opaque. */
+ * (src/kzg/time.rs:24-27) as the MSM operand.  The bases are copied; `handle` is opaque.  Cost: one upload and one
+ * repacking pass; NO fixed-base tables are built here (a registration may serve a single MSM) -- a key that stays
+ * resident asks for them with gm_g1_bases_precompute(handle, -1). */
 int gm_g1_bases_register(const void* bases, size_t base_stride, size_t n, uint64_t* handle);
 int gm_g1_bases_free(uint64_t handle);
 int gm_g1_bases_len(uint64_t handle, size_t* n);
@@ -82,11 +84,15 @@ int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96);
  * all windows: c = 20 instead of 16 (13 instead of 16 base additions per pair), no per-window bucket
  * reduction and c instead of 256 doublings at the end.  Results are identical (tests compare both
  * paths).  Setup cost is comparable to generating the SRS; like CommitterKey::new it is outside the
- * prover timer.  c = 0 picks the default (20).  No reference counterpart: ark-ec recomputes. */
+ * prover timer.  c = 0 picks the default (20); c = -1 is AUTOMATIC: the rule of gm_set_auto_tables below (2^17 .. 2^26 - 1
+ * points, byte budget, free memory; a no-op returning GM_OK when the tables do not fit or exist already).
+ * No reference counterpart: ark-ec recomputes. */
 int gm_g1_bases_precompute(uint64_t handle, int c);
-/* Tables BY DEFAULT (on = 1 at gm_init): every registration (gm_g1_bases_register, gm_g1_fixed_base_register,
- * gm_g1_srs_register) of 2^17 .. 2^26 - 1 points builds the tables above when W x n x 96 bytes fit `max_bytes`
- * (0 = 30 % of the device memory) and the free memory; otherwise, silently, the plain path serves the key.
+/* Tables BY DEFAULT (on = 1 at gm_init) for the KEY CONSTRUCTORS: gm_g1_fixed_base_register, gm_g1_srs_register and
+ * gm_g1_srs_register_segments (the CommitterKey::new analogues) build the tables above for 2^17 .. 2^26 - 1 points when
+ * W x n x 96 bytes fit `max_bytes` (0 = 30 % of the device memory) and the free memory; otherwise, silently, the plain path
+ * serves the key.  Cost at registration: ~240 doublings per point and W x n x 96 bytes (1.3 GB at 2^20 points).
+ * gm_g1_bases_register (points uploaded from the host) never builds them on its own: gm_g1_bases_precompute(handle, -1).
  * A committer key is registered once and serves ~3 N pairs of MSMs per proof; the build is setup, like
  * CommitterKey::new (src/kzg/time.rs:49-72, which builds a window table of its own to generate the key). */
 int gm_set_auto_tables(int on, size_t max_bytes);
@@ -194,7 +200,7 @@ int gm_set_msm_split(int on);
  * level adds the sorted entries of each bucket pairwise in affine coordinates with one shared field
  * inversion (6 instead of 10 field products per addition).  The result does not depend on it.
  * A round-2 EXPERIMENT, slower at every size: the kernels are only in builds with -DGM_EXPERIMENTS
- * (gemini_amd/csrc/msm_levels.inc); otherwise any levels != 0 returns GM_ESTATE. */
+ * (gemini_amd/csrc/msm_levels.inc); otherwise -1 and 0 both mean "none" and any levels > 0 returns GM_EINVAL. */
 int gm_set_msm_affine_levels(int levels);
 
 /* Per-stage device timing (HIP events on the library's stream).  Stages, in order:

@@ -221,6 +221,7 @@ class CommitterKey {
  public:
   explicit CommitterKey(const std::vector<G1Affine>& powers_of_g) : n_(powers_of_g.size()) {
     check(gm_g1_bases_register(powers_of_g.data(), sizeof(G1Affine), n_, &h_));
+    check(gm_g1_bases_precompute(h_, -1));  // a committer key stays resident: fixed-base tables when they fit (gm_set_auto_tables)
   }
   ~CommitterKey() {
     if (h_) gm_g1_bases_free(h_);

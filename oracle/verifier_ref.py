@@ -203,6 +203,32 @@ def dummy_matrix_evaluations(e: int, n: int):
     return m_of
 
 
+def dummy_matrix_evaluations_closed_form(e: int, n: int):
+    """The same three inner products for dummy_r1cs(e, n), n a power of two, in O(log n): with A = B = C = diag(1 / e),
+    A * powers(x) = powers(x) / e, and  <powers(x), tensor(rho)> = prod_j (1 + rho_j x^(2^j))  (evaluate_tensor_poly,
+    src/misc.rs:373-382),  <powers(x), tensor(rho) o powers(alpha)> = the same product at alpha x,  <powers(x), powers(alpha)> =
+    geometric(alpha x, n) (src/misc.rs:387-389).  Held equal to the O(n) hook above in tests/test_oracle_verifier.py; it is what
+    lets the verifier run on a 2^28-constraint proof."""
+    inv_e = pow(e, -1, R)
+
+    def m_of(point: int, ch1, alpha: int, etas):
+        assert 1 << len(ch1) == n
+        ax = alpha * point % R
+        geo = n % R if ax == 1 else (pow(ax, n, R) - 1) * pow(ax - 1, -1, R) % R
+        parts = [_tensor_poly(ch1, ax), _tensor_poly(ch1, point), geo]
+        return inv_e * P.ip(parts, etas) % R
+
+    return m_of
+
+
+def _tensor_poly(elements, x: int) -> int:
+    res, s = 1, x % R
+    for el in elements:
+        res = res * (1 + el * s) % R
+        s = s * s % R
+    return res
+
+
 def snark_verify(proof, r1cs, vk: VerifierKey, m_of=None) -> None:
     """:19-119; raises VerificationError on rejection.  `r1cs` as in snark_ref (rows of (value, column) pairs); `m_of`
     (optional) replaces the O(n) evaluation of the matrices at the powers of +-beta (dummy_matrix_evaluations)."""

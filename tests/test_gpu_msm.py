@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from tests.util import assert_same_point, is_normalised, jac_to_affine_ints, rand_bases
+from tests.util import assert_same_point, dot_ints, is_normalised, jac_to_affine_ints, rand_bases
 
 pytestmark = pytest.mark.gpu
 
@@ -240,7 +240,26 @@ def test_tables_are_the_default_for_a_resident_key(gm, oracle):
         reg = gm.G1Bases.fixed_base(oracle.g1_generator(), ks)
         assert reg.table_info() == (0, 0)
         assert (reg.msm_bigint(sc) == with_tables).all()
+        host = reg.download()
         reg.free()
+        # points uploaded from the host: a registration may serve ONE MSM (VariableBaseMSM::msm), so it builds nothing;
+        # a key that stays resident asks with precompute(-1), which follows the same budget rule
+        gm.capi.check(lib.gm_set_auto_tables(C.c_int(1), C.c_size_t(0)))
+        up = gm.G1Bases.register(host)
+        assert up.table_info() == (0, 0)
+        assert (up.msm_bigint(sc) == with_tables).all()
+        up.precompute(-1)
+        assert up.table_info() == (20, 13 * n * 96)
+        up.precompute(-1)  # idempotent
+        assert (up.msm_bigint(sc) == with_tables).all()
+        up.free()
+        ck = gm.CommitterKey.from_powers(host, 3)
+        assert ck.powers_of_g.table_info() == (20, 13 * n * 96)
+        ck.powers_of_g.free()
+        tiny = gm.G1Bases.register(host[:4096])
+        tiny.precompute(-1)
+        assert tiny.table_info() == (0, 0)
+        tiny.free()
     finally:
         gm.capi.check(lib.gm_set_auto_tables(C.c_int(1), C.c_size_t(0)))
 
@@ -265,6 +284,9 @@ def test_msm_2_20_properties(gm, oracle, pyref):
         ki = oracle.limbs_to_ints(ks[: 1 << 12])
         small = reg.msm_bigint(a[: 1 << 12])
         assert jac_to_affine_ints(oracle, small) == pyref.g1_mul(pyref.G1_GEN, sum(x * y for x, y in zip(ai, ki)) % pyref.R_MOD)
+        # ... and on ALL 2^20 pairs: the whole result against (sum a_i k_i mod r) * G, no oracle MSM involved
+        assert dot_ints(a[: 1 << 12], ks[: 1 << 12]) == sum(x * y for x, y in zip(ai, ki))
+        assert jac_to_affine_ints(oracle, full) == pyref.g1_mul(pyref.G1_GEN, dot_ints(a, ks) % pyref.R_MOD)
         # all-equal scalars (the dummy_r1cs witness): e * sum P_i
         e = oracle.random_fr(83, 1)[0]
         ones = np.tile(oracle.ints_to_limbs([1], 4)[0], (n, 1))
@@ -324,6 +346,14 @@ def test_msm_2_24_properties(gm, oracle, pyref):
         m = 1 << 11
         ai, ki = oracle.limbs_to_ints(a[:m]), oracle.limbs_to_ints(ks[:m])
         assert jac_to_affine_ints(oracle, reg.msm_bigint(a[:m])) == pyref.g1_mul(pyref.G1_GEN, sum(x * y for x, y in zip(ai, ki)) % pyref.R_MOD)
+        # the WHOLE 2^24-pair result (tables path: the key was built by a constructor) and the same pairs on the plain path
+        want = pyref.g1_mul(pyref.G1_GEN, dot_ints(a, ks) % pyref.R_MOD)
+        assert jac_to_affine_ints(oracle, full) == want
+        gm.capi.check(gm.capi.load().gm_set_msm_table_min(C.c_size_t(1 << 62)))
+        try:
+            assert (reg.msm_bigint(a) == full).all()
+        finally:
+            gm.capi.check(gm.capi.load().gm_set_msm_table_min(C.c_size_t(1 << 17)))
         e = oracle.random_fr(2425, 1)[0]
         ones = np.tile(oracle.ints_to_limbs([1], 4)[0], (n - 1, 1))
         s1 = reg.msm_bigint(ones)
@@ -384,6 +414,19 @@ def test_segmented_srs_and_batch_with_offsets(gm, oracle, pyref):
         assert all(oracle.g1_jac_eq(part[j], single[j]) for j in range(len(ns)))
         # and against the plain key's own range: segment 2 = powers 1000 .. 1199
         assert (plain.msm_vec(vecs[1], n=200, offset=1000) == single[1]).all()
+        # reversed: call j starts AT offsets[j] and walks down (the Reverse(powers_of_g) view of src/kzg/space.rs:95-125)
+        roffs = [299, 499, 500, 628, 300]
+        rsingle = [seg.msm_vec(v, n=m, offset=o, reversed_=True) for v, m, o in zip(vecs, ns, roffs)]
+        rnorm = seg.msm_vec_batch_at(vecs, ns, roffs, reversed_=True)
+        assert all((rnorm[j] == rsingle[j]).all() for j in range(len(ns)))
+        rpart = seg.msm_vec_batch_at(vecs, ns, roffs, reversed_=True, partial=True)
+        assert all(oracle.g1_jac_eq(rpart[j], rsingle[j]) for j in range(len(ns)))
+        rev = oracle.fr_to_mont(oracle.random_fr(80, 300))[::-1].copy()
+        rv = FrVec.from_host(rev)  # reversed walk over reversed scalars == the forward call
+        assert (seg.msm_vec_batch_at([rv], [300], [299], reversed_=True)[0] == single[0]).all()
+        rv.free()
+        with pytest.raises(gm.capi.GeminiHipError):
+            seg.msm_vec_batch_at(vecs[:1], [300], [298], reversed_=True)  # walks below base 0
         with pytest.raises(gm.capi.GeminiHipError):
             seg.msm_vec_batch_at(vecs[:1], [300], [400])  # runs past the end of the key
         for v in vecs:

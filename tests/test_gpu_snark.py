@@ -538,20 +538,13 @@ def test_snark_elastic_config4_shape_at_logn_22(gm, oracle, pyref):
     ck.powers_of_g.free()
 
 
-def test_snark_elastic_config4_at_logn_26_closed_forms(gm, oracle, pyref):
-    """BASELINE configs[3] two powers short of its own size (`examples/snark -i 28` needs the 8 GPUs of the config; one GPU
-    proves it in 3 s, see profiles/): the elastic prover on dummy_r1cs_stream(2^26) over the GENERATOR-COPIES key of
-    examples/snark.rs:59-63, max_msm_buffer = 2^20 (:57), default flush merging.  Checked through what the instance fixes in
-    closed form -- every base is g and w = [e; n - 1], so commitment(w) = e (n - 1) g; z_c = [1; n], so
-    zc(alpha) = (alpha^n - 1) / (alpha - 1) with alpha re-derived by the oracle's Merlin from that commitment; the first
-    sumcheck message on all-ones vectors -- and the space -> time hand-off after 4 rounds (SPACE_TIME_THRESHOLD = 22)."""
+def _elastic_closed_forms(gm, oracle, pyref, logn, native):
     from gemini_amd.circuit import R1csStream, dummy_r1cs
     from gemini_amd.kzg import CommitterKey, CommitterKeyStream, g1_generator_mont
     from gemini_amd.msm import G1Bases
     from gemini_amd.snark import Proof
 
     R = pyref.R_MOD
-    logn = 26
     n = 1 << logn
     e = 0x0F1E2D3C4B5A69788796A5B4C3D2E1F00112233445566778 % R
     ones = np.zeros((n + 1, 4), dtype=np.uint64)
@@ -560,7 +553,7 @@ def test_snark_elastic_config4_at_logn_26_closed_forms(gm, oracle, pyref):
     del ones
     r1cs = dummy_r1cs(e, n)
     stream = R1csStream(r1cs)
-    proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << 20)
+    proof = Proof.new_elastic(stream, CommitterKeyStream.from_committer_key(ck), 1 << 20, native=native)
     inv = lambda v: pow(v % R, -1, R)
     want_cm = pyref.g1_mul(pyref.G1_GEN, e * (n - 1) % R)
     assert jac_to_affine_ints(oracle, proof.witness_commitment) == want_cm
@@ -574,9 +567,40 @@ def test_snark_elastic_config4_at_logn_26_closed_forms(gm, oracle, pyref):
     assert len(msgs) == logn
     assert I(msgs[0][0]) == a0 and I(msgs[0][1]) == a0 * (1 + alpha) % R
     assert len(proof.tensorcheck_proof.folded_polynomials_commitments) == logn - 1
+    # ... and the WHOLE verifier of src/snark/verifier.rs:19-119 on this proof: the generator-copies key is the key of the
+    # trapdoor tau = 1 (`powers_of_g2: vec![g2; 4]`, examples/snark.rs:63), and for dummy_r1cs the verifier's O(n) matrix
+    # evaluations have an O(log n) closed form (oracle/verifier_ref.py::dummy_matrix_evaluations_closed_form, held equal to
+    # the generic evaluation in tests/test_oracle_verifier.py) -- both sumcheck subclaims, the tensor relation of all
+    # logn - 1 levels and the pairing check of the batched opening
+    from oracle import verifier_ref as V
+    from tests.util import snark_proof_to_ints
+
+    V.snark_verify(snark_proof_to_ints(gm, oracle, proof), {"a": range(n), "x": [e]}, V.VerifierKey.from_trapdoor(1, 3),
+                   m_of=V.dummy_matrix_evaluations_closed_form(e, n))
+    size = proof.compressed_size()
     stream.free()
     r1cs.free()
     ck.powers_of_g.free()
+    gm.capi.load().gm_pool_trim()
+    return size
+
+
+def test_snark_elastic_config4_at_logn_26_closed_forms(gm, oracle, pyref):
+    """BASELINE configs[3] two powers short of its own size: the elastic prover (Python-driven) on dummy_r1cs_stream(2^26) over
+    the GENERATOR-COPIES key of examples/snark.rs:59-63, max_msm_buffer = 2^20 (:57), default flush merging.  Checked through
+    what the instance fixes in closed form -- every base is g and w = [e; n - 1], so commitment(w) = e (n - 1) g; z_c = [1; n],
+    so zc(alpha) = (alpha^n - 1) / (alpha - 1) with alpha re-derived by the oracle's Merlin from that commitment; the first
+    sumcheck message on all-ones vectors -- and the space -> time hand-off after 4 rounds (SPACE_TIME_THRESHOLD = 22)."""
+    _elastic_closed_forms(gm, oracle, pyref, 26, native=False)
+
+
+def test_snark_elastic_config4_at_its_own_size_logn_28(gm, oracle, pyref):
+    """BASELINE configs[3] AT ITS OWN SIZE: `examples/snark -i 28`, elastic prover (examples/snark.rs:54-66), on ONE MI355X
+    (the config names 8; 288 GB hold it whole: 26 GB of key, 8.6 GB per vector) through the compiled driver
+    gm_snark_new_elastic, the same closed forms as at 2^26 -- and the proof size the example prints (:96) follows from logn
+    alone."""
+    s28 = _elastic_closed_forms(gm, oracle, pyref, 28, native=True)
+    assert s28 > 0
 
 
 def test_stream_commit_crosses_the_merge_floor(gm, oracle):

@@ -33,9 +33,9 @@ def _single(extra=()):
     return _SINGLE[key]
 
 
-def _run(world, extra):
+def _run(world, extra, tool="run_snark.py", logn=12):
     env = dict(os.environ, GM_BENCH_BACKEND="gloo", GM_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    script = [os.path.join(ROOT, "tools", "run_snark.py"), "-i", "12", "--repeat", "1"] + extra
+    script = [os.path.join(ROOT, "tools", tool), "-i", str(logn), "--repeat", "1"] + extra
     if world == 1:
         cmd = [sys.executable] + script
     else:
@@ -55,6 +55,18 @@ def test_two_ranks_one_gpu_same_proof(extra):
         assert many["n_gpus"] == world
         assert many["proof_sha256"] == one["proof_sha256"], (world, extra)
 
+
+
+@pytest.mark.parametrize("extra", [[], ["--elastic"]], ids=["time", "elastic"])
+def test_psnark_two_and_three_ranks_one_gpu_same_proof(extra):
+    """BASELINE configs[4] is the 8-GPU preprocessing SNARK (examples/psnark.rs:54-81): `psnark` time and elastic provers over
+    the element-cyclic sharded key on 2 and 3 ranks must produce the single-GPU proof byte for byte (src/psnark/tests.rs:14-125
+    holds time == elastic on one key; here every rank count must agree with one GPU)."""
+    one = _run(1, list(extra), tool="run_psnark.py", logn=10)
+    for world in (2, 3):
+        many = _run(world, list(extra), tool="run_psnark.py", logn=10)
+        assert many["n_gpus"] == world
+        assert many["proof_sha256"] == one["proof_sha256"], (world, extra)
 
 
 @pytest.mark.parametrize("tail_log", [4, 6])

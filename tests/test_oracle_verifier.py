@@ -202,6 +202,13 @@ def test_c_backed_matrix_evaluations_equal_the_generic_ones(honest):
     a_bp = sr.matvec(inst["a"], bp)
     want = P.ip([P.ip(a_bp, [x * y % R for x, y in zip(t, ap)]), sum(x * y for x, y in zip(a_bp, t)) % R, P.ip(a_bp, ap)], etas)
     assert V.dummy_matrix_evaluations(e, n)(beta, ch1, alpha, etas) == want
+    # ... and the O(log n) closed form of the same hook (the verifier of a 2^28-constraint proof)
+    assert V.dummy_matrix_evaluations_closed_form(e, n)(beta, ch1, alpha, etas) == want
+    assert V.dummy_matrix_evaluations_closed_form(e, n)((-beta) % R, ch1, alpha, etas) == V.dummy_matrix_evaluations(e, n)((-beta) % R, ch1, alpha, etas)
+    V.snark_verify(proof, {"a": range(n), "x": [e]}, vk, m_of=V.dummy_matrix_evaluations_closed_form(e, n))
+    # the generator-copies key of examples/snark.rs:59-63 is the key of the trapdoor tau = 1
+    p1 = sr.snark_new_time(inst, sr.srs(1, 2 * n + 1))
+    V.snark_verify(p1, {"a": range(n), "x": [e]}, V.VerifierKey.from_trapdoor(1, 3), m_of=V.dummy_matrix_evaluations_closed_form(e, n))
     # a proof for another instance value is rejected through the hook as well
     with pytest.raises(V.VerificationError):
         V.snark_verify(proof, {"a": range(n), "x": [e]}, vk, m_of=V.dummy_matrix_evaluations((e + 1) % R, n))

@@ -90,19 +90,19 @@ def test_deserialize_rejects_malformed_points():
     wire.g1_deserialize(unc, 0, False, validate=False)
     with pytest.raises(wire.WireError):
         wire.fr_deserialize(P.R_MOD.to_bytes(32, "little"), 0)
-    # non-canonical encodings ark-ec 0.4 accepts (recalled): accepted by default, rejected with strict = True
+    # non-canonical encodings ark-ec 0.4 accepts (recalled): rejected by default (one byte string per proof), accepted with strict = False
     gu = bytearray(wire.g1_serialize(wire.g1_from_affine_ints(P.G1_GEN), False))
     gu[-1] ^= 0x80  # the y-sign flag of an uncompressed point
-    pt, _ = wire.g1_deserialize(bytes(gu), 0, False)
+    pt, _ = wire.g1_deserialize(bytes(gu), 0, False, strict=False)
     assert np.array_equal(pt, wire.g1_from_affine_ints(P.G1_GEN))
     with pytest.raises(wire.WireError):
-        wire.g1_deserialize(bytes(gu), 0, False, strict=True)
+        wire.g1_deserialize(bytes(gu), 0, False)
     inf = bytearray(wire.g1_serialize(wire.g1_from_affine_ints(None), True))
     inf[0] = 7  # infinity flag over a non-zero x
-    pt, _ = wire.g1_deserialize(bytes(inf), 0, True)
+    pt, _ = wire.g1_deserialize(bytes(inf), 0, True, strict=False)
     assert np.array_equal(pt, wire.g1_from_affine_ints(None))
     with pytest.raises(wire.WireError):
-        wire.g1_deserialize(bytes(inf), 0, True, strict=True)
+        wire.g1_deserialize(bytes(inf), 0, True)
 
 
 def _synthetic_snark(rounds=5, seed=3):

@@ -8,6 +8,26 @@ def rand_bases(orc, seed: int, n: int) -> np.ndarray:
     return orc.g1_fixed_base_mul(orc.g1_generator(), ks)
 
 
+def dot_ints(a: np.ndarray, k: np.ndarray) -> int:
+    """sum_i a_i * k_i as an exact integer, a and k (n, 4) little-endian u64 limbs.  No oracle involved: 16-bit limbs as
+    float64 columns, one 16 x 16 BLAS product per block of 2^20 rows (partial sums < 2^32 * 2^20 = 2^52, exact), recombined
+    with Python integers.  With bases k_i * G the whole MSM result must be (dot mod r) * G -- a check of ALL n pairs that
+    takes about a second at 2^24."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    k = np.ascontiguousarray(k, dtype=np.uint64).reshape(-1, 4)
+    assert a.shape == k.shape
+    total = 0
+    for lo in range(0, len(a), 1 << 20):
+        A = a[lo: lo + (1 << 20)].view(np.uint16).reshape(-1, 16).astype(np.float64)
+        K = k[lo: lo + (1 << 20)].view(np.uint16).reshape(-1, 16).astype(np.float64)
+        M = A.T @ K
+        assert M.max() < 2.0 ** 53
+        for j in range(16):
+            for l in range(16):
+                total += int(M[j, l]) << (16 * (j + l))
+    return total
+
+
 def jac_to_affine_ints(orc, jac):
     return orc.affine_to_ints(orc.g1_to_affine(jac))
 

@@ -60,8 +60,7 @@ def main():
     if world > 1:
         from gemini_amd.dist import ShardedCommitterKey
 
-        assert not args.elastic, "the sharded preprocessing prover runs the time prover"
-        ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
+        ck = ShardedCommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau, rank, world)
     else:
         ck = CommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
     t_srs = time.perf_counter() - t0
@@ -79,7 +78,13 @@ def main():
             from gemini_amd.kzg import CommitterKeyStream
 
             stream = R1csStream(r1cs)
-            proof = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20)
+            if world > 1:
+                from gemini_amd.dist import ShardedCommitterKeyStream
+
+                cks = ShardedCommitterKeyStream.from_sharded_key(ck)
+            else:
+                cks = CommitterKeyStream.from_committer_key(ck)
+            proof = Proof.new_elastic(cks, stream, index, 1 << 20)
             stream.free()
         else:
             proof = Proof.new_time(ck, r1cs, index, native=args.native)
@@ -95,9 +100,10 @@ def main():
     out["proof_sha256"] = hashlib.sha256(proof.serialize_compressed()).hexdigest()
     if world > 1:
         allt = [None] * world
-        dist.all_gather_object(allt, (out.get("time_prover_s"), out["proof_sha256"]))
+        tkey = "elastic_prover_s" if args.elastic else "time_prover_s"
+        dist.all_gather_object(allt, (out[tkey], out["proof_sha256"]))
         assert len({d for _, d in allt}) == 1, "ranks produced different proofs"
-        out["time_prover_s"] = max(t for t, _ in allt)
+        out[tkey] = max(t for t, _ in allt)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
