@@ -489,6 +489,41 @@ int gm_psnark_preprocess_free(gm_psnark_instance* instance);
 /* psnark::Proof::index (src/psnark/time_prover.rs:49-64): commitments to row, col, val_a, val_b, val_c; out = 5 x 18 limbs */
 int gm_psnark_index(const gm_psnark_instance* instance, uint64_t ck_bases, uint64_t* out_jac);
 
+/* ---- Multi-GPU: the collective layer (gemini_amd/csrc/dist.cpp) ------------------------------------------------------
+ * One process per GPU (gm_init(LOCAL_RANK)).  The reference has no multi-device code: what shards is its own loop structure --
+ * the MSM behind every commitment (src/kzg/time.rs:81-107: pairs split across ranks, 144-byte partial points all-gathered and
+ * added on every rank), the rounds of Sumcheck::prove (src/subprotocols/sumcheck/proof.rs:36-66: 64 bytes per round), the
+ * O(n) vector passes of snark::Proof::new_time (src/snark/time_prover.rs:19-117).  The ONE primitive is an all-gather; three
+ * transports provide it:
+ *   gm_dist_init_rccl  ncclAllGather over xGMI on a communicator of the library's own (librccl dlopen'ed at this call).
+ *                      Rank 0 draws the id with gm_dist_rccl_unique_id and hands the 128 bytes to its peers out of band
+ *                      (the launcher's store, a file, MPI ...).
+ *   gm_dist_init_hook  the embedder's all-gather of host buffers: fn(ctx, send, bytes, recv) fills recv with the `world`
+ *                      payloads in rank order and returns 0.
+ *   gm_dist_init_shm   ranks of one node over a POSIX shared-memory segment `name` ("/something", the same on every rank;
+ *                      slot_bytes = 0: 1 MiB per rank and call, longer payloads are cut): the payloads of this path are
+ *                      host results of <= 1 KiB, which cross processes in ~1 us this way.
+ * Without any of them (or world = 1) an all-gather is a copy.  Collective calls must be made by every rank in the same order. */
+typedef int (*gm_allgather_fn)(void* ctx, const void* send, size_t bytes, void* recv);
+int gm_dist_init_hook(int rank, int world, gm_allgather_fn fn, void* ctx);
+int gm_dist_rccl_unique_id(uint8_t out[128]);
+int gm_dist_init_rccl(int rank, int world, const uint8_t unique_id[128]);
+int gm_dist_init_shm(int rank, int world, const char* name, size_t slot_bytes);
+int gm_dist_finalize(void);
+/* transport: 0 none, 1 hook, 2 RCCL, 3 shm */
+int gm_dist_info(int* rank, int* world, int* transport);
+/* recv = world x bytes, rank order.  Host buffers (an MSM partial is finished by the host Horner; sumcheck messages and
+ * evaluations are host values too). */
+int gm_dist_allgather_host(const void* send, size_t bytes, void* recv);
+/* out = the local vectors of ranks 0 .. world - 1 back to back (equal lengths; out needs capacity world x len and is
+ * resized): device to device over RCCL, staged through the host on the other transports. */
+int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec);
+/* collectives issued by this rank so far, the bytes they received and the wall time spent inside them */
+int gm_dist_stats(uint64_t* calls, uint64_t* bytes, double* seconds, int reset_counters);
+/* Patterns of 8 B .. 64 KiB through the active transport, checked on every rank.  With NO transport initialised it opens
+ * a one-rank RCCL communicator for the test, so the binding runs on a single-GPU box too. */
+int gm_dist_selftest(void);
+
 #ifdef __cplusplus
 }
 #endif
