@@ -57,6 +57,10 @@ struct Bases {
   uint8_t* table = nullptr;
   int tab_c = 0, tab_W = 0;
   size_t tab_min = 0;  // smallest call the tables pay off for (depends on their window width)
+  // a CYCLIC SHARE of a committer key (gm_g1_bases_set_cyclic): these n points are the powers i = cyc_rank (mod cyc_world)
+  // of a key of cyclic_n powers; gm_ck_* and the provers commit through the all-gather of dist.cpp.  0 = a whole key
+  size_t cyclic_n = 0;
+  int cyc_rank = 0, cyc_world = 1;
 };
 
 struct FrVec {

@@ -30,7 +30,7 @@ Fr fr_pow(Fr base, size_t e) {
 int commit(uint64_t ck, size_t nck, uint64_t v, uint64_t out[18]) {
   size_t n = 0;
   RC(vec_len(v, &n));
-  return gm_g1_msm_v(ck, 0, 0, v, 0, n < nck ? n : nck, out);
+  return gm_ck_msm(ck, 0, 0, v, 0, n < nck ? n : nck, out);
 }
 int batch_commit(uint64_t ck, size_t nck, const std::vector<uint64_t>& vs, uint64_t* out) {
   std::vector<size_t> ns(vs.size());
@@ -38,7 +38,7 @@ int batch_commit(uint64_t ck, size_t nck, const std::vector<uint64_t>& vs, uint6
     RC(vec_len(vs[k], &ns[k]));
     if (ns[k] > nck) ns[k] = nck;
   }
-  return gm_g1_msm_v_batch(ck, 0, 0, vs.data(), ns.data(), vs.size(), out);
+  return gm_ck_msm_batch(ck, vs.data(), ns.data(), vs.size(), out);
 }
 
 // batch_open_multi_points (src/kzg/time.rs:149-159): commit((sum_i chal^i p_i) / prod (x - point_j))
@@ -108,7 +108,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   Vecs V;
   size_t nz = 0, nck = 0;
   RC(vec_len(I->z, &nz));
-  RC(gm_g1_bases_len(ck_bases, &nck));
+  RC(gm_ck_len(ck_bases, &nck));
   const size_t nnz = I->nnz;
   if (nck < nnz || nck < I->ext_fre_row_len || nck < I->ext_fre_col_len) return GM_EINVAL;  // index_by zips need as many powers as indices (:119-127,179-183)
   uint64_t one[4];
@@ -569,6 +569,6 @@ extern "C" int gm_psnark_preprocess_free(gm_psnark_instance* I) {
 extern "C" int gm_psnark_index(const gm_psnark_instance* I, uint64_t ck_bases, uint64_t* out_jac) {
   if (!I || !out_jac) return GM_EINVAL;
   size_t nck = 0;
-  RC(gm_g1_bases_len(ck_bases, &nck));
+  RC(gm_ck_len(ck_bases, &nck));
   return batch_commit(ck_bases, nck, {I->row, I->col, I->val_a, I->val_b, I->val_c}, out_jac);
 }

@@ -22,7 +22,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   size_t nz = 0, nw = 0, nck = 0;
   RC(vec_len(z, &nz));
   RC(vec_len(w, &nw));
-  RC(gm_g1_bases_len(ck_bases, &nck));
+  RC(gm_ck_len(ck_bases, &nck));
   // z_a, z_b, z_c (:32-34)
   // shapes: A, B, C have |z| columns and their transposes |z| rows -- abc_tensored below is exposed over all |z| entries
   for (int k = 0; k < 6; k++) {
@@ -44,7 +44,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   P->spans[0] = since(t_all);
 
   auto t0 = Clock::now();
-  RC(gm_g1_msm_v(ck_bases, 0, 0, w, 0, nw < nck ? nw : nck, P->witness_commitment));  // ck.commit(&r1cs.w) :42
+  RC(gm_ck_msm(ck_bases, 0, 0, w, 0, nw < nck ? nw : nck, P->witness_commitment));  // ck.commit(&r1cs.w) :42
   P->spans[1] = since(t0);
   RC(gm_transcript_append_g1(T.h, L("witness"), 7, P->witness_commitment, 1, 0));
   uint64_t alpha[4];
@@ -127,7 +127,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   if (P->nfold) {
     std::vector<size_t> ns(P->nfold);
     for (size_t k = 0; k < P->nfold; k++) ns[k] = fold_len[k] < nck ? fold_len[k] : nck;
-    RC(gm_g1_msm_v_batch(ck_bases, 0, 0, foldings.data(), ns.data(), P->nfold, P->fold_commitments));  // batch_commit :98-107
+    RC(gm_ck_msm_batch(ck_bases, foldings.data(), ns.data(), P->nfold, P->fold_commitments));  // batch_commit :98-107
   }
   for (size_t k = 0; k < P->nfold; k++) RC(gm_transcript_append_g1(T.h, L("commitment"), 10, P->fold_commitments + 18 * k, 1, 0));
   uint64_t pts[12];  // beta^2, beta, -beta
@@ -169,7 +169,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
     RC(gm_fr_div_vanishing(combined, pts, 3, quotient, rem));
     size_t lq = 0;
     RC(vec_len(quotient, &lq));
-    RC(gm_g1_msm_v(ck_bases, 0, 0, quotient, 0, lq < nck ? lq : nck, P->evaluation_proof));
+    RC(gm_ck_msm(ck_bases, 0, 0, quotient, 0, lq < nck ? lq : nck, P->evaluation_proof));
   }
   P->spans[5] = since(t0);
   P->spans[6] = since(t_all);
@@ -198,12 +198,12 @@ constexpr size_t SPACE_TIME_THRESHOLD = 22;  // src/lib.rs:76
 int stream_msm(uint64_t bases, uint64_t stream, size_t len, size_t top, size_t chunk, uint64_t out[18]) {
   if (len == 0) return gm_g1_sum(nullptr, 0, out);
   if (chunk == 0) chunk = 1;
-  if (len <= chunk) return gm_g1_msm_v(bases, top, 1, stream, 0, len, out);
+  if (len <= chunk) return gm_ck_msm(bases, top, 1, stream, 0, len, out);
   std::vector<uint64_t> parts;
   for (size_t off = 0; off < len; off += chunk) {
     const size_t m = len - off < chunk ? len - off : chunk;
     parts.resize(parts.size() + 18);
-    RC(gm_g1_msm_v(bases, top - off, 1, stream, off, m, parts.data() + parts.size() - 18));
+    RC(gm_ck_msm(bases, top - off, 1, stream, off, m, parts.data() + parts.size() - 18));
   }
   return gm_g1_sum(parts.data(), parts.size() / 18, out);
 }
@@ -274,7 +274,7 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
   RC(vec_len(z_stream, &nz));
   RC(vec_len(w_stream, &nw));
   RC(vec_len(zc_stream, &nzc));
-  RC(gm_g1_bases_len(ck_bases, &nck));
+  RC(gm_ck_len(ck_bases, &nck));
   if (nw > nck || nz > nck) return GM_EINVAL;  // the streaming committer insists on a key as long as every stream (space.rs:169-175)
   for (int k = 0; k < 3; k++) {
     size_t rows = 0;
@@ -380,7 +380,7 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
     bool cut = false;
     for (size_t l : level_len) cut = cut || l > lvl_flush;
     if (!cut) {  // no level is cut: the commitments are sum_i level[i] * tau^i g whichever way the pairs are walked
-      RC(gm_g1_msm_v_batch(ck_bases, 0, 0, levels.data(), level_len.data(), P->nfold, P->fold_commitments));
+      RC(gm_ck_msm_batch(ck_bases, levels.data(), level_len.data(), P->nfold, P->fold_commitments));
     } else {
       for (size_t k = 0; k < P->nfold; k++) {
         uint64_t s;

@@ -524,6 +524,60 @@ int gm_dist_stats(uint64_t* calls, uint64_t* bytes, double* seconds, int reset_c
  * a one-rank RCCL communicator for the test, so the binding runs on a single-GPU box too. */
 int gm_dist_selftest(void);
 
+/* A committer key SHARDED ELEMENT-CYCLICALLY over the ranks: power i of the key lives on rank i mod world, local index
+ * i / world.  Every polynomial the provers commit to is a prefix of the key, foldings of length n/2, n/4, ... included, so
+ * every rank gets len / world pairs (+-1) of EVERY commitment.  gm_g1_bases_set_cyclic marks a registered handle as such a
+ * share (its length must be the rank's count); gm_g1_srs_register_cyclic generates the share on the device (base tau^rank g,
+ * ratio tau^world: CommitterKey::new, src/kzg/time.rs:49-72, every rank its own powers).
+ * gm_ck_*: CommitterKey::{commit, batch_commit} (:81-107) and the stream view of src/kzg/space.rs:95-125 against a key
+ * handle that is either a whole key (then these are gm_g1_msm_v / gm_g1_msm_v_batch) or a cyclic share: strided gather of the
+ * rank's scalars (the polynomials are replicated), local MSMs as one pipelined batch, ONE all-gather of k x 144 bytes, the EC
+ * adds -- identical bytes on every rank.  offset / reversed address the GLOBAL key as in gm_g1_msm_v.
+ * gm_snark_new_time, gm_snark_new_elastic, gm_psnark_new_time and gm_psnark_index commit through these: handed a cyclic
+ * share they run on N GPUs with the MSMs sharded and the field arithmetic replicated. */
+int gm_g1_bases_set_cyclic(uint64_t handle, size_t n_global, int rank, int world);
+int gm_g1_srs_register_cyclic(const uint64_t base_affine[12], const uint64_t tau[4], size_t n_global, int rank, int world, uint64_t* handle);
+int gm_ck_len(uint64_t ck, size_t* n_global);
+int gm_ck_msm(uint64_t ck, size_t offset, int reversed, uint64_t vec, size_t voffset, size_t n, uint64_t out_jac[18]);
+int gm_ck_msm_batch(uint64_t ck, const uint64_t* vecs, const size_t* ns, size_t k, uint64_t* out_jac);
+
+/* Sumcheck::prove (src/subprotocols/sumcheck/proof.rs:36-66) with f and g BLOCK-sharded: this rank holds elements
+ * [lo, lo + len) (lo even) of vectors of n_global elements.  Per round the rank's partial message (64 bytes) is all-gathered
+ * and summed mod r; when the blocks get short (<= 2^10 elements) they are gathered once and every rank finishes the protocol
+ * on the whole vectors.  Same outputs as gm_sumcheck_prove, on every rank. */
+int gm_sumcheck_prove_sharded(uint64_t transcript, uint64_t f_block, uint64_t g_block, const uint64_t twist_mont[4], size_t lo, size_t n_global,
+                              uint64_t* messages, uint64_t* challenges, size_t cap_rounds, uint64_t final_foldings[8], size_t* rounds);
+
+/* snark::Proof::new_time (src/snark/time_prover.rs:19-117) with the FIELD ARITHMETIC sharded as well: rank r of g (powers of
+ * two) holds elements [r m, (r + 1) m), m = n / g, of every vector of the prover.
+ *   matrices     row blocks [r m, (r + 1) m) of A, B, C and of A^T, B^T, C^T (gm_spm handles, m rows each), either with GLOBAL
+ *                column indices (m x n: any Matrix<F>, src/misc.rs:100-110, src/circuit.rs:43 -- then z is the WHOLE z on every
+ *                rank, and tensor(rho) / powers(alpha) are computed whole on every rank: an O(n) pass at HBM speed is cheaper
+ *                than n elements over xGMI) or with LOCAL ones (m x m: a block-diagonal instance such as dummy_r1cs,
+ *                src/circuit.rs:349-365 -- then z is this rank's block and nothing of size n is ever touched)
+ *   w_block      elements [r m, (r + 1) m) of w (the top rank's block is shorter: |w| = n - |x|)
+ *   key          gm_snark_shard_key_new: this rank's slice of the key for every block-sharded level of the folding tree plus the
+ *                replicated prefix for the gathered levels, ONE handle (offsets / counts: key_segments entries)
+ * Sumchecks through gm_sumcheck_prove_sharded; foldings keep the top index bits, so level j stays block-sharded while its
+ * blocks hold >= 2^tail_log elements and is gathered after that; commitments are one pipelined batch against the slices and
+ * one all-gather; evaluations are block evaluations scaled on the host; the opening is sum_i eta_i commit(p_i div Z) with the
+ * carry between blocks interpolated from the evaluations already gathered.  The proof is byte-identical to
+ * gm_snark_new_time's on every rank (tests/test_gpu_dist_native.py: 1 / 2 / 4 / 8 ranks). */
+typedef struct gm_snark_shard {
+  uint64_t matrices[6];
+  uint64_t z;
+  uint64_t w_block;
+  uint64_t key;
+  const size_t* key_offsets;
+  const size_t* key_counts;
+  size_t key_segments;
+  size_t n;
+  size_t tail_log;
+} gm_snark_shard;
+int gm_snark_shard_key_new(const uint64_t base_affine[12], const uint64_t tau[4], size_t n, size_t tail_log, uint64_t* key, size_t offsets[64],
+                           size_t counts[64], size_t* segments);
+int gm_snark_new_time_sharded(const gm_snark_shard* shard, int g1_encoding, size_t cap_rounds, gm_snark_proof* proof);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,132 @@
+"""The N-GPU provers COMPILED INTO THE LIBRARY (gemini_amd/csrc/sharded.cpp) over its own collective layer
+(gemini_amd/csrc/dist.cpp): N processes sharing the one GPU of the test box must produce the single-GPU proof byte for byte.
+
+  * transport shm  : no torch.distributed anywhere -- what a Rust / C++ embedder gets from the C ABI alone
+  * transport hook : the same calls over torch.distributed (gloo) behind gm_dist_init_hook
+  * transport rccl : ncclAllGather on the library's own communicator.  RCCL refuses two ranks on one device, so here it runs
+                     with ONE rank (binding, staging, stream order) -- and gm_dist_selftest() runs it whenever a box has more.
+Reference: src/snark/time_prover.rs:19-117, src/subprotocols/sumcheck/proof.rs:36-66, src/kzg/time.rs:81-107,
+src/misc.rs:100-110 (general matrices), examples/psnark.rs:54-81."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, extra, tool="run_snark.py", logn=12, transport="shm"):
+    env = dict(os.environ, GM_BENCH_BACKEND="gloo", GM_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = [os.path.join(ROOT, "tools", tool), "-i", str(logn), "--repeat", "1"] + list(extra)
+    if world == 1 and transport is None:
+        cmd = [sys.executable] + script
+    else:
+        script += ["--transport", transport]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_port())] + script
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+_ONE = {}
+
+
+def _single(extra=(), tool="run_snark.py", logn=12):
+    key = (tuple(extra), tool, logn)
+    if key not in _ONE:
+        _ONE[key] = _run(1, extra, tool, logn, transport=None)
+    return _ONE[key]
+
+
+def test_rccl_binding_with_one_rank():
+    """ncclAllGather through the library's own communicator: host payloads (pinned -> device -> all-gather -> pinned, one wait)
+    and a device vector, plus the self-test that opens its own one-rank communicator"""
+    import ctypes as C
+
+    import gemini_amd as gm
+    from gemini_amd import collective
+    from gemini_amd.fr import FrVec
+
+    gm.capi.init()
+    collective.finalize()
+    collective.selftest()  # no transport: a temporary one-rank RCCL communicator
+    assert collective.info() == (0, 1, "none")
+    uid = np.zeros(128, dtype=np.uint8)
+    gm.capi.check(gm.capi.load().gm_dist_rccl_unique_id(uid.ctypes.data_as(C.POINTER(C.c_uint8))))
+    assert uid.any()
+    gm.capi.check(gm.capi.load().gm_dist_init_rccl(C.c_int(0), C.c_int(1), uid.ctypes.data_as(C.POINTER(C.c_uint8))))
+    try:
+        assert collective.info() == (0, 1, "rccl")
+        collective.selftest()
+        x = np.arange(18 * 5, dtype=np.uint64).reshape(5, 18) * np.uint64(0x9E3779B97F4A7C15)
+        assert (collective.allgather_host(x) == x[None]).all()
+        rng = np.random.default_rng(3)
+        host = rng.integers(0, 2**62, size=(3000, 4), dtype=np.uint64)
+        v = FrVec.from_host(host)
+        out = collective.allgather_vec(v)
+        assert len(out) == 3000 and (out.to_host() == host).all()
+        st = collective.stats()
+        assert st["collectives"] >= 8 and st["bytes_received"] > 3000 * 32
+        v.free()
+        out.free()
+    finally:
+        collective.finalize()
+
+
+@pytest.mark.parametrize("extra", [[], ["--elastic"]], ids=["time", "elastic"])
+def test_cyclic_key_native_provers_same_proof(extra):
+    """gm_snark_new_time / gm_snark_new_elastic handed a CYCLIC SHARE of the key: 2 and 3 ranks == 1 GPU"""
+    one = _single(extra)
+    for world, transport in ((2, "shm"), (3, "shm"), (2, "hook")):
+        many = _run(world, extra, transport=transport)
+        assert many["n_gpus"] == world and many["transport"] == transport
+        assert many["proof_sha256"] == one["proof_sha256"], (world, transport, extra)
+        assert many["collectives"]["collectives"] > 10
+
+
+@pytest.mark.parametrize("extra", [[]], ids=["time"])
+def test_cyclic_key_native_psnark_same_proof(extra):
+    """BASELINE configs[4] (`psnark`, 8 GPUs): gm_psnark_new_time (and the elastic prover) over cyclic shares on 2 and 3 ranks"""
+    one = _single(extra, tool="run_psnark.py", logn=10)
+    for world in (2, 3):
+        many = _run(world, extra, tool="run_psnark.py", logn=10)
+        assert many["n_gpus"] == world and many["proof_sha256"] == one["proof_sha256"], (world, extra)
+
+
+@pytest.mark.parametrize("tail_log", [4, 6])
+def test_block_sharded_native_prover_same_proof(tail_log):
+    """gm_snark_new_time_sharded, block-diagonal instance (local columns): 1 / 2 / 4 / 8 ranks == gm_snark_new_time"""
+    one = _single()
+    for world in ((1, 2, 4, 8) if tail_log == 4 else (2, 4)):
+        many = _run(world, ["--block-sharded", "--tail-log", str(tail_log)])
+        assert many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
+    many = _run(2, ["--block-sharded", "--tail-log", str(tail_log)], transport="hook")
+    assert many["proof_sha256"] == one["proof_sha256"]
+
+
+def test_block_sharded_native_prover_general_matrices():
+    """any Matrix<F> (src/misc.rs:100-110): a random satisfied R1CS with entries in arbitrary columns, row blocks with global column
+    indices, on 2 and 4 ranks == the single-GPU prover on the same instance; and dummy_r1cs posed as a general matrix"""
+    one = _single(["--random-r1cs", "77"], logn=10)
+    assert one["proof_sha256"] != _single(logn=10)["proof_sha256"]
+    for world in (1, 2, 4):
+        many = _run(world, ["--random-r1cs", "77", "--block-sharded", "--tail-log", "5"], logn=10)
+        assert many["proof_sha256"] == one["proof_sha256"], world
+    dummy = _single()
+    for world in (2, 4):
+        many = _run(world, ["--block-sharded", "--global-columns", "--tail-log", "6"])
+        assert many["proof_sha256"] == dummy["proof_sha256"], world

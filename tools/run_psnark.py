@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--native", action="store_true", help="gm_psnark_new_time: the prover's orchestration compiled into the library (one call per proof)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/psnark.rs elastic_snark_main) instead of --time-prover")
+    ap.add_argument("--transport", choices=["shm", "hook", "rccl"], default=None, help="N ranks through the collective layer inside the library "
+                    "(gemini_amd/csrc/dist.cpp): the key is an element-cyclic share and the provers compiled into the library commit through gm_ck_*")
     ap.add_argument("--verifiable-key", action="store_true", help="one more power than examples/psnark.rs:76 asks for: the reference's "
                     "time-prover key (2n + 1 powers) is one short of the longest committed polynomial (2n + 2 coefficients), so the proof "
                     "of the example's configuration does not verify (tests/test_oracle_verifier.py::test_reference_example_key_is_one_power_short)")
@@ -39,7 +41,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if os.environ.get("GM_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    lib_dist = args.transport is not None
+    if world > 1 and not (lib_dist and args.transport == "shm"):
         import torch
         import torch.distributed as dist
 
@@ -50,6 +53,15 @@ def main():
         else:
             dist.init_process_group(backend)
     gm.capi.init(local_rank)
+    if lib_dist:
+        from gemini_amd import collective
+
+        if args.transport == "shm":
+            collective.init_shm(rank, world, "/gm_run_psnark_%s" % os.environ.get("MASTER_PORT", "0"))
+        elif world > 1:
+            collective.init_hook_torch() if args.transport == "hook" else collective.init_rccl_from_torch()
+        if world > 1:
+            collective.selftest()
     n = 1 << args.instance_logsize
     rng = np.random.default_rng(2022420)
     rnd = lambda: int.from_bytes(rng.bytes(40), "little") % gm.fr.R_MOD
@@ -57,7 +69,11 @@ def main():
     t0 = time.perf_counter()
     tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
     # examples/psnark.rs: time main num_constraints + num_variables powers (:76), elastic main 3 * instance_size + 1 (:62)
-    if world > 1:
+    if lib_dist:
+        from gemini_amd.sharded import cyclic_committer_key
+
+        ck = cyclic_committer_key(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
+    elif world > 1:
         from gemini_amd.dist import ShardedCommitterKey
 
         ck = ShardedCommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau, rank, world)
@@ -65,7 +81,7 @@ def main():
         ck = CommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
-    index = Proof.index(ck, r1cs)
+    index = Proof.index(ck, r1cs, native=True) if lib_dist else Proof.index(ck, r1cs)
     t_index = time.perf_counter() - t0
     out = {"logn": args.instance_logsize, "srs_s": round(t_srs, 3), "index_s": round(t_index, 3), "runs": []}
     stamps = []  # clock readings around every proof, for tools/exposed_time.py --stamps
@@ -78,16 +94,16 @@ def main():
             from gemini_amd.kzg import CommitterKeyStream
 
             stream = R1csStream(r1cs)
-            if world > 1:
+            if world > 1 and not lib_dist:
                 from gemini_amd.dist import ShardedCommitterKeyStream
 
                 cks = ShardedCommitterKeyStream.from_sharded_key(ck)
             else:
                 cks = CommitterKeyStream.from_committer_key(ck)
-            proof = Proof.new_elastic(cks, stream, index, 1 << 20)
+            proof = Proof.new_elastic(cks, stream, index, 1 << 20, native=True) if lib_dist else Proof.new_elastic(cks, stream, index, 1 << 20)
             stream.free()
         else:
-            proof = Proof.new_time(ck, r1cs, index, native=args.native)
+            proof = Proof.new_time(ck, r1cs, index, native=args.native or lib_dist)
         stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         out["proof_size_B"] = proof.compressed_size()
@@ -98,7 +114,18 @@ def main():
 
     out["n_gpus"] = world
     out["proof_sha256"] = hashlib.sha256(proof.serialize_compressed()).hexdigest()
-    if world > 1:
+    if lib_dist:
+        tkey = "elastic_prover_s" if args.elastic else "time_prover_s"
+        mine = np.frombuffer(hashlib.sha256(proof.serialize_compressed()).digest() + np.float64(out[tkey]).tobytes(), dtype=np.uint64)
+        allr = collective.allgather_host(mine)
+        assert (allr[:, :4] == allr[0, :4]).all(), "ranks produced different proofs"
+        out[tkey] = float(allr[:, 4].view(np.float64).max())
+        out["transport"] = collective.info()[2]
+        out["collectives"] = collective.stats()
+        collective.finalize()
+        if world > 1 and args.transport != "shm":
+            dist.destroy_process_group()
+    elif world > 1:
         allt = [None] * world
         tkey = "elastic_prover_s" if args.elastic else "time_prover_s"
         dist.all_gather_object(allt, (out[tkey], out["proof_sha256"]))
