@@ -213,6 +213,8 @@ int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]);
 int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_t* results);
 int fr_eval_le_batch(Context* C, FrVec* const* ps, size_t k, const uint64_t* xs, size_t npoints, uint64_t* results);
 int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out);
+int fr_scale_into(Context* C, FrVec* in, const uint64_t c[4], FrVec* out, size_t offset);
+int fr_add_at(Context* C, FrVec* v, const size_t* idx, const uint64_t* vals, size_t k);
 int fr_fill(Context* C, FrVec* v, const uint64_t val[4]);
 int fr_reverse(Context* C, FrVec* in, FrVec* out);
 int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y);
@@ -886,6 +888,19 @@ int gm_fr_eval_le_batch(const uint64_t* polys, size_t k, const uint64_t* xs_mont
     GM_CHECK(ps[j] != nullptr, GM_EHANDLE, "fr_eval_le_batch: unknown vector handle %llu", (unsigned long long)polys[j]);
   }
   return fr_eval_le_batch(C, ps.data(), k, xs_mont, npoints, results_mont);
+}
+int gm_fr_scale_into(uint64_t in, const uint64_t c_mont[4], uint64_t out, size_t out_offset) {
+  GM_CTX();
+  GM_VEC(vi, in, "fr_scale_into");
+  GM_VEC(vo, out, "fr_scale_into");
+  GM_CHECK(c_mont != nullptr, GM_EINVAL, "fr_scale_into: null pointer");
+  return fr_scale_into(C, vi, c_mont, vo, out_offset);
+}
+int gm_fr_add_at(uint64_t v, const size_t* positions, const uint64_t* values_mont, size_t k) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_add_at");
+  GM_CHECK(k == 0 || (positions && values_mont), GM_EINVAL, "fr_add_at: null pointer");
+  return fr_add_at(C, vv, positions, values_mont, k);
 }
 int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, uint64_t out) {
   GM_CTX();

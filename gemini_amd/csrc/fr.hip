@@ -309,6 +309,12 @@ __global__ void k_fr_stride(const uint8_t* __restrict__ in, size_t start, size_t
     fp_store<FrParams>(out + i * FR_BYTES, fp_load<FrParams>(in + (start + i * stride) * FR_BYTES));
 }
 
+// v[idx[j]] += val[j] for a handful of distinct positions (the carries / remainders at the seams of the laid-out opening)
+__global__ void k_add_at(uint8_t* __restrict__ v, const unsigned long long* __restrict__ idx, const uint8_t* __restrict__ vals, unsigned k) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < k) fp_store<FrParams>(v + idx[j] * FR_BYTES, fr_add(fp_load<FrParams>(v + idx[j] * FR_BYTES), fp_load<FrParams>(vals + (size_t)j * FR_BYTES)));
+}
+
 // out[i] = in[n - 1 - i]: big-endian stream <-> little-endian coefficient vector (Reverse, src/iterable/slice.rs:17-39)
 __global__ void k_reverse(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -1290,6 +1296,51 @@ int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVe
   GM_HIP(hipStreamSynchronize(C->stream));
   out->len = n;
   return fr_trim(C, out);
+}
+
+// out[offset + i] = c * in[i], i < len(in): several scaled vectors laid out in ONE vector at chosen offsets (the quotients of the
+// block-sharded opening against the back-to-back key slices: one MSM instead of one per level)
+int fr_scale_into(Context* C, FrVec* in, const uint64_t c[4], FrVec* out, size_t offset) {
+  GM_FR_LOCK(C);
+  GM_CHECK(in != out, GM_EINVAL, "scale_into: output must not alias the input");
+  GM_CHECK(offset <= out->len && in->len <= out->len - offset, GM_EINVAL, "scale_into: [%zu, %zu) outside a vector of length %zu", offset, offset + in->len,
+           out->len);
+  if (in->len == 0) return GM_OK;
+  LincombArgs A;
+  memset(&A, 0, sizeof A);
+  A.k = 1;
+  A.p[0] = in->d;
+  A.len[0] = in->len;
+  memcpy(A.c[0], c, 32);
+  hipLaunchKernelGGL(k_lincomb, dim3(grid_for(in->len)), dim3(256), 0, C->stream, A, in->len, out->d + offset * FR_BYTES);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
+
+// v[idx[j]] += vals[j]; the positions must be distinct (each is updated by its own lane) and inside the vector
+int fr_add_at(Context* C, FrVec* v, const size_t* idx, const uint64_t* vals, size_t k) {
+  GM_FR_LOCK(C);
+  GM_CHECK(k <= 4096, GM_EINVAL, "add_at: %zu positions (at most 4096)", k);
+  if (k == 0) return GM_OK;
+  std::vector<unsigned long long> packed(k * 5);
+  for (size_t j = 0; j < k; j++) {
+    GM_CHECK(idx[j] < v->len, GM_EINVAL, "add_at: position %zu outside a vector of length %zu", idx[j], v->len);
+    packed[j] = idx[j];
+  }
+  {
+    std::vector<size_t> sorted(idx, idx + k);
+    std::sort(sorted.begin(), sorted.end());
+    GM_CHECK(std::adjacent_find(sorted.begin(), sorted.end()) == sorted.end(), GM_EINVAL, "add_at: repeated position");
+  }
+  memcpy(packed.data() + k, vals, k * 32);
+  uint8_t* d;
+  int rc = upload_small(C, packed.data(), k * 40, &d);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_add_at, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, C->stream, v->d, (const unsigned long long*)d, d + k * 8, (unsigned)k);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
 }
 
 int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y) {

@@ -16,6 +16,7 @@
 //                                    columns).  gemini_amd/dist_prover.py is the same sequence in Python (the tests hold the
 //                                    two, and the single-GPU prover, byte for byte equal).
 #include <algorithm>
+#include <utility>
 
 #include "ctx.hpp"
 #include "prover_common.hpp"
@@ -306,6 +307,19 @@ static void interp3(const Fr xs[3], const Fr ys[3], Fr c[3]) {
 
 static Fr fr_pow_u64(const Fr& x, uint64_t e) { return x.pow(&e, 1); }
 
+// GM_SHARD_TRACE=1: the phases of the sharded tensor check on stderr (rank 0)
+struct PhaseTrace {
+  bool on;
+  Clock::time_point t;
+  explicit PhaseTrace(bool enable) : on(enable), t(Clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto now = Clock::now();
+    fprintf(stderr, "[gm shard] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
 int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t cap_rounds, gm_snark_proof* P) {
   GM_CTX();
   GM_CHECK(S && P && P->messages[0] && P->messages[1] && P->fold_commitments && P->fold_evaluations, GM_EINVAL, "snark_new_time_sharded: null pointer");
@@ -475,6 +489,8 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
 
   // ---- TensorcheckProof::new_time(transcript, ck, [w], [([abc_tensored, z], challenges)])   tensorcheck/mod.rs:190-275
   t0 = Clock::now();
+  static const bool trace_env = getenv("GM_SHARD_TRACE") != nullptr;
+  PhaseTrace TR(trace_env && r == 0);
   uint64_t batch_challenge[4];
   RC(gm_transcript_challenge_fr(T.h, L("batch_challenge"), 15, batch_challenge));
   uint64_t body;
@@ -516,6 +532,7 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
       cur = nxt;
     }
   }
+  TR.mark("body + folds");
   P->nfold = sharded.size() + small.size();
   GM_CHECK(P->nfold <= cap_rounds, GM_EINVAL, "snark_new_time_sharded: %zu foldings exceed capacity %zu", P->nfold, cap_rounds);
   if (P->nfold) {
@@ -531,6 +548,7 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
     if (!sharded.empty()) RC(gather_sum(parts.data(), sharded.size(), P->fold_commitments));
     for (size_t i = 0; i < small.size(); i++) RC(gm_g1_sum(parts.data() + 18 * (sharded.size() + i), 1, P->fold_commitments + 18 * (sharded.size() + i)));
   }
+  TR.mark("fold commitments");
   for (size_t k = 0; k < P->nfold; k++) RC(gm_transcript_append_g1(T.h, L("commitment"), 10, P->fold_commitments + 18 * k, 1, 0));
   uint64_t pts[12];  // beta^2, beta, -beta
   RC(gm_transcript_challenge_fr(T.h, L("evaluation-chal"), 15, pts + 4));
@@ -569,19 +587,47 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
   uint64_t open_chal[4];
   RC(gm_transcript_challenge_fr(T.h, L("open-chal"), 9, open_chal));
   const Fr oc = Fr::from_limbs(open_chal);
+  TR.mark("evaluations + transcript");
   // the opening (batch_open_multi_points, src/kzg/time.rs:149-159): commit((sum_i eta_i p_i) / Z) = sum_i eta_i commit(p_i div Z).
-  // The quotient of block r of p needs the carry from the blocks above: the polynomial of degree < 3 that agrees with
-  // S_r(x) = sum_{r' > r} x^((r' - r - 1) L) P_r'(x) at the three roots of Z -- values that were all-gathered above.  Rank r
-  // divides [P_r, carry] (L + 3 coefficients) once and commits the quotient against the level's slice; the eta_i are applied
-  // to the normalised partial points in one tiny MSM.
+  // The quotient of block r of p_i needs the carry from the blocks above: the polynomial c_i of degree < 3 that agrees with
+  // S_r(x) = sum_{r' > r} x^((r' - r - 1) L) P_r'(x) at the three roots of Z -- values that were all-gathered above -- and leaves
+  // a remainder rem_i, the polynomial of degree < 3 that agrees with G_i = eta_i [P_i, c_i] at the roots (host values again:
+  // G_i(x) = eta_i (P_i(x) + x^L c_i(x))).  Level i's quotient q_i = (G_i - rem_i) / Z pairs with the level's key slice, and the
+  // slices sit back to back in ONE registered key at offsets off_i.  So the blocks are laid out in ONE vector at the slices'
+  // offsets, F = sum_i x^(off_i) (G_i - rem_i): eta_i P_i by one scaling pass per level, the 3 + 3 seam coefficients c_i and
+  // -rem_i by one sparse update.  F is exactly divisible, F / Z = sum_i x^(off_i) q_i: ONE division and ONE MSM of ~2 m pairs for
+  // the whole opening (instead of a latency-bound division and MSM per level).  The replicated small levels ride in the prefix
+  // segment on rank 0 only.
   {
     const size_t nb = blocks.size();
-    std::vector<uint64_t> quots;
-    std::vector<size_t> q_levels, q_idx;
-    for (size_t i = 0; i < nb; i++) {
-      const size_t Lb = m >> i;
+    const size_t span = S->key_offsets[PREFIX] + S->key_counts[PREFIX];
+    uint64_t laid;
+    RC(V.alloc(span + 3, &laid));
+    {
+      uint64_t zero[4] = {0, 0, 0, 0};
+      RC(gm_fr_vec_fill(laid, zero));
+    }
+    std::vector<std::pair<size_t, Fr>> seams;  // (position, value to add)
+    auto seam = [&](size_t pos, const Fr& v) {
+      for (auto& s : seams)
+        if (s.first == pos) {
+          s.second = s.second + v;
+          return;
+        }
+      seams.emplace_back(pos, v);
+    };
+    Fr eta_i = Fr::one();
+    for (size_t i = 0; i < nb; i++, eta_i = eta_i * oc) {
+      const size_t Lb = m >> i, off = S->key_offsets[i];
+      size_t len = 0;
+      RC(vec_len(blocks[i], &len));
+      GM_CHECK(len <= Lb && (r + 1 == g || len == Lb), GM_ESTATE, "snark_new_time_sharded: block of %zu elements at level %zu (blocks hold %zu)", len, i, Lb);
+      uint64_t e[4];
+      eta_i.to_limbs(e);
+      RC(gm_fr_scale_into(blocks[i], e, laid, off));
+      Fr gv[3], c[3] = {Fr::zero(), Fr::zero(), Fr::zero()}, rem[3];
       if (r + 1 < g) {
-        Fr ys[3], c[3];
+        Fr ys[3];
         for (int q = 0; q < 3; q++) {
           const Fr step = fr_pow_u64(xs[q], Lb);
           Fr acc = Fr::zero(), xp = Fr::one();
@@ -592,32 +638,18 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
           ys[q] = acc;
         }
         interp3(xs, ys, c);
-        size_t len = 0;
-        RC(vec_len(blocks[i], &len));
-        GM_CHECK(len == Lb, GM_ESTATE, "snark_new_time_sharded: a block below the top rank has %zu elements, not %zu", len, Lb);
-        uint64_t tail3[12];
-        for (int q = 0; q < 3; q++) c[q].to_limbs(tail3 + 4 * q);
-        RC(gm_fr_vec_set_len(blocks[i], len + 3));
-        RC(gm_fr_vec_upload(blocks[i], len, tail3, 3));
+        for (int q = 0; q < 3; q++) seam(off + Lb + q, eta_i * c[q]);
       }
-      size_t len = 0;
-      RC(vec_len(blocks[i], &len));
-      uint64_t q;
-      RC(V.alloc(len ? len - 1 : 0, &q));  // the division's working capacity; the quotient has len - 3 coefficients
-      uint64_t rem[12];
-      RC(gm_fr_div_vanishing(blocks[i], pts, 3, q, rem));
-      size_t lq = 0;
-      RC(vec_len(q, &lq));
-      if (lq) {
-        quots.push_back(q);
-        q_levels.push_back(i);
-        q_idx.push_back(i);
+      for (int q = 0; q < 3; q++) {
+        const Fr cx = c[0] + xs[q] * (c[1] + xs[q] * c[2]);
+        gv[q] = eta_i * (Fr::from_limbs(allr.data() + 4 * ((r * nb + i) * 3 + q)) + fr_pow_u64(xs[q], Lb) * cx);
       }
+      interp3(xs, gv, rem);
+      for (int q = 0; q < 3; q++) seam(off + q, rem[q].neg());
     }
-    bool have_comb = false;
-    if (!small.empty()) {
+    if (!small.empty() && r == 0) {
       std::vector<uint64_t> etas(4 * small.size());
-      Fr acc = fr_pow_u64(oc, nb);
+      Fr acc = eta_i;  // open_chal^nb
       size_t longest = 0;
       for (size_t i = 0; i < small.size(); i++) {
         acc.to_limbs(etas.data() + 4 * i);
@@ -631,38 +663,45 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
       RC(gm_fr_lincomb(small.data(), etas.data(), small.size(), comb));
       size_t lc = 0;
       RC(vec_len(comb, &lc));
-      if (lc > 3) {
-        uint64_t q, rem[12];
-        RC(V.alloc(lc - 1, &q));
-        RC(gm_fr_div_vanishing(comb, pts, 3, q, rem));
-        quots.push_back(q);
-        q_levels.push_back(PREFIX);
-        have_comb = true;
+      GM_CHECK(lc <= S->key_counts[PREFIX] + 3, GM_ESTATE, "snark_new_time_sharded: the small levels hold %zu coefficients, the prefix %zu powers", lc,
+               S->key_counts[PREFIX]);
+      if (lc) {
+        uint64_t one_l[4], cv[12];
+        Fr::one().to_limbs(one_l);
+        RC(gm_fr_scale_into(comb, one_l, laid, S->key_offsets[PREFIX]));
+        RC(gm_fr_eval_le(comb, pts, 3, cv));
+        Fr gv[3], rem[3];
+        for (int q = 0; q < 3; q++) gv[q] = Fr::from_limbs(cv + 4 * q);
+        interp3(xs, gv, rem);
+        for (int q = 0; q < 3; q++) seam(S->key_offsets[PREFIX] + q, rem[q].neg());
       }
     }
-    std::vector<uint64_t> qparts(18 * std::max<size_t>(quots.size(), 1));
-    if (!quots.empty()) RC(key_commit(q_levels, quots, qparts.data()));
-    // my share of sum_i eta_i commit(quotient_i): the partial points normalised, scaled in one small MSM
-    std::vector<uint64_t> pts96, sc;
-    for (size_t t = 0; t < q_idx.size(); t++) {
-      uint64_t norm[18];
-      RC(gm_g1_sum(qparts.data() + 18 * t, 1, norm));
-      bool ident = true;
-      for (int l = 12; l < 18; l++) ident = ident && norm[l] == 0;
-      if (ident) continue;
-      pts96.insert(pts96.end(), norm, norm + 12);
-      uint64_t e[4];
-      fr_pow_u64(oc, q_idx[t]).to_canonical(e);
-      sc.insert(sc.end(), e, e + 4);
+    {
+      std::vector<size_t> pos(seams.size());
+      std::vector<uint64_t> val(4 * seams.size());
+      for (size_t t = 0; t < seams.size(); t++) {
+        pos[t] = seams[t].first;
+        seams[t].second.to_limbs(val.data() + 4 * t);
+      }
+      RC(gm_fr_add_at(laid, pos.data(), val.data(), pos.size()));
     }
+    uint64_t quot, remz[12];
+    RC(V.alloc(span + 2, &quot));
+    RC(gm_fr_div_vanishing(laid, pts, 3, quot, remz));
+    for (int l = 0; l < 12; l++) GM_CHECK(remz[l] == 0, GM_ESTATE, "snark_new_time_sharded: the laid-out opening is not divisible by Z (seam %d)", l / 4);
+    TR.mark("carries + division");
+    size_t lq = 0;
+    RC(vec_len(quot, &lq));
     uint64_t mine[18];
-    if (sc.empty()) memcpy(mine, identity_point(), 144);
-    else RC(gm_g1_msm(pts96.data(), 96, sc.data(), sc.size() / 4, mine));
-    std::vector<uint64_t> pieces(18 * (g + 1));
-    RC(gm_dist_allgather_host(mine, 144, pieces.data()));
-    size_t np = g;
-    if (have_comb) memcpy(pieces.data() + 18 * np++, qparts.data() + 18 * (quots.size() - 1), 144);
-    RC(gm_g1_sum(pieces.data(), np, P->evaluation_proof));
+    if (lq == 0) {
+      memcpy(mine, identity_point(), 144);
+    } else {
+      const size_t zero_off = 0;
+      lq = std::min(lq, span);
+      RC(gm_g1_msm_v_batch_at(S->key, &zero_off, 0, &quot, &lq, 1, 1, mine));
+    }
+    TR.mark("opening MSM");
+    RC(gather_sum(mine, 1, P->evaluation_proof));
   }
   P->spans[5] = since(t0);
   P->spans[6] = since(t_all);

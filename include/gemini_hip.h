@@ -255,6 +255,11 @@ int gm_fr_eval_le_batch(const uint64_t* polys, size_t k, const uint64_t* xs_mont
 /* out = sum_j c_j p_j padded to the longest; logical length trimmed of high zeros
  *                                                                  src/misc.rs:37-48 */
 int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, uint64_t out);
+/* out[out_offset + i] = c * in[i] for i < len(in), inside out's current length: scaled vectors laid out side by side in one
+ * vector (the per-level quotients of the block-sharded opening, committed by ONE MSM against the back-to-back key slices) */
+int gm_fr_scale_into(uint64_t in, const uint64_t c_mont[4], uint64_t out, size_t out_offset);
+/* v[positions[j]] += values[j] for k <= 4096 DISTINCT positions inside the vector (seam corrections of the laid-out opening) */
+int gm_fr_add_at(uint64_t v, const size_t* positions, const uint64_t* values_mont, size_t k);
 /* quotient of f by the monic vanishing polynomial of `points` (degree k <= 3); rem gets k values.
  * Replaces DensePolynomial::div in open_multi_points           src/kzg/time.rs:134-145 */
 int gm_fr_div_vanishing(uint64_t f, const uint64_t* points_mont, size_t k, uint64_t quotient, uint64_t* rem_mont);
