@@ -118,38 +118,38 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
     tau = np.array([(tau_i >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
     block_sharded = world > 1 and world & (world - 1) == 0 and n // world >= 1 << 12 and os.environ.get("GM_BENCH_SHARDING", "block") == "block"
     if block_sharded:
-        # N ranks, a power of two: every vector of the prover and the key in blocks (gemini_amd/dist_prover.py) -- the field
-        # arithmetic is sharded as well as the MSMs
-        from gemini_amd.dist_prover import BlockLayout, BlockShardedKey, R1csBlock, new_time_block_sharded
+        # N ranks, a power of two: every vector of the prover and the key in blocks, the whole prover compiled into the library
+        # (gm_snark_new_time_sharded over the library's own all-gather, gemini_amd/csrc/{sharded,dist}.cpp) -- the field arithmetic
+        # is sharded as well as the MSMs
+        from gemini_amd.sharded import R1csShard, ShardKey, new_time_sharded
 
         r1cs.free()
-        r1cs = R1csBlock.dummy(e, BlockLayout(n, rank, world))
-        ck = BlockShardedKey.new(n, 5, tau, rank, world)
+        r1cs = R1csShard.dummy(e, n)
+        ck = ShardKey(n, 10, tau)
     elif world > 1:
-        from gemini_amd.dist import ShardedCommitterKey
+        # any other rank count: the native single-GPU prover over an element-cyclic share of the key (MSMs sharded, gm_ck_*)
+        from gemini_amd.sharded import cyclic_committer_key
 
-        ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
+        ck = cyclic_committer_key(2 * n, 5, tau, with_g2=False)
     else:
         ck = CommitterKey.new(2 * n, 5, tau)
     t_srs = time.perf_counter() - t0
 
     def timed_runs(k):
-        import torch
-        import torch.distributed as dist
+        from gemini_amd import collective
 
         out = []
         for _ in range(k):
             if world > 1:
-                dist.barrier()
+                collective.allgather_host(np.zeros(1, dtype=np.uint64))  # barrier through the library's own transport
             if block_sharded:
-                p = new_time_block_sharded(r1cs, ck)
+                p = new_time_sharded(r1cs, ck)
             else:
-                p = Proof.new_time(r1cs, ck, native=(world == 1))  # one rank: gm_snark_new_time, the orchestration inside the library
+                p = Proof.new_time(r1cs, ck, native=True)  # gm_snark_new_time, the orchestration inside the library
             sp = dict(p.spans)
             if world > 1:  # the span of the slowest rank
-                t = torch.tensor([sp[SPAN]], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                sp[SPAN] = float(t.item())
+                allt = collective.allgather_host(np.array([sp[SPAN]], dtype=np.float64).view(np.uint64))
+                sp[SPAN] = float(allt.view(np.float64).max())
             out.append((sp, p))
         return out
 
@@ -161,7 +161,11 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
 
     digest = hashlib.sha256(runs[-1][1].serialize_compressed()).hexdigest()
     per_rank = None
+    coll = None
     if world > 1:
+        from gemini_amd import collective
+
+        coll = dict(collective.stats(), transport=collective.info()[2])
         # every rank's own stage breakdown of its median run (the field arithmetic is replicated, the MSMs are sharded: the
         # spread between the ranks and the share of the commitment spans say what N GPUs bought)
         import torch.distributed as dist
@@ -197,7 +201,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
 
     # The key was registered with the library's default: fixed-base window tables when they fit (gm_set_auto_tables), so the
     # runs above ARE the default configuration.  The same prover on the plain path (no tables) beside it.
-    tab_c, tab_bytes = ck.powers_of_g.table_info() if world == 1 else (ck.bases.table_info() if block_sharded else (0, 0))
+    tab_c, tab_bytes = ck.bases.table_info() if block_sharded else ck.powers_of_g.table_info()
     tables = {"window_bits": tab_c, "table_bytes": tab_bytes, "built_at": "key registration (CommitterKey::new, outside the prover span)"}
     plain = None
     if world == 1 and tab_c:
@@ -301,9 +305,10 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         "verifier": verdict,
         "proof_sha256": digest,
         "driver": "gm_snark_new_time (prover orchestration compiled into the library, gemini_amd/csrc/snark.cpp)" if world == 1
-                  else ("gemini_amd/dist_prover.py: field arithmetic and key block-sharded over the ranks" if block_sharded
-                        else "gemini_amd/snark.py step by step over the element-cyclic sharded key (field arithmetic replicated)"),
-        "fr_work_rank0": getattr(runs[-1][1], "fr_work", None),
+                  else ("gm_snark_new_time_sharded (gemini_amd/csrc/sharded.cpp): field arithmetic and key block-sharded over the ranks, "
+                        "all-gathers inside the library" if block_sharded
+                        else "gm_snark_new_time over an element-cyclic share of the key (gm_ck_*: MSMs sharded, field arithmetic replicated)"),
+        "collectives": coll,
         "note": "median of 3 after one warm-up; instance (diagonal CSR) and SRS resident in HBM before the timer; proof elements equal the CPU "
                 "restatement at logn 3/6/9 (tests/test_gpu_snark.py)",
     }
@@ -359,6 +364,34 @@ def main():
 
     gm.capi.init(local_rank)
     lib = gm.capi.load()
+    transport_note = None
+    if world > 1:
+        # the all-gathers of the N > 1 path run INSIDE the library (gemini_amd/csrc/dist.cpp): its own RCCL communicator over xGMI on a
+        # GPU node (the unique id travels over torch.distributed), the torch process group behind a hook with the gloo test backend.
+        # GM_BENCH_TRANSPORT = rccl | hook | shm overrides; an RCCL communicator that cannot be built or fails its self-test falls back
+        # to the hook and says so in the output.
+        from gemini_amd import collective
+
+        want = os.environ.get("GM_BENCH_TRANSPORT") or ("rccl" if backend == "nccl" else "hook")
+        ok = 0
+        if want == "rccl":
+            try:
+                collective.init_rccl_from_torch()
+                collective.selftest()
+                ok = 1
+            except Exception as ex:  # noqa: BLE001
+                transport_note = f"library RCCL communicator unavailable on rank {rank} ({ex}); fell back to the torch.distributed hook"
+            flags = [None] * world
+            dist.all_gather_object(flags, ok)
+            if not all(flags):
+                collective.finalize()
+                want = "hook"
+                transport_note = transport_note or "library RCCL communicator unavailable on a peer; fell back to the torch.distributed hook"
+        if want == "shm":
+            collective.init_shm(rank, world, "/gm_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+        elif want == "hook":
+            collective.init_hook_torch()
+        collective.selftest()
     n = 1 << args.logn
     rng = np.random.default_rng(0x47454D494E49 + rank)
 
@@ -380,20 +413,18 @@ def main():
     bases = gm.G1Bases.fixed_base(g_aff, ks)
     dev_scalars = [torch.from_numpy(s.view(np.int64)).cuda() for s in host_scalars]
     torch.cuda.synchronize()
-    gather = torch.empty((world, 18), dtype=torch.int64, device=coll_dev) if world > 1 else None
 
     def step(i: int) -> np.ndarray:
         d = dev_scalars[i & 1]
         part = bases.msm_device(d.data_ptr(), n, mont=False, partial=world > 1)
         if world == 1:
             return part
-        mine = torch.from_numpy(part.view(np.int64)).to(coll_dev)
-        dist.all_gather_into_tensor(gather.view(-1), mine)
-        return g1_sum(gather.cpu().numpy().view(np.uint64))
+        # the final reduce of the partial G1 points: ONE all-gather of 144 bytes inside the library, EC adds on every rank
+        return g1_sum(collective.allgather_host(part))
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            collective.allgather_host(np.zeros(1, dtype=np.uint64))  # through the transport the timed steps use
         torch.cuda.synchronize()
 
     results = {}
@@ -413,9 +444,7 @@ def main():
     elapsed = time.perf_counter() - t0
     throttled_in_loop = cpu_throttled_usec() - throttled0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(collective.allgather_host(np.array([elapsed], dtype=np.float64).view(np.uint64)).view(np.float64).max())
 
     ms = (C.c_double * 7)()
     cnt = (C.c_uint64 * 7)()
@@ -586,6 +615,8 @@ def main():
                 "workload": f"2^{args.logn} G1 MSM per GPU (BASELINE configs[1]: 2^20 G1 MSM on one MI355X)",
                 "pairs_per_gpu": n,
                 "parallelism": f"pairs sharded over {world} GPU(s), all-gather of 144-byte partial points + local EC add",
+                "collective": None if world == 1 else {"transport": collective.info()[2], "inside_library": "gm_dist_allgather_host (gemini_amd/csrc/dist.cpp)",
+                                                       "note": transport_note},
             },
             "roofline": {
                 "bound": "hbm",
