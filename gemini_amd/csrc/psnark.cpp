@@ -16,89 +16,6 @@ namespace {
 
 using namespace gmprover;
 
-Fr fr_pow(Fr base, size_t e) {
-  Fr acc = Fr::one();
-  while (e) {
-    if (e & 1) acc = acc * base;
-    base = base.sqr();
-    e >>= 1;
-  }
-  return acc;
-}
-
-// ck.commit(v): msm_unchecked truncates to the shorter side (src/kzg/time.rs:82)
-int commit(uint64_t ck, size_t nck, uint64_t v, uint64_t out[18]) {
-  size_t n = 0;
-  RC(vec_len(v, &n));
-  return gm_ck_msm(ck, 0, 0, v, 0, n < nck ? n : nck, out);
-}
-int batch_commit(uint64_t ck, size_t nck, const std::vector<uint64_t>& vs, uint64_t* out) {
-  std::vector<size_t> ns(vs.size());
-  for (size_t k = 0; k < vs.size(); k++) {
-    RC(vec_len(vs[k], &ns[k]));
-    if (ns[k] > nck) ns[k] = nck;
-  }
-  return gm_ck_msm_batch(ck, vs.data(), ns.data(), vs.size(), out);
-}
-
-// batch_open_multi_points (src/kzg/time.rs:149-159): commit((sum_i chal^i p_i) / prod (x - point_j))
-int batch_open(Vecs& V, uint64_t ck, size_t nck, const std::vector<uint64_t>& polys, const uint64_t* pts, size_t npts, const uint64_t chal[4],
-               uint64_t out[18]) {
-  std::vector<uint64_t> etas(4 * polys.size());
-  Fr acc = Fr::one();
-  const Fr c = Fr::from_limbs(chal);
-  size_t longest = 0;
-  for (size_t k = 0; k < polys.size(); k++) {
-    acc.to_limbs(etas.data() + 4 * k);
-    acc = acc * c;
-    size_t l = 0;
-    RC(vec_len(polys[k], &l));
-    longest = l > longest ? l : longest;
-  }
-  uint64_t combined, quotient;
-  RC(V.alloc(longest, &combined));
-  RC(gm_fr_lincomb(polys.data(), etas.data(), polys.size(), combined));
-  size_t lc = 0;
-  RC(vec_len(combined, &lc));
-  RC(V.alloc(lc ? lc - 1 : 0, &quotient));
-  uint64_t rem[12];
-  RC(gm_fr_div_vanishing(combined, pts, npts, quotient, rem));
-  V.release(combined);
-  const int rc = commit(ck, nck, quotient, out);
-  V.release(quotient);
-  return rc;
-}
-
-// plookup (plookup/time_prover.rs:89-112) -> lookup_set, lookup_subset, lookup_sorted
-int plookup(Vecs& V, uint64_t subset, uint64_t set_, uint64_t index, size_t index_len, uint64_t ext_fre, size_t ext_len, const uint64_t y[4],
-            const uint64_t z[4], const uint64_t zeta[4], uint64_t out[3]) {
-  size_t nset = 0, nsub = 0;
-  RC(vec_len(set_, &nset));
-  RC(vec_len(subset, &nsub));
-  uint64_t set_h = set_, subset_h = subset;
-  if (!Fr::from_limbs(zeta).is_zero()) {
-    RC(V.alloc(nset, &set_h));
-    RC(gm_fr_alg_hash(set_, 0, zeta, set_h));
-    const size_t n = nsub < index_len ? nsub : index_len;
-    RC(V.alloc(n, &subset_h));
-    RC(gm_fr_alg_hash(subset, index, zeta, subset_h));
-    nsub = n;
-  }
-  RC(V.alloc(nset ? nset + 1 : 0, &out[0]));
-  RC(gm_fr_plookup_set(set_h, y, z, out[0]));
-  RC(V.alloc(nsub, &out[1]));
-  RC(gm_fr_add_scalar(subset_h, y, out[1]));
-  uint64_t srt;
-  RC(V.alloc(ext_len, &srt));
-  RC(gm_fr_gather(set_h, ext_fre, srt));
-  RC(V.alloc(ext_len ? ext_len + 1 : 0, &out[2]));
-  RC(gm_fr_plookup_set(srt, y, z, out[2]));
-  V.release(srt);
-  if (set_h != set_) V.release(set_h);
-  if (subset_h != subset) V.release(subset_h);
-  return GM_OK;
-}
-
 }  // namespace
 
 extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases, int g1_encoding, size_t cap_rounds, gm_psnark_proof* P) {

@@ -190,78 +190,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
 // -- and the time prover, `assert_eq!(time_proof, space_proof)` src/snark/tests.rs:56 -- byte for byte equal.
 // =====================================================================================================================
 namespace {
-
-constexpr size_t SPACE_TIME_THRESHOLD = 22;  // src/lib.rs:76
-
-// sum over stream positions k < len: stream[k] * power[top - k], flushed every max(chunk, min_chunk) pairs
-// (msm_chunks / ChunkedPippenger composition, src/kzg/space.rs:22-55)
-int stream_msm(uint64_t bases, uint64_t stream, size_t len, size_t top, size_t chunk, uint64_t out[18]) {
-  if (len == 0) return gm_g1_sum(nullptr, 0, out);
-  if (chunk == 0) chunk = 1;
-  if (len <= chunk) return gm_ck_msm(bases, top, 1, stream, 0, len, out);
-  std::vector<uint64_t> parts;
-  for (size_t off = 0; off < len; off += chunk) {
-    const size_t m = len - off < chunk ? len - off : chunk;
-    parts.resize(parts.size() + 18);
-    RC(gm_ck_msm(bases, top - off, 1, stream, off, m, parts.data() + parts.size() - 18));
-  }
-  return gm_g1_sum(parts.data(), parts.size() / 18, out);
-}
-
-// Sumcheck::prove over an ElasticProver: a SpaceProver that becomes a TimeProver when fewer than
-// SPACE_TIME_THRESHOLD rounds remain (elastic_prover.rs:44-57); Prover::next_message folds first.
-int sumcheck_new_elastic(uint64_t transcript, uint64_t f_stream, uint64_t g_stream, const uint64_t twist[4], uint64_t* messages,
-                         std::vector<uint64_t>& challenges, size_t cap_rounds, uint64_t final_foldings[8], size_t* rounds) {
-  uint64_t space = 0, time = 0;
-  RC(gm_sp_new_v(f_stream, g_stream, twist, &space));
-  struct Guard {
-    uint64_t &s, &t;
-    ~Guard() {
-      if (t) (void)gm_sc_free(t);
-      if (s) (void)gm_sp_free(s);
-    }
-  } guard{space, time};
-  challenges.assign(cap_rounds * 4, 0);
-  size_t k = 0;
-  const uint64_t* vm = nullptr;
-  for (;;) {
-    if (vm && !time) {  // ElasticProver::fold
-      size_t tot = 0, rnd = 0;
-      RC(gm_sp_rounds(space, &tot, &rnd));
-      if (tot - rnd < SPACE_TIME_THRESHOLD) {
-        RC(gm_sp_to_time(space, &time));
-        RC(gm_sc_fold(time, vm));
-        (void)gm_sp_free(space);
-        space = 0;
-      } else {
-        RC(gm_sp_fold(space, vm));
-      }
-      vm = nullptr;
-    }
-    uint64_t a[4], b[4];
-    int has = 0;
-    if (time) RC(gm_sc_round(time, vm, a, b, &has));
-    else RC(gm_sp_round(space, vm, a, b, &has));
-    if (!has) break;
-    if (k >= cap_rounds) return GM_EINVAL;
-    memcpy(messages + 8 * k, a, 32);
-    memcpy(messages + 8 * k + 4, b, 32);
-    RC(gm_transcript_append_fr(transcript, L("evaluations"), 11, messages + 8 * k, 2));
-    RC(gm_transcript_challenge_fr(transcript, L("challenge"), 9, challenges.data() + 4 * k));
-    vm = challenges.data() + 4 * k;
-    k++;
-  }
-  int has = 0;
-  if (time) RC(gm_sc_final(time, final_foldings, final_foldings + 4, &has));
-  else RC(gm_sp_final(space, final_foldings, final_foldings + 4, &has));
-  if (!has) return GM_ESTATE;
-  RC(gm_transcript_append_fr(transcript, L("final-folding"), 13, final_foldings, 1));
-  RC(gm_transcript_append_fr(transcript, L("final-folding"), 13, final_foldings + 4, 1));
-  *rounds = k;
-  challenges.resize(k * 4);
-  return GM_OK;
-}
-
+using namespace gmprover;
 }  // namespace
 
 extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_stream, uint64_t w_stream, uint64_t za_stream, uint64_t zb_stream,

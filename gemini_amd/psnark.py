@@ -464,11 +464,16 @@ class Proof:
         return proof
 
     @staticmethod
-    def new_elastic(ck, r1cs_stream, index: list, max_msm_buffer: int) -> "Proof":
+    def new_elastic(ck, r1cs_stream, index: list, max_msm_buffer: int, native: bool = False) -> "Proof":
         """src/psnark/elastic_prover.rs:60-634 over device-resident streams: `ck` is a CommitterKeyStream,
         every polynomial a big-endian stream (reversed device vector); commitments are chunked stream MSMs,
         sumchecks run on the space / elastic provers, the tensor check on FoldedPolynomialTrees.  The
-        reference's test asserts this proof equals new_time's (src/psnark/tests.rs:56-124)."""
+        reference's test asserts this proof equals new_time's (src/psnark/tests.rs:56-124).  native: the same sequence compiled
+        into the library (gm_psnark_new_elastic, gemini_amd/csrc/psnark_elastic.cpp), one call per proof."""
+        from .kzg import CommitterKeyStream
+
+        if native and type(ck) is CommitterKeyStream:
+            return _new_time_native(ck, r1cs_stream.r1cs, index, elastic=(ck, r1cs_stream, max_msm_buffer))
         from .fr import fold_polynomial, reverse
         from .kzg import FoldedPolynomialTree
         from .msm import g1_sum
@@ -737,7 +742,8 @@ def _psnark_ctypes():
     return Instance, ProofRec
 
 
-def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_library: bool = False) -> "Proof":
+def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_library: bool = False, elastic=None) -> "Proof":
+    """gm_psnark_new_time; elastic = (ck_stream, r1cs_stream, max_msm_buffer): gm_psnark_new_elastic over the same instance record"""
     import ctypes as C
 
     from . import capi
@@ -774,8 +780,15 @@ def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_li
     P.cap_folds = cap_folds
     P.fold_commitments = fc.ctypes.data_as(U)
     P.fold_evaluations = fe.ctypes.data_as(U)
-    capi.check(capi.load().gm_psnark_new_time(C.byref(I), C.c_uint64(ck.powers_of_g.handle), C.c_int(int(default_group_encoding())), C.c_size_t(cap),
-                                              C.byref(P)))
+    if elastic is None:
+        capi.check(capi.load().gm_psnark_new_time(C.byref(I), C.c_uint64(ck.powers_of_g.handle), C.c_int(int(default_group_encoding())), C.c_size_t(cap),
+                                                  C.byref(P)))
+    else:
+        cks, st, max_msm_buffer = elastic
+        h = lambda v: C.c_uint64(v.handle)  # noqa: E731
+        capi.check(capi.load().gm_psnark_new_elastic(C.byref(I), h(st.z), h(st.witness), h(st.z_a), h(st.z_b), h(st.z_c), C.c_uint64(cks.powers_of_g.handle),
+                                                     C.c_size_t(max_msm_buffer), C.c_size_t(cks.min_device_chunk), C.c_int(int(default_group_encoding())),
+                                                     C.c_size_t(cap), C.byref(P)))
     A = lambda a: np.array(a, dtype=np.uint64)  # noqa: E731
     msgs = lambda k: [(m[k][i, :4].copy(), m[k][i, 4:].copy()) for i in range(P.rounds[k])]  # noqa: E731
     ff = lambda rec: [(A(rec)[:4].copy(), A(rec)[4:].copy())]  # noqa: E731
@@ -798,4 +811,6 @@ def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_li
         ralpha_star_acc_mu_evals=[A(P.ralpha_star_acc_mu_evals[k]) for k in range(10)], ralpha_star_acc_mu_proof=A(P.ralpha_star_acc_mu_proof),
         rstars_vals=[A(P.rstars_vals[0]), A(P.rstars_vals[1])], third_sumcheck_msgs=(msgs(2), third_ff), tensorcheck_proof=tc)
     proof.spans = {name: P.spans[i] for i, name in enumerate(_PSNARK_SPANS)}
+    if elastic is not None:
+        proof.spans["ark_gemini::psnark::elastic_prover"] = proof.spans.pop("ark_gemini::psnark::time_prover")
     return proof

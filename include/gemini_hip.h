@@ -481,6 +481,15 @@ typedef struct gm_psnark_proof {
   double spans[12];
 } gm_psnark_proof;
 int gm_psnark_new_time(const gm_psnark_instance* instance, uint64_t ck_bases, int g1_encoding, size_t cap_rounds, gm_psnark_proof* proof);
+/* psnark::Proof::new_elastic (src/psnark/elastic_prover.rs:60-634) over device-resident big-endian streams (reversed vectors: z,
+ * the witness, A z, B z, C z -- R1csStream, src/circuit.rs), everything else of `instance` as for gm_psnark_new_time (its z / w
+ * fields are not read).  Commitments and openings are the chunked stream MSMs of CommitterKeyStream (src/kzg/space.rs:95-285)
+ * with the flush rule of gm_snark_new_elastic (max_msm_buffer [/ depth], never below min_device_chunk); the sumchecks run on space
+ * provers that become time provers below SPACE_TIME_THRESHOLD rounds (sumcheck/elastic_prover.rs:44-57), the third one as
+ * prove_batch over 13 of them.  Same bytes as gm_psnark_new_time (src/psnark/tests.rs:56-124); spans as there. */
+int gm_psnark_new_elastic(const gm_psnark_instance* instance, uint64_t z_stream, uint64_t w_stream, uint64_t za_stream, uint64_t zb_stream,
+                          uint64_t zc_stream, uint64_t ck_bases, size_t max_msm_buffer, size_t min_device_chunk, int g1_encoding, size_t cap_rounds,
+                          gm_psnark_proof* proof);
 
 /* Everything of `instance` that depends on the MATRICES only, built inside the library from the three registered matrices
  * (`sum_matrices` + `joint_matrices`, src/misc.rs:269-366: the union of the supports of A, B, C walked column-major, the three value

@@ -98,7 +98,7 @@ def test_cyclic_key_native_provers_same_proof(extra):
         assert many["collectives"]["collectives"] > 10
 
 
-@pytest.mark.parametrize("extra", [[]], ids=["time"])
+@pytest.mark.parametrize("extra", [[], ["--elastic"]], ids=["time", "elastic"])
 def test_cyclic_key_native_psnark_same_proof(extra):
     """BASELINE configs[4] (`psnark`, 8 GPUs): gm_psnark_new_time (and the elastic prover) over cyclic shares on 2 and 3 ranks"""
     one = _single(extra, tool="run_psnark.py", logn=10)

@@ -203,9 +203,15 @@ def test_psnark_consistency_time_vs_elastic(gm, oracle, pyref, kind):
     assert [(I(x), I(y)) for x, y in time_proof.third_sumcheck_msgs[0]] == [(I(x), I(y)) for x, y in elastic_proof.third_sumcheck_msgs[0]]
     assert (time_proof.tensorcheck_proof.evaluation_proof == elastic_proof.tensorcheck_proof.evaluation_proof).all()
     assert a == b
+    # gm_psnark_new_elastic: the same prover compiled into the library (one call per proof)
+    native = Proof.new_elastic(ck_stream, stream, index, 1 << 20, native=True)
+    assert native == time_proof and native.serialize_compressed() == a
+    assert "ark_gemini::psnark::elastic_prover" in native.spans
     # a small MSM buffer changes the chunking only
     ck_stream.min_device_chunk = 1
     assert Proof.new_elastic(ck_stream, stream, index, 1 << 6).serialize_compressed() == a
+    assert Proof.new_elastic(ck_stream, stream, index, 1 << 6, native=True).serialize_compressed() == a  # every flush literal, down to 64 / depth pairs
+    assert Proof.new_elastic(ck_stream, stream, index, 1, native=True).serialize_compressed() == a
     stream.free()
     r1cs.free()
 
@@ -326,8 +332,15 @@ def test_psnark_config5_shape_time_equals_elastic(gm, oracle, pyref, logn):
     index = Proof.index(ck, r1cs)
     time_proof = Proof.new_time(ck, r1cs, index)
     stream = R1csStream(r1cs)
-    elastic_proof = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20)
+    # 2^18: the Python-driven elastic prover beside the compiled one; above: the compiled one (gm_psnark_new_elastic) alone
+    if logn == 18:
+        stepwise = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20)
+        assert stepwise == time_proof and stepwise.serialize_compressed() == time_proof.serialize_compressed()
+    elastic_proof = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20, native=True)
     assert elastic_proof == time_proof and elastic_proof.serialize_compressed() == time_proof.serialize_compressed()
+    if logn == 22:  # the flushes cut literally: 2^20-pair stream MSMs (and 2^20 / depth in commit_folding), sumchecks that start as space provers
+        literal = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck, min_device_chunk=1), stream, index, 1 << 20, native=True)
+        assert literal.serialize_compressed() == time_proof.serialize_compressed()
     # closed forms
     I = gm.fr.fr_to_int
     tr = pyref.GeminiTranscript(pyref.PROTOCOL_NAME)

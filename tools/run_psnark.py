@@ -100,7 +100,7 @@ def main():
                 cks = ShardedCommitterKeyStream.from_sharded_key(ck)
             else:
                 cks = CommitterKeyStream.from_committer_key(ck)
-            proof = Proof.new_elastic(cks, stream, index, 1 << 20, native=True) if lib_dist else Proof.new_elastic(cks, stream, index, 1 << 20)
+            proof = Proof.new_elastic(cks, stream, index, 1 << 20, native=args.native or lib_dist)
             stream.free()
         else:
             proof = Proof.new_time(ck, r1cs, index, native=args.native or lib_dist)
