@@ -546,12 +546,28 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
   }
   P->nfold = nfold;
   if (nfold > P->cap_folds) return GM_EINVAL;
+  std::vector<uint64_t> all_levels;
+  for (auto& t : trees) all_levels.insert(all_levels.end(), t.levels.begin(), t.levels.end());
   {
-    size_t at = 0;
-    for (auto& t : trees) {  // commit_folding (space.rs:192-223): one ChunkedPippenger of max_msm_buffer / depth per level
-      const size_t depth = t.levels.size();
-      if (depth) RC(K.commit_many(V, t.levels, max_msm_buffer / depth, P->fold_commitments + 18 * at));
-      at += depth;
+    // commit_folding (space.rs:192-223): one ChunkedPippenger of max_msm_buffer / depth per level of a tree.  When no level of any
+    // tree is cut by its flush size every commitment is sum_i level[i] tau^i g whichever way the pairs are walked: the levels of
+    // all four trees go through ONE pipelined batch; otherwise tree by tree, level by level, as streams
+    bool cut = false;
+    for (auto& t : trees)
+      for (uint64_t lv : t.levels) {
+        size_t l = 0;
+        RC(vec_len(lv, &l));
+        cut = cut || l > K.flush(max_msm_buffer / t.levels.size());
+      }
+    if (!cut) {
+      if (nfold) RC(K.commit_many(V, all_levels, (size_t)1 << 62, P->fold_commitments));
+    } else {
+      size_t at = 0;
+      for (auto& t : trees) {
+        const size_t depth = t.levels.size();
+        if (depth) RC(K.commit_many(V, t.levels, max_msm_buffer / depth, P->fold_commitments + 18 * at));
+        at += depth;
+      }
     }
   }
   for (size_t k = 0; k < nfold; k++) RC(gm_transcript_append_g1(T.h, L("commitment"), 10, P->fold_commitments + 18 * k, 1, 0));
@@ -562,8 +578,6 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
     beta.sqr().to_limbs(pts);
     beta.neg().to_limbs(pts + 8);
   }
-  std::vector<uint64_t> all_levels;
-  for (auto& t : trees) all_levels.insert(all_levels.end(), t.levels.begin(), t.levels.end());
   RC(gm_fr_eval_le_batch(all_levels.data(), nfold, pts + 4, 2, P->fold_evaluations));  // evaluate_folding, tree by tree
   std::vector<uint64_t> base = {w_le, ralpha_star, r_star, alpha_star, z_star, I->row, I->col, I->val_a, I->val_b, I->val_c, sorted[0], sorted[1], sorted[2]};
   base.insert(base.end(), accs, accs + 9);
@@ -580,57 +594,29 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
       acc.to_limbs(ocs.data() + 4 * k);
       acc = acc * oc;
     }
-    std::vector<uint64_t> parts;
-    {  // open_multi_points(partial_eval) (space.rs:128-166)
-      size_t longest = 0;
-      for (uint64_t p : base) {
-        size_t l = 0;
-        RC(vec_len(p, &l));
-        longest = std::max(longest, l);
-      }
-      uint64_t pe, q, rem[12];
-      RC(V.alloc(longest, &pe));
-      RC(gm_fr_lincomb(base.data(), ocs.data(), base.size(), pe));
-      size_t lp = 0;
-      RC(vec_len(pe, &lp));
-      RC(V.alloc(lp ? lp - 1 : 0, &q));
-      RC(gm_fr_div_vanishing(pe, pts, 3, q, rem));
-      V.release(pe);
-      parts.resize(18);
-      RC(K.msm_le(V, q, max_msm_buffer, parts.data()));
-      V.release(q);
+    // The reference sums five openings: open_multi_points(partial_eval) (space.rs:128-166) and one open_folding per tree (:229-285),
+    // each sum_i eta_i commit(p_i div Z), the HashMapPippenger of open_folding merging the scalars of equal bases.  Division by the
+    // same Z is linear and all five walk the same key, so the merge extends over all of them: ONE linear combination of the 22 base
+    // polynomials and every level, ONE division, one stream MSM (flushed every max_msm_buffer pairs) -- instead of a division
+    // per level (~100 latency-bound three-phase scans)
+    std::vector<uint64_t> all = base;
+    all.insert(all.end(), all_levels.begin(), all_levels.end());
+    size_t longest = 0;
+    for (uint64_t p : all) {
+      size_t l = 0;
+      RC(vec_len(p, &l));
+      longest = std::max(longest, l);
     }
-    size_t off = base.size();
-    for (auto& t : trees) {  // open_folding (space.rs:229-285): HashMapPippenger merges equal bases = the linear combination of the quotients
-      std::vector<uint64_t> quots, etas;
-      size_t longest = 0;
-      for (size_t i = 0; i < t.levels.size(); i++) {
-        size_t l = 0;
-        RC(vec_len(t.levels[i], &l));
-        if (l > 3) {
-          uint64_t q, rem[12];
-          RC(V.alloc(l - 1, &q));
-          RC(gm_fr_div_vanishing(t.levels[i], pts, 3, q, rem));
-          quots.push_back(q);
-          etas.insert(etas.end(), ocs.begin() + 4 * (off + i), ocs.begin() + 4 * (off + i) + 4);
-          longest = std::max(longest, l - 3);
-        }
-      }
-      off += t.levels.size();
-      parts.resize(parts.size() + 18);
-      uint64_t* out = parts.data() + parts.size() - 18;
-      if (quots.empty()) {
-        RC(gm_g1_sum(nullptr, 0, out));
-        continue;
-      }
-      uint64_t batched;
-      RC(V.alloc(longest, &batched));
-      RC(gm_fr_lincomb(quots.data(), etas.data(), quots.size(), batched));
-      for (uint64_t q : quots) V.release(q);
-      RC(K.msm_le(V, batched, max_msm_buffer, out));
-      V.release(batched);
-    }
-    RC(gm_g1_sum(parts.data(), parts.size() / 18, P->evaluation_proof));
+    uint64_t pe, q, rem[12];
+    RC(V.alloc(longest, &pe));
+    RC(gm_fr_lincomb(all.data(), ocs.data(), all.size(), pe));
+    size_t lp = 0;
+    RC(vec_len(pe, &lp));
+    RC(V.alloc(lp ? lp - 1 : 0, &q));
+    RC(gm_fr_div_vanishing(pe, pts, 3, q, rem));
+    V.release(pe);
+    RC(K.msm_le(V, q, max_msm_buffer, P->evaluation_proof));
+    V.release(q);
   }
   P->spans[10] = since(t0);
   P->spans[11] = since(t_all);
