@@ -376,12 +376,18 @@ int gm_set_msm_window(int c) {
 
 int gm_set_msm_glv(int on) {
   GM_CTX();
+#ifndef GM_EXPERIMENTS
+  GM_CHECK(on == 0, GM_EINVAL, "gm_set_msm_glv: the GLV experiment is not in this build (make EXTRA=-DGM_EXPERIMENTS; DESIGN.md section 8)");
+#endif
   C->msm_glv = on != 0;
   return GM_OK;
 }
 
 int gm_set_msm_split(int on) {
   GM_CTX();
+#ifndef GM_EXPERIMENTS
+  GM_CHECK(on == 0, GM_EINVAL, "gm_set_msm_split: the window-group experiment is not in this build (make EXTRA=-DGM_EXPERIMENTS; DESIGN.md section 8)");
+#endif
   C->msm_split = on != 0;
   return GM_OK;
 }

@@ -99,166 +99,23 @@ struct DigitIter {
   }
 };
 
-// ------------------------------------------------------------------------------------------
-// GLV split.  BLS12-381 G1 has the endomorphism phi(x, y) = (beta x, y) = lambda (x, y) with lambda = z^2 - 1 (128
-// bits, z the curve parameter) and lambda^2 + lambda + 1 = r.  A scalar s < r is written s = v1 + v2 lambda (mod r)
-// with |v1|, |v2| < 2^127 (top 16 bits <= 0x5622), so s P = v1 P + v2 phi(P): the same number of bucket additions
-// (two half-length digit strings instead of one), but HALF the windows -- half the bucket sets to reduce (k_group_sum
-// level 1 is two full additions per bucket) and half the doublings of the final Horner.  phi(P_i) is stored next to
-// the registered bases (one product per point, once).  The group element is the same: bit-exact after normalisation.
-//   q = floor(s / lambda) by Barrett (mu = floor(2^256 / lambda)), r1 = s - q lambda;
-//   r1 > lambda / 2      ->  v1 = r1 - lambda, q += 1
-//   q  > (lambda + 1)/2  ->  v2 = q - (lambda + 1), v1 -= 1            (r = lambda (lambda + 1) + 1)
-// ------------------------------------------------------------------------------------------
-struct GlvHalves {
-  uint32_t m[2][4];  // magnitudes of v1, v2
-  bool neg[2];
-};
-GM_DEV GlvHalves glv_split(const uint32_t s_in[8]) {
-  constexpr uint32_t LAM[4] = {0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u};
-  constexpr uint32_t MU[5] = {0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};
-  constexpr uint32_t HALF_LAM[4] = {0x7fffffffu, 0x00000000u, 0x8000d201u, 0x5622d200u};   // floor(lambda / 2)
-  constexpr uint32_t HALF_LAM1[4] = {0x80000000u, 0x00000000u, 0x8000d201u, 0x5622d200u};  // (lambda + 1) / 2
-  uint32_t s[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) s[i] = s_in[i];
-  // s mod r (a canonical scalar is already reduced; anything below 2^256 needs at most four subtractions)
-#pragma unroll 1
-  for (int it = 0; it < 4; it++) {
-    uint32_t t[8], borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      uint32_t b;
-      t[i] = __builtin_subc(s[i], FrParams::MOD[i], borrow, &b);
-      borrow = b;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = borrow ? s[i] : t[i];
-  }
-  // q = (s * mu) >> 256   (q <= floor(s / lambda) <= q + 2)
-  uint32_t prod[13];
-#pragma unroll
-  for (int i = 0; i < 13; i++) prod[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t carry = 0;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      const uint64_t x = (uint64_t)s[i] * MU[j] + prod[i + j] + carry;
-      prod[i + j] = (uint32_t)x;
-      carry = x >> 32;
-    }
-    prod[i + 5] = (uint32_t)carry;
-  }
-  uint32_t q[5];
-#pragma unroll
-  for (int i = 0; i < 5; i++) q[i] = prod[8 + i];
-  // r1 = s - q * lambda  (< 3 lambda: five limbs)
-  uint32_t ql[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) ql[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    uint64_t carry = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (i + j < 6) {
-        const uint64_t x = (uint64_t)q[i] * LAM[j] + ql[i + j] + carry;
-        ql[i + j] = (uint32_t)x;
-        carry = x >> 32;
-      }
-    }
-    if (i + 4 < 6) ql[i + 4] += (uint32_t)carry;
-  }
-  uint32_t r1[5];
-  {
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      uint32_t b;
-      r1[i] = __builtin_subc(s[i], ql[i], borrow, &b);
-      borrow = b;
-    }
-  }
-#pragma unroll 1
-  for (int it = 0; it < 3; it++) {  // while (r1 >= lambda) { r1 -= lambda; q += 1; }
-    uint32_t t[5], borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      uint32_t b;
-      t[i] = __builtin_subc(r1[i], i < 4 ? LAM[i] : 0u, borrow, &b);
-      borrow = b;
-    }
-    const bool ge = borrow == 0;
-    uint32_t carry = ge ? 1u : 0u;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      r1[i] = ge ? t[i] : r1[i];
-      uint32_t c2;
-      q[i] = __builtin_addc(q[i], 0u, carry, &c2);
-      carry = c2;
-    }
-  }
-  // signed values in five-limb two's complement
-  auto gt4 = [](const uint32_t* a, const uint32_t* b) {  // a (five limbs, non-negative) > b (four limbs)
-    if (a[4]) return true;
-    for (int i = 3; i >= 0; i--) {
-      if (a[i] != b[i]) return a[i] > b[i];
-    }
-    return false;
-  };
-  uint32_t v1[5], v2[5];
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    v1[i] = r1[i];
-    v2[i] = q[i];
-  }
-  if (gt4(r1, HALF_LAM)) {  // v1 = r1 - lambda, v2 += 1
-    uint32_t borrow = 0, carry = 1;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      uint32_t b, c2;
-      v1[i] = __builtin_subc(r1[i], i < 4 ? LAM[i] : 0u, borrow, &b);
-      borrow = b;
-      v2[i] = __builtin_addc(v2[i], 0u, carry, &c2);
-      carry = c2;
-    }
-  }
-  if (gt4(v2, HALF_LAM1)) {  // v2 -= lambda + 1, v1 -= 1
-    constexpr uint32_t LAM1[5] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u, 0x00000000u};
-    uint32_t borrow = 0, borrow1 = 1;
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      uint32_t b, b1;
-      v2[i] = __builtin_subc(v2[i], LAM1[i], borrow, &b);
-      borrow = b;
-      v1[i] = __builtin_subc(v1[i], 0u, borrow1, &b1);
-      borrow1 = b1;
-    }
-  }
-  GlvHalves h;
-  const uint32_t* v[2] = {v1, v2};
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const bool neg = (v[k][4] >> 31) != 0;
-    h.neg[k] = neg;
-    uint32_t carry = neg ? 1u : 0u;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {  // |v| = neg ? ~v + 1 : v   (fits four limbs: |v| < 2^127)
-      uint32_t c2;
-      h.m[k][i] = __builtin_addc(neg ? ~v[k][i] : v[k][i], 0u, carry, &c2);
-      carry = c2;
-    }
-  }
-  return h;
-}
+// GLV addressing (two half-length digit strings per scalar, the second one on phi(P)) and the window-group split of one-call
+// MSMs are measured-negative experiments: their code is in the hot translation unit only with
+// -DGM_EXPERIMENTS; otherwise GM_GLV(x) is the constant 0 and the compiler drops every branch that mentions it.
+#ifdef GM_EXPERIMENTS
+#include "msm_glv.inc"
+#define GM_GLV(x) (x)
+#else
+#define GM_GLV(x) 0
+#endif
 
 constexpr int ENTRY_HALF_SHIFT = 30;  // entry idx field, GLV calls: pair index in bits 0..25, bit 30 = the phi(P) half
 // the digit strings of one scalar: one string over the whole scalar, or -- GLV -- two strings over |v1|, |v2|
 struct ScalarDigits {
   DigitIter it;
-  GlvHalves h;
   bool bad;
+#ifdef GM_EXPERIMENTS
+  GlvHalves h;
   GM_DEV void load(const uint32_t* p, bool active, int mont, int glv) {
     it.init(p, active, mont);
     bad = it.bad;
@@ -267,6 +124,15 @@ struct ScalarDigits {
   GM_DEV void start(int half, bool active, int glv) {
     if (glv) it.init_mag(h.m[half], active, bad);
   }
+  GM_DEV bool neg(int half) const { return h.neg[half]; }
+#else
+  GM_DEV void load(const uint32_t* p, bool active, int mont, int) {
+    it.init(p, active, mont);
+    bad = it.bad;
+  }
+  GM_DEV void start(int, bool, int) {}
+  GM_DEV bool neg(int) const { return false; }
+#endif
 };
 
 // One atomic per wave when every participating lane has the same key (the all-equal-scalars
@@ -347,10 +213,10 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     const uint32_t i = first + s;
     const bool active = i < n;
     ScalarDigits sd;
-    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, sg.glv);
+    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, GM_GLV(sg.glv));
     DigitIter& it = sd.it;
-    for (int half = 0; half <= sg.glv; half++) {
-      sd.start(half, active, sg.glv);
+    for (int half = 0; half <= GM_GLV(sg.glv); half++) {
+      sd.start(half, active, GM_GLV(sg.glv));
       for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
         int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
         if (w < sg.w_lo) continue;  // wave-uniform
@@ -378,11 +244,11 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
     const uint32_t i = first + s;
     const bool active = i < n;
     ScalarDigits sd;
-    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, sg.glv);
+    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, GM_GLV(sg.glv));
     DigitIter& it = sd.it;
-    for (int half = 0; half <= sg.glv; half++) {
-      sd.start(half, active, sg.glv);
-      const bool hneg = sg.glv && sd.h.neg[half];
+    for (int half = 0; half <= GM_GLV(sg.glv); half++) {
+      sd.start(half, active, GM_GLV(sg.glv));
+      const bool hneg = GM_GLV(sg.glv) && sd.neg(half);
       for (int w = 0; w < sg.w_lo + sg.Wg; w++) {
         int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
         if (w < sg.w_lo) continue;
@@ -409,7 +275,7 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
                                                        uint32_t* __restrict__ gcursor, uint64_t* __restrict__ tmp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + (size_t)SORT_TS * sg.Wg * (1 + sg.glv));
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(buf + (size_t)SORT_TS * sg.Wg * (1 + GM_GLV(sg.glv)));
   uint32_t* base = cnt + sg.G;
   uint32_t* lst = base + sg.G;
   uint32_t* scan = lst + sg.G;
@@ -421,30 +287,30 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
   uint64_t e[SORT1_STAGE_WMAX];
   {
     ScalarDigits sd;
-    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, sg.glv);
+    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, GM_GLV(sg.glv));
     DigitIter& it = sd.it;
     // GLV: the register slots are split between the halves (Wg <= SORT1_STAGE_WMAX / 2 windows each)
     constexpr int HS = SORT1_STAGE_WMAX / 2;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      if (half <= sg.glv) {
-        sd.start(half, active, sg.glv);
+      if (half <= GM_GLV(sg.glv)) {
+        sd.start(half, active, GM_GLV(sg.glv));
         for (int w = 0; w < sg.w_lo; w++) it.next(sg.c);  // the recurrence starts at window 0
       }
-      const bool hneg = sg.glv && half <= sg.glv && sd.h.neg[half];
+      const bool hneg = GM_GLV(sg.glv) && half <= GM_GLV(sg.glv) && sd.neg(half);
 #pragma unroll
       for (int jj = 0; jj < HS; jj++) {
         // without GLV the one string fills all SORT1_STAGE_WMAX slots: "half 1" continues it at window w_lo + HS
         const int j = half * HS + jj;
-        const int jw = sg.glv ? jj : j;  // window of this slot, relative to w_lo
+        const int jw = GM_GLV(sg.glv) ? jj : j;  // window of this slot, relative to w_lo
         const int w = sg.w_lo + jw;
         e[j] = ~0ull;
-        if (jw < sg.Wg && (sg.glv || half == 0 || sg.Wg > HS)) {
+        if (jw < sg.Wg && (GM_GLV(sg.glv) || half == 0 || sg.Wg > HS)) {
           int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
           if (active && d != 0) {
             const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             const uint32_t key = (sg.shared ? 0u : (uint32_t)jw * sg.B) + (mag - 1u);
-            const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : (i | ((uint32_t)(sg.glv ? half : 0) << ENTRY_HALF_SHIFT));
+            const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : (i | ((uint32_t)(GM_GLV(sg.glv) ? half : 0) << ENTRY_HALF_SHIFT));
             e[j] = ((uint64_t)key << 32) | ((uint64_t)(((d < 0) != hneg) ? 1u : 0u) << 31) | (uint64_t)idx;
           }
         }
@@ -789,12 +655,14 @@ __global__ __launch_bounds__(256) void k_digits_flat(const uint32_t* __restrict_
     if (mont) v = fp_from_mont<FrParams>(v);
     if (!SCATTER && blockIdx.y == 0 && (v.l[7] >> 31)) atomicOr(err, 1u);  // >= 2^255: not an Fr image
     bool hneg = false;
+#ifdef GM_EXPERIMENTS
     if (fg.glv) {
       const GlvHalves h = glv_split(v.l);
       hneg = h.neg[half];
 #pragma unroll
       for (int l = 0; l < 8; l++) v.l[l] = l < 4 ? h.m[half][l] : 0u;
     }
+#endif
     uint32_t t[9];
     uint32_t carry = 0;
 #pragma unroll
@@ -1596,7 +1464,7 @@ static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t st
   // before.  Results are identical (tests/test_gpu_msm.py::test_msm_window_group_split).
   const bool tables = bases->table != nullptr && !C->msm_c_override && n >= std::max(C->msm_table_min, bases->tab_min) &&
                       n < ((size_t)1 << ENTRY_W_SHIFT);
-  const bool split = C->msm_split && n >= MSM_SPLIT_MIN_N && !tables && C->msm_affine_levels == 0 && C->stream_b && C->small_stream[0];
+  const bool split = GM_GLV(1) && C->msm_split && n >= MSM_SPLIT_MIN_N && !tables && C->msm_affine_levels == 0 && C->stream_b && C->small_stream[0];
   if (!split) {
     MsmPending P;
     int rc = msm_enqueue(C, C->msm, MsmStreams{C->stream, C->stream, C->stream}, bases, first, step, d_scalars, mont, n, 0, &P);
@@ -1745,7 +1613,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   // not latency-bound); 2 leaves 112 registers per lane of a SIMD for other kernels
   static const int acc0_waves = getenv("GM_ACC0_WAVES") ? atoi(getenv("GM_ACC0_WAVES")) : 2;
   const size_t bucket_bytes = XYZZ30_BYTES;  // buckets, partials, row / column sums: 208-byte loose records (g1.cuh: Acc30)
-  const bool use_glv = bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && n <= ((size_t)1 << 26);
+  const bool use_glv = GM_GLV(1) && bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && n <= ((size_t)1 << 26);
   const int W = ((use_glv ? 128 : 256) + c - 1) / c;
   GM_CHECK(nparts == 1 || !use_table, GM_EINVAL, "msm: the fixed-base table path is not split into window groups");
   const int w_lo = part * W / nparts, Wg = (part + 1) * W / nparts - w_lo;  // this call's window group
@@ -2334,6 +2202,11 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
 //   it (0.16 -> 0.52 ms at the tuned chunk length), the gathers touch two arrays (k_acc0 +1.8 %) and the key doubles in
 //   HBM: no net gain where it matters.  Results are identical (tests/test_gpu_msm.py::test_msm_glv_same_results).
 int bases_build_phi(Context* C, Bases* b) {
+#ifndef GM_EXPERIMENTS
+  (void)C;
+  (void)b;
+  return GM_OK;  // the GLV addressing mode is not in this build (msm_glv.inc, -DGM_EXPERIMENTS)
+#else
   static const bool glv_env = getenv("GM_GLV") && !strcmp(getenv("GM_GLV"), "1");
   if (!(glv_env || C->msm_glv) || b->n == 0 || b->phi) return GM_OK;
   GM_HIP(dev_malloc((void**)&b->phi, b->n * AFF_BYTES));
@@ -2341,6 +2214,7 @@ int bases_build_phi(Context* C, Bases* b) {
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
+#endif
 }
 
 int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out96) {

@@ -191,10 +191,11 @@ int gm_set_msm_window(int c);
 int gm_set_msm_table_min(size_t n);
 /* Tuning knob (default 0), read when bases are REGISTERED: also store phi(P_i) = (beta x_i, y_i) = lambda P_i and run
  * MSMs on those bases with every scalar split as s = v1 + v2 lambda, |v1|, |v2| < 2^127 (GLV): half the windows, twice
- * the base memory.  Same results; no net gain on MI355X as measured (gemini_amd/csrc/msm.hip: bases_build_phi). */
+ * the base memory.  Same results; no net gain on MI355X as measured.  A round-3 EXPERIMENT: the code
+ * (gemini_amd/csrc/msm_glv.inc) is only in builds with -DGM_EXPERIMENTS; otherwise on != 0 returns GM_EINVAL. */
 int gm_set_msm_glv(int on);
 /* Tuning knob (default 0): run one-call MSMs of >= 2^17 pairs as two window groups pipelined over three streams.
- * Same results; slower on MI355X as measured (gemini_amd/csrc/msm.hip: msm_run_one). */
+ * Same results; slower on MI355X as measured.  Builds with -DGM_EXPERIMENTS only; otherwise on != 0 returns GM_EINVAL. */
 int gm_set_msm_split(int on);
 /* Affine tree levels in front of the XYZZ bucket accumulation (0 = none, -1 = automatic, <= 8): every
  * level adds the sorted entries of each bucket pairwise in affine coordinates with one shared field
