@@ -144,3 +144,65 @@ def test_cpp_host_layer(oracle, pyref, tmp_path):
                                                           len(pexp.tensorcheck_proof.folded_polynomials_commitments)]
     pr1cs.free()
     pck.powers_of_g.free()
+
+
+def test_sharded_provers_from_plain_c_abi_processes(oracle, pyref, tmp_path):
+    """tests/cpp/test_sharded_ranks.cpp: forked PROCESSES with nothing but the C ABI -- gm_dist_init_shm, gm_snark_shard_key_new,
+    gm_snark_new_time_sharded (block-diagonal and general-matrix form) and gm_snark_new_time over gm_g1_srs_register_cyclic shares
+    -- must all produce the digest of the one-process run (what a Rust embedder of include/gemini_hip.h gets; no Python, no torch
+    in the ranks)."""
+    exe = str(tmp_path / "test_sharded_ranks")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_sharded_ranks.cpp"),
+                           "-L", os.path.join(ROOT, "gemini_amd"), "-lgemini_hip", "-Wl,-rpath," + os.path.join(ROOT, "gemini_amd"), "-o", exe])
+    R = pyref.R_MOD
+    e_i = oracle.limbs_to_ints(oracle.random_fr(9001, 1))[0]
+    tau_i = oracle.limbs_to_ints(oracle.random_fr(9002, 1))[0]
+    hexl = lambda limbs: "".join(f"{int(v):016x}" for v in limbs)  # noqa: E731
+    ev = oracle.fr_to_mont(oracle.ints_to_limbs([e_i, pow(e_i, -1, R)], 4))
+    args = [hexl(ev[0]), hexl(ev[1]), hexl(oracle.g1_generator()), hexl(oracle.ints_to_limbs([tau_i], 4)[0])]
+
+    def run(world, mode, cols="local", logn=10):
+        out = subprocess.run([exe, str(world), str(logn), mode, cols] + args, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.split()[1]
+
+    one = run(1, "cyclic")
+    assert run(1, "block") == one
+    for world in (2, 4, 8):
+        assert run(world, "block") == one, world
+    assert run(4, "block", "global") == one
+    for world in (2, 3, 5):
+        assert run(world, "cyclic") == one, world
+    # and the digest is the one of the Python mirror's single-GPU native prover on the same instance and key
+    import gemini_amd as gm
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.kzg import CommitterKey
+    from gemini_amd.snark import Proof
+
+    gm.capi.init()
+    n = 1 << 10
+    ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau_i], 4)[0])
+    r1cs = dummy_r1cs(e_i, n)
+    p = Proof.new_time(r1cs, ck, native=True)
+
+    def fnv(h, b):
+        for x in b:
+            h = ((h ^ x) * 0x100000001B3) & (2**64 - 1)
+        return h
+
+    A = lambda a: np.ascontiguousarray(a, dtype=np.uint64).tobytes()  # noqa: E731
+    h = fnv(0xCBF29CE484222325, A(p.witness_commitment))
+    h = fnv(h, A(p.zc_alpha))
+    for msgs, ff in (p.first_sumcheck_msgs, p.second_sumcheck_msgs):
+        h = fnv(h, len(msgs).to_bytes(8, "little"))
+        h = fnv(h, b"".join(A(a) + A(b) for a, b in msgs))
+        h = fnv(h, A(ff[0][0]) + A(ff[0][1]))
+    tc = p.tensorcheck_proof
+    h = fnv(h, len(tc.folded_polynomials_commitments).to_bytes(8, "little"))
+    h = fnv(h, b"".join(A(c) for c in tc.folded_polynomials_commitments))
+    h = fnv(h, b"".join(A(e2) for e2 in tc.folded_polynomials_evaluations))
+    h = fnv(h, A(tc.evaluation_proof))
+    h = fnv(h, A(tc.base_polynomials_evaluations[0]))
+    assert f"{h:016x}" == one
+    r1cs.free()
+    ck.powers_of_g.free()
