@@ -11,6 +11,9 @@
 //   gm::Transcript (GeminiTranscript over merlin)           src/transcript.rs:8-34
 //   gm::Sumcheck::{prove, new_time}                         src/subprotocols/sumcheck/proof.rs:36-66,125-130
 //   gm::R1cs, gm::SnarkProof::{new_time, new_elastic}       src/circuit.rs, src/snark/time_prover.rs:19-117, elastic_prover.rs:174-266
+//   gm::dist::{init_rccl, init_shm, init_hook, ...}         the all-gather between the per-GPU processes (no reference counterpart:
+//                                                           the reference is single-device; gemini_amd/csrc/dist.cpp)
+//   gm::CommitterKey::cyclic_share                          CommitterKey::new (src/kzg/time.rs:49-72), every rank its powers i = rank (mod world)
 #pragma once
 #include <array>
 #include <cstdint>
@@ -34,6 +37,37 @@ inline void check(int rc) {
   if (rc != GM_OK) throw Error(rc, gm_last_error());
 }
 inline void init(int device = 0) { check(gm_init(device)); }
+
+// One process per GPU: after gm::init(local_rank) pick the transport of the library's all-gathers.  Every native prover
+// (SnarkProof::new_time ..., gm_snark_new_time_sharded) then runs on N GPUs when its key is a cyclic share / a shard key.
+namespace dist {
+inline std::array<uint8_t, 128> rccl_unique_id() {  // rank 0; the 128 bytes reach the peers out of band
+  std::array<uint8_t, 128> id{};
+  check(gm_dist_rccl_unique_id(id.data()));
+  return id;
+}
+inline void init_rccl(int rank, int world, const std::array<uint8_t, 128>& id) { check(gm_dist_init_rccl(rank, world, id.data())); }
+inline void init_shm(int rank, int world, const std::string& name, size_t slot_bytes = 0) { check(gm_dist_init_shm(rank, world, name.c_str(), slot_bytes)); }
+inline void init_hook(int rank, int world, gm_allgather_fn fn, void* ctx) { check(gm_dist_init_hook(rank, world, fn, ctx)); }
+inline void selftest() { check(gm_dist_selftest()); }
+inline void finalize() { check(gm_dist_finalize()); }
+inline int rank() {
+  int r = 0;
+  check(gm_dist_info(&r, nullptr, nullptr));
+  return r;
+}
+inline int world() {
+  int w = 1;
+  check(gm_dist_info(nullptr, &w, nullptr));
+  return w;
+}
+template <class T>
+inline std::vector<T> allgather(const T& mine) {  // trivially copyable host values, rank order
+  std::vector<T> all((size_t)world());
+  check(gm_dist_allgather_host(&mine, sizeof(T), all.data()));
+  return all;
+}
+}  // namespace dist
 
 using Fr = std::array<uint64_t, 4>;        // Montgomery limbs (ark-ff memory image)
 using BigInt = std::array<uint64_t, 4>;    // canonical integer (Fr::into_bigint)
@@ -223,6 +257,16 @@ class CommitterKey {
     check(gm_g1_bases_register(powers_of_g.data(), sizeof(G1Affine), n_, &h_));
     check(gm_g1_bases_precompute(h_, -1));  // a committer key stays resident: fixed-base tables when they fit (gm_set_auto_tables)
   }
+  // this rank's ELEMENT-CYCLIC share of CommitterKey::new(max_degree, ..) with trapdoor tau (canonical) and generator g: powers
+  // i = rank (mod world), generated on the device; commit / batch_commit and every prover handed this key then shard their MSMs
+  // over the ranks (gm::dist::init_* first).  One rank: the whole key.
+  static CommitterKey cyclic_share(const uint64_t g_affine[12], const BigInt& tau, size_t max_degree) {
+    CommitterKey k;
+    k.n_ = max_degree + 1;
+    check(gm_g1_srs_register_cyclic(g_affine, tau.data(), k.n_, dist::rank(), dist::world(), &k.h_));
+    return k;
+  }
+  CommitterKey(CommitterKey&& o) noexcept : h_(o.h_), n_(o.n_) { o.h_ = 0; }
   ~CommitterKey() {
     if (h_) gm_g1_bases_free(h_);
   }
@@ -236,7 +280,7 @@ class CommitterKey {
     check(gm_fr_vec_alloc(n, &hv));
     G1Projective out;
     int rc = gm_fr_vec_upload(hv, 0, polynomial[0].data(), n);
-    if (!rc) rc = gm_g1_msm_v(h_, 0, 0, hv, 0, n, out.data());
+    if (!rc) rc = gm_ck_msm(h_, 0, 0, hv, 0, n, out.data());  // a whole key: gm_g1_msm_v; a cyclic share: local MSM + all-gather
     gm_fr_vec_free(hv);
     check(rc);
     return out;
@@ -254,7 +298,7 @@ class CommitterKey {
       rc = gm_fr_vec_alloc(ns[j], &hv[j]);
       if (!rc && ns[j]) rc = gm_fr_vec_upload(hv[j], 0, polynomials[j][0].data(), ns[j]);
     }
-    if (!rc && k) rc = gm_g1_msm_v_batch(h_, 0, 0, hv.data(), ns.data(), k, out[0].data());
+    if (!rc && k) rc = gm_ck_msm_batch(h_, hv.data(), ns.data(), k, out[0].data());
     for (uint64_t h : hv)
       if (h) gm_fr_vec_free(h);
     check(rc);
@@ -262,8 +306,9 @@ class CommitterKey {
   }
 
  private:
+  CommitterKey() = default;
   uint64_t h_ = 0;
-  size_t n_;
+  size_t n_ = 0;  // powers of the WHOLE key
 };
 
 struct RoundMsg {

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/msm20 -o msm20 -- p
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --headline-only > /dev/null 2> $OUT/pmc_$c.err
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/snark24 -o snark24 -- python $GRAFT_REPO_ROOT/tools/run_snark.py -i 24 --repeat 3 > $OUT/snark24_run.json 2> $OUT/snark24.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/snark24 -o snark24 -- python $GRAFT_REPO_ROOT/tools/run_snark.py -i 24 --repeat 3 --native > $OUT/snark24_run.json 2> $OUT/snark24.err
 find $OUT -name "*.csv" | head -20
 # keep the merge-back small: the per-dispatch traces are large, the stats and counter tables are what is read
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
