@@ -167,7 +167,9 @@ struct MsmStream {
   bool acc_set = false;
 };
 
-constexpr int MSM_SMALL_LANES = 4;
+constexpr int MSM_SMALL_LANES = 6;  // small calls of a batch in flight side by side (GM_MSM_SMALL_LANES uses fewer); a lane's workspace is ~150 MB.
+// Measured on one box, snark -i 18 / -i 20 / sharded -i 21 / -i 22 (ms): 2 lanes 14.6 / 21.5 / 36.0 / 50.7, 4 lanes 13.1 / 19.8 / 33.5 / 48.1,
+// 6 lanes 11.7 / 18.7 / 32.0 / 47.4, 8 lanes 17.0 / 21.1 / 33.6 / 48.5, 12 lanes 17.6 / 22.5 / 35.0 / 51.3: beyond six the chains only get in each other's way
 struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
   DevBuf clk;  // {shader cycles, 100 MHz ticks} of the first wave of the last k_acc0 (read only while profiling: gm_prof_read_clock)

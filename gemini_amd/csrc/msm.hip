@@ -1422,8 +1422,13 @@ struct MsmStreams {
 };
 static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
                        int mont, size_t n, int slot, MsmPending* P, int part = 0, int nparts = 1);
-static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18]);
-static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18]) { return msm_finish_parts(C, &P, 1, normalize, out_jac); }
+static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18], bool use_pool = true);
+// the helper threads of the host tail (class HornerPool, below)
+static void horner_pool_prewake();
+static void horner_pool_run(int n, const std::function<void(int)>& fn);
+static int msm_finish(Context* C, const MsmPending& P, bool normalize, uint64_t out_jac[18], bool use_pool = true) {
+  return msm_finish_parts(C, &P, 1, normalize, out_jac, use_pool);
+}
 
 // Calls larger than 2^26 pairs are split into 2^26-pair MSMs whose results are added on the host --
 // the same composition ChunkedPippenger / msm_chunks use (src/kzg/space.rs:41-53), with the chunk
@@ -1533,12 +1538,8 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     int lane;  // 0 = main workspace, 1.. = small workspaces
     MsmPending P;
   };
-  std::vector<Inflight> q;  // FIFO, at most 2 + MSM_SMALL_LANES long
-  size_t head = 0;
-  auto drain_one = [&]() {
-    Inflight& e = q[head++];
-    return msm_finish(C, e.P, normalize, out_jac + 18 * e.j);
-  };
+  std::vector<Inflight> q;  // calls enqueued so far, in order; at most 4 big + MSM_SMALL_LANES small ones are unfinished at a time
+  std::vector<char> finished;
   auto fail = [&](int rc) {
     (void)hipStreamSynchronize(C->stream);
     for (int s = 0; s < MSM_SMALL_LANES; s++)
@@ -1546,26 +1547,94 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     if (C->stream_b) (void)hipStreamSynchronize(C->stream_b);
     return rc;
   };
+  auto busy = [&](int lane, int hslot) {
+    for (size_t t = 0; t < q.size(); t++)
+      if (!finished[t] && q[t].lane == lane && q[t].P.slot == hslot) return true;
+    return false;
+  };
+  // The host tail of a small call is ~0.2 ms, most of it the 256 dependent doublings of the window Horner.  Every small call in flight
+  // is finished at once, one per helper thread (each tail serial on its thread), instead of one after the other on the calling
+  // thread.  Measured NEUTRAL (GM_MSM_PAR_FINISH=0 / 1: snark -i 20 20.1 / 19.8 ms, -i 22 48.2 / 48.1): a batch is bound by how its
+  // kernels share the GPU, not by the host (enqueueing twenty calls takes 0.7 ms of 9.3, GM_MSM_TRACE=1).
+  auto finish_smalls = [&]() -> int {
+    std::vector<size_t> idx;
+    for (size_t t = 0; t < q.size(); t++)
+      if (!finished[t] && q[t].lane > 0) idx.push_back(t);
+    if (idx.empty()) return GM_OK;
+    std::vector<int> rcs(idx.size(), GM_OK);
+    static const bool par_finish = !(getenv("GM_MSM_PAR_FINISH") && !strcmp(getenv("GM_MSM_PAR_FINISH"), "0"));  // A/B knob
+    if (!par_finish) {
+      for (size_t i = 0; i < idx.size(); i++) rcs[i] = msm_finish(C, q[idx[i]].P, normalize, out_jac + 18 * q[idx[i]].j);
+    } else if (idx.size() == 1) {
+      rcs[0] = msm_finish(C, q[idx[0]].P, normalize, out_jac + 18 * q[idx[0]].j);
+    } else {
+      horner_pool_prewake();
+      horner_pool_run((int)idx.size(), [&](int i) { rcs[(size_t)i] = msm_finish(C, q[idx[(size_t)i]].P, normalize, out_jac + 18 * q[idx[(size_t)i]].j, false); });
+    }
+    int rc = GM_OK;
+    for (size_t i = 0; i < idx.size(); i++) {
+      finished[idx[i]] = 1;
+      if (rcs[i] && !rc) rc = rcs[i];
+    }
+    return rc;
+  };
+  auto drain_oldest = [&]() -> int {
+    for (size_t t = 0; t < q.size(); t++) {
+      if (finished[t]) continue;
+      if (q[t].lane > 0) return finish_smalls();
+      finished[t] = 1;
+      return msm_finish(C, q[t].P, normalize, out_jac + 18 * q[t].j);
+    }
+    return GM_OK;
+  };
+  static const bool batch_trace = getenv("GM_MSM_TRACE") != nullptr;  // host time of the batch: enqueueing vs finishing
+  double enqueue_s = 0.0;
+  const auto t_batch0 = std::chrono::steady_clock::now();
+  static const int small_lanes = std::max(1, std::min(MSM_SMALL_LANES, getenv("GM_MSM_SMALL_LANES") ? atoi(getenv("GM_MSM_SMALL_LANES")) : MSM_SMALL_LANES));
   int big_rr = 0, small_rr = 0;
-  for (size_t j = 0; j < k; j++) {
-    const bool small = ns[j] <= MSM_SMALL_N && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0;
+  auto is_small = [&](size_t j) { return ns[j] <= MSM_SMALL_N && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0; };
+  // ORDER.  Small calls do not progress beside the accumulation of a big one: the SIMD arbiter serves the oldest waves first
+  // (section 4.1) and a k_acc0 grid keeps every SIMD supplied with older waves, so a small call's kernels crawl (a memset of
+  // a few KB was seen to take 0.7 ms there) and its XYZZ + XYZZ kernels (214 VGPRs) do not even fit beside two accumulation waves.
+  // Small calls do overlap with EACH OTHER (latency-bound chains on their own streams).  An experiment puts the small calls of a batch FIRST,
+  // all side by side, with the big ones behind them (GM_MSM_BATCH_ORDER=smalls): measured no better (batch of 2^20 .. 2 pairs: 10.3 against
+  // 9.8 ms; the provers 0.5-4 ms slower), so the caller's order stays the default.
+  static const bool smalls_first = getenv("GM_MSM_BATCH_ORDER") && !strcmp(getenv("GM_MSM_BATCH_ORDER"), "smalls");
+  std::vector<size_t> order;
+  if (smalls_first) {
+    for (size_t j = 0; j < k; j++)
+      if (is_small(j)) order.push_back(j);
+    for (size_t j = 0; j < k; j++)
+      if (!is_small(j)) order.push_back(j);
+  } else {
+    for (size_t j = 0; j < k; j++) order.push_back(j);
+  }
+  bool gated = false;
+  for (size_t jo = 0; jo < k; jo++) {
+    const size_t j = order[jo];
+    const bool small = is_small(j);
     // big calls alternate between the two full-size lanes (0 and -1), each with two result buffers
     static const bool two_big = !(getenv("GM_MSM_BIG_LANES") && !strcmp(getenv("GM_MSM_BIG_LANES"), "1"));
     int lane, hslot;
     if (small) {
-      lane = 1 + (small_rr++ % MSM_SMALL_LANES);
+      lane = 1 + (small_rr++ % small_lanes);
       hslot = 0;
     } else {
       lane = (two_big && C->stream_b && (big_rr & 1)) ? -1 : 0;
       hslot = (big_rr >> 1) & 1;
       big_rr++;
+      if (smalls_first && !gated) {  // the big lanes start behind the small calls that are still in flight
+        gated = true;
+        for (size_t t = 0; t < q.size(); t++)
+          if (!finished[t] && q[t].lane > 0 && !q[t].P.empty) {
+            GM_HIP(hipStreamWaitEvent(C->stream, q[t].P.ws->done_ev[q[t].P.slot], 0));
+            if (C->stream_b) GM_HIP(hipStreamWaitEvent(C->stream_b, q[t].P.ws->done_ev[q[t].P.slot], 0));
+          }
+      }
     }
     // a (workspace, result buffer) pair is free again once its previous call has been finished
-    for (;;) {
-      bool busy = false;
-      for (size_t t = head; t < q.size(); t++) busy = busy || (q[t].lane == lane && q[t].P.slot == hslot);
-      if (!busy) break;
-      int rc = drain_one();
+    while (busy(lane, hslot)) {
+      int rc = drain_oldest();
       if (rc) return fail(rc);
     }
     Inflight e;
@@ -1574,15 +1643,24 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     MsmWorkspace& ws = lane > 0 ? C->msm_small[lane - 1] : (lane < 0 ? C->msm_b : C->msm);
     hipStream_t st = lane > 0 ? C->small_stream[lane - 1] : (lane < 0 ? C->stream_b : C->stream);
     if (st != C->stream) GM_HIP(hipStreamWaitEvent(st, C->start_ev, 0));  // scalars produced on the main stream
+    const auto tq0 = std::chrono::steady_clock::now();
     int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, (pair_offsets ? (int64_t)pair_offsets[j] : (firsts ? firsts[j] : first)), step, d_scalars[j], mont,
                          ns[j], hslot, &e.P);
+    enqueue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
     if (rc) return fail(rc);
     q.push_back(e);
+    finished.push_back(0);
   }
-  while (head < q.size()) {
-    int rc = drain_one();
+  for (;;) {
+    bool left = false;
+    for (char f : finished) left = left || !f;
+    if (!left) break;
+    int rc = drain_oldest();
     if (rc) return fail(rc);
   }
+  if (batch_trace)
+    fprintf(stderr, "[gm msm batch] %zu calls: %.3f ms, of which enqueueing %.3f ms\n", k,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_batch0).count(), enqueue_s * 1e3);
   return GM_OK;
 }
 
@@ -2111,7 +2189,12 @@ class HornerPool {
   bool stop_ = false;
 };
 
-static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18]) {
+static void horner_pool_prewake() { HornerPool::get().prewake(); }
+static void horner_pool_run(int n, const std::function<void(int)>& fn) { HornerPool::get().run(n, fn); }
+
+// use_pool = false: the whole tail on the calling thread (the batch finishes several small calls side by side, ONE per helper
+// thread -- a small call's tail is 256 dependent doublings that no pool can split, and a batch of twenty of them was HOST-bound)
+static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18], bool use_pool) {
   gmh::G1 result = gmh::G1::identity();
   // Horner over bit positions, window groups and bucket sets high -> low (variable_base.rs:168-175 with the
   // weighted bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w).
@@ -2122,7 +2205,7 @@ static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, boo
     const MsmPending& P = parts[p];
     if (P.empty) continue;
     MsmWorkspace& ws = *P.ws;
-    if (P.Wb > 1) HornerPool::get().prewake();
+    if (P.Wb > 1 && use_pool) HornerPool::get().prewake();
     GM_HIP(hipEventSynchronize(ws.done_ev[P.slot]));
     const uint64_t* hp = ws.host_planes[P.slot];
     if ((uint32_t)hp[P.plane_count * 24] != 0) {
@@ -2136,7 +2219,7 @@ static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, boo
     };
     // S_w = sum_j 2^j Z_{w,j} + Tot_w, one task per bucket set
     std::vector<gmh::G1> S((size_t)P.Wb);
-    HornerPool::get().run(P.Wb, [&](int w) {
+    auto window_sum = [&](int w) {
       gmh::G1 s = gmh::G1::identity();
       int field = P.m - 1;
       uint32_t jj = P.wf[field];
@@ -2152,14 +2235,17 @@ static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, boo
       gmh::G1 tot = plane_at(w, 0, P.wf[0]);  // the low field's elements with bit 0 clear ...
       if (P.wf[0] >= 1) tot = tot.add(plane_at(w, 0, 0));  // ... + those with bit 0 set = Tot_w
       S[(size_t)w] = s.add(tot);
-    });
+    };
+    if (use_pool) HornerPool::get().run(P.Wb, window_sum);
+    else
+      for (int w = 0; w < P.Wb; w++) window_sum(w);
     for (int w = P.Wb - 1; w >= 0; w--) {
       for (int j = 0; j < P.c; j++) result = result.dbl();
       result = result.add(S[(size_t)w]);
     }
   }
-  C->prof.collect();
-  if (C->prof.on)  // the clock readings of the call's k_acc0 travelled with the plane sums
+  if (use_pool) C->prof.collect();
+  if (C->prof.on && use_pool)  // the clock readings of the call's k_acc0 travelled with the plane sums
     for (int p = 0; p < nparts; p++)
       if (!parts[p].empty) {
         const uint64_t* hp = parts[p].ws->host_planes[parts[p].slot] + parts[p].plane_count * 24;
