@@ -29,8 +29,8 @@ SYMBOLS = [
     "gm_fr_acc_product",
     "gm_fr_vec_alloc", "gm_fr_vec_free", "gm_fr_vec_len", "gm_fr_vec_upload", "gm_fr_vec_download",
     "gm_fr_vec_fill", "gm_fr_vec_ptr", "gm_fr_vec_set_len",
-    "gm_fr_reverse", "gm_fr_stride", "gm_fr_fold", "gm_fr_powers", "gm_fr_tensor", "gm_fr_hadamard", "gm_fr_ip", "gm_fr_eval_le", "gm_fr_eval_le_batch",
-    "gm_fr_lincomb", "gm_fr_scale_into", "gm_fr_add_at", "gm_fr_div_vanishing",
+    "gm_fr_reverse", "gm_fr_stride", "gm_fr_fold", "gm_fr_fold_chain", "gm_fr_powers", "gm_fr_tensor", "gm_fr_hadamard", "gm_fr_ip", "gm_fr_eval_le", "gm_fr_eval_le_batch",
+    "gm_fr_lincomb", "gm_fr_scale_into", "gm_fr_scale_into_many", "gm_fr_add_at", "gm_fr_div_vanishing",
     "gm_spm_register", "gm_spm_free", "gm_spm_mul", "gm_spm_shape", "gm_snark_new_time", "gm_snark_new_elastic", "gm_psnark_new_time", "gm_psnark_new_elastic", "gm_psnark_preprocess", "gm_psnark_preprocess_free", "gm_psnark_index", "gm_spm_download",
     "gm_sc_new", "gm_sc_new_v", "gm_sc_round", "gm_sc_round_begin", "gm_sc_round_end", "gm_sc_fold", "gm_sc_rounds", "gm_sc_final", "gm_sc_free",
     "gm_sc_set_shard", "gm_sc_lens", "gm_sc_download",

@@ -214,6 +214,8 @@ int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_
 int fr_eval_le_batch(Context* C, FrVec* const* ps, size_t k, const uint64_t* xs, size_t npoints, uint64_t* results);
 int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVec* out);
 int fr_scale_into(Context* C, FrVec* in, const uint64_t c[4], FrVec* out, size_t offset);
+int fr_fold_chain(Context* C, FrVec* f, const uint64_t* challenges, size_t k, FrVec** outs);
+int fr_scale_into_many(Context* C, FrVec** ins, const uint64_t* coeffs, size_t k, FrVec* out, const size_t* offsets);
 int fr_add_at(Context* C, FrVec* v, const size_t* idx, const uint64_t* vals, size_t k);
 int fr_fill(Context* C, FrVec* v, const uint64_t val[4]);
 int fr_reverse(Context* C, FrVec* in, FrVec* out);
@@ -287,6 +289,7 @@ void gm_shutdown(void) {
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
   for (auto& kv : C->space_provers) sp_destroy(C, kv.second.get());
   for (auto& kv : C->herring_g1) hg1_destroy(C, kv.second.get());
+  C->partial_bufs.release_all();
   for (auto& kv : C->indices)
     if (kv.second->d) (void)hipFree(kv.second->d);
   for (auto& kv : C->matrices) {
@@ -851,6 +854,18 @@ int gm_fr_stride(uint64_t in, size_t start, size_t stride, size_t count, uint64_
   GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
+int gm_fr_fold_chain(uint64_t f, const uint64_t* challenges_mont, size_t k, const uint64_t* outs) {
+  GM_CTX();
+  GM_VEC(vf, f, "fr_fold_chain");
+  GM_CHECK(k == 0 || (challenges_mont && outs), GM_EINVAL, "fr_fold_chain: null pointer");
+  std::vector<FrVec*> vo(k);
+  for (size_t j = 0; j < k; j++) {
+    vo[j] = find_vec(outs[j]);
+    GM_CHECK(vo[j] != nullptr, GM_EHANDLE, "fr_fold_chain: unknown vector handle %llu", (unsigned long long)outs[j]);
+    for (size_t i = 0; i < j; i++) GM_CHECK(vo[i] != vo[j], GM_EINVAL, "fr_fold_chain: repeated output vector");
+  }
+  return fr_fold_chain(C, vf, challenges_mont, k, vo.data());
+}
 int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out) {
   GM_CTX();
   GM_VEC(vf, f, "fr_fold");
@@ -901,6 +916,17 @@ int gm_fr_scale_into(uint64_t in, const uint64_t c_mont[4], uint64_t out, size_t
   GM_VEC(vo, out, "fr_scale_into");
   GM_CHECK(c_mont != nullptr, GM_EINVAL, "fr_scale_into: null pointer");
   return fr_scale_into(C, vi, c_mont, vo, out_offset);
+}
+int gm_fr_scale_into_many(const uint64_t* ins, const uint64_t* coeffs_mont, size_t k, uint64_t out, const size_t* out_offsets) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_scale_into_many");
+  GM_CHECK(k == 0 || (ins && coeffs_mont && out_offsets), GM_EINVAL, "fr_scale_into_many: null pointer");
+  std::vector<FrVec*> ps(k);
+  for (size_t j = 0; j < k; j++) {
+    ps[j] = find_vec(ins[j]);
+    GM_CHECK(ps[j] != nullptr, GM_EHANDLE, "fr_scale_into_many: unknown vector handle %llu", (unsigned long long)ins[j]);
+  }
+  return fr_scale_into_many(C, ps.data(), coeffs_mont, k, vo, out_offsets);
 }
 int gm_fr_add_at(uint64_t v, const size_t* positions, const uint64_t* values_mont, size_t k) {
   GM_CTX();

@@ -111,7 +111,8 @@ struct SpaceProver {
   std::vector<uint64_t> challenges, twisted;  // 4 limbs each, Montgomery
   uint64_t twist[4];
   size_t round = 0, tot_rounds = 0;
-  DevBuf tables;
+  uint8_t* tables = nullptr;  // weight tables + reduced ping / pong vectors of the current message: a block of the vector pool
+  size_t tables_cap = 0;       // (hipMalloc / hipFree per prover cost a device-wide synchronisation each)
   uint8_t *wf_lo = nullptr, *wf_hi = nullptr, *wg_lo = nullptr, *wg_hi = nullptr;
   uint8_t* partials = nullptr;
   uint64_t* host_partials = nullptr;
@@ -211,8 +212,21 @@ struct DevPool {
   void release_all();
 };
 
+// the (device, pinned host) buffer pair a sumcheck / space prover collects its per-block partial sums in: 32 KiB each.  hipMalloc,
+// hipHostMalloc and above all hipFree (a device-wide synchronisation) cost 0.1-0.3 ms apiece -- the preprocessing prover creates 15
+// provers per proof -- so freed pairs are kept for the next prover
+struct PartialBufs {
+  std::mutex mu;
+  std::vector<std::pair<uint8_t*, uint64_t*>> free_pairs;
+  int take(uint8_t** dev, uint64_t** host);
+  void give(uint8_t* dev, uint64_t* host);
+  void release_all();
+};
+constexpr size_t PARTIAL_BUF_BYTES = 512 * 2 * 32;
+
 struct Context {
   int device = -1;
+  PartialBufs partial_bufs;
   DevPool pool;
   Profiler prof;
   hipStream_t stream = nullptr;

@@ -687,6 +687,41 @@ static size_t ceil_log2_sz(size_t n) {
   return b;
 }
 
+int PartialBufs::take(uint8_t** dev, uint64_t** host) {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!free_pairs.empty()) {
+      *dev = free_pairs.back().first;
+      *host = free_pairs.back().second;
+      free_pairs.pop_back();
+      return GM_OK;
+    }
+  }
+  GM_HIP(dev_malloc((void**)dev, PARTIAL_BUF_BYTES));
+  GM_HIP(hipHostMalloc((void**)host, PARTIAL_BUF_BYTES, hipHostMallocDefault));
+  return GM_OK;
+}
+void PartialBufs::give(uint8_t* dev, uint64_t* host) {
+  if (!dev && !host) return;
+  if (dev && host) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_pairs.size() < 64) {
+      free_pairs.emplace_back(dev, host);
+      return;
+    }
+  }
+  if (dev) (void)hipFree(dev);
+  if (host) (void)hipHostFree(host);
+}
+void PartialBufs::release_all() {
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& p : free_pairs) {
+    (void)hipFree(p.first);
+    (void)hipHostFree(p.second);
+  }
+  free_pairs.clear();
+}
+
 int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_t ng, bool src_is_device,
               const uint64_t twist[4], uint64_t* handle) {
   GM_CHECK(nf >= 1 && ng >= 1, GM_EINVAL, "sumcheck: empty vectors");
@@ -700,8 +735,7 @@ int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_
   if ((rc = C->pool.alloc(((nf + 1) / 2) * FR_BYTES, (void**)&S->f[1], &S->fcap[1]))) return rc;
   if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g[0], &S->gcap[0]))) return rc;
   if ((rc = C->pool.alloc(((ng + 1) / 2) * FR_BYTES, (void**)&S->g[1], &S->gcap[1]))) return rc;
-  GM_HIP(dev_malloc((void**)&S->partials, 512 * 2 * FR_BYTES));
-  GM_HIP(hipHostMalloc((void**)&S->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
+  if ((rc = C->partial_bufs.take(&S->partials, &S->host_partials))) return rc;
   hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   GM_HIP(hipMemcpyAsync(S->f[0], f_src, nf * FR_BYTES, kind, C->stream));
   GM_HIP(hipMemcpyAsync(S->g[0], g_src, ng * FR_BYTES, kind, C->stream));
@@ -718,8 +752,13 @@ void sc_destroy(Sumcheck* S) {
       C->pool.free(S->g[i], S->gcap[i]);
     }
   }
-  if (S->partials) (void)hipFree(S->partials);
-  if (S->host_partials) (void)hipHostFree(S->host_partials);
+  if (C) C->partial_bufs.give(S->partials, S->host_partials);
+  else {
+    if (S->partials) (void)hipFree(S->partials);
+    if (S->host_partials) (void)hipHostFree(S->host_partials);
+  }
+  S->partials = nullptr;
+  S->host_partials = nullptr;
 }
 
 // the stream the round was enqueued on has been waited for
@@ -854,9 +893,15 @@ static int sp_reduce(Context* C, SpaceProver* S, SpReduced* R) {
   //         [f ping][f pong][g ping][g pong]
   const size_t f0 = ceil_shift(S->nf, SP_LV), f1 = ceil_shift(S->nf, 2 * SP_LV), g0 = ceil_shift(S->ng, SP_LV), g1 = ceil_shift(S->ng, 2 * SP_LV);
   const size_t tab_bytes = (size_t)2 * k * 32 + ((size_t)levels + 1) * 2 * ntab * FR_BYTES;
-  int rc = S->tables.ensure(tab_bytes + (f0 + f1 + g0 + g1 + 4) * FR_BYTES + 256);
-  if (rc) return rc;
-  uint8_t* base = S->tables.as<uint8_t>();
+  const size_t tables_need = tab_bytes + (f0 + f1 + g0 + g1 + 4) * FR_BYTES + 256;
+  if (S->tables_cap < tables_need) {
+    if (S->tables) C->pool.free(S->tables, S->tables_cap);
+    S->tables = nullptr;
+    S->tables_cap = 0;
+    int rc = C->pool.alloc(tables_need, (void**)&S->tables, &S->tables_cap);
+    if (rc) return rc;
+  }
+  uint8_t* base = S->tables;
   uint8_t* ch_t = base;
   uint8_t* ch_p = base + (size_t)k * 32;
   uint8_t* tabs = base + (size_t)2 * k * 32;
@@ -907,8 +952,7 @@ int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream,
   int rc;
   if ((rc = C->pool.alloc(nf * FR_BYTES, (void**)&S->f, &S->fcap))) return rc;
   if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g, &S->gcap))) return rc;
-  GM_HIP(dev_malloc((void**)&S->partials, 512 * 2 * FR_BYTES));
-  GM_HIP(hipHostMalloc((void**)&S->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
+  if ((rc = C->partial_bufs.take(&S->partials, &S->host_partials))) return rc;
   hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   GM_HIP(hipMemcpyAsync(S->f, f_stream, nf * FR_BYTES, kind, C->stream));
   GM_HIP(hipMemcpyAsync(S->g, g_stream, ng * FR_BYTES, kind, C->stream));
@@ -924,9 +968,19 @@ void sp_destroy(Context* C, SpaceProver* S) {
     C->pool.free(S->f, S->fcap);
     C->pool.free(S->g, S->gcap);
   }
-  S->tables.release();
-  if (S->partials) (void)hipFree(S->partials);
-  if (S->host_partials) (void)hipHostFree(S->host_partials);
+  if (S->tables) {
+    if (C) C->pool.free(S->tables, S->tables_cap);
+    else (void)hipFree(S->tables);
+  }
+  S->tables = nullptr;
+  S->tables_cap = 0;
+  if (C) C->partial_bufs.give(S->partials, S->host_partials);
+  else {
+    if (S->partials) (void)hipFree(S->partials);
+    if (S->host_partials) (void)hipHostFree(S->host_partials);
+  }
+  S->partials = nullptr;
+  S->host_partials = nullptr;
 }
 
 // Prover::fold for the space prover: store the randomness aside        space_prover.rs:245-249
@@ -1041,8 +1095,10 @@ int sp_to_time(Context* C, SpaceProver* S, uint64_t* time_handle) {
   if (rc) return rc;
   if ((rc = C->pool.alloc(((T->nf + 1) / 2) * FR_BYTES, (void**)&T->f[1], &T->fcap[1]))) return rc;
   if ((rc = C->pool.alloc(((T->ng + 1) / 2) * FR_BYTES, (void**)&T->g[1], &T->gcap[1]))) return rc;
-  GM_HIP(dev_malloc((void**)&T->partials, 512 * 2 * FR_BYTES));
-  GM_HIP(hipHostMalloc((void**)&T->host_partials, 512 * 2 * FR_BYTES, hipHostMallocDefault));
+  {
+    int rcp = C->partial_bufs.take(&T->partials, &T->host_partials);
+    if (rcp) return rcp;
+  }
   memcpy(T->twist, S->twist, 32);
   T->round = S->round;  // "copy other informations such us round(s) and twist"
   T->tot_rounds = S->tot_rounds;
@@ -1075,6 +1131,27 @@ static int upload_small(Context* C, const void* src, size_t bytes, uint8_t** dpt
   if (rc) return rc;
   GM_HIP(hipMemcpyAsync(C->fr_scratch.p, src, bytes, hipMemcpyHostToDevice, C->stream));
   *dptr = C->fr_scratch.as<uint8_t>();
+  return GM_OK;
+}
+
+// foldings_polynomial (tensorcheck/mod.rs:124-133): outs[j] = fold(outs[j - 1], challenge j), outs[-1] = f.  k launches, ONE wait
+// (a folding tree is ~20 tiny launches behind the first two: one wait per level was most of their cost)
+int fr_fold_chain(Context* C, FrVec* f, const uint64_t* challenges, size_t k, FrVec** outs) {
+  GM_FR_LOCK(C);
+  FrVec* cur = f;
+  for (size_t j = 0; j < k; j++) {
+    const size_t m = (cur->len + 1) / 2;
+    GM_CHECK(outs[j]->cap >= m, GM_EINVAL, "fold: output capacity %zu < %zu", outs[j]->cap, m);
+    GM_CHECK(outs[j] != cur && outs[j] != f, GM_EINVAL, "fold: output must not alias an input");
+    uint8_t* dr;
+    int rc = upload_small(C, challenges + 4 * j, 32, &dr);  // same staging slot every level: the copy is ordered behind the previous kernel
+    if (rc) return rc;
+    if (m) hipLaunchKernelGGL(k_fold, dim3(grid_for(m)), dim3(256), 0, C->stream, cur->d, cur->len, (const uint32_t*)dr, outs[j]->d);
+    outs[j]->len = m;
+    cur = outs[j];
+  }
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
 
@@ -1298,25 +1375,33 @@ int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVe
   return fr_trim(C, out);
 }
 
-// out[offset + i] = c * in[i], i < len(in): several scaled vectors laid out in ONE vector at chosen offsets (the quotients of the
-// block-sharded opening against the back-to-back key slices: one MSM instead of one per level)
-int fr_scale_into(Context* C, FrVec* in, const uint64_t c[4], FrVec* out, size_t offset) {
+// out[offsets[j] + i] = c_j * in_j[i], i < len(in_j): several scaled vectors laid out in ONE vector at chosen offsets (the quotients
+// of the block-sharded opening against the back-to-back key slices: one division and one MSM instead of one per level).  k launches,
+// ONE wait.  The ranges must lie inside out's current length (they may not overlap each other: the launches are not ordered by data)
+int fr_scale_into_many(Context* C, FrVec** ins, const uint64_t* coeffs, size_t k, FrVec* out, const size_t* offsets) {
   GM_FR_LOCK(C);
-  GM_CHECK(in != out, GM_EINVAL, "scale_into: output must not alias the input");
-  GM_CHECK(offset <= out->len && in->len <= out->len - offset, GM_EINVAL, "scale_into: [%zu, %zu) outside a vector of length %zu", offset, offset + in->len,
-           out->len);
-  if (in->len == 0) return GM_OK;
-  LincombArgs A;
-  memset(&A, 0, sizeof A);
-  A.k = 1;
-  A.p[0] = in->d;
-  A.len[0] = in->len;
-  memcpy(A.c[0], c, 32);
-  hipLaunchKernelGGL(k_lincomb, dim3(grid_for(in->len)), dim3(256), 0, C->stream, A, in->len, out->d + offset * FR_BYTES);
+  for (size_t j = 0; j < k; j++) {
+    GM_CHECK(ins[j] != out, GM_EINVAL, "scale_into: output must not alias an input");
+    GM_CHECK(offsets[j] <= out->len && ins[j]->len <= out->len - offsets[j], GM_EINVAL, "scale_into: [%zu, %zu) outside a vector of length %zu", offsets[j],
+             offsets[j] + ins[j]->len, out->len);
+  }
+  bool any = false;
+  for (size_t j = 0; j < k; j++) {
+    if (ins[j]->len == 0) continue;
+    LincombArgs A;
+    memset(&A, 0, sizeof A);
+    A.k = 1;
+    A.p[0] = ins[j]->d;
+    A.len[0] = ins[j]->len;
+    memcpy(A.c[0], coeffs + 4 * j, 32);
+    hipLaunchKernelGGL(k_lincomb, dim3(grid_for(ins[j]->len)), dim3(256), 0, C->stream, A, ins[j]->len, out->d + offsets[j] * FR_BYTES);
+    any = true;
+  }
   GM_HIP(hipGetLastError());
-  GM_HIP(hipStreamSynchronize(C->stream));
+  if (any) GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
+int fr_scale_into(Context* C, FrVec* in, const uint64_t c[4], FrVec* out, size_t offset) { return fr_scale_into_many(C, &in, c, 1, out, &offset); }
 
 // v[idx[j]] += vals[j]; the positions must be distinct (each is updated by its own lane) and inside the vector
 int fr_add_at(Context* C, FrVec* v, const size_t* idx, const uint64_t* vals, size_t k) {

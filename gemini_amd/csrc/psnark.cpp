@@ -309,18 +309,16 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
     uint64_t batched;
     RC(V.alloc(longest, &batched));
     RC(gm_fr_lincomb(b.polys.data(), bc.data(), b.polys.size(), batched));
-    uint64_t cur = batched;
     size_t len = 0;
-    RC(vec_len(cur, &len));
-    const size_t nch = b.challenges.size() / 4;
+    RC(vec_len(batched, &len));
+    const size_t nch = b.challenges.size() / 4, first_level = foldings.size();
     for (size_t k = 0; k + 1 < nch; k++) {  // foldings_polynomial: all challenges but the last (:124-133)
       uint64_t nxt;
       len = (len + 1) / 2;
       RC(V.alloc(len, &nxt));
-      RC(gm_fr_fold(cur, b.challenges.data() + 4 * k, nxt));
       foldings.push_back(nxt);
-      cur = nxt;
     }
+    RC(gm_fr_fold_chain(batched, b.challenges.data(), foldings.size() - first_level, foldings.data() + first_level));  // one wait per tree
   }
   P->nfold = foldings.size();
   if (P->nfold > P->cap_folds) return GM_EINVAL;

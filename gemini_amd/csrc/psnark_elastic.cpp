@@ -531,17 +531,15 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
   for (int k = 0; k < 9; k++) V.release(shifts[k]);
   size_t nfold = 0;
   for (auto& t : trees) {  // FoldedPolynomialTree: the levels, little-endian
-    uint64_t cur = t.body;
     size_t len = 0;
-    RC(vec_len(cur, &len));
+    RC(vec_len(t.body, &len));
     for (size_t k = 0; k < t.challenges.size() / 4; k++) {
       uint64_t nxt;
       len = (len + 1) / 2;
       RC(V.alloc(len, &nxt));
-      RC(gm_fr_fold(cur, t.challenges.data() + 4 * k, nxt));
       t.levels.push_back(nxt);
-      cur = nxt;
     }
+    RC(gm_fr_fold_chain(t.body, t.challenges.data(), t.levels.size(), t.levels.data()));
     nfold += t.levels.size();
   }
   P->nfold = nfold;

@@ -616,15 +616,18 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
         }
       seams.emplace_back(pos, v);
     };
+    std::vector<uint64_t> scaled_in, scaled_c;  // eta_i P_i into the slice of level i: one call for all levels
+    std::vector<size_t> scaled_off;
     Fr eta_i = Fr::one();
     for (size_t i = 0; i < nb; i++, eta_i = eta_i * oc) {
       const size_t Lb = m >> i, off = S->key_offsets[i];
       size_t len = 0;
       RC(vec_len(blocks[i], &len));
       GM_CHECK(len <= Lb && (r + 1 == g || len == Lb), GM_ESTATE, "snark_new_time_sharded: block of %zu elements at level %zu (blocks hold %zu)", len, i, Lb);
-      uint64_t e[4];
-      eta_i.to_limbs(e);
-      RC(gm_fr_scale_into(blocks[i], e, laid, off));
+      scaled_in.push_back(blocks[i]);
+      scaled_off.push_back(off);
+      scaled_c.resize(scaled_c.size() + 4);
+      eta_i.to_limbs(scaled_c.data() + scaled_c.size() - 4);
       Fr gv[3], c[3] = {Fr::zero(), Fr::zero(), Fr::zero()}, rem[3];
       if (r + 1 < g) {
         Fr ys[3];
@@ -647,6 +650,7 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
       interp3(xs, gv, rem);
       for (int q = 0; q < 3; q++) seam(off + q, rem[q].neg());
     }
+    RC(gm_fr_scale_into_many(scaled_in.data(), scaled_c.data(), scaled_in.size(), laid, scaled_off.data()));
     if (!small.empty() && r == 0) {
       std::vector<uint64_t> etas(4 * small.size());
       Fr acc = eta_i;  // open_chal^nb

@@ -109,18 +109,16 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   std::vector<uint64_t> foldings;
   std::vector<size_t> fold_len;
   {
-    uint64_t cur = batched;
     size_t len = 0;
-    RC(vec_len(cur, &len));
+    RC(vec_len(batched, &len));
     for (size_t k = 0; k + 1 < P->rounds[1]; k++) {
       uint64_t nxt;
       len = (len + 1) / 2;
       RC(V.alloc(len, &nxt));
-      RC(gm_fr_fold(cur, ch2.data() + 4 * k, nxt));
       foldings.push_back(nxt);
       fold_len.push_back(len);
-      cur = nxt;
     }
+    RC(gm_fr_fold_chain(batched, ch2.data(), foldings.size(), foldings.data()));  // one wait for the whole tree
   }
   P->nfold = foldings.size();
   if (P->nfold > cap_rounds) return GM_EINVAL;
@@ -288,18 +286,16 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
   std::vector<uint64_t> levels;
   std::vector<size_t> level_len;
   {
-    uint64_t cur = body_le;
     size_t len = 0;
-    RC(vec_len(cur, &len));
+    RC(vec_len(body_le, &len));
     for (size_t k = 0; k + 1 < P->rounds[1]; k++) {  // strip_last
       uint64_t nxt;
       len = (len + 1) / 2;
       RC(V.alloc(len, &nxt));
-      RC(gm_fr_fold(cur, ch2.data() + 4 * k, nxt));
       levels.push_back(nxt);
       level_len.push_back(len);
-      cur = nxt;
     }
+    RC(gm_fr_fold_chain(body_le, ch2.data(), levels.size(), levels.data()));
   }
   P->nfold = levels.size();
   if (P->nfold > cap_rounds) return GM_EINVAL;

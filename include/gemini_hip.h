@@ -239,6 +239,9 @@ int gm_fr_reverse(uint64_t in, uint64_t out);
 int gm_fr_stride(uint64_t in, size_t start, size_t stride, size_t count, uint64_t out);
 /* out = [f[2i] + r * f[2i+1]], len ceil(n/2)                       src/misc.rs:52-56 */
 int gm_fr_fold(uint64_t f, const uint64_t r_mont[4], uint64_t out);
+/* foldings_polynomial (src/subprotocols/tensorcheck/mod.rs:124-133): outs[j] = fold(outs[j - 1], challenge j) with outs[-1] = f;
+ * k launches behind one another, ONE wait.  outs[j] needs capacity ceil(len / 2^(j + 1)). */
+int gm_fr_fold_chain(uint64_t f, const uint64_t* challenges_mont, size_t k, const uint64_t* outs);
 /* out = [1, x, x^2, ...]                                          src/misc.rs:59-65 */
 int gm_fr_powers(const uint64_t x_mont[4], size_t n, uint64_t out);
 /* out[sum b_j 2^j] = prod rho_j^{b_j}, len 2^k                    src/misc.rs:133-149 */
@@ -259,6 +262,8 @@ int gm_fr_lincomb(const uint64_t* polys, const uint64_t* coeffs_mont, size_t k, 
 /* out[out_offset + i] = c * in[i] for i < len(in), inside out's current length: scaled vectors laid out side by side in one
  * vector (the per-level quotients of the block-sharded opening, committed by ONE MSM against the back-to-back key slices) */
 int gm_fr_scale_into(uint64_t in, const uint64_t c_mont[4], uint64_t out, size_t out_offset);
+/* the same for k vectors into disjoint ranges of `out`: k launches, one wait */
+int gm_fr_scale_into_many(const uint64_t* ins, const uint64_t* coeffs_mont, size_t k, uint64_t out, const size_t* out_offsets);
 /* v[positions[j]] += values[j] for k <= 4096 DISTINCT positions inside the vector (seam corrections of the laid-out opening) */
 int gm_fr_add_at(uint64_t v, const size_t* positions, const uint64_t* values_mont, size_t k);
 /* quotient of f by the monic vanishing polynomial of `points` (degree k <= 3); rem gets k values.
