@@ -1587,6 +1587,17 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     }
     return GM_OK;
   };
+  // free a (workspace, result buffer) pair: finish the call that holds IT -- not the oldest call of the batch, which may be a big
+  // one that still has milliseconds of accumulation ahead while the small lanes have long been idle
+  auto drain_pair = [&](int lane, int hslot) -> int {
+    for (size_t t = 0; t < q.size(); t++) {
+      if (finished[t] || q[t].lane != lane || q[t].P.slot != hslot) continue;
+      if (lane > 0) return finish_smalls();
+      finished[t] = 1;
+      return msm_finish(C, q[t].P, normalize, out_jac + 18 * q[t].j);
+    }
+    return GM_OK;
+  };
   static const bool batch_trace = getenv("GM_MSM_TRACE") != nullptr;  // host time of the batch: enqueueing vs finishing
   double enqueue_s = 0.0;
   const auto t_batch0 = std::chrono::steady_clock::now();
@@ -1617,8 +1628,11 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     static const bool two_big = !(getenv("GM_MSM_BIG_LANES") && !strcmp(getenv("GM_MSM_BIG_LANES"), "1"));
     int lane, hslot;
     if (small) {
-      lane = 1 + (small_rr++ % small_lanes);
-      hslot = 0;
+      // two result buffers per small lane as well: the second call of a lane is enqueued behind the first (same stream, same
+      // workspace: stream order keeps them apart) without a host round trip in between
+      lane = 1 + (small_rr % small_lanes);
+      hslot = (small_rr / small_lanes) & 1;
+      small_rr++;
     } else {
       lane = (two_big && C->stream_b && (big_rr & 1)) ? -1 : 0;
       hslot = (big_rr >> 1) & 1;
@@ -1634,7 +1648,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     }
     // a (workspace, result buffer) pair is free again once its previous call has been finished
     while (busy(lane, hslot)) {
-      int rc = drain_oldest();
+      int rc = drain_pair(lane, hslot);
       if (rc) return fail(rc);
     }
     Inflight e;
