@@ -302,11 +302,10 @@ void gm_shutdown(void) {
                       &w.pp[1], &w.rows, &w.cols, &w.planes, &w.misc, &w.lvl_cnt, &w.lvl_pos, &w.lvl_pts[0], &w.lvl_pts[1], &w.lvl_keys[0],
                       &w.lvl_keys[1], &w.lvl_prefix, &w.lvl_lane, &w.lvl_entries, &w.lvl_n})
       b->release();
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < MSM_SLOTS; k++)
       if (w.host_planes[k]) (void)hipHostFree(w.host_planes[k]);
     if (w.have_done_ev) {
-      (void)hipEventDestroy(w.done_ev[0]);
-      (void)hipEventDestroy(w.done_ev[1]);
+      for (int e = 0; e < MSM_SLOTS; e++) (void)hipEventDestroy(w.done_ev[e]);
     }
   };
   release_ws(C->msm);

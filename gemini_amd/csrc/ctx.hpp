@@ -168,6 +168,7 @@ struct MsmStream {
   bool acc_set = false;
 };
 
+constexpr int MSM_SLOTS = 4;
 constexpr int MSM_SMALL_LANES = 6;  // small calls of a batch in flight side by side (GM_MSM_SMALL_LANES uses fewer); a lane's workspace is ~150 MB.
 // Measured on one box, snark -i 18 / -i 20 / sharded -i 21 / -i 22 (ms): 2 lanes 14.6 / 21.5 / 36.0 / 50.7, 4 lanes 13.1 / 19.8 / 33.5 / 48.1,
 // 6 lanes 11.7 / 18.7 / 32.0 / 47.4, 8 lanes 17.0 / 21.1 / 33.6 / 48.5, 12 lanes 17.6 / 22.5 / 35.0 / 51.3: beyond six the chains only get in each other's way
@@ -175,9 +176,11 @@ struct MsmWorkspace {
   DevBuf scalars, counts, offsets, cursor, entries, tmp_entries, sortmeta, buckets, pk[2], pp[2], rows, cols, planes, misc;
   DevBuf clk;  // {shader cycles, 100 MHz ticks} of the first wave of the last k_acc0 (read only while profiling: gm_prof_read_clock)
   DevBuf lvl_cnt, lvl_pos, lvl_pts[2], lvl_keys[2], lvl_prefix, lvl_lane, lvl_entries, lvl_n;  // affine tree levels
-  uint64_t* host_planes[2] = {nullptr, nullptr};  // pinned staging for the D2H of window bit-planes (two calls in flight)
-  size_t host_planes_cap[2] = {0, 0};
-  hipEvent_t done_ev[2];
+  // pinned staging for the D2H of window bit-planes + the event behind it, per result slot: MSM_SLOTS calls of a lane can be enqueued
+  // behind one another before the host finishes the first (big lanes use two, small lanes all of them)
+  uint64_t* host_planes[MSM_SLOTS] = {};
+  size_t host_planes_cap[MSM_SLOTS] = {};
+  hipEvent_t done_ev[MSM_SLOTS];
   hipEvent_t sort_ev, acc_ev;  // phase hand-over between the streams of a split call
   bool have_done_ev = false;
 };

@@ -1601,6 +1601,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
   static const bool batch_trace = getenv("GM_MSM_TRACE") != nullptr;  // host time of the batch: enqueueing vs finishing
   double enqueue_s = 0.0;
   const auto t_batch0 = std::chrono::steady_clock::now();
+  static const int small_slots = std::max(1, std::min(MSM_SLOTS, getenv("GM_MSM_SMALL_SLOTS") ? atoi(getenv("GM_MSM_SMALL_SLOTS")) : MSM_SLOTS));
   static const int small_lanes = std::max(1, std::min(MSM_SMALL_LANES, getenv("GM_MSM_SMALL_LANES") ? atoi(getenv("GM_MSM_SMALL_LANES")) : MSM_SMALL_LANES));
   int big_rr = 0, small_rr = 0;
   auto is_small = [&](size_t j) { return ns[j] <= MSM_SMALL_N && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0; };
@@ -1628,10 +1629,10 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     static const bool two_big = !(getenv("GM_MSM_BIG_LANES") && !strcmp(getenv("GM_MSM_BIG_LANES"), "1"));
     int lane, hslot;
     if (small) {
-      // two result buffers per small lane as well: the second call of a lane is enqueued behind the first (same stream, same
+      // several result buffers per small lane as well: the next call of a lane is enqueued behind the first (same stream, same
       // workspace: stream order keeps them apart) without a host round trip in between
       lane = 1 + (small_rr % small_lanes);
-      hslot = (small_rr / small_lanes) & 1;
+      hslot = (small_rr / small_lanes) % small_slots;
       small_rr++;
     } else {
       lane = (two_big && C->stream_b && (big_rr & 1)) ? -1 : 0;
@@ -1872,8 +1873,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   GM_CHECK(levels == 0, GM_EINVAL, "msm: affine tree levels are an experiment of round 2; rebuild with -DGM_EXPERIMENTS (DESIGN.md section 8)");
 #endif
   if (!ws.have_done_ev) {
-    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[0], hipEventDisableTiming));
-    GM_HIP(hipEventCreateWithFlags(&ws.done_ev[1], hipEventDisableTiming));
+    for (int e = 0; e < MSM_SLOTS; e++) GM_HIP(hipEventCreateWithFlags(&ws.done_ev[e], hipEventDisableTiming));
     GM_HIP(hipEventCreateWithFlags(&ws.sort_ev, hipEventDisableTiming));
     GM_HIP(hipEventCreateWithFlags(&ws.acc_ev, hipEventDisableTiming));
     ws.have_done_ev = true;
