@@ -145,6 +145,8 @@ struct MsmPending {
   uint32_t nbits = 0, wf[3] = {0, 0, 0};
   size_t plane_off[3] = {0, 0, 0};
   size_t plane_count = 0;
+  int multi_levels = 0;  // > 0: several small MSMs in ONE pass (msm.hip: MsmMulti); bucket sets [l W, (l + 1) W) belong to call l
+  int multi_W = 0;
 };
 struct MsmStreamSlot {
   uint8_t *raw = nullptr, *packed = nullptr, *scalars = nullptr;  // staged records, device-form bases, scalars

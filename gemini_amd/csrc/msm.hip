@@ -699,6 +699,70 @@ __global__ __launch_bounds__(256) void k_digits_flat(const uint32_t* __restrict_
     entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(neg ? 1u : 0u) << 31) | (uint64_t)(i | ((uint32_t)half << ENTRY_HALF_SHIFT));
 }
 
+// Several SMALL MSMs in one pass (the folding commitments of a tensor check end in a dozen calls of 2^13 ... 2 pairs, each a
+// latency-bound chain of ~15 launches that runs in ~0.3-0.5 ms whatever its size): the calls become "levels" of ONE call whose
+// bucket sets are (level, window) pairs.  Element i of the concatenation belongs to level l = the range start[l] <= i < start[l + 1],
+// its scalar is scal[l][i - start[l]], its base index base0[l] + step (i - start[l]) (absolute: k_acc0 runs with first = 0,
+// step = 1), its key (l W + w) B + (|digit| - 1).  Digits as in k_digits_flat.
+constexpr int MULTI_MAX_LEVELS = 16;
+struct MultiGeom {
+  int c, W, levels, step;
+  uint32_t B;
+  uint32_t K[8];
+  uint32_t start[MULTI_MAX_LEVELS + 1];
+  const uint32_t* scal[MULTI_MAX_LEVELS];
+  long long base0[MULTI_MAX_LEVELS];
+};
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_digits_multi(MultiGeom mg, int mont, uint32_t* __restrict__ counts_or_cursor, uint64_t* __restrict__ entries,
+                                                      uint32_t* __restrict__ err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = (int)blockIdx.y;
+  const bool active = i < mg.start[mg.levels];
+  uint32_t key = KEY_INV, idx = 0;
+  bool neg = false;
+  if (active) {
+    int l = 0;
+    while (l + 1 < mg.levels && i >= mg.start[l + 1]) l++;
+    const uint32_t il = i - mg.start[l];
+    Fr v = fp_load<FrParams>(mg.scal[l] + 8 * (size_t)il);
+    if (mont) v = fp_from_mont<FrParams>(v);
+    if (!SCATTER && blockIdx.y == 0 && (v.l[7] >> 31)) atomicOr(err, 1u);  // >= 2^255: not an Fr image
+    uint32_t t[9];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      uint32_t cy;
+      t[q] = __builtin_addc(v.l[q], mg.K[q], carry, &cy);
+      carry = cy;
+    }
+    t[8] = carry;
+    const uint32_t bit = (uint32_t)(mg.c * w), lo = bit >> 5, sh = bit & 31u;
+    uint64_t two = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      if ((uint32_t)q == lo) two |= (uint64_t)t[q];
+      if ((uint32_t)q == lo + 1) two |= (uint64_t)t[q] << 32;
+    }
+    uint32_t u = (uint32_t)(two >> sh);
+    int32_t d;
+    if (w == mg.W - 1) {
+      d = (int32_t)min(u, mg.B);
+    } else {
+      u &= (1u << mg.c) - 1u;
+      d = (int32_t)u - (int32_t)(1u << (mg.c - 1));
+    }
+    if (d != 0) {
+      key = (uint32_t)(l * mg.W + w) * mg.B + ((uint32_t)(d < 0 ? -d : d) - 1u);
+      neg = d < 0;
+      idx = (uint32_t)(mg.base0[l] + (long long)mg.step * (long long)il);
+    }
+  }
+  const uint32_t pos = wave_atomic_inc(counts_or_cursor, key);
+  if (SCATTER && key != KEY_INV) entries[pos] = ((uint64_t)key << 32) | ((uint64_t)(neg ? 1u : 0u) << 31) | (uint64_t)idx;
+}
+
+
 // exclusive scan of m <= 2^18 counters in one block (the three-launch scan is for the millions of buckets of big calls)
 __global__ __launch_bounds__(1024) void k_scan_small(const uint32_t* __restrict__ counts, uint32_t m, uint32_t* __restrict__ offsets,
                                                      uint32_t* __restrict__ cursor) {
@@ -1420,9 +1484,18 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
 struct MsmStreams {
   hipStream_t sort, acc, tail;
 };
+// several small calls as the levels of ONE pass (k_digits_multi): level l pairs scalars[l][i], i < n[l], with base start[l] + step i
+struct MsmMulti {
+  int levels = 0;
+  const void* scalars[MULTI_MAX_LEVELS];
+  size_t n[MULTI_MAX_LEVELS];
+  int64_t start[MULTI_MAX_LEVELS];
+};
+constexpr size_t MSM_MULTI_MAX_N = (size_t)1 << 13;  // calls this small (c = 8 on their own as well) are fused
 static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
-                       int mont, size_t n, int slot, MsmPending* P, int part = 0, int nparts = 1);
-static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18], bool use_pool = true);
+                       int mont, size_t n, int slot, MsmPending* P, int part = 0, int nparts = 1, const MsmMulti* multi = nullptr);
+static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18], bool use_pool = true,
+                            uint64_t* const* multi_out = nullptr);
 // the helper threads of the host tail (class HornerPool, below)
 static void horner_pool_prewake();
 static void horner_pool_run(int n, const std::function<void(int)>& fn);
@@ -1537,6 +1610,13 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     size_t j;
     int lane;  // 0 = main workspace, 1.. = small workspaces
     MsmPending P;
+    std::vector<size_t> fused;  // the calls of a fused pass (MsmMulti), in level order; empty: the one call j
+  };
+  auto finish_entry = [&](Inflight& e, bool use_pool) -> int {
+    if (e.fused.empty()) return msm_finish(C, e.P, normalize, out_jac + 18 * e.j, use_pool);
+    std::vector<uint64_t*> outs(e.fused.size());
+    for (size_t l = 0; l < e.fused.size(); l++) outs[l] = out_jac + 18 * e.fused[l];
+    return msm_finish_parts(C, &e.P, 1, normalize, nullptr, use_pool, outs.data());
   };
   std::vector<Inflight> q;  // calls enqueued so far, in order; at most 4 big + MSM_SMALL_LANES small ones are unfinished at a time
   std::vector<char> finished;
@@ -1562,14 +1642,32 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       if (!finished[t] && q[t].lane > 0) idx.push_back(t);
     if (idx.empty()) return GM_OK;
     std::vector<int> rcs(idx.size(), GM_OK);
+    // a fused pass has hundreds of bucket sets: its tail is pool work of its own (window sums, then one Horner per call)
+    {
+      std::vector<size_t> rest;
+      int rc_f = GM_OK;
+      for (size_t t : idx) {
+        if (q[t].fused.empty()) {
+          rest.push_back(t);
+          continue;
+        }
+        const int r1 = finish_entry(q[t], true);
+        finished[t] = 1;
+        if (r1 && !rc_f) rc_f = r1;
+      }
+      if (rc_f) return rc_f;
+      idx.swap(rest);
+      if (idx.empty()) return GM_OK;
+      rcs.assign(idx.size(), GM_OK);
+    }
     static const bool par_finish = !(getenv("GM_MSM_PAR_FINISH") && !strcmp(getenv("GM_MSM_PAR_FINISH"), "0"));  // A/B knob
     if (!par_finish) {
-      for (size_t i = 0; i < idx.size(); i++) rcs[i] = msm_finish(C, q[idx[i]].P, normalize, out_jac + 18 * q[idx[i]].j);
+      for (size_t i = 0; i < idx.size(); i++) rcs[i] = finish_entry(q[idx[i]], true);
     } else if (idx.size() == 1) {
-      rcs[0] = msm_finish(C, q[idx[0]].P, normalize, out_jac + 18 * q[idx[0]].j);
+      rcs[0] = finish_entry(q[idx[0]], true);
     } else {
       horner_pool_prewake();
-      horner_pool_run((int)idx.size(), [&](int i) { rcs[(size_t)i] = msm_finish(C, q[idx[(size_t)i]].P, normalize, out_jac + 18 * q[idx[(size_t)i]].j, false); });
+      horner_pool_run((int)idx.size(), [&](int i) { rcs[(size_t)i] = finish_entry(q[idx[(size_t)i]], false); });
     }
     int rc = GM_OK;
     for (size_t i = 0; i < idx.size(); i++) {
@@ -1583,7 +1681,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       if (finished[t]) continue;
       if (q[t].lane > 0) return finish_smalls();
       finished[t] = 1;
-      return msm_finish(C, q[t].P, normalize, out_jac + 18 * q[t].j);
+      return finish_entry(q[t], true);
     }
     return GM_OK;
   };
@@ -1594,7 +1692,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       if (finished[t] || q[t].lane != lane || q[t].P.slot != hslot) continue;
       if (lane > 0) return finish_smalls();
       finished[t] = 1;
-      return msm_finish(C, q[t].P, normalize, out_jac + 18 * q[t].j);
+      return finish_entry(q[t], true);
     }
     return GM_OK;
   };
@@ -1621,10 +1719,26 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
   } else {
     for (size_t j = 0; j < k; j++) order.push_back(j);
   }
-  bool gated = false;
+  // the tiny calls of the batch (<= 2^13 pairs: the tail of every folding tree) become the levels of ONE fused pass (MsmMulti): a dozen
+  // latency-bound chains of ~15 launches collapse into one.  It is enqueued where the first of them stood.  GM_MSM_FUSE=0 keeps them apart.
+  static const bool fuse_env = !(getenv("GM_MSM_FUSE") && !strcmp(getenv("GM_MSM_FUSE"), "0"));
+  std::vector<size_t> fused_js;
+  if (fuse_env && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0 && !C->msm_c_override) {
+    for (size_t j = 0; j < k && fused_js.size() < (size_t)MULTI_MAX_LEVELS; j++)
+      if (ns[j] >= 1 && ns[j] <= MSM_MULTI_MAX_N) fused_js.push_back(j);
+    if (fused_js.size() < 2) fused_js.clear();
+  }
+  auto in_fused = [&](size_t j) {
+    for (size_t f : fused_js)
+      if (f == j) return true;
+    return false;
+  };
+  bool gated = false, fused_done = false;
   for (size_t jo = 0; jo < k; jo++) {
     const size_t j = order[jo];
-    const bool small = is_small(j);
+    const bool fused_here = in_fused(j);
+    if (fused_here && fused_done) continue;
+    const bool small = fused_here || is_small(j);
     // big calls alternate between the two full-size lanes (0 and -1), each with two result buffers
     static const bool two_big = !(getenv("GM_MSM_BIG_LANES") && !strcmp(getenv("GM_MSM_BIG_LANES"), "1"));
     int lane, hslot;
@@ -1659,7 +1773,21 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     hipStream_t st = lane > 0 ? C->small_stream[lane - 1] : (lane < 0 ? C->stream_b : C->stream);
     if (st != C->stream) GM_HIP(hipStreamWaitEvent(st, C->start_ev, 0));  // scalars produced on the main stream
     const auto tq0 = std::chrono::steady_clock::now();
-    int rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, (pair_offsets ? (int64_t)pair_offsets[j] : (firsts ? firsts[j] : first)), step, d_scalars[j], mont,
+    auto start_of = [&](size_t jj) { return pair_offsets ? (int64_t)pair_offsets[jj] : (firsts ? firsts[jj] : first); };
+    int rc;
+    if (fused_here) {
+      MsmMulti M;
+      M.levels = (int)fused_js.size();
+      for (size_t l = 0; l < fused_js.size(); l++) {
+        M.scalars[l] = d_scalars[fused_js[l]];
+        M.n[l] = ns[fused_js[l]];
+        M.start[l] = start_of(fused_js[l]);
+      }
+      e.fused = fused_js;
+      fused_done = true;
+      rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, 0, step, nullptr, mont, 0, hslot, &e.P, 0, 1, &M);
+    } else
+      rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, start_of(j), step, d_scalars[j], mont,
                          ns[j], hslot, &e.P);
     enqueue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
     if (rc) return fail(rc);
@@ -1680,15 +1808,28 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
 }
 
 static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
-                       int mont, size_t n, int slot, MsmPending* P, int part, int nparts) {
+                       int mont, size_t n, int slot, MsmPending* P, int part, int nparts, const MsmMulti* multi) {
   hipStream_t st = sts.sort;  // memsets + sort; the accumulation runs on sts.acc, everything after it on sts.tail
   const size_t nbases = bases->n;
   P->ws = &ws;
   P->slot = slot;
+  P->multi_levels = 0;
+  if (multi) {
+    GM_CHECK(multi->levels >= 1 && multi->levels <= MULTI_MAX_LEVELS && nparts == 1, GM_EINVAL, "msm: %d fused calls (1 .. %d)", multi->levels, MULTI_MAX_LEVELS);
+    n = 0;
+    for (int l = 0; l < multi->levels; l++) {
+      GM_CHECK(multi->n[l] >= 1 && multi->n[l] <= MSM_MULTI_MAX_N, GM_EINVAL, "msm: a fused call of %zu pairs", multi->n[l]);
+      const int64_t lo = multi->start[l], hi = multi->start[l] + step * (int64_t)(multi->n[l] - 1);
+      GM_CHECK(lo >= 0 && hi >= 0 && (size_t)lo < nbases && (size_t)hi < nbases, GM_EINVAL, "msm: base range [%lld .. %lld] outside registered bases (len %zu)",
+               (long long)lo, (long long)hi, nbases);
+      n += multi->n[l];
+    }
+    first = 0;  // the entries carry absolute base indices
+  }
   P->empty = n == 0;
   if (n == 0) return GM_OK;
   GM_CHECK(n < (1ull << 31), GM_EINVAL, "msm: n = %zu exceeds 2^31 - 1 pairs per call; chunk the stream", n);
-  {
+  if (!multi) {
     int64_t last = first + step * (int64_t)(n - 1);
     GM_CHECK(first >= 0 && last >= 0 && (size_t)first < nbases && (size_t)last < nbases, GM_EINVAL,
              "msm: base range [%lld .. %lld] outside registered bases (len %zu)", (long long)first, (long long)last,
@@ -1697,8 +1838,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   // fixed-base tables (gm_g1_bases_precompute) serve large MSMs; small ones are latency-bound and
   // cheaper with few buckets
   const size_t tab_min = std::max(C->msm_table_min, bases->tab_min);
-  const bool use_table = bases->table != nullptr && !C->msm_c_override && n >= tab_min && n < ((size_t)1 << ENTRY_W_SHIFT);
-  const int c = use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n));
+  const bool use_table = !multi && bases->table != nullptr && !C->msm_c_override && n >= tab_min && n < ((size_t)1 << ENTRY_W_SHIFT);
+  const int c = multi ? 8 : (use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n)));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
   // GLV (glv_split): two 128-bit digit strings per scalar over HALF the windows, the second one on phi(P)
   static const bool sort_atomic_env0 = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
@@ -1706,12 +1847,12 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   // not latency-bound); 2 leaves 112 registers per lane of a SIMD for other kernels
   static const int acc0_waves = getenv("GM_ACC0_WAVES") ? atoi(getenv("GM_ACC0_WAVES")) : 2;
   const size_t bucket_bytes = XYZZ30_BYTES;  // buckets, partials, row / column sums: 208-byte loose records (g1.cuh: Acc30)
-  const bool use_glv = GM_GLV(1) && bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && n <= ((size_t)1 << 26);
+  const bool use_glv = GM_GLV(1) && !multi && bases->phi != nullptr && !use_table && C->msm_affine_levels == 0 && !sort_atomic_env0 && n <= ((size_t)1 << 26);
   const int W = ((use_glv ? 128 : 256) + c - 1) / c;
   GM_CHECK(nparts == 1 || !use_table, GM_EINVAL, "msm: the fixed-base table path is not split into window groups");
   const int w_lo = part * W / nparts, Wg = (part + 1) * W / nparts - w_lo;  // this call's window group
   const uint32_t B = 1u << (c - 1);
-  const int Wb = use_table ? 1 : Wg;  // bucket sets
+  const int Wb = multi ? multi->levels * W : (use_table ? 1 : Wg);  // bucket sets (fused calls: one set per (call, window))
   const size_t nbuckets = (size_t)Wb * B;
   const uint8_t* d_bases = use_table ? bases->table : bases->d;
   const long long tab_stride = use_table ? (long long)bases->n : 0;
@@ -1779,7 +1920,37 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   static const bool sort_flat_env = !(getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "blocks"));
   const bool sort_atomic = sort_atomic_env && !use_table && nparts == 1;
   const bool sort_flat = sort_flat_env && !sort_atomic && !use_table && nparts == 1 && N <= ((uint64_t)1 << 21) && nbuckets <= ((size_t)1 << 18);
-  if (sort_flat) {
+  if (multi) {
+    MultiGeom mg{};
+    mg.c = c;
+    mg.W = W;
+    mg.levels = multi->levels;
+    mg.step = (int)step;
+    mg.B = B;
+    for (int j = 0; j + 1 < W; j++) {
+      const int b = c * j + c - 1;
+      if (b < 256) mg.K[b >> 5] |= 1u << (b & 31);
+    }
+    uint32_t at = 0;
+    for (int l = 0; l < multi->levels; l++) {
+      mg.start[l] = at;
+      mg.scal[l] = reinterpret_cast<const uint32_t*>(multi->scalars[l]);
+      mg.base0[l] = (long long)multi->start[l];
+      at += (uint32_t)multi->n[l];
+    }
+    mg.start[multi->levels] = at;
+    GM_CHECK(N <= ((uint64_t)1 << 21) && nbuckets <= ((size_t)1 << 18), GM_EINVAL, "msm: fused calls too large for the flat sort (%llu entries, %zu buckets)",
+             (unsigned long long)N, nbuckets);
+    const dim3 grid((uint32_t)((n + 255) / 256), (uint32_t)W);
+    pf.begin(part, PROF_DIGITS, st);
+    hipLaunchKernelGGL(k_digits_multi<false>, grid, dim3(256), 0, st, mg, mont, ws.counts.as<uint32_t>(), (uint64_t*)nullptr, d_err);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, ws.counts.as<uint32_t>(), (uint32_t)nbuckets, ws.offsets.as<uint32_t>(),
+                       ws.cursor.as<uint32_t>());
+    pf.end(part, PROF_DIGITS, st);
+    pf.begin(part, PROF_SCATTER, st);
+    hipLaunchKernelGGL(k_digits_multi<true>, grid, dim3(256), 0, st, mg, mont, ws.cursor.as<uint32_t>(), ws.entries.as<uint64_t>(), d_err);
+    pf.end(part, PROF_SCATTER, st);
+  } else if (sort_flat) {
     FlatGeom fg{};
     fg.c = c;
     fg.W = W;
@@ -1864,7 +2035,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint64_t* acc_entries = ws.entries.as<uint64_t>();
   const uint32_t* acc_total = ws.offsets.as<uint32_t>() + nbuckets;
   const uint8_t* acc_bases = d_bases;
-  long long acc_first = (long long)first, acc_step = (long long)step, acc_tab = tab_stride;
+  long long acc_first = (long long)first, acc_step = multi ? 1ll : (long long)step, acc_tab = tab_stride;
 #ifdef GM_EXPERIMENTS
 #define GM_MSM_LEVELS_HOST 1
 #include "msm_levels.inc"
@@ -2049,6 +2220,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   GM_HIP(hipMemcpyAsync(ws.host_planes[slot], planes, plane_bytes, hipMemcpyDeviceToHost, st));
   GM_HIP(hipEventRecord(ws.done_ev[slot], st));
   P->Wb = Wb;
+  P->multi_levels = multi ? multi->levels : 0;
+  P->multi_W = multi ? W : 0;
   P->plane_count = plane_count;
   P->c = c;
   P->m = m;
@@ -2208,7 +2381,7 @@ static void horner_pool_run(int n, const std::function<void(int)>& fn) { HornerP
 
 // use_pool = false: the whole tail on the calling thread (the batch finishes several small calls side by side, ONE per helper
 // thread -- a small call's tail is 256 dependent doublings that no pool can split, and a batch of twenty of them was HOST-bound)
-static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18], bool use_pool) {
+static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18], bool use_pool, uint64_t* const* multi_out) {
   gmh::G1 result = gmh::G1::identity();
   // Horner over bit positions, window groups and bucket sets high -> low (variable_base.rs:168-175 with the
   // weighted bucket sum unrolled into its bit-planes): total = sum_w 2^(cw) * (sum_j 2^j Z_{w,j} + Tot_w).
@@ -2253,6 +2426,22 @@ static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, boo
     if (use_pool) HornerPool::get().run(P.Wb, window_sum);
     else
       for (int w = 0; w < P.Wb; w++) window_sum(w);
+    if (P.multi_levels > 0) {  // fused small calls: bucket sets [l W, (l + 1) W) are the windows of call l
+      if (!multi_out || nparts != 1) return GM_ESTATE;
+      auto level = [&](int l) {
+        gmh::G1 r = gmh::G1::identity();
+        for (int w = P.multi_W - 1; w >= 0; w--) {
+          for (int j = 0; j < P.c; j++) r = r.dbl();
+          r = r.add(S[(size_t)(l * P.multi_W + w)]);
+        }
+        if (normalize) r = r.normalized();
+        r.to_limbs(multi_out[l]);
+      };
+      if (use_pool) HornerPool::get().run(P.multi_levels, level);
+      else
+        for (int l = 0; l < P.multi_levels; l++) level(l);
+      return GM_OK;
+    }
     for (int w = P.Wb - 1; w >= 0; w--) {
       for (int j = 0; j < P.c; j++) result = result.dbl();
       result = result.add(S[(size_t)w]);

@@ -387,6 +387,49 @@ def test_batch_msm_equals_single_calls(gm, oracle):
     b.free()
 
 
+def test_fused_small_calls_of_a_batch(gm, oracle):
+    """the calls of <= 2^13 pairs of a batch (the tail of every folding tree, src/subprotocols/tensorcheck/mod.rs:124-133,
+    src/kzg/time.rs:98-107) run as the levels of ONE fused pass (msm.hip: MsmMulti, k_digits_multi): twenty of them (more than one
+    pass takes: the rest run on their own), between two larger calls, with all-equal scalars, zero scalars, identity bases, P and -P
+    in one bucket, offsets and reversed walks -- every result equal to the single call's, and to the oracle's on two of them."""
+    from gemini_amd.fr import FrVec
+
+    n = 1 << 15
+    bases_h = rand_bases(oracle, 4401, n)
+    bases_h[5] = 0
+    bases_h[9] = bases_h[8]
+    b = gm.G1Bases.register(bases_h)
+    rng = np.random.default_rng(44)
+    sizes = [1 << 15, 8192, 8191, 4097, 1, 2, 3, 64, 65, 1000, 2048, 31, 32, 33, 5000, 7, 600, 8192, 129, 255, 256, 12, 1 << 14]
+    hosts = [oracle.fr_to_mont(oracle.random_fr(4500 + j, m)) for j, m in enumerate(sizes)]
+    hosts[3][:] = hosts[3][0]  # all-equal scalars: one bucket per window
+    hosts[9][::2] = 0  # zero scalars
+    vecs = [FrVec.from_host(h) for h in hosts]
+    try:
+        single = [b.msm_vec(v, n=m) for v, m in zip(vecs, sizes)]
+        for _ in range(2):
+            got = b.msm_vec_batch(vecs, sizes)
+            assert all((got[j] == single[j]).all() for j in range(len(sizes))), [j for j in range(len(sizes)) if not (got[j] == single[j]).all()]
+        for j in (2, 14):
+            assert_same_point(oracle, got[j], oracle.msm_pippenger(bases_h[: sizes[j]], oracle.fr_from_mont(hosts[j])))
+        offs = [int(rng.integers(0, n - m + 1)) for m in sizes]
+        single_at = [b.msm_vec(v, n=m, offset=o) for v, m, o in zip(vecs, sizes, offs)]
+        got = b.msm_vec_batch_at(vecs, sizes, offs)
+        assert all((got[j] == single_at[j]).all() for j in range(len(sizes)))
+        part = b.msm_vec_batch_at(vecs, sizes, offs, partial=True)
+        assert all(oracle.g1_jac_eq(part[j], single_at[j]) for j in range(len(sizes)))
+        roffs = [o + m - 1 for o, m in zip(offs, sizes)]
+        single_rev = [b.msm_vec(v, n=m, offset=o, reversed_=True) for v, m, o in zip(vecs, sizes, roffs)]
+        got = b.msm_vec_batch_at(vecs, sizes, roffs, reversed_=True)
+        assert all((got[j] == single_rev[j]).all() for j in range(len(sizes)))
+        with pytest.raises(gm.capi.GeminiHipError):
+            b.msm_vec_batch_at(vecs[1:3], sizes[1:3], [n - 100, 0])  # a fused level that runs past the end of the key
+    finally:
+        for v in vecs:
+            v.free()
+        b.free()
+
+
 def test_segmented_srs_and_batch_with_offsets(gm, oracle, pyref):
     """gm_g1_srs_register_segments: ranges of tau^i g back to back in one handle (a rank's slices of
     CommitterKey::powers_of_g, src/kzg/time.rs:24-27) == the same ranges of the plain key;
