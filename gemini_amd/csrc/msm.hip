@@ -1458,6 +1458,9 @@ static int choose_window(size_t n) {
   static const size_t c20_min = getenv("GM_MSM_C20_MIN") ? (size_t)strtoull(getenv("GM_MSM_C20_MIN"), nullptr, 10) : ((size_t)7 << 21);  // tuning override
   if (n >= c20_min) return 20;
   if (lg >= 23) return 19;  // 14 windows: -2.5 % at 2^23, -7 % at 2^24, -11 % at 2^26 against c = 16 (the 3.7 M buckets cost 2.7 ms to reduce)
+  // (GM_MSM_C_MEDIUM: A/B knob for 2^14 .. 2^17 pairs, the calls that share the GPU with the big ones inside a batch)
+  static const int c_medium = getenv("GM_MSM_C_MEDIUM") ? atoi(getenv("GM_MSM_C_MEDIUM")) : 0;
+  if (c_medium && lg >= 14 && lg <= 17) return c_medium;
   if (lg >= 14) return 16;
   // small calls, re-tuned with the flat digit kernels (tools/tune_small.py, round 2): the launch chain and the
   // merge depth dominate, so sparse buckets (c = 8: <= 2 lanes per bucket at L = 4) win from 2^11 pairs on --
