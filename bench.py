@@ -568,9 +568,9 @@ def main():
 
     # HBM traffic of the dominant kernel: NOT measured in this run -- hardware counters need rocprofv3 --pmc passes
     # of their own (tools/profile_round.sh); the figure of the committed passes of this library is quoted with its
-    # source (profiles/r2_pmc_msm20.json says how it was collected and corrected)
+    # source (profiles/r4_pmc_msm20.json says how it was collected and corrected)
     traffic, traffic_source = None, None
-    for tag in ("r3", "r2", "r1"):
+    for tag in ("r4", "r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_msm20.json")) as fh:
                 if args.logn == LOG_N:
