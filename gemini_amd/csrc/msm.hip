@@ -1725,22 +1725,26 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
   // the tiny calls of the batch (<= 2^13 pairs: the tail of every folding tree) become the levels of ONE fused pass (MsmMulti): a dozen
   // latency-bound chains of ~15 launches collapse into one.  It is enqueued where the first of them stood.  GM_MSM_FUSE=0 keeps them apart.
   static const bool fuse_env = !(getenv("GM_MSM_FUSE") && !strcmp(getenv("GM_MSM_FUSE"), "0"));
-  std::vector<size_t> fused_js;
+  std::vector<std::vector<size_t>> fused_groups;  // each: <= MULTI_MAX_LEVELS tiny calls, in batch order (a preprocessing proof has ~50)
+  std::vector<int> group_of(k, -1);
   if (fuse_env && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0 && !C->msm_c_override) {
-    for (size_t j = 0; j < k && fused_js.size() < (size_t)MULTI_MAX_LEVELS; j++)
-      if (ns[j] >= 1 && ns[j] <= MSM_MULTI_MAX_N) fused_js.push_back(j);
-    if (fused_js.size() < 2) fused_js.clear();
+    std::vector<size_t> tiny;
+    for (size_t j = 0; j < k; j++)
+      if (ns[j] >= 1 && ns[j] <= MSM_MULTI_MAX_N) tiny.push_back(j);
+    if (tiny.size() >= 2)
+      for (size_t at = 0; at < tiny.size(); at += MULTI_MAX_LEVELS) {
+        std::vector<size_t> grp(tiny.begin() + at, tiny.begin() + std::min(tiny.size(), at + MULTI_MAX_LEVELS));
+        if (grp.size() < 2) break;  // a lone leftover runs on its own
+        for (size_t j : grp) group_of[j] = (int)fused_groups.size();
+        fused_groups.push_back(std::move(grp));
+      }
   }
-  auto in_fused = [&](size_t j) {
-    for (size_t f : fused_js)
-      if (f == j) return true;
-    return false;
-  };
-  bool gated = false, fused_done = false;
+  std::vector<char> group_done(fused_groups.size(), 0);
+  bool gated = false;
   for (size_t jo = 0; jo < k; jo++) {
     const size_t j = order[jo];
-    const bool fused_here = in_fused(j);
-    if (fused_here && fused_done) continue;
+    const bool fused_here = group_of[j] >= 0;
+    if (fused_here && group_done[(size_t)group_of[j]]) continue;
     const bool small = fused_here || is_small(j);
     // big calls alternate between the two full-size lanes (0 and -1), each with two result buffers
     static const bool two_big = !(getenv("GM_MSM_BIG_LANES") && !strcmp(getenv("GM_MSM_BIG_LANES"), "1"));
@@ -1779,15 +1783,16 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     auto start_of = [&](size_t jj) { return pair_offsets ? (int64_t)pair_offsets[jj] : (firsts ? firsts[jj] : first); };
     int rc;
     if (fused_here) {
+      const std::vector<size_t>& grp = fused_groups[(size_t)group_of[j]];
       MsmMulti M;
-      M.levels = (int)fused_js.size();
-      for (size_t l = 0; l < fused_js.size(); l++) {
-        M.scalars[l] = d_scalars[fused_js[l]];
-        M.n[l] = ns[fused_js[l]];
-        M.start[l] = start_of(fused_js[l]);
+      M.levels = (int)grp.size();
+      for (size_t l = 0; l < grp.size(); l++) {
+        M.scalars[l] = d_scalars[grp[l]];
+        M.n[l] = ns[grp[l]];
+        M.start[l] = start_of(grp[l]);
       }
-      e.fused = fused_js;
-      fused_done = true;
+      e.fused = grp;
+      group_done[(size_t)group_of[j]] = 1;
       rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, 0, step, nullptr, mont, 0, hslot, &e.P, 0, 1, &M);
     } else
       rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, start_of(j), step, d_scalars[j], mont,
