@@ -20,6 +20,11 @@ def init_shm(rank: int, world: int, name: str, slot_bytes: int = 0) -> None:
     capi.check(capi.load().gm_dist_init_shm(C.c_int(rank), C.c_int(world), name.encode(), C.c_size_t(slot_bytes)))
 
 
+def init_rccl_node(rank: int, world: int, name: str) -> None:
+    """the library's own RCCL communicator on one node, the unique id carried through a shared-memory segment: no torch.distributed"""
+    capi.check(capi.load().gm_dist_init_rccl_node(C.c_int(rank), C.c_int(world), name.encode()))
+
+
 def init_hook(rank: int, world: int, fn) -> None:
     """fn(send: bytes) -> bytes of world payloads in rank order"""
 

@@ -380,6 +380,33 @@ int gm_dist_init_shm(int rank, int world, const char* name, size_t slot_bytes) {
   return shm_allgather(d, &one, sizeof one, all.data());
 }
 
+// RCCL on ONE node with no out-of-band channel of the embedder's: the ranks meet in a shared-memory segment `name` (as for
+// gm_dist_init_shm), rank 0 draws the unique id and the segment carries its 128 bytes to the peers; then the segment is left and the
+// communicator is built.  One call per rank after gm_init(local_rank).
+int gm_dist_init_rccl_node(int rank, int world, const char* name) {
+  int rc = gm_dist_init_shm(rank, world, name, 4096);
+  if (rc) return rc;
+  uint8_t mine[128];
+  memset(mine, 0, sizeof mine);
+  if (rank == 0 && (rc = gm_dist_rccl_unique_id(mine))) {
+    (void)gm_dist_finalize();
+    return rc;
+  }
+  std::vector<uint8_t> all((size_t)world * 128);
+  rc = gm_dist_allgather_host(mine, 128, all.data());
+  if (rc) {
+    (void)gm_dist_finalize();
+    return rc;
+  }
+  // everybody has read rank 0's slot before anybody leaves the segment (the last one out unlinks it)
+  uint64_t one = 1;
+  std::vector<uint64_t> seen((size_t)world);
+  rc = gm_dist_allgather_host(&one, 8, seen.data());
+  (void)gm_dist_finalize();
+  if (rc) return rc;
+  return gm_dist_init_rccl(rank, world, all.data());
+}
+
 int gm_dist_finalize(void) {
   Dist& d = D();
   std::lock_guard<std::mutex> lk(d.mu);

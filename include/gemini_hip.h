@@ -529,6 +529,9 @@ int gm_dist_init_hook(int rank, int world, gm_allgather_fn fn, void* ctx);
 int gm_dist_rccl_unique_id(uint8_t out[128]);
 int gm_dist_init_rccl(int rank, int world, const uint8_t unique_id[128]);
 int gm_dist_init_shm(int rank, int world, const char* name, size_t slot_bytes);
+/* RCCL on one node without any out-of-band channel: the ranks meet in the shared-memory segment `name`, which carries rank 0's
+ * unique id to the peers, then build the communicator (gm_dist_rccl_unique_id + gm_dist_init_rccl in one call per rank). */
+int gm_dist_init_rccl_node(int rank, int world, const char* name);
 int gm_dist_finalize(void);
 /* transport: 0 none, 1 hook, 2 RCCL, 3 shm */
 int gm_dist_info(int* rank, int* world, int* transport);

@@ -47,6 +47,7 @@ inline std::array<uint8_t, 128> rccl_unique_id() {  // rank 0; the 128 bytes rea
   return id;
 }
 inline void init_rccl(int rank, int world, const std::array<uint8_t, 128>& id) { check(gm_dist_init_rccl(rank, world, id.data())); }
+inline void init_rccl_node(int rank, int world, const std::string& name) { check(gm_dist_init_rccl_node(rank, world, name.c_str())); }
 inline void init_shm(int rank, int world, const std::string& name, size_t slot_bytes = 0) { check(gm_dist_init_shm(rank, world, name.c_str(), slot_bytes)); }
 inline void init_hook(int rank, int world, gm_allgather_fn fn, void* ctx) { check(gm_dist_init_hook(rank, world, fn, ctx)); }
 inline void selftest() { check(gm_dist_selftest()); }

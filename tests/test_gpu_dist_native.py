@@ -85,6 +85,13 @@ def test_rccl_binding_with_one_rank():
         out.free()
     finally:
         collective.finalize()
+    # one node, no out-of-band channel: the unique id travels through a shared-memory segment (gm_dist_init_rccl_node)
+    collective.init_rccl_node(0, 1, f"/gm_test_rcclnode_{os.getpid()}")
+    try:
+        assert collective.info() == (0, 1, "rccl")
+        collective.selftest()
+    finally:
+        collective.finalize()
 
 
 @pytest.mark.parametrize("extra", [[], ["--elastic"]], ids=["time", "elastic"])
