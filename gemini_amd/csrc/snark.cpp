@@ -346,40 +346,34 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
     RC(stream_msm(ck_bases, qs, lq, lq ? lq - 1 : 0, flush, proof_w));
   }
   {  // open_folding (space.rs:229-285): sum_i open_chal^(i + 1) * commit(quotient of level i); HashMapPippenger merges the
-     // equal bases, i.e. the scalars are the linear combination of the quotients
-    std::vector<uint64_t> quots, etas;
+     // equal bases, i.e. the scalars are the linear combination of the quotients -- and division by the same Z is linear, so that
+     // is the quotient of the linear combination of the LEVELS: one division instead of one per level (~20 latency-bound scans)
+    std::vector<uint64_t> etas(4 * P->nfold);
     Fr acc = Fr::from_limbs(open_chal);
     const Fr oc = acc;
+    size_t longest = 0;
     for (size_t k = 0; k < P->nfold; k++) {
-      if (level_len[k] > 3) {
-        uint64_t q, rem[12];
-        RC(V.alloc(level_len[k] - 1, &q));
-        RC(gm_fr_div_vanishing(levels[k], pts, 3, q, rem));
-        quots.push_back(q);
-        etas.resize(etas.size() + 4);
-        acc.to_limbs(etas.data() + etas.size() - 4);
-      }
+      acc.to_limbs(etas.data() + 4 * k);
       acc = acc * oc;
+      longest = level_len[k] > longest ? level_len[k] : longest;
     }
-    if (quots.empty()) {
+    if (longest <= 3) {
       RC(gm_g1_sum(nullptr, 0, proof_f));
     } else {
-      size_t longest = 0;
-      for (uint64_t q : quots) {
-        size_t l = 0;
-        RC(vec_len(q, &l));
-        longest = l > longest ? l : longest;
-      }
-      uint64_t batched, bs;
-      RC(V.alloc(longest, &batched));
-      RC(gm_fr_lincomb(quots.data(), etas.data(), quots.size(), batched));
+      uint64_t combined, q, bs, rem[12];
+      RC(V.alloc(longest, &combined));
+      RC(gm_fr_lincomb(levels.data(), etas.data(), P->nfold, combined));
+      size_t lc = 0;
+      RC(vec_len(combined, &lc));
+      RC(V.alloc(lc ? lc - 1 : 0, &q));
+      RC(gm_fr_div_vanishing(combined, pts, 3, q, rem));
       size_t lb = 0;
-      RC(vec_len(batched, &lb));
+      RC(vec_len(q, &lb));
       if (lb == 0) {
         RC(gm_g1_sum(nullptr, 0, proof_f));
       } else {
         RC(V.alloc(lb, &bs));
-        RC(gm_fr_reverse(batched, bs));
+        RC(gm_fr_reverse(q, bs));
         RC(stream_msm(ck_bases, bs, lb, lb - 1, flush, proof_f));
       }
     }
