@@ -334,55 +334,42 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
   for (size_t k = 0; k < 2 * P->nfold; k++) RC(gm_transcript_append_fr(T.h, L("eval"), 4, P->fold_evaluations + 4 * k, 1));
   uint64_t open_chal[4];
   RC(gm_transcript_challenge_fr(T.h, L("open-chal"), 9, open_chal));
-  uint64_t proof_w[18], proof_f[18];
-  {  // open_multi_points(w) (space.rs:128-166): quotient of w by (x - beta^2)(x - beta)(x + beta), committed as a stream
-    uint64_t q, qs, rem[12];
-    RC(V.alloc(nw ? nw - 1 : 0, &q));
-    RC(gm_fr_div_vanishing(w_le, pts, 3, q, rem));
-    size_t lq = 0;
-    RC(vec_len(q, &lq));
-    RC(V.alloc(lq, &qs));
-    RC(gm_fr_reverse(q, qs));
-    RC(stream_msm(ck_bases, qs, lq, lq ? lq - 1 : 0, flush, proof_w));
-  }
-  {  // open_folding (space.rs:229-285): sum_i open_chal^(i + 1) * commit(quotient of level i); HashMapPippenger merges the
-     // equal bases, i.e. the scalars are the linear combination of the quotients -- and division by the same Z is linear, so that
-     // is the quotient of the linear combination of the LEVELS: one division instead of one per level (~20 latency-bound scans)
-    std::vector<uint64_t> etas(4 * P->nfold);
-    Fr acc = Fr::from_limbs(open_chal);
-    const Fr oc = acc;
-    size_t longest = 0;
-    for (size_t k = 0; k < P->nfold; k++) {
+  {
+    // The reference adds two openings: open_multi_points(w) (space.rs:128-166) and open_folding (:229-285) = sum_i open_chal^(i + 1)
+    // commit(quotient of level i), the HashMapPippenger of the latter merging the scalars of equal bases.  Both walk the same key
+    // and division by the same Z is linear, so the merge extends over both: the quotient of  w + sum_i open_chal^(i + 1) level_i
+    // -- one linear combination, ONE division (instead of one latency-bound scan per level), one stream MSM flushed every
+    // max_msm_buffer pairs.  (It is the polynomial the time prover opens: time_prover.rs:98-107 -> kzg/time.rs:149-159.)
+    std::vector<uint64_t> polys(1 + P->nfold), etas(4 * (1 + P->nfold));
+    polys[0] = w_le;
+    Fr acc = Fr::one();
+    const Fr oc = Fr::from_limbs(open_chal);
+    size_t longest = nw;
+    for (size_t k = 0; k <= P->nfold; k++) {
       acc.to_limbs(etas.data() + 4 * k);
       acc = acc * oc;
-      longest = level_len[k] > longest ? level_len[k] : longest;
+      if (k) {
+        polys[k] = levels[k - 1];
+        longest = level_len[k - 1] > longest ? level_len[k - 1] : longest;
+      }
     }
-    if (longest <= 3) {
-      RC(gm_g1_sum(nullptr, 0, proof_f));
-    } else {
+    size_t lb = 0;
+    if (longest > 3) {
       uint64_t combined, q, bs, rem[12];
       RC(V.alloc(longest, &combined));
-      RC(gm_fr_lincomb(levels.data(), etas.data(), P->nfold, combined));
+      RC(gm_fr_lincomb(polys.data(), etas.data(), polys.size(), combined));
       size_t lc = 0;
       RC(vec_len(combined, &lc));
       RC(V.alloc(lc ? lc - 1 : 0, &q));
       RC(gm_fr_div_vanishing(combined, pts, 3, q, rem));
-      size_t lb = 0;
       RC(vec_len(q, &lb));
-      if (lb == 0) {
-        RC(gm_g1_sum(nullptr, 0, proof_f));
-      } else {
+      if (lb) {
         RC(V.alloc(lb, &bs));
         RC(gm_fr_reverse(q, bs));
-        RC(stream_msm(ck_bases, bs, lb, lb - 1, flush, proof_f));
+        RC(stream_msm(ck_bases, bs, lb, lb - 1, flush, P->evaluation_proof));
       }
     }
-  }
-  {
-    uint64_t both[36];
-    memcpy(both, proof_w, sizeof proof_w);
-    memcpy(both + 18, proof_f, sizeof proof_f);
-    RC(gm_g1_sum(both, 2, P->evaluation_proof));
+    if (lb == 0) RC(gm_g1_sum(nullptr, 0, P->evaluation_proof));
   }
   P->spans[5] = since(t0);
   P->spans[6] = since(t_all);
