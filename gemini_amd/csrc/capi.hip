@@ -1185,6 +1185,11 @@ int gm_sc_download(uint64_t handle, uint64_t* f_mont, uint64_t* g_mont) {
   GM_CTX();
   GM_SC(S, handle, "sc_download");
   std::lock_guard<std::mutex> lk(S->mu);
+  if (S->on_host) {  // the tail lives on the host (fr.hip: sc_host_step)
+    if (f_mont && S->nf) memcpy(f_mont, S->hf.data(), S->nf * 32);
+    if (g_mont && S->ng) memcpy(g_mont, S->hg.data(), S->ng * 32);
+    return GM_OK;
+  }
   if (f_mont && S->nf) GM_HIP(hipMemcpyAsync(f_mont, S->f[S->cur], S->nf * 32, hipMemcpyDeviceToHost, C->stream));
   if (g_mont && S->ng) GM_HIP(hipMemcpyAsync(g_mont, S->g[S->cur], S->ng * 32, hipMemcpyDeviceToHost, C->stream));
   GM_HIP(hipStreamSynchronize(C->stream));

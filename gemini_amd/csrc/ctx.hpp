@@ -99,8 +99,15 @@ struct Sumcheck {
   uint8_t* partials = nullptr;   // per-block (a, b) partial sums
   uint64_t* host_partials = nullptr;  // pinned
   unsigned pending_blocks = 0;        // blocks of the round whose partial sums are on their way to host_partials
+  // the TAIL on the host: once the vectors are down to SC_HOST_TAIL elements they are copied out once and the remaining rounds --
+  // a launch, a copy and a wait each on the device, ~45 us for microseconds of arithmetic -- run on the host (fr.hip: sc_host_step)
+  bool on_host = false;
+  std::vector<uint64_t> hf, hg;  // 4 limbs per element, Montgomery
+  uint64_t host_msg[8];          // the message of the round in flight (split-phase rounds)
+  bool host_msg_pending = false;
   std::mutex mu;
 };
+constexpr size_t SC_HOST_TAIL = 256;
 
 struct SpaceProver {
   // src/subprotocols/sumcheck/space_prover.rs:20-40: the witness streams (big-endian, never modified),

@@ -762,6 +762,76 @@ void sc_destroy(Sumcheck* S) {
 }
 
 // the stream the round was enqueued on has been waited for
+// ---- the tail of a sumcheck on the host -------------------------------------------------------------------------------
+// Same arithmetic as k_sc_round (fold f' = f_e + rho tau f_o, g' = g_e + rho g_o, then the message on the folded vectors with the
+// twist of the round, time_prover.rs:75-123), on <= SC_HOST_TAIL elements: the last ~8 rounds of EVERY sumcheck -- time provers,
+// elastic ones after their switch, the provers of a batch, the replicated tail of a sharded one.
+static bool sc_host_ready(Context* C, Sumcheck* S, int* rc) {
+  *rc = GM_OK;
+  if (S->on_host) return true;
+  static const size_t tail = getenv("GM_SC_HOST_TAIL") ? (size_t)strtoull(getenv("GM_SC_HOST_TAIL"), nullptr, 10) : SC_HOST_TAIL;  // A/B knob, 0 = off
+  const size_t n = S->nf > S->ng ? S->nf : S->ng;
+  if (tail == 0 || n > tail || S->pending_blocks != 0 || C->prof.on) return false;
+  S->hf.assign(4 * S->nf, 0);
+  S->hg.assign(4 * S->ng, 0);
+  hipError_t e = hipSuccess;
+  if (S->nf) e = hipMemcpyAsync(S->hf.data(), S->f[S->cur], S->nf * FR_BYTES, hipMemcpyDeviceToHost, C->stream);
+  if (e == hipSuccess && S->ng) e = hipMemcpyAsync(S->hg.data(), S->g[S->cur], S->ng * FR_BYTES, hipMemcpyDeviceToHost, C->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
+  if (e != hipSuccess) {
+    *rc = hip_fail(e, "sumcheck tail: copy to the host", __FILE__, __LINE__);
+    return false;
+  }
+  S->on_host = true;
+  return true;
+}
+static void sc_host_step(Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho) {
+  using gmh::Fr;
+  const Fr tau = Fr::from_limbs(S->twist);
+  Fr tau_msg = fold ? tau.sqr() : tau;
+  if (S->herring) tau_msg = Fr::one();
+  const uint64_t elem_off = fold ? S->pair_offset : 2 * S->pair_offset;
+  if (fold) {
+    const Fr rho_tau = rho * tau;
+    auto fold_vec = [](std::vector<uint64_t>& v, size_t n, const Fr& c) {
+      const size_t m = (n + 1) / 2;
+      for (size_t i = 0; i < m; i++) {
+        Fr x = Fr::from_limbs(v.data() + 8 * i);
+        if (2 * i + 1 < n) x = x + c * Fr::from_limbs(v.data() + 8 * i + 4);
+        x.to_limbs(v.data() + 4 * i);  // slot i <= slot 2 i: in place
+      }
+      v.resize(4 * m);
+    };
+    fold_vec(S->hf, S->nf, rho_tau);
+    fold_vec(S->hg, S->ng, rho);
+    S->nf = (S->nf + 1) / 2;
+    S->ng = (S->ng + 1) / 2;
+    tau.sqr().to_limbs(S->twist);
+    S->pair_offset = S->pair_offset / 2;
+  }
+  if (msg) {
+    const Fr tau2 = tau_msg.sqr();
+    Fr runner = Fr::one(), base = tau2;
+    for (uint64_t e = elem_off / 2; e; e >>= 1) {
+      if (e & 1) runner = runner * base;
+      base = base.sqr();
+    }
+    const size_t pf = (S->nf + 1) / 2, pg = (S->ng + 1) / 2, np = pf < pg ? pf : pg;  // a pair with a side missing contributes nothing
+    Fr a = Fr::zero(), b = Fr::zero();
+    for (size_t i = 0; i < np; i++) {
+      const Fr fe = Fr::from_limbs(S->hf.data() + 8 * i), ge = Fr::from_limbs(S->hg.data() + 8 * i);
+      const Fr fo = 2 * i + 1 < S->nf ? Fr::from_limbs(S->hf.data() + 8 * i + 4) : Fr::zero();
+      const Fr go = 2 * i + 1 < S->ng ? Fr::from_limbs(S->hg.data() + 8 * i + 4) : Fr::zero();
+      a = a + fe * ge * runner;
+      b = b + (fe * go + ge * fo * tau_msg) * runner;
+      runner = runner * tau2;
+    }
+    a.to_limbs(S->host_msg);
+    b.to_limbs(S->host_msg + 4);
+    S->host_msg_pending = true;
+  }
+}
+
 static void sc_collect(Context* C, Sumcheck* S, uint64_t a_out[4], uint64_t b_out[4]) {
   gmh::Fr a = gmh::Fr::zero(), b = gmh::Fr::zero();
   for (unsigned i = 0; i < S->pending_blocks; i++) {
@@ -775,7 +845,18 @@ static void sc_collect(Context* C, Sumcheck* S, uint64_t a_out[4], uint64_t b_ou
 }
 
 static int sc_launch(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho, uint64_t a_out[4], uint64_t b_out[4]) {
-  int rc = sc_enqueue(C, S, fold, msg, rho);
+  int rc;
+  if (sc_host_ready(C, S, &rc)) {
+    sc_host_step(S, fold, msg, rho);
+    if (msg) {
+      memcpy(a_out, S->host_msg, 32);
+      memcpy(b_out, S->host_msg + 4, 32);
+      S->host_msg_pending = false;
+    }
+    return GM_OK;
+  }
+  if (rc) return rc;
+  rc = sc_enqueue(C, S, fold, msg, rho);
   if (rc) return rc;
   if (msg) {
     GM_HIP(hipStreamSynchronize(C->stream));
@@ -810,13 +891,18 @@ int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], 
 int sc_round_begin(Context* C, Sumcheck* S, const uint64_t* challenge, int* has_msg) {
   std::lock_guard<std::mutex> lk(S->mu);
   GM_CHECK(S->round <= S->tot_rounds, GM_ESTATE, "More rounds than needed.");
-  GM_CHECK(S->pending_blocks == 0, GM_ESTATE, "sc_round_begin: the previous round has not been collected");
+  GM_CHECK(S->pending_blocks == 0 && !S->host_msg_pending, GM_ESTATE, "sc_round_begin: the previous round has not been collected");
   const bool fold = challenge != nullptr;
   const bool msg = S->round != S->tot_rounds;
   gmh::Fr rho = fold ? gmh::Fr::from_limbs(challenge) : gmh::Fr::zero();
   if (fold || msg) {
-    int rc = sc_enqueue(C, S, fold, msg, rho);
-    if (rc) return rc;
+    int rc;
+    if (sc_host_ready(C, S, &rc)) sc_host_step(S, fold, msg, rho);
+    else {
+      if (rc) return rc;
+      rc = sc_enqueue(C, S, fold, msg, rho);
+      if (rc) return rc;
+    }
   }
   if (!msg) {
     *has_msg = 0;
@@ -828,6 +914,12 @@ int sc_round_begin(Context* C, Sumcheck* S, const uint64_t* challenge, int* has_
 }
 int sc_round_end(Context* C, Sumcheck* S, uint64_t a[4], uint64_t b[4]) {
   std::lock_guard<std::mutex> lk(S->mu);
+  if (S->host_msg_pending) {
+    memcpy(a, S->host_msg, 32);
+    memcpy(b, S->host_msg + 4, 32);
+    S->host_msg_pending = false;
+    return GM_OK;
+  }
   GM_CHECK(S->pending_blocks != 0, GM_ESTATE, "sc_round_end: no round in flight");
   GM_HIP(hipStreamSynchronize(C->stream));
   sc_collect(C, S, a, b);
@@ -853,6 +945,14 @@ int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has) 
   std::lock_guard<std::mutex> lk(S->mu);
   if (S->round != S->tot_rounds) {
     *has = 0;
+    return GM_OK;
+  }
+  if (S->on_host) {
+    memset(f0, 0, 32);
+    memset(g0, 0, 32);
+    if (S->nf) memcpy(f0, S->hf.data(), 32);
+    if (S->ng) memcpy(g0, S->hg.data(), 32);
+    *has = 1;
     return GM_OK;
   }
   GM_HIP(hipMemcpyAsync(f0, S->f[S->cur], FR_BYTES, hipMemcpyDeviceToHost, C->stream));
