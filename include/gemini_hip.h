@@ -522,7 +522,9 @@ int gm_psnark_index(const gm_psnark_instance* instance, uint64_t ck_bases, uint6
  *                      payloads in rank order and returns 0.
  *   gm_dist_init_shm   ranks of one node over a POSIX shared-memory segment `name` ("/something", the same on every rank;
  *                      slot_bytes = 0: 1 MiB per rank and call, longer payloads are cut): the payloads of this path are
- *                      host results of <= 1 KiB, which cross processes in ~1 us this way.
+ *                      host results of <= 1 KiB, which cross processes in ~1 us this way.  Use a FRESH name per run (a pid, the
+ *                      launcher's port): rank 0 removes a stale segment of that name before creating it, and a peer that had already
+ *                      opened the stale one would wait for it until the timeout (GM_DIST_TIMEOUT_S, default 300 s).
  * Without any of them (or world = 1) an all-gather is a copy.  Collective calls must be made by every rank in the same order. */
 typedef int (*gm_allgather_fn)(void* ctx, const void* send, size_t bytes, void* recv);
 int gm_dist_init_hook(int rank, int world, gm_allgather_fn fn, void* ctx);
