@@ -1709,10 +1709,14 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
   // ORDER.  Small calls do not progress beside the accumulation of a big one: the SIMD arbiter serves the oldest waves first
   // (section 4.1) and a k_acc0 grid keeps every SIMD supplied with older waves, so a small call's kernels crawl (a memset of
   // a few KB was seen to take 0.7 ms there) and its XYZZ + XYZZ kernels (214 VGPRs) do not even fit beside two accumulation waves.
-  // Small calls do overlap with EACH OTHER (latency-bound chains on their own streams).  An experiment puts the small calls of a batch FIRST,
-  // all side by side, with the big ones behind them (GM_MSM_BATCH_ORDER=smalls): measured no better (batch of 2^20 .. 2 pairs: 10.3 against
-  // 9.8 ms; the provers 0.5-4 ms slower), so the caller's order stays the default.
-  static const bool smalls_first = getenv("GM_MSM_BATCH_ORDER") && !strcmp(getenv("GM_MSM_BATCH_ORDER"), "smalls");
+  // So the small calls of a batch are ENQUEUED FIRST: they get their sorts and accumulations in while the first big call is still
+  // sorting, instead of queueing up behind three accumulations (snark -i 20 15.8 -> 15.2 ms, -i 24 119.3 -> 118.6, the sharded share
+  // 29.8 -> 29.1, psnark -i 22 369 -> 368: two A/B runs each).  Holding the big calls back until the small ones are DONE
+  // (GM_MSM_BATCH_ORDER=smalls) is worse than either (10.3 against 9.8 ms for the batch 2^20 .. 2); GM_MSM_BATCH_ORDER=given keeps the
+  // caller's order.
+  static const bool order_given = getenv("GM_MSM_BATCH_ORDER") && !strcmp(getenv("GM_MSM_BATCH_ORDER"), "given");
+  static const bool order_gated = getenv("GM_MSM_BATCH_ORDER") && !strcmp(getenv("GM_MSM_BATCH_ORDER"), "smalls");
+  const bool smalls_first = !order_given, smalls_nogate = !order_gated;
   std::vector<size_t> order;
   if (smalls_first) {
     for (size_t j = 0; j < k; j++)
@@ -1759,7 +1763,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       lane = (two_big && C->stream_b && (big_rr & 1)) ? -1 : 0;
       hslot = (big_rr >> 1) & 1;
       big_rr++;
-      if (smalls_first && !gated) {  // the big lanes start behind the small calls that are still in flight
+      if (smalls_first && !smalls_nogate && !gated) {  // the big lanes start behind the small calls that are still in flight
         gated = true;
         for (size_t t = 0; t < q.size(); t++)
           if (!finished[t] && q[t].lane > 0 && !q[t].P.empty) {
@@ -1802,16 +1806,27 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     q.push_back(e);
     finished.push_back(0);
   }
+  const auto t_enqueued = std::chrono::steady_clock::now();
   for (;;) {
     bool left = false;
     for (char f : finished) left = left || !f;
     if (!left) break;
+    const auto td0 = std::chrono::steady_clock::now();
+    size_t before = 0;
+    for (char f : finished) before += f ? 1 : 0;
     int rc = drain_oldest();
     if (rc) return fail(rc);
+    if (batch_trace) {
+      size_t after = 0;
+      for (char f : finished) after += f ? 1 : 0;
+      fprintf(stderr, "[gm msm batch]   drain: %zu call(s) finished in %.3f ms\n", after - before,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count());
+    }
   }
   if (batch_trace)
-    fprintf(stderr, "[gm msm batch] %zu calls: %.3f ms, of which enqueueing %.3f ms\n", k,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_batch0).count(), enqueue_s * 1e3);
+    fprintf(stderr, "[gm msm batch] %zu calls: %.3f ms, of which enqueueing %.3f ms, final drains %.3f ms\n", k,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_batch0).count(), enqueue_s * 1e3,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enqueued).count());
   return GM_OK;
 }
 
