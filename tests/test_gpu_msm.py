@@ -430,6 +430,46 @@ def test_fused_small_calls_of_a_batch(gm, oracle):
         b.free()
 
 
+def test_batch_randomised_differential(gm, oracle):
+    """gm_g1_msm_v_batch_at against single calls on random batches: 2 .. 40 calls of log-uniform sizes 1 .. 2^15 (so that some batches
+    have several fused groups of tiny calls, medium calls on the small lanes and big ones), random offsets, forward and reversed,
+    normalised and partial; scalars uniform / all-equal / sparse per call."""
+    from gemini_amd.fr import FrVec
+
+    n = 1 << 15
+    b = gm.G1Bases.register(rand_bases(oracle, 7701, n))
+    rng = np.random.default_rng(7702)
+    pool = oracle.fr_to_mont(oracle.random_fr(7703, n))
+    try:
+        for it in range(6):
+            k = int(rng.integers(2, 41))
+            sizes = [int(min(n, max(1, round(2 ** rng.uniform(0, 15))))) for _ in range(k)]
+            if it == 0:
+                sizes[:4] = [1, 8192, 8193, n]
+            hosts = []
+            for m in sizes:
+                h = pool[int(rng.integers(0, n - m + 1)):][:m].copy()
+                kind = int(rng.integers(0, 4))
+                if kind == 1:
+                    h[:] = h[0]
+                elif kind == 2:
+                    h[rng.random(m) < 0.7] = 0
+                hosts.append(h)
+            vecs = [FrVec.from_host(h) for h in hosts]
+            rev = bool(it & 1)
+            offs = [int(rng.integers(0, n - m + 1)) + (m - 1 if rev else 0) for m in sizes]
+            single = [b.msm_vec(v, n=m, offset=o, reversed_=rev) for v, m, o in zip(vecs, sizes, offs)]
+            got = b.msm_vec_batch_at(vecs, sizes, offs, reversed_=rev)
+            bad = [j for j in range(k) if not (got[j] == single[j]).all()]
+            assert not bad, (it, k, [sizes[j] for j in bad])
+            part = b.msm_vec_batch_at(vecs, sizes, offs, reversed_=rev, partial=True)
+            assert all(oracle.g1_jac_eq(part[j], single[j]) for j in range(k)), it
+            for v in vecs:
+                v.free()
+    finally:
+        b.free()
+
+
 def test_segmented_srs_and_batch_with_offsets(gm, oracle, pyref):
     """gm_g1_srs_register_segments: ranges of tau^i g back to back in one handle (a rank's slices of
     CommitterKey::powers_of_g, src/kzg/time.rs:24-27) == the same ranges of the plain key;
