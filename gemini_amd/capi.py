@@ -32,9 +32,9 @@ SYMBOLS = [
     "gm_fr_reverse", "gm_fr_stride", "gm_fr_fold", "gm_fr_fold_chain", "gm_fr_powers", "gm_fr_tensor", "gm_fr_hadamard", "gm_fr_ip", "gm_fr_eval_le", "gm_fr_eval_le_batch",
     "gm_fr_lincomb", "gm_fr_scale_into", "gm_fr_scale_into_many", "gm_fr_add_at", "gm_fr_div_vanishing",
     "gm_spm_register", "gm_spm_free", "gm_spm_mul", "gm_spm_shape", "gm_snark_new_time", "gm_snark_new_elastic", "gm_psnark_new_time", "gm_psnark_new_elastic", "gm_psnark_preprocess", "gm_psnark_preprocess_free", "gm_psnark_index", "gm_spm_download",
-    "gm_sc_new", "gm_sc_new_v", "gm_sc_round", "gm_sc_round_begin", "gm_sc_round_end", "gm_sc_fold", "gm_sc_rounds", "gm_sc_final", "gm_sc_free",
+    "gm_sc_new", "gm_sc_new_v", "gm_sc_new_borrow", "gm_sc_round", "gm_sc_round_begin", "gm_sc_round_end", "gm_sc_fold", "gm_sc_rounds", "gm_sc_final", "gm_sc_free",
     "gm_sc_set_shard", "gm_sc_lens", "gm_sc_download",
-    "gm_sp_new", "gm_sp_new_v", "gm_sp_round", "gm_sp_fold", "gm_sp_rounds", "gm_sp_final", "gm_sp_to_time", "gm_sp_free",
+    "gm_sp_new", "gm_sp_new_v", "gm_sp_new_borrow", "gm_sp_round", "gm_sp_fold", "gm_sp_rounds", "gm_sp_final", "gm_sp_to_time", "gm_sp_free",
     "gm_sc_set_herring", "gm_hg1_new", "gm_hg1_round", "gm_hg1_fold", "gm_hg1_rounds", "gm_hg1_final", "gm_hg1_free",
     "gm_transcript_new", "gm_transcript_free", "gm_transcript_append_message", "gm_transcript_challenge_bytes",
     "gm_transcript_append_fr", "gm_transcript_append_g1", "gm_transcript_set_g1_encoding", "gm_transcript_challenge_fr", "gm_sumcheck_prove", "gm_sumcheck_prove_batch",

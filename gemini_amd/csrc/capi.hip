@@ -185,7 +185,7 @@ int hg1_fold(Context* C, HerringG1* H, const uint64_t r[4]);
 int hg1_round(Context* C, HerringG1* H, const uint64_t* challenge, uint64_t a_jac[18], uint64_t b_jac[18], int* has_msg);
 int hg1_final(Context* C, HerringG1* H, uint64_t f0_jac[18], uint64_t g0[4], int* has);
 int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_t ng, bool src_is_device,
-              const uint64_t twist[4], uint64_t* handle);
+              const uint64_t twist[4], uint64_t* handle, bool borrow = false);
 void sc_destroy(Sumcheck* S);
 int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
 int sc_round_begin(Context* C, Sumcheck* S, const uint64_t* challenge, int* has_msg);
@@ -193,7 +193,7 @@ int sc_round_end(Context* C, Sumcheck* S, uint64_t a[4], uint64_t b[4]);
 int sc_fold(Context* C, Sumcheck* S, const uint64_t challenge[4]);
 int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has);
 int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream, size_t ng, bool src_is_device,
-              const uint64_t twist[4], uint64_t* handle);
+              const uint64_t twist[4], uint64_t* handle, bool borrow = false);
 void sp_destroy(Context* C, SpaceProver* S);
 int sp_fold(Context* C, SpaceProver* S, const uint64_t challenge[4]);
 int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
@@ -268,6 +268,7 @@ int gm_init(int device) {
   for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithPriority(&C->small_stream[k], hipStreamNonBlocking, prio ? prio_hi : 0));
   GM_HIP(hipStreamCreateWithPriority(&C->stream_b, hipStreamNonBlocking, prio ? prio_hi : 0));
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
+  if (const char* e = getenv("GM_ZERO_COPY")) C->zero_copy = atoi(e);
   g_ctx = C;
   return GM_OK;
 }
@@ -1134,6 +1135,13 @@ int gm_sc_new_v(uint64_t f_vec, uint64_t g_vec, const uint64_t twist_mont[4], ui
   GM_CHECK(twist_mont && handle, GM_EINVAL, "sc_new_v: null pointer");
   return sc_create(C, vf->d, vf->len, vg->d, vg->len, true, twist_mont, handle);
 }
+int gm_sc_new_borrow(uint64_t f_vec, uint64_t g_vec, const uint64_t twist_mont[4], uint64_t* handle) {
+  GM_CTX();
+  GM_VEC(vf, f_vec, "sc_new_borrow");
+  GM_VEC(vg, g_vec, "sc_new_borrow");
+  GM_CHECK(twist_mont && handle, GM_EINVAL, "sc_new_borrow: null pointer");
+  return sc_create(C, vf->d, vf->len, vg->d, vg->len, true, twist_mont, handle, true);
+}
 int gm_sc_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg) {
   GM_CTX();
   GM_SC(S, handle, "sc_round");
@@ -1280,6 +1288,13 @@ int gm_sp_new_v(uint64_t f_stream_vec, uint64_t g_stream_vec, const uint64_t twi
   GM_VEC(vf, f_stream_vec, "sp_new_v");
   GM_VEC(vg, g_stream_vec, "sp_new_v");
   return sp_create(C, vf->d, vf->len, vg->d, vg->len, true, twist_mont, handle);
+}
+int gm_sp_new_borrow(uint64_t f_stream_vec, uint64_t g_stream_vec, const uint64_t twist_mont[4], uint64_t* handle) {
+  GM_CTX();
+  GM_CHECK(twist_mont && handle, GM_EINVAL, "sp_new_borrow: null pointer");
+  GM_VEC(vf, f_stream_vec, "sp_new_borrow");
+  GM_VEC(vg, g_stream_vec, "sp_new_borrow");
+  return sp_create(C, vf->d, vf->len, vg->d, vg->len, true, twist_mont, handle, true);
 }
 int gm_sp_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg) {
   GM_CTX();

@@ -90,6 +90,9 @@ struct Sumcheck {
   uint8_t* f[2] = {nullptr, nullptr};
   uint8_t* g[2] = {nullptr, nullptr};
   size_t fcap[2] = {0, 0}, gcap[2] = {0, 0};  // pooled allocation sizes
+  // gm_sc_new_borrow: f[0] / g[0] are the CALLER's vectors, read until the first fold has written the halves into f[1] / g[1]; the
+  // slot gets a quarter-size buffer of the prover's own when the second fold needs somewhere to write
+  bool borrowed = false;
   int cur = 0;
   size_t nf = 0, ng = 0;
   uint64_t twist[4];  // Montgomery
@@ -115,6 +118,7 @@ struct SpaceProver {
   uint8_t* f = nullptr;
   uint8_t* g = nullptr;
   size_t nf = 0, ng = 0, fcap = 0, gcap = 0;
+  bool borrowed = false;  // gm_sp_new_borrow: f / g are the caller's stream vectors (a space prover never writes them)
   std::vector<uint64_t> challenges, twisted;  // 4 limbs each, Montgomery
   uint64_t twist[4];
   size_t round = 0, tot_rounds = 0;
@@ -277,6 +281,9 @@ struct Context {
   int msm_split = 0;          // one-call MSMs as two window groups over three streams (gm_set_msm_split)
   int msm_affine_levels = 0;  // affine tree levels in front of the XYZZ accumulation; -1 = automatic
   size_t msm_table_min = (size_t)1 << 17;  // smallest MSM that uses fixed-base tables when present
+  // small results (per-block partial sums, the bit-plane sums of an MSM) are written by their kernels straight into pinned host
+  // memory instead of a device buffer that a blit kernel then copies (GM_ZERO_COPY: bit 0 field paths, bit 1 MSM planes)
+  int zero_copy = 0;
   bool auto_tables = true;    // build fixed-base tables when bases are registered, if they fit (gm_set_auto_tables)
   size_t auto_tables_max = 0;  // byte budget of one key's tables; 0 = 30 % of the device memory
   int cu_count = 256;

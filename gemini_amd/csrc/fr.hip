@@ -615,6 +615,14 @@ static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::F
   // herring's bilinear-module prover uses the twist only when folding; its message is the plain
   // a = <f_e, g_e>, b = <f_e, g_o> + <f_o, g_e> (src/herring/time_prover.rs:104-117)
   if (S->herring) tau_msg = gmh::Fr::one();
+  if (fold && S->borrowed && S->cur == 1) {  // the second fold would write into the caller's vectors: the slot becomes ours
+    S->borrowed = false;
+    S->f[0] = S->g[0] = nullptr;
+    S->fcap[0] = S->gcap[0] = 0;
+    int rcb;
+    if ((rcb = C->pool.alloc(((S->nf + 1) / 2) * FR_BYTES, (void**)&S->f[0], &S->fcap[0]))) return rcb;
+    if ((rcb = C->pool.alloc(((S->ng + 1) / 2) * FR_BYTES, (void**)&S->g[0], &S->gcap[0]))) return rcb;
+  }
   A.f_in = S->f[S->cur];
   A.g_in = S->g[S->cur];
   A.f_out = S->f[S->cur ^ 1];
@@ -653,18 +661,20 @@ static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::F
   // with provers driven one at a time
   Profiler& prof = C->prof;
   prof.begin(PROF_SC_ROUND, st);
+  const bool zc = (C->zero_copy & 1) != 0;  // the blocks write their partial sums into the pinned buffer themselves
+  uint8_t* part_out = zc ? reinterpret_cast<uint8_t*>(S->host_partials) : S->partials;
   if (fold && msg)
-    hipLaunchKernelGGL((k_sc_round<true, true>), dim3(blocks), dim3(256), 0, st, A, S->partials);
+    hipLaunchKernelGGL((k_sc_round<true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
   else if (fold)
-    hipLaunchKernelGGL((k_sc_round<true, false>), dim3(blocks), dim3(256), 0, st, A, S->partials);
+    hipLaunchKernelGGL((k_sc_round<true, false>), dim3(blocks), dim3(256), 0, st, A, part_out);
   else
-    hipLaunchKernelGGL((k_sc_round<false, true>), dim3(blocks), dim3(256), 0, st, A, S->partials);
+    hipLaunchKernelGGL((k_sc_round<false, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
   prof.end(PROF_SC_ROUND, st);
   GM_HIP(hipGetLastError());
   if (prof.on && !msg) GM_HIP(hipStreamSynchronize(st));
   S->pending_blocks = 0;
   if (msg) {
-    GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, st));
+    if (!zc) GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, st));
     S->pending_blocks = blocks;
   }
   if (fold) {
@@ -722,8 +732,10 @@ void PartialBufs::release_all() {
   free_pairs.clear();
 }
 
+// borrow = true: no copy -- the prover reads the caller's device vectors in place until its first fold (the native provers hand it
+// temporaries or vectors that outlive the sumcheck): 2 x n x 32 bytes less to move and to hold per prover
 int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_t ng, bool src_is_device,
-              const uint64_t twist[4], uint64_t* handle) {
+              const uint64_t twist[4], uint64_t* handle, bool borrow) {
   GM_CHECK(nf >= 1 && ng >= 1, GM_EINVAL, "sumcheck: empty vectors");
   auto S = std::make_unique<Sumcheck>();
   S->nf = nf;
@@ -731,6 +743,16 @@ int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_
   memcpy(S->twist, twist, 32);
   S->tot_rounds = ceil_log2_sz(nf > ng ? nf : ng);  // time_prover.rs:35-38
   int rc;
+  if (borrow && src_is_device) {
+    S->borrowed = true;
+    S->f[0] = const_cast<uint8_t*>(static_cast<const uint8_t*>(f_src));
+    S->g[0] = const_cast<uint8_t*>(static_cast<const uint8_t*>(g_src));
+    if ((rc = C->pool.alloc(((nf + 1) / 2) * FR_BYTES, (void**)&S->f[1], &S->fcap[1]))) return rc;
+    if ((rc = C->pool.alloc(((ng + 1) / 2) * FR_BYTES, (void**)&S->g[1], &S->gcap[1]))) return rc;
+    if ((rc = C->partial_bufs.take(&S->partials, &S->host_partials))) return rc;
+    *handle = put_prover(std::move(S));
+    return GM_OK;
+  }
   if ((rc = C->pool.alloc(nf * FR_BYTES, (void**)&S->f[0], &S->fcap[0]))) return rc;
   if ((rc = C->pool.alloc(((nf + 1) / 2) * FR_BYTES, (void**)&S->f[1], &S->fcap[1]))) return rc;
   if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g[0], &S->gcap[0]))) return rc;
@@ -747,7 +769,7 @@ int sc_create(Context* C, const void* f_src, size_t nf, const void* g_src, size_
 void sc_destroy(Sumcheck* S) {
   Context* C = context();
   for (int i = 0; i < 2; i++) {
-    if (C) {
+    if (C && !(i == 0 && S->borrowed)) {
       C->pool.free(S->f[i], S->fcap[i]);
       C->pool.free(S->g[i], S->gcap[i]);
     }
@@ -1042,7 +1064,7 @@ static int sp_reduce(Context* C, SpaceProver* S, SpReduced* R) {
 static size_t ceil_shift(size_t n, uint32_t k) { return k >= 63 ? (n ? 1 : 0) : (n + (((size_t)1 << k) - 1)) >> k; }
 
 int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream, size_t ng, bool src_is_device,
-              const uint64_t twist[4], uint64_t* handle) {
+              const uint64_t twist[4], uint64_t* handle, bool borrow) {
   GM_CHECK(nf >= 1 && ng >= 1, GM_EINVAL, "space prover: empty streams");
   auto S = std::make_unique<SpaceProver>();
   S->nf = nf;
@@ -1050,6 +1072,16 @@ int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream,
   memcpy(S->twist, twist, 32);
   S->tot_rounds = ceil_log2_sz(nf < ng ? nf : ng);  // space_prover.rs:74-77: log2(min(len))
   int rc;
+  if (borrow && src_is_device) {  // the streams are read in place for the life of the prover (it never writes them)
+    S->borrowed = true;
+    S->f = const_cast<uint8_t*>(static_cast<const uint8_t*>(f_stream));
+    S->g = const_cast<uint8_t*>(static_cast<const uint8_t*>(g_stream));
+    if ((rc = C->partial_bufs.take(&S->partials, &S->host_partials))) return rc;
+    std::lock_guard<std::mutex> lk(C->mu);
+    *handle = C->next_handle++;
+    C->space_provers[*handle] = std::move(S);
+    return GM_OK;
+  }
   if ((rc = C->pool.alloc(nf * FR_BYTES, (void**)&S->f, &S->fcap))) return rc;
   if ((rc = C->pool.alloc(ng * FR_BYTES, (void**)&S->g, &S->gcap))) return rc;
   if ((rc = C->partial_bufs.take(&S->partials, &S->host_partials))) return rc;
@@ -1064,7 +1096,7 @@ int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream,
 }
 
 void sp_destroy(Context* C, SpaceProver* S) {
-  if (C) {
+  if (C && !S->borrowed) {
     C->pool.free(S->f, S->fcap);
     C->pool.free(S->g, S->gcap);
   }
@@ -1133,9 +1165,10 @@ int sp_round(Context* C, SpaceProver* S, const uint64_t* challenge, uint64_t a_o
   while (lt < 17 && ((size_t)1 << lt) < A.npairs) lt++;
   A.log_threads = lt;
   const unsigned blocks = (unsigned)(((size_t)1 << lt) / 256);
-  hipLaunchKernelGGL(k_sp_message, dim3(blocks), dim3(256), 0, C->stream, A, S->partials);
+  const bool zc = (C->zero_copy & 1) != 0;
+  hipLaunchKernelGGL(k_sp_message, dim3(blocks), dim3(256), 0, C->stream, A, zc ? reinterpret_cast<uint8_t*>(S->host_partials) : S->partials);
   GM_HIP(hipGetLastError());
-  GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  if (!zc) GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
   GM_HIP(hipStreamSynchronize(C->stream));
   gmh::Fr a = gmh::Fr::zero(), b = gmh::Fr::zero();
   for (unsigned i = 0; i < blocks; i++) {
@@ -1333,9 +1366,11 @@ int fr_ip(Context* C, FrVec* a, FrVec* b, uint64_t result[4]) {
   const unsigned blocks = grid_for(a->len, 512);
   int rc = C->fr_scratch.ensure(1 << 20);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_ip, dim3(blocks), dim3(256), 0, C->stream, a->d, b->d, a->len, C->fr_scratch.as<uint8_t>());
+  const bool zc = (C->zero_copy & 1) != 0;
+  hipLaunchKernelGGL(k_ip, dim3(blocks), dim3(256), 0, C->stream, a->d, b->d, a->len,
+                     zc ? reinterpret_cast<uint8_t*>(C->host_small) : C->fr_scratch.as<uint8_t>());
   GM_HIP(hipGetLastError());
-  GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, (size_t)blocks * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  if (!zc) GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, (size_t)blocks * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
   GM_HIP(hipStreamSynchronize(C->stream));
   gmh::Fr s = gmh::Fr::zero();
   for (unsigned i = 0; i < blocks; i++) s = s + gmh::Fr::from_limbs(C->host_small + (size_t)i * 4);
@@ -1370,9 +1405,11 @@ int fr_eval_le(Context* C, FrVec* p, const uint64_t* xs, size_t npoints, uint64_
   const unsigned blocks = (unsigned)(((size_t)1 << lt) / 256);
   int rc = C->fr_scratch.ensure(1 << 20);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_eval_le, dim3(blocks), dim3(256), 0, C->stream, p->d, p->len, A, C->fr_scratch.as<uint8_t>());
+  const bool zc = (C->zero_copy & 1) != 0;
+  hipLaunchKernelGGL(k_eval_le, dim3(blocks), dim3(256), 0, C->stream, p->d, p->len, A,
+                     zc ? reinterpret_cast<uint8_t*>(C->host_small) : C->fr_scratch.as<uint8_t>());
   GM_HIP(hipGetLastError());
-  GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, (size_t)blocks * 3 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+  if (!zc) GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, (size_t)blocks * 3 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
   GM_HIP(hipStreamSynchronize(C->stream));
   for (size_t k = 0; k < npoints; k++) {
     gmh::Fr s = gmh::Fr::zero();
@@ -1405,14 +1442,16 @@ int fr_eval_le_batch(Context* C, FrVec* const* ps, size_t k, const uint64_t* xs,
     C->host_batch_cap = k * slot;
   }
   std::vector<unsigned> nblocks(k);
+  const bool zc = (C->zero_copy & 1) != 0;
   for (size_t j = 0; j < k; j++) {
     uint32_t lt = 8;
     while (lt < 17 && ((size_t)1 << lt) < ps[j]->len) lt++;
     A.log_threads = lt;
     nblocks[j] = (unsigned)(((size_t)1 << lt) / 256);
-    hipLaunchKernelGGL(k_eval_le, dim3(nblocks[j]), dim3(256), 0, C->stream, ps[j]->d, ps[j]->len, A, C->fr_scratch.as<uint8_t>() + j * slot);
-    GM_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(C->host_batch) + j * slot, C->fr_scratch.as<uint8_t>() + j * slot,
-                          (size_t)nblocks[j] * 3 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+    uint8_t* hdst = reinterpret_cast<uint8_t*>(C->host_batch) + j * slot;
+    hipLaunchKernelGGL(k_eval_le, dim3(nblocks[j]), dim3(256), 0, C->stream, ps[j]->d, ps[j]->len, A,
+                       zc ? hdst : C->fr_scratch.as<uint8_t>() + j * slot);
+    if (!zc) GM_HIP(hipMemcpyAsync(hdst, C->fr_scratch.as<uint8_t>() + j * slot, (size_t)nblocks[j] * 3 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
   }
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));

@@ -2197,8 +2197,21 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     plane_off[k] = plane_count;
     plane_count += (size_t)Wb * (wf[k] + 1);
   }
-  if ((rc = ws.planes.ensure(plane_count * XYZZ_BYTES + 64))) return rc;
-  planes = ws.planes.as<uint8_t>();
+  const size_t plane_bytes = plane_count * XYZZ_BYTES + 24;  // + the scalar-range flag + k_acc0's clock readings
+  if (ws.host_planes_cap[slot] < plane_bytes) {
+    if (ws.host_planes[slot]) (void)hipHostFree(ws.host_planes[slot]);
+    ws.host_planes[slot] = nullptr;
+    ws.host_planes_cap[slot] = 0;
+    GM_HIP(hipHostMalloc((void**)&ws.host_planes[slot], plane_bytes, hipHostMallocDefault));
+    ws.host_planes_cap[slot] = plane_bytes;
+  }
+  const bool zc = (C->zero_copy & 2) != 0;  // the last reduction launch writes what the host reads into the pinned buffer itself
+  if (zc) {
+    planes = reinterpret_cast<uint8_t*>(ws.host_planes[slot]);
+  } else {
+    if ((rc = ws.planes.ensure(plane_count * XYZZ_BYTES + 64))) return rc;
+    planes = ws.planes.as<uint8_t>();
+  }
   const uint8_t* X = ws.buckets.as<uint8_t>();
   const uint32_t n0 = 1u << wf[0], n1 = 1u << wf[1], n2 = 1u << wf[2];
   if (m == 1) {
@@ -2232,15 +2245,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   }
   pf.end(part, PROF_REDUCE, st);
   GM_HIP(hipGetLastError());
-  const size_t plane_bytes = plane_count * XYZZ_BYTES + 24;  // + the scalar-range flag + k_acc0's clock readings
-  if (ws.host_planes_cap[slot] < plane_bytes) {
-    if (ws.host_planes[slot]) (void)hipHostFree(ws.host_planes[slot]);
-    ws.host_planes[slot] = nullptr;
-    ws.host_planes_cap[slot] = 0;
-    GM_HIP(hipHostMalloc((void**)&ws.host_planes[slot], plane_bytes, hipHostMallocDefault));
-    ws.host_planes_cap[slot] = plane_bytes;
-  }
-  GM_HIP(hipMemcpyAsync(ws.host_planes[slot], planes, plane_bytes, hipMemcpyDeviceToHost, st));
+  if (!zc) GM_HIP(hipMemcpyAsync(ws.host_planes[slot], planes, plane_bytes, hipMemcpyDeviceToHost, st));
   GM_HIP(hipEventRecord(ws.done_ev[slot], st));
   P->Wb = Wb;
   P->multi_levels = multi ? multi->levels : 0;

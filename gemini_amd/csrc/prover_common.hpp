@@ -54,11 +54,12 @@ inline const uint8_t* L(const char* s) { return reinterpret_cast<const uint8_t*>
 
 inline int vec_len(uint64_t v, size_t* n) { return gm_fr_vec_len(v, n); }
 
-// Sumcheck::new_time (proof.rs:125-130): prover over copies of f and g, round loop inside the library
+// Sumcheck::new_time (proof.rs:125-130): the prover reads f and g in place (the round loop runs inside this call and the
+// callers do not touch the vectors meanwhile), its folds go to buffers of its own
 inline int sumcheck_new_time(uint64_t transcript, uint64_t f, uint64_t g, const uint64_t twist[4], uint64_t* messages, std::vector<uint64_t>& challenges,
                              size_t cap_rounds, uint64_t final_foldings[8], size_t* rounds) {
   uint64_t prover = 0;
-  RC(gm_sc_new_v(f, g, twist, &prover));
+  RC(gm_sc_new_borrow(f, g, twist, &prover));
   challenges.assign(cap_rounds * 4, 0);
   int rc = gm_sumcheck_prove(transcript, prover, messages, challenges.data(), cap_rounds, final_foldings, rounds);
   (void)gm_sc_free(prover);
@@ -90,7 +91,7 @@ inline int stream_msm(uint64_t bases, uint64_t stream, size_t len, size_t top, s
 inline int sumcheck_new_elastic(uint64_t transcript, uint64_t f_stream, uint64_t g_stream, const uint64_t twist[4], uint64_t* messages,
                          std::vector<uint64_t>& challenges, size_t cap_rounds, uint64_t final_foldings[8], size_t* rounds) {
   uint64_t space = 0, time = 0;
-  RC(gm_sp_new_v(f_stream, g_stream, twist, &space));
+  RC(gm_sp_new_borrow(f_stream, g_stream, twist, &space));
   struct Guard {
     uint64_t &s, &t;
     ~Guard() {

@@ -169,7 +169,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
 
   // EntryProduct::new_time_batch (entryproduct/time_prover.rs:53-114)   :223-239
   t0 = Clock::now();
-  std::vector<uint64_t> provers;
+  std::vector<uint64_t> provers, borrowed_tmp;
   struct ProverGuard {
     std::vector<uint64_t>& p;
     ~ProverGuard() {
@@ -190,9 +190,9 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
     RC(gm_transcript_challenge_fr(T.h, L("ep-chal"), 7, psi));
     for (int k = 0; k < 9; k++) {
       uint64_t h = 0;
-      RC(gm_sc_new_v(acc_vec[k], rrot[k], psi, &h));  // the prover copies its vectors
+      RC(gm_sc_new_borrow(acc_vec[k], rrot[k], psi, &h));  // read in place until the first fold: released after the batch
       provers.push_back(h);
-      V.release(rrot[k]);
+      borrowed_tmp.push_back(rrot[k]);
     }
     uint64_t acc_chal[9][4];
     RC(gm_fr_eval_le_batch(acc_vec, 9, psi, 1, &acc_chal[0][0]));
@@ -232,12 +232,12 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
       uint64_t h, pr = 0;
       RC(V.alloc(nnz, &h));
       RC(gm_fr_hadamard(lhs[k], second_challenges, h));
-      RC(gm_sc_new_v(h, rhs[k], one, &pr));
+      RC(gm_sc_new_borrow(h, rhs[k], one, &pr));
       provers.push_back(pr);
-      V.release(h);
+      borrowed_tmp.push_back(h);
     }
     uint64_t pr = 0;
-    RC(gm_sc_new_v(r_star, alpha_star, psi, &pr));
+    RC(gm_sc_new_borrow(r_star, alpha_star, psi, &pr));
     provers.push_back(pr);
   }
   t0 = Clock::now();
@@ -245,6 +245,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   RC(gm_sumcheck_prove_batch(T.h, provers.data(), provers.size(), P->messages[2], ch3.data(), cap_rounds, &P->third_final_foldings[0][0], &P->rounds[2]));  // :293
   for (uint64_t h : provers) (void)gm_sc_free(h);
   provers.clear();
+  for (uint64_t v : borrowed_tmp) V.release(v);
   P->spans[9] = since(t0);
   for (uint64_t v : {second_challenges, r_star_val, a_ch, b_ch, c_ch, ahp[0], ahp[1], ahp[2], z_abc[0], z_abc[1], z_abc[2]}) V.release(v);
 

@@ -37,7 +37,8 @@ struct ElasticSc {
   }
   int init(uint64_t f_stream, uint64_t g_stream, const uint64_t twist[4], bool elastic) {
     allow_switch = elastic;
-    return gm_sp_new_v(f_stream, g_stream, twist, &space);
+    // no copy: the space prover reads the caller's streams until it is freed (every caller below keeps them that long)
+    return gm_sp_new_borrow(f_stream, g_stream, twist, &space);
   }
   int rounds(size_t* tot) const { return time ? gm_sc_rounds(time, tot, nullptr) : gm_sp_rounds(space, tot, nullptr); }
   // next_message(vm), first half: fold (switching to the time prover when it is time), launch the round
@@ -327,6 +328,7 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
     ElasticSc S2;
     RC(S2.init(zs, rs, one, true));  // Sumcheck::new_elastic :195
     RC(prove_one(T.h, S2, P->messages[1], ch2, cap_rounds, P->final_foldings[1], &P->rounds[1]));
+    S2.reset();
     V.release(zs);
     V.release(rs);
   }
@@ -390,6 +392,7 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
   // EntryProduct::new_elastic_batch (entryproduct/elastic_prover.rs:66-127)
   t0 = Clock::now();
   std::vector<ElasticSc> provers(13);
+  std::vector<uint64_t> batch_streams;  // reversed streams the 13 provers read in place
   uint64_t psi[4];
   {
     RC(K.commit_many(V, std::vector<uint64_t>(accs, accs + 9), (size_t)1 << 20, &P->acc_v_commitments[0][0]));
@@ -405,9 +408,9 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
       uint64_t as, ss;
       RC(reversed(V, accs[k], &as));
       RC(reversed(V, shifts[k], &ss));
-      RC(provers[k].init(as, ss, psi, true));  // the provers copy their streams
-      V.release(as);
-      V.release(ss);
+      RC(provers[k].init(as, ss, psi, true));  // the provers read their streams in place: released after the batch
+      batch_streams.push_back(as);
+      batch_streams.push_back(ss);
     }
   }
   P->spans[7] = since(t0);
@@ -459,21 +462,22 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
       RC(reversed(V, lh[k], &ls));
       RC(reversed(V, vals[k], &vs));
       RC(provers[9 + k].init(ls, vs, one, true));
-      V.release(ls);
-      V.release(vs);
+      batch_streams.push_back(ls);
+      batch_streams.push_back(vs);
       V.release(lh[k]);
     }
     uint64_t rs, as;
     RC(reversed(V, r_star, &rs));
     RC(reversed(V, alpha_star, &as));
     RC(provers[12].init(rs, as, psi, true));
-    V.release(rs);
-    V.release(as);
+    batch_streams.push_back(rs);
+    batch_streams.push_back(as);
   }
   t0 = Clock::now();
   std::vector<uint64_t> ch3(cap_rounds * 4, 0);
   RC(prove_batch(T.h, provers, P->messages[2], ch3.data(), cap_rounds, &P->third_final_foldings[0][0], &P->rounds[2]));  // :380
   provers.clear();
+  for (uint64_t v : batch_streams) V.release(v);
   P->spans[9] = since(t0);
   for (uint64_t v : {ep_r, a_ch, b_ch, c_ch}) V.release(v);
 

@@ -184,7 +184,7 @@ int gm_sumcheck_prove_sharded(uint64_t transcript, uint64_t f_block, uint64_t g_
   RC(dist_rank_world(&rank, &world));
   constexpr size_t TAIL = (size_t)1 << 10;
   uint64_t prover = 0;
-  RC(gm_sc_new_v(f_block, g_block, twist, &prover));
+  RC(gm_sc_new_borrow(f_block, g_block, twist, &prover));
   struct Guard {
     uint64_t& p;
     ~Guard() {

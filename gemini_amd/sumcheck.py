@@ -12,14 +12,19 @@ from .fr import FrVec
 
 
 class TimeProver:
-    def __init__(self, f, g, twist_mont):
-        """Witness::new + TimeProver::new: copies f and g (time_prover.rs:26-32, 57-67)."""
+    def __init__(self, f, g, twist_mont, borrow=False):
+        """Witness::new + TimeProver::new: copies f and g (time_prover.rs:26-32, 57-67).  borrow=True (device vectors only):
+        no copy, the prover reads f and g in place until its first fold -- the caller leaves them alone until then."""
         capi.ensure_init()
         h = C.c_uint64()
         tw = capi.u64(twist_mont).reshape(4)
         if isinstance(f, FrVec) and isinstance(g, FrVec):
-            capi.check(capi.load().gm_sc_new_v(C.c_uint64(f.handle), C.c_uint64(g.handle), capi.ptr(tw), C.byref(h)))
+            new = capi.load().gm_sc_new_borrow if borrow else capi.load().gm_sc_new_v
+            capi.check(new(C.c_uint64(f.handle), C.c_uint64(g.handle), capi.ptr(tw), C.byref(h)))
+            self._keep = (f, g) if borrow else None
         else:
+            if borrow:
+                raise ValueError("borrow=True needs device vectors (FrVec)")
             fm = capi.u64(f).reshape(-1, 4)
             gm = capi.u64(g).reshape(-1, 4)
             capi.check(capi.load().gm_sc_new(capi.ptr(fm), C.c_size_t(len(fm)), capi.ptr(gm), C.c_size_t(len(gm)), capi.ptr(tw), C.byref(h)))
@@ -79,13 +84,18 @@ class SpaceProver:
     """src/subprotocols/sumcheck/space_prover.rs: keeps the big-endian streams and the challenges only;
     every message is recomputed from the streams on the device (gm_sp_*)."""
 
-    def __init__(self, f_stream, g_stream, twist_mont):
+    def __init__(self, f_stream, g_stream, twist_mont, borrow=False):
+        """borrow=True (device vectors only): the prover reads the streams in place for its whole life"""
         capi.ensure_init()
         h = C.c_uint64()
         tw = capi.u64(twist_mont).reshape(4)
         if isinstance(f_stream, FrVec) and isinstance(g_stream, FrVec):
-            capi.check(capi.load().gm_sp_new_v(C.c_uint64(f_stream.handle), C.c_uint64(g_stream.handle), capi.ptr(tw), C.byref(h)))
+            new = capi.load().gm_sp_new_borrow if borrow else capi.load().gm_sp_new_v
+            capi.check(new(C.c_uint64(f_stream.handle), C.c_uint64(g_stream.handle), capi.ptr(tw), C.byref(h)))
+            self._keep = (f_stream, g_stream) if borrow else None
         else:
+            if borrow:
+                raise ValueError("borrow=True needs device vectors (FrVec)")
             fm = capi.u64(f_stream).reshape(-1, 4)
             gm_ = capi.u64(g_stream).reshape(-1, 4)
             capi.check(capi.load().gm_sp_new(capi.ptr(fm), C.c_size_t(len(fm)), capi.ptr(gm_), C.c_size_t(len(gm_)), capi.ptr(tw), C.byref(h)))

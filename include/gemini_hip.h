@@ -316,6 +316,10 @@ int gm_sc_new(const uint64_t* f_mont, size_t nf, const uint64_t* g_mont, size_t 
               uint64_t* handle);
 /* from device vectors (copied), for a prover that keeps its state in HBM */
 int gm_sc_new_v(uint64_t f_vec, uint64_t g_vec, const uint64_t twist_mont[4], uint64_t* handle);
+/* the same WITHOUT the copy: the prover reads f_vec and g_vec in place until its first fold has written their halves into its own
+ * buffers -- the caller keeps both vectors alive and unmodified until then (the provers compiled into the library do: the vectors
+ * are theirs).  2 x n x 32 bytes less to move and to hold per prover. */
+int gm_sc_new_borrow(uint64_t f_vec, uint64_t g_vec, const uint64_t twist_mont[4], uint64_t* handle);
 /* next_message(verifier_message): challenge_or_null == NULL is `None`.  *has_msg = 0 means the
  * reference returned None (round == tot_rounds).                     time_prover.rs:83-123 */
 int gm_sc_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg);
@@ -345,6 +349,9 @@ int gm_sp_new(const uint64_t* f_stream_mont, size_t nf, const uint64_t* g_stream
               uint64_t* handle);
 /* same, the streams taken from device-resident vectors (copied, like gm_sc_new_v) */
 int gm_sp_new_v(uint64_t f_stream_vec, uint64_t g_stream_vec, const uint64_t twist_mont[4], uint64_t* handle);
+/* without the copy: a space prover never writes its streams, so it reads the caller's vectors for its whole life -- they
+ * stay alive and unmodified until gm_sp_free (gm_sp_to_time materialises the time prover in vectors of its own). */
+int gm_sp_new_borrow(uint64_t f_stream_vec, uint64_t g_stream_vec, const uint64_t twist_mont[4], uint64_t* handle);
 int gm_sp_round(uint64_t handle, const uint64_t* challenge_or_null, uint64_t a_mont[4], uint64_t b_mont[4], int* has_msg);
 int gm_sp_fold(uint64_t handle, const uint64_t challenge_mont[4]);
 int gm_sp_rounds(uint64_t handle, size_t* tot_rounds, size_t* round);

@@ -230,6 +230,53 @@ def test_messages_consistency_space_time(gm, oracle):
         tt.free()
 
 
+@pytest.mark.parametrize("nf,ng", [(1, 1), (2, 2), (5, 3), (1000, 1000), (1 << 13, (1 << 13) - 7), (700, 1 << 12)])
+def test_borrowing_provers_leave_their_sources_alone(gm, oracle, nf, ng):
+    """gm_sc_new_borrow / gm_sp_new_borrow: the same messages and foldings as the copying constructors, and the caller's
+    vectors come back bit for bit after the last round (the second fold must not land in them)."""
+    from gemini_amd.fr import FrVec
+
+    f = oracle.fr_to_mont(oracle.random_fr(7100 + nf, nf))
+    g = oracle.fr_to_mont(oracle.random_fr(7200 + ng, ng))
+    tw = oracle.fr_to_mont(oracle.random_fr(7300, 1))[0]
+    chal = oracle.fr_to_mont(oracle.random_fr(7400, 20))
+    fv, gv = FrVec.from_host(f), FrVec.from_host(g)
+    ref, bor = gm.TimeProver(f, g, tw), gm.TimeProver(fv, gv, tw, borrow=True)
+    vm, k = None, 0
+    while True:
+        m1, m2 = ref.next_message(vm), bor.next_message(vm)
+        assert (m1 is None) == (m2 is None)
+        if m1 is None:
+            break
+        assert (m1[0] == m2[0]).all() and (m1[1] == m2[1]).all(), k
+        vm = chal[k]
+        k += 1
+    f1, f2 = ref.final_foldings(), bor.final_foldings()
+    assert (f1[0] == f2[0]).all() and (f1[1] == f2[1]).all()
+    ref.free()
+    bor.free()
+    assert (fv.to_host() == f).all() and (gv.to_host() == g).all()
+    # the space prover over the reversed streams, through its hand-off to a time prover after one round
+    n = min(nf, ng)
+    if n >= 4:
+        fs, gs = FrVec.from_host(f[::-1].copy()), FrVec.from_host(g[::-1].copy())
+        sp_ref, sp_bor = gm.SpaceProver(f[::-1].copy(), g[::-1].copy(), tw), gm.SpaceProver(fs, gs, tw, borrow=True)
+        m1, m2 = sp_ref.next_message(None), sp_bor.next_message(None)
+        assert (m1[0] == m2[0]).all() and (m1[1] == m2[1]).all()
+        m1, m2 = sp_ref.next_message(chal[0]), sp_bor.next_message(chal[0])
+        assert (m1[0] == m2[0]).all() and (m1[1] == m2[1]).all()
+        t1, t2 = sp_ref.to_time_prover(), sp_bor.to_time_prover()
+        sp_ref.free()
+        sp_bor.free()
+        m1, m2 = t1.next_message(chal[1]), t2.next_message(chal[1])
+        assert (m1 is None) == (m2 is None)
+        if m1 is not None:
+            assert (m1[0] == m2[0]).all() and (m1[1] == m2[1]).all()
+        t1.free()
+        t2.free()
+        assert (fs.to_host() == f[::-1]).all() and (gs.to_host() == g[::-1]).all()
+
+
 def test_consistency_elastic(gm, oracle):
     """tests.rs:90-111: elastic == time.  With 30 coefficients the switch happens at the first fold;
     a 2^12-long instance with a lowered threshold exercises several space rounds before the hand-off."""
