@@ -282,8 +282,8 @@ struct Context {
   int msm_affine_levels = 0;  // affine tree levels in front of the XYZZ accumulation; -1 = automatic
   size_t msm_table_min = (size_t)1 << 17;  // smallest MSM that uses fixed-base tables when present
   // small results (per-block partial sums, the bit-plane sums of an MSM) are written by their kernels straight into pinned host
-  // memory instead of a device buffer that a blit kernel then copies (GM_ZERO_COPY: bit 0 field paths, bit 1 MSM planes)
-  int zero_copy = 0;
+  // memory instead of a device buffer that a blit kernel then copies (GM_ZERO_COPY=0 restores the copies; bit 0 field paths, bit 1 MSM planes.  Two A/B runs on one box: snark -i 20 14.9 -> 14.5 ms, -i 24 117.8 -> 117.0, psnark -i 20 129 -> 127, same proof bytes: profiles/r4_zero_copy_probe.txt)
+  int zero_copy = 3;
   bool auto_tables = true;    // build fixed-base tables when bases are registered, if they fit (gm_set_auto_tables)
   size_t auto_tables_max = 0;  // byte budget of one key's tables; 0 = 30 % of the device memory
   int cu_count = 256;
