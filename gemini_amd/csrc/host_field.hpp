@@ -256,6 +256,7 @@ struct G1 {
   // (X/Z^2, Y/Z^3, 1): the unique representative, so equal points give equal bytes
   G1 normalized() const {
     if (is_identity()) return identity();
+    if (z == Fq::one()) return *this;  // what an MSM hands out already is: the transcript and the proof encoders ask again (an inversion is ~20 us)
     Fq zi = z.inv(), zi2 = zi.sqr();
     G1 r;
     r.x = x * zi2;
