@@ -175,6 +175,7 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
 int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* d_scalars, int mont, size_t n,
                         std::unique_ptr<Bases>& out);
 int bases_precompute(Context* C, Bases* b, int c);
+void bases_free_tables(Bases* b);
 int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out96);
 int bases_build_phi(Context* C, Bases* b);
 int sc_set_herring(Sumcheck* S, int on);
@@ -279,7 +280,7 @@ void gm_shutdown(void) {
   Context* C = g_ctx;
   (void)hipStreamSynchronize(C->stream);
   for (auto& kv : C->bases) {
-    if (kv.second->table) (void)hipFree(kv.second->table);
+    bases_free_tables(kv.second.get());
     if (kv.second->phi) (void)hipFree(kv.second->phi);
     if (kv.second->d) (void)hipFree(kv.second->d);
   }
@@ -414,7 +415,7 @@ static int maybe_auto_tables(Context* C, Bases* b) {
   if (!C->auto_tables || b->n < C->msm_table_min || b->n < ((size_t)1 << 17) || b->n >= ((size_t)1 << 26)) return GM_OK;  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT)
   const int c = b->n >= ((size_t)1 << 23) ? 22 : 20;
   const size_t W = (256 + c - 1) / c;
-  const size_t bytes = W * b->n * 96 + (std::min<size_t>(b->n, (size_t)1 << 22) * 192);
+  const size_t bytes = W * b->n * 96 + (std::min<size_t>(b->n, (size_t)1 << 22) * 192) + (c >= 22 ? (size_t)13 * 96 << 22 : 0);  // + the prefix table
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GM_OK;
   const size_t budget = C->auto_tables_max ? C->auto_tables_max : total_b / 100 * 30;
@@ -452,7 +453,7 @@ int gm_g1_bases_free(uint64_t handle) {
     b = std::move(it->second);
     C->bases.erase(it);
   }
-  if (b->table) (void)hipFree(b->table);
+  bases_free_tables(b.get());
   if (b->phi) (void)hipFree(b->phi);
   if (b->d) GM_HIP(hipFree(b->d));
   return GM_OK;
@@ -471,7 +472,10 @@ int gm_g1_bases_table_info(uint64_t handle, int* c, size_t* bytes) {
   Bases* b = find_bases(handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "bases_table_info: unknown handle %llu", (unsigned long long)handle);
   if (c) *c = b->table ? b->tab_c : 0;
-  if (bytes) *bytes = b->table ? (size_t)b->tab_W * b->n * 96 : 0;
+  if (bytes) {
+    *bytes = b->table ? (size_t)b->tab_W * b->n * 96 : 0;
+    for (const auto& ts : b->extra) *bytes += (size_t)ts.W * ts.n * 96;  // prefix tables for the calls below the main table's range
+  }
   return GM_OK;
 }
 

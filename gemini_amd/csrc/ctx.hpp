@@ -57,6 +57,16 @@ struct Bases {
   uint8_t* table = nullptr;
   int tab_c = 0, tab_W = 0;
   size_t tab_min = 0;  // smallest call the tables pay off for (depends on their window width)
+  // PREFIX tables for the calls the main tables do not serve: a wide-window table (c = 22: 2^21 buckets to reduce) loses below
+  // 2^22 pairs, but the short calls of a prover -- the low levels of a folding tree -- walk the FIRST powers of the key, so a second
+  // table over that prefix with a narrower window costs a few GB (13 x 2^22 x 96 B).  A call [first, first + step * n) inside
+  // the prefix with min_n <= n < max_n takes the set.
+  struct TableSet {
+    uint8_t* t = nullptr;
+    int c = 0, W = 0;
+    size_t n = 0, min_n = 0, max_n = 0;
+  };
+  std::vector<TableSet> extra;
   // a CYCLIC SHARE of a committer key (gm_g1_bases_set_cyclic): these n points are the powers i = cyc_rank (mod cyc_world)
   // of a key of cyclic_n powers; gm_ck_* and the provers commit through the all-gather of dist.cpp.  0 = a whole key
   size_t cyclic_n = 0;

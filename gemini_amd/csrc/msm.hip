@@ -1861,8 +1861,27 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   // fixed-base tables (gm_g1_bases_precompute) serve large MSMs; small ones are latency-bound and
   // cheaper with few buckets
   const size_t tab_min = std::max(C->msm_table_min, bases->tab_min);
-  const bool use_table = !multi && bases->table != nullptr && !C->msm_c_override && n >= tab_min && n < ((size_t)1 << ENTRY_W_SHIFT);
-  const int c = multi ? 8 : (use_table ? bases->tab_c : (C->msm_c_override ? C->msm_c_override : choose_window(n)));
+  const uint8_t* tab_ptr = nullptr;  // the table set this call takes: the key's main one, or a prefix set that covers its range
+  int tab_c_sel = 0;
+  size_t tab_n = 0;
+  if (!multi && !C->msm_c_override && n < ((size_t)1 << ENTRY_W_SHIFT)) {
+    if (bases->table != nullptr && n >= tab_min) {
+      tab_ptr = bases->table;
+      tab_c_sel = bases->tab_c;
+      tab_n = bases->n;
+    } else if (C->msm_table_min <= ((size_t)1 << 17) || n >= C->msm_table_min) {
+      const int64_t last = first + step * (int64_t)(n - 1);
+      for (const Bases::TableSet& ts : bases->extra)
+        if (n >= ts.min_n && n < ts.max_n && first >= 0 && last >= 0 && (size_t)first < ts.n && (size_t)last < ts.n) {
+          tab_ptr = ts.t;
+          tab_c_sel = ts.c;
+          tab_n = ts.n;
+          break;
+        }
+    }
+  }
+  const bool use_table = tab_ptr != nullptr;
+  const int c = multi ? 8 : (use_table ? tab_c_sel : (C->msm_c_override ? C->msm_c_override : choose_window(n)));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
   // GLV (glv_split): two 128-bit digit strings per scalar over HALF the windows, the second one on phi(P)
   static const bool sort_atomic_env0 = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
@@ -1877,8 +1896,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint32_t B = 1u << (c - 1);
   const int Wb = multi ? multi->levels * W : (use_table ? 1 : Wg);  // bucket sets (fused calls: one set per (call, window))
   const size_t nbuckets = (size_t)Wb * B;
-  const uint8_t* d_bases = use_table ? bases->table : bases->d;
-  const long long tab_stride = use_table ? (long long)bases->n : 0;
+  const uint8_t* d_bases = use_table ? tab_ptr : bases->d;
+  const long long tab_stride = use_table ? (long long)tab_n : 0;
   const uint64_t Nall = (uint64_t)n * (uint64_t)W * (use_glv ? 2u : 1u);
   const uint64_t N = (uint64_t)n * (uint64_t)(use_table ? W : Wg) * (use_glv ? 2u : 1u);  // entries of this window group
   GM_CHECK(Nall < (1ull << 32), GM_EINVAL, "msm: n*W = %llu entries exceed 2^32; chunk the stream", (unsigned long long)Nall);
@@ -2879,6 +2898,45 @@ int hg1_final(Context* C, HerringG1* H, uint64_t f0_jac[18], uint64_t g0[4], int
   return GM_OK;
 }
 
+// table[w * n + i] = 2^(c w) * d[i], w < ceil(256 / c); row 0 is a copy of d
+static int build_window_table(Context* C, const uint8_t* d, size_t n, int c, uint8_t** out) {
+  const int W = (256 + c - 1) / c;
+  uint8_t* t = nullptr;
+  GM_HIP(dev_malloc((void**)&t, (size_t)W * n * AFF_BYTES));
+  GM_HIP(hipMemcpyAsync(t, d, n * AFF_BYTES, hipMemcpyDeviceToDevice, C->stream));
+  // one slab of XYZZ results at a time (192 B per point), normalised NORM_K points per inversion
+  const size_t slab = std::min<size_t>(n, (size_t)1 << 22);
+  uint8_t* xy = nullptr;
+  {
+    const hipError_t e = dev_malloc((void**)&xy, slab * XYZZ_BYTES);
+    if (e != hipSuccess) (void)hipFree(t);
+    GM_HIP(e);
+  }
+  for (int w = 0; w + 1 < W; w++)
+    for (size_t off = 0; off < n; off += slab) {
+      const size_t m = std::min(slab, n - off);
+      hipLaunchKernelGGL(k_table_next, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, C->stream,
+                         t + ((size_t)w * n + off) * AFF_BYTES, xy, m, c);
+      hipLaunchKernelGGL(k_xyzz_to_affine_batch, dim3((unsigned)(((m + NORM_K - 1) / NORM_K + 255) / 256)), dim3(256), 0, C->stream, xy, m,
+                         t + ((size_t)(w + 1) * n + off) * AFF_BYTES);
+    }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
+  (void)hipFree(xy);
+  if (e != hipSuccess) (void)hipFree(t);
+  GM_HIP(e);
+  *out = t;
+  return GM_OK;
+}
+
+void bases_free_tables(Bases* b) {
+  if (b->table) (void)hipFree(b->table);
+  b->table = nullptr;
+  for (auto& ts : b->extra)
+    if (ts.t) (void)hipFree(ts.t);
+  b->extra.clear();
+}
+
 // gm_g1_bases_precompute
 int bases_precompute(Context* C, Bases* b, int c) {
   // automatic width (measured): c = 20 (13 windows, 2^19 shared buckets) wins from 2^17 pairs on -- 4.14 vs 4.76 ms at
@@ -2890,36 +2948,27 @@ int bases_precompute(Context* C, Bases* b, int c) {
   GM_CHECK(b->n >= 1 && b->n < ((size_t)1 << ENTRY_W_SHIFT), GM_EINVAL, "bases_precompute: %zu bases (need 1 .. 2^26 - 1)", b->n);
   const int W = (256 + c - 1) / c;
   GM_MSM_LOCK(C);
-  if (b->table) {
-    (void)hipFree(b->table);
-    b->table = nullptr;
-  }
+  bases_free_tables(b);
   uint8_t* t = nullptr;
-  GM_HIP(dev_malloc((void**)&t, (size_t)W * b->n * AFF_BYTES));
-  GM_HIP(hipMemcpyAsync(t, b->d, b->n * AFF_BYTES, hipMemcpyDeviceToDevice, C->stream));
-  // one slab of XYZZ results at a time (192 B per point), normalised NORM_K points per inversion
-  const size_t slab = std::min<size_t>(b->n, (size_t)1 << 22);
-  uint8_t* xy = nullptr;
-  {
-    const hipError_t e = dev_malloc((void**)&xy, slab * XYZZ_BYTES);
-    if (e != hipSuccess) (void)hipFree(t);
-    GM_HIP(e);
-  }
-  for (int w = 0; w + 1 < W; w++)
-    for (size_t off = 0; off < b->n; off += slab) {
-      const size_t m = std::min(slab, b->n - off);
-      hipLaunchKernelGGL(k_table_next, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, C->stream,
-                         t + ((size_t)w * b->n + off) * AFF_BYTES, xy, m, c);
-      hipLaunchKernelGGL(k_xyzz_to_affine_batch, dim3((unsigned)(((m + NORM_K - 1) / NORM_K + 255) / 256)), dim3(256), 0, C->stream, xy, m,
-                         t + ((size_t)(w + 1) * b->n + off) * AFF_BYTES);
-    }
-  GM_HIP(hipGetLastError());
-  GM_HIP(hipStreamSynchronize(C->stream));
-  GM_HIP(hipFree(xy));
+  int rc = build_window_table(C, b->d, b->n, c, &t);
+  if (rc) return rc;
   b->table = t;
   b->tab_c = c;
   b->tab_W = W;
   b->tab_min = c >= 22 ? ((size_t)1 << 22) : (c >= 21 ? ((size_t)1 << 21) : 0);
+  // the calls below tab_min: a c = 20 table over the first 2^22 points (GM_PREFIX_TABLES=0: none)
+  static const bool prefix_env = !(getenv("GM_PREFIX_TABLES") && atoi(getenv("GM_PREFIX_TABLES")) == 0);
+  if (auto_c && b->tab_min > 0 && prefix_env) {
+    Bases::TableSet ts;
+    ts.c = 20;
+    ts.W = (256 + ts.c - 1) / ts.c;
+    ts.n = std::min<size_t>(b->n, b->tab_min);
+    ts.min_n = (size_t)1 << 17;
+    ts.max_n = b->tab_min;
+    rc = build_window_table(C, b->d, ts.n, ts.c, &ts.t);
+    if (rc == GM_OK) b->extra.push_back(ts);
+    else if (rc != GM_ENOMEM) return rc;  // no room: those calls keep the plain path
+  }
   return GM_OK;
 }
 

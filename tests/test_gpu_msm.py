@@ -216,6 +216,40 @@ def test_msm_2_23_vs_oracle(gm, oracle):
         reg.free()
 
 
+def test_prefix_tables_serve_the_short_calls_of_a_big_key(gm, oracle):
+    """A key of >= 2^23 points gets c = 22 tables, which lose below 2^22 pairs; calls of 2^17 .. 2^22 - 1 pairs that stay inside the
+    first 2^22 points (the low levels of a folding tree) take a c = 20 table over that prefix.  Same group elements as the plain
+    path, wherever the range lies: inside the prefix, ending at its last point, crossing it (plain path), walked backwards."""
+    import bench
+    from gemini_amd.fr import FrVec
+
+    lib = gm.capi.load()
+    n = 1 << 23
+    rng = np.random.default_rng(2223)
+    reg = gm.G1Bases.fixed_base(oracle.g1_generator(), bench.uniform_fr(rng, n))
+    try:
+        assert reg.table_info() == (22, 12 * n * 96 + 13 * (1 << 22) * 96)
+        P = 1 << 22
+        cases = [((1 << 17) + 5, 0, False), (1 << 18, 12345, False), (1 << 19, P - (1 << 19), False), (1 << 19, P - (1 << 19) + 1, False),
+                 ((1 << 17) + 9, 1 << 20, True), (1 << 21, P - 1, True), (1 << 18, P, True), ((1 << 22) - 1, 0, False), ((1 << 17) - 1, 0, False)]
+        scs = [bench.uniform_fr(rng, m) for m, _, _ in cases]
+        got = [reg.msm_bigint(sc, offset=o, reversed_=r) for sc, (m, o, r) in zip(scs, cases)]
+        levels = [FrVec.from_host(oracle.fr_to_mont(bench.uniform_fr(rng, 1 << k))) for k in range(21, 9, -1)]
+        got_batch = reg.msm_vec_batch(levels, [len(v) for v in levels])
+        gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1 << 62)))  # no tables of any kind
+        for sc, (m, o, r), g in zip(scs, cases, got):
+            assert (reg.msm_bigint(sc, offset=o, reversed_=r) == g).all(), (m, o, r)
+        assert (reg.msm_vec_batch(levels, [len(v) for v in levels]) == got_batch).all()
+        for v in levels:
+            v.free()
+        # and one of them against the CPU Pippenger
+        m, o, r = cases[0]
+        assert_same_point(oracle, got[0], oracle.msm_pippenger(reg.download(o, m), scs[0]))
+    finally:
+        gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1 << 17)))
+        reg.free()
+
+
 def test_tables_are_the_default_for_a_resident_key(gm, oracle):
     """gm_set_auto_tables (on at gm_init): registering 2^17 .. 2^26 - 1 bases builds the fixed-base tables when they fit the
     budget; smaller keys, a tiny budget or the knob turned off leave the plain path.  Same group element either way."""
