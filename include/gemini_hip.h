@@ -84,7 +84,9 @@ int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96);
  * all windows: c = 20 instead of 16 (13 instead of 16 base additions per pair), no per-window bucket
  * reduction and c instead of 256 doublings at the end.  Results are identical (tests compare both
  * paths).  Setup cost is comparable to generating the SRS; like CommitterKey::new it is outside the
- * prover timer.  c = 0 picks the default (20); c = -1 is AUTOMATIC: the rule of gm_set_auto_tables below (2^17 .. 2^26 - 1
+ * prover timer.  c = 0 picks the default (20 below 2^23 points; 22 from there on, which serves calls from 2^22 pairs on, PLUS a
+ * c = 20 table over the first 2^22 points -- 5.2 GB -- for the calls of 2^17 .. 2^22 - 1 pairs whose index range stays inside that
+ * prefix: the low levels of a folding tree); c = -1 is AUTOMATIC: the rule of gm_set_auto_tables below (2^17 .. 2^26 - 1
  * points, byte budget, free memory; a no-op returning GM_OK when the tables do not fit or exist already).
  * No reference counterpart: ark-ec recomputes. */
 int gm_g1_bases_precompute(uint64_t handle, int c);
@@ -96,7 +98,7 @@ int gm_g1_bases_precompute(uint64_t handle, int c);
  * A committer key is registered once and serves ~3 N pairs of MSMs per proof; the build is setup, like
  * CommitterKey::new (src/kzg/time.rs:49-72, which builds a window table of its own to generate the key). */
 int gm_set_auto_tables(int on, size_t max_bytes);
-/* Window width (0 = no tables) and size in bytes of the tables of a handle. */
+/* Window width of the main tables (0 = no tables) and size in bytes of all tables of a handle (prefix table included). */
 int gm_g1_bases_table_info(uint64_t handle, int* c, size_t* bytes);
 /* Give the freed blocks of the device-vector pool (up to 55 % of the device memory) back to the driver -- for a host
  * process that shares the GPU with another allocator (torch, a second rank). */
