@@ -1961,6 +1961,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   static const bool sort_atomic_env = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
   static const bool sort_flat_env = !(getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "blocks"));
   const bool sort_atomic = sort_atomic_env && !use_table && nparts == 1;
+  // (a table call keeps the block sort at every size: one shared bucket set means 16 x the contention on the flat path's global
+  // counters -- measured with a flat variant for tables: 0.63 against 0.61 ms at 2^14 pairs, 0.90 against 0.81 at 2^16)
   const bool sort_flat = sort_flat_env && !sort_atomic && !use_table && nparts == 1 && N <= ((uint64_t)1 << 21) && nbuckets <= ((size_t)1 << 18);
   if (multi) {
     MultiGeom mg{};
@@ -2968,6 +2970,23 @@ int bases_precompute(Context* C, Bases* b, int c) {
     rc = build_window_table(C, b->d, ts.n, ts.c, &ts.t);
     if (rc == GM_OK) b->extra.push_back(ts);
     else if (rc != GM_ENOMEM) return rc;  // no room: those calls keep the plain path
+  }
+  // small calls (GM_SMALL_TABLE_C=0: none): a c = 16 table over the first 2^17 points (201 MB) -- the same 16 additions per pair as
+  // the plain path, but ONE bucket set (2^15 instead of 16 x 2^15 buckets to reduce) and 16 instead of 256 final doublings on the
+  // host, for the latency-bound calls of 2^11 .. 2^17 - 1 pairs at the end of a folding tree.  One call at 2^14 pairs 0.72 -> 0.61 ms,
+  // snark -i 20 14.2 -> 13.6 ms, psnark -i 18 54.5 -> 53.0 ms; c = 12 / 14 / 17 / 18 lose (profiles/r4_small_tables_probe.txt)
+  static const int small_c = getenv("GM_SMALL_TABLE_C") ? atoi(getenv("GM_SMALL_TABLE_C")) : 16;
+  static const int small_min_log = getenv("GM_SMALL_TABLE_MIN") ? atoi(getenv("GM_SMALL_TABLE_MIN")) : 11;
+  if (auto_c && small_c >= 8 && small_c <= 20) {
+    Bases::TableSet ts;
+    ts.c = small_c;
+    ts.W = (256 + ts.c - 1) / ts.c;
+    ts.n = std::min<size_t>(b->n, (size_t)1 << 17);
+    ts.min_n = (size_t)1 << small_min_log;
+    ts.max_n = (size_t)1 << 17;
+    rc = build_window_table(C, b->d, ts.n, ts.c, &ts.t);
+    if (rc == GM_OK) b->extra.push_back(ts);
+    else if (rc != GM_ENOMEM) return rc;
   }
   return GM_OK;
 }

@@ -228,10 +228,13 @@ def test_prefix_tables_serve_the_short_calls_of_a_big_key(gm, oracle):
     rng = np.random.default_rng(2223)
     reg = gm.G1Bases.fixed_base(oracle.g1_generator(), bench.uniform_fr(rng, n))
     try:
-        assert reg.table_info() == (22, 12 * n * 96 + 13 * (1 << 22) * 96)
+        assert reg.table_info() == (22, (12 * n + 13 * (1 << 22) + 16 * (1 << 17)) * 96)
         P = 1 << 22
+        S = 1 << 17  # ... and calls of 2^11 .. 2^17 - 1 pairs inside the first 2^17 points a c = 16 table (one bucket set, 16 final doublings)
         cases = [((1 << 17) + 5, 0, False), (1 << 18, 12345, False), (1 << 19, P - (1 << 19), False), (1 << 19, P - (1 << 19) + 1, False),
-                 ((1 << 17) + 9, 1 << 20, True), (1 << 21, P - 1, True), (1 << 18, P, True), ((1 << 22) - 1, 0, False), ((1 << 17) - 1, 0, False)]
+                 ((1 << 17) + 9, 1 << 20, True), (1 << 21, P - 1, True), (1 << 18, P, True), ((1 << 22) - 1, 0, False), ((1 << 17) - 1, 0, False),
+                 (1 << 11, 0, False), ((1 << 11) - 1, 0, False), ((1 << 13) + 1, 777, False), (1 << 16, S - (1 << 16), False), (1 << 16, S - (1 << 16) + 1, False),
+                 (1 << 14, S - 1, True), (1 << 14, S, True), (3000, 2999, True)]
         scs = [bench.uniform_fr(rng, m) for m, _, _ in cases]
         got = [reg.msm_bigint(sc, offset=o, reversed_=r) for sc, (m, o, r) in zip(scs, cases)]
         levels = [FrVec.from_host(oracle.fr_to_mont(bench.uniform_fr(rng, 1 << k))) for k in range(21, 9, -1)]
@@ -259,7 +262,7 @@ def test_tables_are_the_default_for_a_resident_key(gm, oracle):
     sc = oracle.random_fr(2902, n)
     try:
         reg = gm.G1Bases.fixed_base(oracle.g1_generator(), ks)
-        assert reg.table_info() == (20, 13 * n * 96)
+        assert reg.table_info() == (20, (13 * n + 16 * (1 << 17)) * 96)  # + the c = 16 table of the small calls over the first 2^17 points
         with_tables = reg.msm_bigint(sc)
         assert_same_point(oracle, with_tables, oracle.msm_pippenger(reg.download(), sc))
         reg.free()
@@ -283,14 +286,14 @@ def test_tables_are_the_default_for_a_resident_key(gm, oracle):
         assert up.table_info() == (0, 0)
         assert (up.msm_bigint(sc) == with_tables).all()
         up.precompute(-1)
-        assert up.table_info() == (20, 13 * n * 96)
+        assert up.table_info() == (20, (13 * n + 16 * (1 << 17)) * 96)
         up.precompute(-1)  # idempotent
         assert (up.msm_bigint(sc) == with_tables).all()
         up.free()
         from gemini_amd.kzg import CommitterKey
 
         ck = CommitterKey.from_powers(host, 3)
-        assert ck.powers_of_g.table_info() == (20, 13 * n * 96)
+        assert ck.powers_of_g.table_info() == (20, (13 * n + 16 * (1 << 17)) * 96)
         ck.powers_of_g.free()
         tiny = gm.G1Bases.register(host[:4096])
         tiny.precompute(-1)
