@@ -1767,29 +1767,50 @@ int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k
   uint8_t* seg_sums = sums + nch0 * FR_BYTES;
   uint8_t* carry = seg_sums + nseg0 * FR_BYTES;
   uint8_t* tmp = carry + (nseg0 + 8) * FR_BYTES;
+  // page-locked staging: [alpha_j, alpha_j^64 of every pass][segment sums][carries] -- the parameters of all passes go up in one
+  // copy, phase 2a writes its segment sums straight into host memory, and the carries go back from page-locked memory, so a
+  // pass waits ONCE (for the segment sums) instead of three times around two pageable copies
+  const size_t stage_bytes = k * 64 + 2 * nseg0 * FR_BYTES;
+  if (C->host_batch_cap < stage_bytes) {
+    if (C->host_batch) (void)hipHostFree(C->host_batch);
+    C->host_batch = nullptr;
+    C->host_batch_cap = 0;
+    GM_HIP(hipHostMalloc((void**)&C->host_batch, stage_bytes, hipHostMallocDefault));
+    C->host_batch_cap = stage_bytes;
+  }
+  uint64_t* h_par = C->host_batch;
+  uint64_t* h_seg = h_par + k * 8;
+  uint64_t* h_carry = h_seg + nseg0 * 4;
+  const bool zc = (C->zero_copy & 1) != 0;
+  uint8_t* d_par = base + 4096;  // k <= 8 passes x 64 bytes, inside the 1 MiB head of the scratch
+  std::vector<gmh::Fr> ms(k);
+  for (size_t j = 0; j < k; j++) {
+    const gmh::Fr alpha = gmh::Fr::from_limbs(points + 4 * j);
+    gmh::Fr m = alpha;
+    for (int s6 = 0; s6 < 6; s6++) m = m.sqr();  // alpha^64 = alpha^DIV_K
+    ms[j] = m;
+    memcpy(h_par + 8 * j, alpha.l, 32);
+    memcpy(h_par + 8 * j + 4, m.l, 32);
+  }
+  GM_HIP(hipMemcpyAsync(d_par, h_par, k * 64, hipMemcpyHostToDevice, C->stream));
   const uint8_t* src = f->d;
   size_t n = n0;
   for (size_t j = 0; j < k; j++) {
     // ping-pong so the final quotient lands in q: passes write q, tmp, q, ... ending in q
     uint8_t* dst = ((k - 1 - j) % 2 == 0) ? q->d : tmp;
-    gmh::Fr alpha = gmh::Fr::from_limbs(points + 4 * j);
-    gmh::Fr m = alpha;
-    for (int s = 0; s < 6; s++) m = m.sqr();  // alpha^64 = alpha^DIV_K
+    const gmh::Fr m = ms[j];
     PowTable mt;
     make_pow_table(m, mt);
-    uint64_t small[8];
-    memcpy(small, alpha.l, 32);
-    memcpy(small + 4, m.l, 32);
-    GM_HIP(hipMemcpyAsync(base, small, 64, hipMemcpyHostToDevice, C->stream));
+    const uint32_t* d_alpha = reinterpret_cast<const uint32_t*>(d_par + 64 * j);
     const size_t nch = (n + DIV_K - 1) / DIV_K, nseg = (nch + seg - 1) / seg;
-    hipLaunchKernelGGL(k_div_phase1, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums);
-    hipLaunchKernelGGL(k_div_phase2a, dim3(grid_for(nseg, 1u << 22)), dim3(256), 0, C->stream, sums, nch, seg, (const uint32_t*)(base + 32), seg_sums);
+    hipLaunchKernelGGL(k_div_phase1, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, src, n, d_alpha, sums);
+    hipLaunchKernelGGL(k_div_phase2a, dim3(grid_for(nseg, 1u << 22)), dim3(256), 0, C->stream, sums, nch, seg, d_alpha + 8,
+                       zc ? reinterpret_cast<uint8_t*>(h_seg) : seg_sums);
     {
       // phase 2b on the host: nseg (<= n/4096) sequential steps of a first-order recurrence cost
       // microseconds on a CPU core and milliseconds on a single GPU lane
-      std::vector<uint64_t> hs(nseg * 4), hc(nseg * 4);
-      GM_HIP(hipMemcpyAsync(hs.data(), seg_sums, nseg * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
-      GM_HIP(hipStreamSynchronize(C->stream));
+      if (!zc) GM_HIP(hipMemcpyAsync(h_seg, seg_sums, nseg * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+      GM_HIP(hipStreamSynchronize(C->stream));  // (also: phase 3 of the previous pass has read the carries that are overwritten now)
       gmh::Fr acc = gmh::Fr::zero();
       auto mpow = [&](size_t e) {
         gmh::Fr r = gmh::Fr::one(), b = m;
@@ -1802,24 +1823,20 @@ int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k
       };
       const gmh::Fr mseg = mpow(seg);
       for (size_t sgi = nseg; sgi-- > 0;) {
-        acc.to_limbs(hc.data() + 4 * sgi);
+        acc.to_limbs(h_carry + 4 * sgi);
         const size_t len = std::min(seg, nch - sgi * seg);
-        acc = acc * (len == seg ? mseg : mpow(len)) + gmh::Fr::from_limbs(hs.data() + 4 * sgi);
+        acc = acc * (len == seg ? mseg : mpow(len)) + gmh::Fr::from_limbs(h_seg + 4 * sgi);
       }
-      GM_HIP(hipMemcpyAsync(carry, hc.data(), nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
-      GM_HIP(hipStreamSynchronize(C->stream));  // hc goes out of scope
+      GM_HIP(hipMemcpyAsync(carry, h_carry, nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
     }
-    hipLaunchKernelGGL(k_div_phase3, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, src, n, (const uint32_t*)base, sums, carry, seg, mt, dst,
+    hipLaunchKernelGGL(k_div_phase3, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, src, n, d_alpha, sums, carry, seg, mt, dst,
                        base + 128 + j * 32);
     GM_HIP(hipGetLastError());
-    GM_HIP(hipStreamSynchronize(C->stream));  // `small` staging reused next pass
     src = dst;
     n -= 1;
   }
-  if (rem_out) {
-    GM_HIP(hipMemcpyAsync(rem_out, base + 128, k * 32, hipMemcpyDeviceToHost, C->stream));
-    GM_HIP(hipStreamSynchronize(C->stream));
-  }
+  if (rem_out) GM_HIP(hipMemcpyAsync(rem_out, base + 128, k * 32, hipMemcpyDeviceToHost, C->stream));
+  GM_HIP(hipStreamSynchronize(C->stream));
   q->len = n;
   return GM_OK;
 }
