@@ -1674,21 +1674,31 @@ int fr_acc_product(Context* C, FrVec* v, FrVec* out) {
   uint8_t* prods = C->fr_scratch.as<uint8_t>() + (1 << 20);
   uint8_t* seg_prods = prods + nch * FR_BYTES;
   uint8_t* carry = seg_prods + nseg * FR_BYTES;
+  // page-locked staging as in fr_div_linear_factors: [segment products][carries]
+  if (C->host_batch_cap < 2 * nseg * FR_BYTES) {
+    if (C->host_batch) (void)hipHostFree(C->host_batch);
+    C->host_batch = nullptr;
+    C->host_batch_cap = 0;
+    GM_HIP(hipHostMalloc((void**)&C->host_batch, 2 * nseg * FR_BYTES, hipHostMallocDefault));
+    C->host_batch_cap = 2 * nseg * FR_BYTES;
+  }
+  uint64_t* hs = C->host_batch;
+  uint64_t* hc = hs + nseg * 4;
+  const bool zc = (C->zero_copy & 1) != 0;
   hipLaunchKernelGGL(k_accp_phase1, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, v->d, n, prods);
-  hipLaunchKernelGGL(k_accp_phase2a, dim3(grid_for(nseg, 1u << 22)), dim3(256), 0, C->stream, prods, nch, seg, seg_prods);
+  hipLaunchKernelGGL(k_accp_phase2a, dim3(grid_for(nseg, 1u << 22)), dim3(256), 0, C->stream, prods, nch, seg,
+                     zc ? reinterpret_cast<uint8_t*>(hs) : seg_prods);
   GM_HIP(hipGetLastError());
   {
     // carry[s] = product of the segments above s: nseg <= n / 4096 sequential host multiplications
-    std::vector<uint64_t> hs(nseg * 4), hc(nseg * 4);
-    GM_HIP(hipMemcpyAsync(hs.data(), seg_prods, nseg * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+    if (!zc) GM_HIP(hipMemcpyAsync(hs, seg_prods, nseg * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
     GM_HIP(hipStreamSynchronize(C->stream));
     gmh::Fr acc = gmh::Fr::one();
     for (size_t s = nseg; s-- > 0;) {
-      acc.to_limbs(hc.data() + 4 * s);
-      acc = acc * gmh::Fr::from_limbs(hs.data() + 4 * s);
+      acc.to_limbs(hc + 4 * s);
+      acc = acc * gmh::Fr::from_limbs(hs + 4 * s);
     }
-    GM_HIP(hipMemcpyAsync(carry, hc.data(), nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
-    GM_HIP(hipStreamSynchronize(C->stream));
+    GM_HIP(hipMemcpyAsync(carry, hc, nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
   }
   hipLaunchKernelGGL(k_accp_phase3, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, v->d, n, prods, carry, seg, out->d);
   GM_HIP(hipGetLastError());

@@ -86,7 +86,8 @@ int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96);
  * paths).  Setup cost is comparable to generating the SRS; like CommitterKey::new it is outside the
  * prover timer.  c = 0 picks the default (20 below 2^23 points; 22 from there on, which serves calls from 2^22 pairs on, PLUS a
  * c = 20 table over the first 2^22 points -- 5.2 GB -- for the calls of 2^17 .. 2^22 - 1 pairs whose index range stays inside that
- * prefix: the low levels of a folding tree); c = -1 is AUTOMATIC: the rule of gm_set_auto_tables below (2^17 .. 2^26 - 1
+ * prefix: the low levels of a folding tree -- and, for every key, a c = 16 table over the first 2^17 points, 201 MB, for the
+ * latency-bound calls of 2^11 .. 2^17 - 1 pairs: one bucket set, 16 final doublings); c = -1 is AUTOMATIC: the rule of gm_set_auto_tables below (2^17 .. 2^26 - 1
  * points, byte budget, free memory; a no-op returning GM_OK when the tables do not fit or exist already).
  * No reference counterpart: ark-ec recomputes. */
 int gm_g1_bases_precompute(uint64_t handle, int c);
