@@ -228,17 +228,17 @@ struct EvalArgs {
   // evaluates every polynomial at beta^2, beta, -beta and every folding at beta, -beta (tensorcheck/mod.rs:228-247).
   uint32_t neg_of[3];
 };
-__global__ __launch_bounds__(256) void k_eval_le(const uint8_t* __restrict__ p, size_t n, EvalArgs A,
-                                                 uint8_t* __restrict__ partials) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
-  const size_t T = (size_t)1 << A.log_threads;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// one block's share of p(x_k): thread t of T owns coefficients t, t + T, ...; partial sums of the block -> out[k]
+__device__ __forceinline__ void eval_le_block(const uint8_t* __restrict__ p, size_t n, const EvalArgs& A, uint32_t log_threads, size_t block,
+                                              uint8_t* __restrict__ out, uint8_t* lds) {
+  const size_t T = (size_t)1 << log_threads;
+  const size_t t = block * blockDim.x + threadIdx.x;
   Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};
   if (t < n) {
     Fr step[3];
     for (uint32_t k = 0; k < 3; k++)
 #pragma unroll
-      for (int i = 0; i < 8; i++) step[k].l[i] = A.xt[k < A.npoints ? k : 0].p[A.log_threads][i];
+      for (int i = 0; i < 8; i++) step[k].l[i] = A.xt[k < A.npoints ? k : 0].p[log_threads][i];
     // highest index owned by this thread
     size_t cnt = (n - t + T - 1) / T;
     for (size_t c = cnt; c-- > 0;) {
@@ -253,7 +253,29 @@ __global__ __launch_bounds__(256) void k_eval_le(const uint8_t* __restrict__ p, 
   }
   block_sum<3>(acc, lds);
   if (threadIdx.x == 0)
-    for (int k = 0; k < 3; k++) fp_store<FrParams>(partials + ((size_t)blockIdx.x * 3 + k) * FR_BYTES, acc[k]);
+    for (int k = 0; k < 3; k++) fp_store<FrParams>(out + k * FR_BYTES, acc[k]);
+}
+__global__ __launch_bounds__(256) void k_eval_le(const uint8_t* __restrict__ p, size_t n, EvalArgs A,
+                                                 uint8_t* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
+  eval_le_block(p, n, A, A.log_threads, blockIdx.x, partials + (size_t)blockIdx.x * 3 * FR_BYTES, lds);
+}
+// several polynomials at the same points in ONE launch (the 23 folding levels of a tensor check: 2^23 ... 2 coefficients, most of
+// them a lone block whose launch costs more than its work): job j owns blocks [blk_start, next job's blk_start)
+struct EvalJob {
+  const uint8_t* p;
+  uint64_t n;
+  uint64_t out_off;  // byte offset of the job's partial records
+  uint32_t log_threads, blk_start;
+};
+__global__ __launch_bounds__(256) void k_eval_le_multi(const EvalJob* __restrict__ jobs, uint32_t njobs, EvalArgs A,
+                                                       uint8_t* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
+  uint32_t j = 0;
+  while (j + 1 < njobs && jobs[j + 1].blk_start <= blockIdx.x) j++;
+  const EvalJob J = jobs[j];
+  const size_t lb = blockIdx.x - J.blk_start;
+  eval_le_block(J.p, (size_t)J.n, A, J.log_threads, lb, partials + J.out_off + lb * 3 * FR_BYTES, lds);
 }
 
 // out[i] = sum_j c_j p_j[i], polynomials of different lengths (missing = 0)      misc.rs:37-48
@@ -1432,27 +1454,41 @@ int fr_eval_le_batch(Context* C, FrVec* const* ps, size_t k, const uint64_t* xs,
   A.npoints = (uint32_t)npoints;
   eval_mark_negations(A, xs, npoints);
   const size_t slot = (size_t)512 * 3 * FR_BYTES;  // per polynomial: <= 2^17 threads = 512 blocks
-  int rc = C->fr_scratch.ensure(k * slot);
+  const size_t jobs_bytes = k * sizeof(EvalJob);
+  int rc = C->fr_scratch.ensure(k * slot + jobs_bytes);
   if (rc) return rc;
-  if (C->host_batch_cap < k * slot) {
+  if (C->host_batch_cap < k * slot + jobs_bytes) {
     if (C->host_batch) (void)hipHostFree(C->host_batch);
     C->host_batch = nullptr;
     C->host_batch_cap = 0;
-    GM_HIP(hipHostMalloc((void**)&C->host_batch, k * slot, hipHostMallocDefault));
-    C->host_batch_cap = k * slot;
+    GM_HIP(hipHostMalloc((void**)&C->host_batch, k * slot + jobs_bytes, hipHostMallocDefault));
+    C->host_batch_cap = k * slot + jobs_bytes;
   }
   std::vector<unsigned> nblocks(k);
   const bool zc = (C->zero_copy & 1) != 0;
+  // the job list rides in page-locked memory behind the result slots; one copy, one launch
+  EvalJob* h_jobs = reinterpret_cast<EvalJob*>(reinterpret_cast<uint8_t*>(C->host_batch) + k * slot);
+  EvalJob* d_jobs = reinterpret_cast<EvalJob*>(C->fr_scratch.as<uint8_t>() + k * slot);
+  uint32_t total_blocks = 0;
   for (size_t j = 0; j < k; j++) {
     uint32_t lt = 8;
     while (lt < 17 && ((size_t)1 << lt) < ps[j]->len) lt++;
-    A.log_threads = lt;
     nblocks[j] = (unsigned)(((size_t)1 << lt) / 256);
-    uint8_t* hdst = reinterpret_cast<uint8_t*>(C->host_batch) + j * slot;
-    hipLaunchKernelGGL(k_eval_le, dim3(nblocks[j]), dim3(256), 0, C->stream, ps[j]->d, ps[j]->len, A,
-                       zc ? hdst : C->fr_scratch.as<uint8_t>() + j * slot);
-    if (!zc) GM_HIP(hipMemcpyAsync(hdst, C->fr_scratch.as<uint8_t>() + j * slot, (size_t)nblocks[j] * 3 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+    h_jobs[j].p = ps[j]->d;
+    h_jobs[j].n = ps[j]->len;
+    h_jobs[j].out_off = j * slot;
+    h_jobs[j].log_threads = lt;
+    h_jobs[j].blk_start = total_blocks;
+    total_blocks += nblocks[j];
   }
+  A.log_threads = 0;  // per job
+  GM_HIP(hipMemcpyAsync(d_jobs, h_jobs, jobs_bytes, hipMemcpyHostToDevice, C->stream));
+  hipLaunchKernelGGL(k_eval_le_multi, dim3(total_blocks), dim3(256), 0, C->stream, d_jobs, (uint32_t)k, A,
+                     zc ? reinterpret_cast<uint8_t*>(C->host_batch) : C->fr_scratch.as<uint8_t>());
+  if (!zc)
+    for (size_t j = 0; j < k; j++)
+      GM_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(C->host_batch) + j * slot, C->fr_scratch.as<uint8_t>() + j * slot, (size_t)nblocks[j] * 3 * FR_BYTES,
+                            hipMemcpyDeviceToHost, C->stream));
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
   for (size_t j = 0; j < k; j++) {
