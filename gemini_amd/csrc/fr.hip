@@ -279,10 +279,13 @@ __global__ __launch_bounds__(256) void k_eval_le_multi(const EvalJob* __restrict
 }
 
 // out[i] = sum_j c_j p_j[i], polynomials of different lengths (missing = 0)      misc.rs:37-48
+// (32 terms: the merged opening polynomial of a tensor check is w + one term per folding level -- 25 at 2^24 constraints, 29 at 2^28 --
+// and a second pass would read and write the 2^n-element sum once more)
+constexpr size_t LINCOMB_MAX = 32;
 struct LincombArgs {
-  const uint8_t* p[24];
-  size_t len[24];
-  uint32_t c[24][8];
+  const uint8_t* p[LINCOMB_MAX];
+  size_t len[LINCOMB_MAX];
+  uint32_t c[LINCOMB_MAX][8];
   uint32_t k;
 };
 __global__ __launch_bounds__(256) void k_lincomb(LincombArgs A, size_t n, uint8_t* __restrict__ out) {
@@ -1528,10 +1531,10 @@ int fr_lincomb(Context* C, FrVec** polys, const uint64_t* coeffs, size_t k, FrVe
     out->len = 0;
     return GM_OK;
   }
-  for (size_t j0 = 0; j0 < k || j0 == 0; j0 += 24) {
+  for (size_t j0 = 0; j0 < k || j0 == 0; j0 += LINCOMB_MAX) {
     LincombArgs A;
     memset(&A, 0, sizeof A);
-    size_t cnt = k - j0 < 24 ? k - j0 : 24;
+    size_t cnt = k - j0 < LINCOMB_MAX ? k - j0 : LINCOMB_MAX;
     A.k = (uint32_t)cnt;
     for (size_t j = 0; j < cnt; j++) {
       A.p[j] = polys[j0 + j]->d;

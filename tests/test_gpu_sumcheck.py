@@ -127,6 +127,34 @@ def test_vector_helpers_vs_oracle(gm, oracle):
         gm.hadamard(f, g[:10])
 
 
+def test_many_term_passes_vs_oracle(gm, oracle, pyref):
+    """linear_combination of more terms than one launch takes (32 per pass: 70 ragged polynomials = three passes) and
+    evaluate_le_batch of a folding-tree-shaped batch in its single launch (2^17 + 3 ... 1 coefficients, 1 to 512 blocks per job,
+    an x / -x pair of points), both against the CPU restatement"""
+    from gemini_amd.fr import FrVec, evaluate_le_batch
+
+    rng = np.random.default_rng(321)
+    lens = [int(v) for v in rng.integers(1, 5000, size=70)]
+    lens[3], lens[40], lens[69] = 6000, 1, 5999
+    polys = [oracle.fr_to_mont(oracle.random_fr(8800 + i, n)) for i, n in enumerate(lens)]
+    ch = oracle.fr_to_mont(oracle.random_fr(8799, 70))
+    assert (gm.linear_combination(polys, ch).to_host() == oracle.linear_combination(polys, ch)).all()
+    x = oracle.fr_to_mont(oracle.random_fr(8798, 1))[0]
+    xi = oracle.limbs_to_ints(oracle.fr_from_mont(x.reshape(1, 4)))[0]
+    pts = np.stack([x, oracle.fr_to_mont(oracle.ints_to_limbs([(pyref.R_MOD - xi) % pyref.R_MOD], 4))[0]])
+    n, tree = (1 << 17) + 3, []
+    while n >= 1:
+        tree.append(oracle.fr_to_mont(oracle.random_fr(8700 + len(tree), n)))
+        n //= 2
+    vecs = [FrVec.from_host(t) for t in tree]
+    got = evaluate_le_batch(vecs, pts)
+    for j, t in enumerate(tree):
+        for q in range(2):
+            assert (got[j][q] == oracle.evaluate_le(t, pts[q])).all(), (j, q)
+    for v in vecs:
+        v.free()
+
+
 def test_reference_known_answers_on_gpu(gm, oracle):
     """the reference's RNG-free tests, run through the device path:
     src/misc.rs:402-422 (linear_combination), src/subprotocols/tensorcheck/mod.rs:388-398 (fold)."""
