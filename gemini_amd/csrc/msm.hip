@@ -1929,7 +1929,9 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint64_t E1 = 2 * T0pad;
 
   int rc;
-  if ((rc = ws.counts.ensure((nbuckets + 2) * 4))) return rc;  // [nbuckets + 1] = scalar-range flag
+  // [nbuckets + 1] = scalar-range flag; behind it the coarse-bin counters of the block sort, so that ONE memset clears both
+  const size_t counts_words = (nbuckets + 2 + SORT_GMAX + 1 + 63) / 64 * 64;
+  if ((rc = ws.counts.ensure(counts_words * 4))) return rc;
   if ((rc = ws.offsets.ensure((nbuckets + 1) * 4))) return rc;
   if ((rc = ws.cursor.ensure((nbuckets + 1) * 4))) return rc;
   if ((rc = ws.misc.ensure((nbuckets / SCAN_PER_BLOCK + 2) * 4))) return rc;
@@ -1942,7 +1944,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   if ((rc = ws.pp[1].ensure(E2 * bucket_bytes))) return rc;
 
   const uint32_t* sc = reinterpret_cast<const uint32_t*>(d_scalars);
-  GM_HIP(hipMemsetAsync(ws.counts.p, 0, (nbuckets + 2) * 4, st));
+  GM_HIP(hipMemsetAsync(ws.counts.p, 0, counts_words * 4, st));
   uint32_t* d_err = ws.counts.as<uint32_t>() + nbuckets + 1;
   // levels (an experiment build) rewrite the entry lists, so the counts no longer say which buckets get written: clear there
   const bool bucket_counts_valid = levels == 0;
@@ -2039,12 +2041,11 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     sg.G = (uint32_t)(nbuckets >> sg.FB);
     GM_CHECK(sg.G <= SORT_GMAX, GM_EINVAL, "msm: %u coarse sort bins exceed %u (window %d too wide for this sort)", sg.G, SORT_GMAX, c);
     if ((rc = ws.tmp_entries.ensure(N * 8))) return rc;
-    if ((rc = ws.sortmeta.ensure((size_t)(4 * (sg.G + 1)) * 4))) return rc;
-    uint32_t* gcount = ws.sortmeta.as<uint32_t>();
-    uint32_t* goff = gcount + (sg.G + 1);
+    if ((rc = ws.sortmeta.ensure((size_t)(3 * (sg.G + 1)) * 4))) return rc;
+    uint32_t* gcount = ws.counts.as<uint32_t>() + nbuckets + 2;  // cleared with the bucket counters above
+    uint32_t* goff = ws.sortmeta.as<uint32_t>();
     uint32_t* gcursor = goff + (sg.G + 1);
     uint32_t* blkoff = gcursor + (sg.G + 1);
-    GM_HIP(hipMemsetAsync(gcount, 0, (sg.G + 1) * 4, st));
     const uint32_t b1 = (uint32_t)((n + SORT_TS - 1) / SORT_TS);
     const uint32_t b2 = (uint32_t)(N / SORT_CH + sg.G + 1);
     pf.begin(part, PROF_DIGITS, st);
