@@ -412,10 +412,15 @@ int gm_set_msm_affine_levels(int levels) {
 // prover (src/kzg/time.rs:49-72 builds a window table of its own to GENERATE the key) -- so when W x n x 96 bytes fit the
 // budget (default: 30 % of the device memory) the tables are built at registration, outside every prover span.
 static int maybe_auto_tables(Context* C, Bases* b) {
-  if (!C->auto_tables || b->n < C->msm_table_min || b->n < ((size_t)1 << 17) || b->n >= ((size_t)1 << 26)) return GM_OK;  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT)
+  if (!C->auto_tables || b->n < C->msm_table_min || b->n < ((size_t)1 << 17)) return GM_OK;
+  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT).  Longer keys -- up to 2^29 points, the keys of `snark -i 26 / 27` --
+  // get tables over their first points only (bases_precompute)
+  const bool prefix_only = b->n >= ((size_t)1 << 26);
+  if (prefix_only && b->n >= ((size_t)1 << 29)) return GM_OK;
   const int c = b->n >= ((size_t)1 << 23) ? 22 : 20;
   const size_t W = (256 + c - 1) / c;
-  const size_t bytes = W * b->n * 96 + (std::min<size_t>(b->n, (size_t)1 << 22) * 192) + (c >= 22 ? (size_t)13 * 96 << 22 : 0);  // + the prefix table
+  const size_t bytes = (prefix_only ? (size_t)12 * 96 << 25 : W * b->n * 96) + (std::min<size_t>(b->n, (size_t)1 << 22) * 192) +
+                       (c >= 22 ? (size_t)13 * 96 << 22 : 0) + ((size_t)16 * 96 << 17);  // + the prefix tables
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GM_OK;
   const size_t budget = C->auto_tables_max ? C->auto_tables_max : total_b / 100 * 30;
@@ -463,7 +468,7 @@ int gm_g1_bases_precompute(uint64_t handle, int c) {
   GM_CTX();
   Bases* b = find_bases(handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "bases_precompute: unknown handle %llu", (unsigned long long)handle);
-  if (c == -1) return b->table ? GM_OK : maybe_auto_tables(C, b);  // automatic: the rule of the key constructors (size range, budget, free memory)
+  if (c == -1) return (b->table || !b->extra.empty()) ? GM_OK : maybe_auto_tables(C, b);  // automatic: the rule of the key constructors (size range, budget, free memory)
   return bases_precompute(C, b, c);
 }
 

@@ -2946,49 +2946,49 @@ int bases_precompute(Context* C, Bases* b, int c) {
   // 2^20 --; a key of >= 2^23 points mostly serves big calls, where c = 22 (12 windows, 2^21 buckets) gives
   // 43.8 vs 47.8 (c = 20) vs 51.5 ms (no tables) at 2^24 but loses below 2^22 pairs to its bucket reduction
   const bool auto_c = c == 0;
+  // a key too long for tables of its own (the pair index of a table entry has 26 bits) still gets PREFIX tables (automatic mode
+  // only): half of the pairs of a proof are folding levels, and they walk the first powers
+  const bool prefix_only = auto_c && b->n >= ((size_t)1 << ENTRY_W_SHIFT);
   if (auto_c) c = b->n >= ((size_t)1 << 23) ? 22 : 20;
   GM_CHECK(c >= 8 && c <= 22, GM_EINVAL, "bases_precompute: window %d outside [8, 22]", c);
-  GM_CHECK(b->n >= 1 && b->n < ((size_t)1 << ENTRY_W_SHIFT), GM_EINVAL, "bases_precompute: %zu bases (need 1 .. 2^26 - 1)", b->n);
+  GM_CHECK(b->n >= 1 && (prefix_only || b->n < ((size_t)1 << ENTRY_W_SHIFT)), GM_EINVAL, "bases_precompute: %zu bases (need 1 .. 2^26 - 1)", b->n);
   const int W = (256 + c - 1) / c;
   GM_MSM_LOCK(C);
   bases_free_tables(b);
-  uint8_t* t = nullptr;
-  int rc = build_window_table(C, b->d, b->n, c, &t);
-  if (rc) return rc;
-  b->table = t;
-  b->tab_c = c;
-  b->tab_W = W;
-  b->tab_min = c >= 22 ? ((size_t)1 << 22) : (c >= 21 ? ((size_t)1 << 21) : 0);
-  // the calls below tab_min: a c = 20 table over the first 2^22 points (GM_PREFIX_TABLES=0: none)
-  static const bool prefix_env = !(getenv("GM_PREFIX_TABLES") && atoi(getenv("GM_PREFIX_TABLES")) == 0);
-  if (auto_c && b->tab_min > 0 && prefix_env) {
-    Bases::TableSet ts;
-    ts.c = 20;
-    ts.W = (256 + ts.c - 1) / ts.c;
-    ts.n = std::min<size_t>(b->n, b->tab_min);
-    ts.min_n = (size_t)1 << 17;
-    ts.max_n = b->tab_min;
-    rc = build_window_table(C, b->d, ts.n, ts.c, &ts.t);
-    if (rc == GM_OK) b->extra.push_back(ts);
-    else if (rc != GM_ENOMEM) return rc;  // no room: those calls keep the plain path
+  int rc = GM_OK;
+  if (!prefix_only) {
+    uint8_t* t = nullptr;
+    if ((rc = build_window_table(C, b->d, b->n, c, &t))) return rc;
+    b->table = t;
+    b->tab_c = c;
+    b->tab_W = W;
+    b->tab_min = c >= 22 ? ((size_t)1 << 22) : (c >= 21 ? ((size_t)1 << 21) : 0);
   }
+  if (!auto_c) return GM_OK;
+  static const bool prefix_env = !(getenv("GM_PREFIX_TABLES") && atoi(getenv("GM_PREFIX_TABLES")) == 0);
+  auto add_set = [&](int sc, size_t points, size_t min_n, size_t max_n) -> int {
+    Bases::TableSet ts;
+    ts.c = sc;
+    ts.W = (256 + sc - 1) / sc;
+    ts.n = std::min<size_t>(b->n, points);
+    ts.min_n = min_n;
+    ts.max_n = max_n;
+    const int r = build_window_table(C, b->d, ts.n, ts.c, &ts.t);
+    if (r == GM_OK) b->extra.push_back(ts);
+    return r == GM_ENOMEM ? GM_OK : r;  // no room: those calls keep the plain path
+  };
+  // (GM_PREFIX_TABLES=0: none of the two)
+  // a long key: c = 22 over the first 2^25 points (38.7 GB) for the calls of 2^22 .. 2^25 pairs inside them
+  if (prefix_only && prefix_env && (rc = add_set(22, (size_t)1 << 25, (size_t)1 << 22, ((size_t)1 << 25) + 1))) return rc;
+  // the calls below the range of a c = 22 table: c = 20 over the first 2^22 points (5.2 GB)
+  if ((prefix_only || b->tab_min > 0) && prefix_env && (rc = add_set(20, (size_t)1 << 22, (size_t)1 << 17, (size_t)1 << 22))) return rc;
   // small calls (GM_SMALL_TABLE_C=0: none): a c = 16 table over the first 2^17 points (201 MB) -- the same 16 additions per pair as
   // the plain path, but ONE bucket set (2^15 instead of 16 x 2^15 buckets to reduce) and 16 instead of 256 final doublings on the
   // host, for the latency-bound calls of 2^11 .. 2^17 - 1 pairs at the end of a folding tree.  One call at 2^14 pairs 0.72 -> 0.61 ms,
   // snark -i 20 14.2 -> 13.6 ms, psnark -i 18 54.5 -> 53.0 ms; c = 12 / 14 / 17 / 18 lose (profiles/r4_small_tables_probe.txt)
   static const int small_c = getenv("GM_SMALL_TABLE_C") ? atoi(getenv("GM_SMALL_TABLE_C")) : 16;
   static const int small_min_log = getenv("GM_SMALL_TABLE_MIN") ? atoi(getenv("GM_SMALL_TABLE_MIN")) : 11;
-  if (auto_c && small_c >= 8 && small_c <= 20) {
-    Bases::TableSet ts;
-    ts.c = small_c;
-    ts.W = (256 + ts.c - 1) / ts.c;
-    ts.n = std::min<size_t>(b->n, (size_t)1 << 17);
-    ts.min_n = (size_t)1 << small_min_log;
-    ts.max_n = (size_t)1 << 17;
-    rc = build_window_table(C, b->d, ts.n, ts.c, &ts.t);
-    if (rc == GM_OK) b->extra.push_back(ts);
-    else if (rc != GM_ENOMEM) return rc;
-  }
+  if (small_c >= 8 && small_c <= 20 && (rc = add_set(small_c, (size_t)1 << 17, (size_t)1 << small_min_log, (size_t)1 << 17))) return rc;
   return GM_OK;
 }
 

@@ -253,6 +253,31 @@ def test_prefix_tables_serve_the_short_calls_of_a_big_key(gm, oracle):
         reg.free()
 
 
+def test_prefix_tables_of_a_key_too_long_for_tables_of_its_own(gm, oracle):
+    """2^26 points and more cannot have whole-key tables (26-bit pair index in a table entry), but the folding levels of a proof --
+    half of its pairs -- walk the first powers: such a key gets c = 22 over its first 2^25 points, c = 20 over the first 2^22 and
+    c = 16 over the first 2^17.  Same group elements as the plain path inside, at the edge of and across each prefix."""
+    import bench
+
+    lib = gm.capi.load()
+    n = (1 << 26) + 5
+    rng = np.random.default_rng(2626)
+    reg = gm.G1Bases.fixed_base(oracle.g1_generator(), bench.uniform_fr(rng, n))
+    try:
+        assert reg.table_info() == (0, (12 * (1 << 25) + 13 * (1 << 22) + 16 * (1 << 17)) * 96)
+        Q = 1 << 25
+        cases = [(1 << 22, 0, False), ((1 << 22) + 3, Q - (1 << 22) - 3, False), (1 << 22, Q - (1 << 22) + 1, False), (1 << 23, Q - 1, True),
+                 (1 << 19, 5, False), (1 << 13, 1 << 16, True), (1 << 22, n - 1, True)]
+        scs = [bench.uniform_fr(rng, m) for m, _, _ in cases]
+        got = [reg.msm_bigint(sc, offset=o, reversed_=r) for sc, (m, o, r) in zip(scs, cases)]
+        gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1 << 62)))  # no tables of any kind
+        for sc, (m, o, r), g in zip(scs, cases, got):
+            assert (reg.msm_bigint(sc, offset=o, reversed_=r) == g).all(), (m, o, r)
+    finally:
+        gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1 << 17)))
+        reg.free()
+
+
 def test_tables_are_the_default_for_a_resident_key(gm, oracle):
     """gm_set_auto_tables (on at gm_init): registering 2^17 .. 2^26 - 1 bases builds the fixed-base tables when they fit the
     budget; smaller keys, a tiny budget or the knob turned off leave the plain path.  Same group element either way."""
