@@ -22,12 +22,33 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 
 // hipMalloc for the long-lived allocations outside the vector pool (bases, tables, matrices, index vectors): when the device
 // is out of memory the pool may be holding up to 55 % of it in freed blocks -- give them back and retry once
+bool release_spare_tables(Context* C) {
+  if (!C || C->msm_busy.load() != 0) return false;
+  std::unique_lock<std::recursive_mutex> lk(C->msm_mu, std::try_to_lock);
+  if (!lk.owns_lock() || C->msm_busy.load() != 0) return false;
+  bool any = false;
+  std::lock_guard<std::mutex> lk2(C->mu);
+  for (auto& kv : C->bases) any = any || !kv.second->extra.empty();
+  if (!any) return false;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : C->bases) {
+    for (auto& ts : kv.second->extra)
+      if (ts.t) (void)hipFree(ts.t);
+    kv.second->extra.clear();
+  }
+  return true;
+}
+
 hipError_t dev_malloc(void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
   if (e == hipErrorOutOfMemory && context()) {
     (void)hipGetLastError();
     context()->pool.release_all();
     e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && release_spare_tables(context())) {
+      (void)hipGetLastError();
+      e = hipMalloc(p, bytes);
+    }
   }
   return e;
 }
@@ -80,6 +101,10 @@ int DevPool::alloc(size_t bytes, void** p, size_t* cap) {
     (void)hipGetLastError();  // the failed attempt must not surface later as a stale hipGetLastError() of an unrelated launch
     release_all();
     e = hipMalloc(p, want);
+    if (e == hipErrorOutOfMemory && release_spare_tables(context())) {  // then the prefix tables of the keys
+      (void)hipGetLastError();
+      e = hipMalloc(p, want);
+    }
   }
   GM_HIP(e);
   *cap = want;
@@ -371,6 +396,12 @@ int gm_pool_trim(void) {
   return GM_OK;
 }
 
+int gm_g1_release_spare_tables(void) {
+  GM_CTX();
+  (void)release_spare_tables(C);
+  return GM_OK;
+}
+
 int gm_set_msm_window(int c) {
   GM_CTX();
   GM_CHECK(c == 0 || (c >= 2 && c <= 22), GM_EINVAL, "gm_set_msm_window: c = %d not in {0} u [2, 22]", c);
@@ -413,10 +444,10 @@ int gm_set_msm_affine_levels(int levels) {
 // budget (default: 30 % of the device memory) the tables are built at registration, outside every prover span.
 static int maybe_auto_tables(Context* C, Bases* b) {
   if (!C->auto_tables || b->n < C->msm_table_min || b->n < ((size_t)1 << 17)) return GM_OK;
-  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT).  Longer keys -- up to 2^29 points, the keys of `snark -i 26 / 27` --
-  // get tables over their first points only (bases_precompute)
+  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT).  Longer keys -- up to 2^28 + 2^20 points, the keys of `snark -i 26 / 27` --
+  // get tables over their first points only (bases_precompute); under memory pressure they are given back (release_spare_tables)
   const bool prefix_only = b->n >= ((size_t)1 << 26);
-  if (prefix_only && b->n >= ((size_t)1 << 29)) return GM_OK;
+  if (prefix_only && b->n > ((size_t)1 << 28) + ((size_t)1 << 20)) return GM_OK;
   const int c = b->n >= ((size_t)1 << 23) ? 22 : 20;
   const size_t W = (256 + c - 1) / c;
   const size_t bytes = (prefix_only ? (size_t)12 * 96 << 25 : W * b->n * 96) + (std::min<size_t>(b->n, (size_t)1 << 22) * 192) +

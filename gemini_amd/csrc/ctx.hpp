@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -294,6 +295,7 @@ struct Context {
   // small results (per-block partial sums, the bit-plane sums of an MSM) are written by their kernels straight into pinned host
   // memory instead of a device buffer that a blit kernel then copies (GM_ZERO_COPY=0 restores the copies; bit 0 field paths, bit 1 MSM planes.  Two A/B runs on one box: snark -i 20 14.9 -> 14.5 ms, -i 24 117.8 -> 117.0, psnark -i 20 129 -> 127, same proof bytes: profiles/r4_zero_copy_probe.txt)
   int zero_copy = 3;
+  std::atomic<int> msm_busy{0};  // open GM_MSM_LOCK scopes
   bool auto_tables = true;    // build fixed-base tables when bases are registered, if they fit (gm_set_auto_tables)
   size_t auto_tables_max = 0;  // byte budget of one key's tables; 0 = 30 % of the device memory
   int cu_count = 256;
@@ -301,6 +303,9 @@ struct Context {
 
 Context* context();  // nullptr before gm_init
 hipError_t dev_malloc(void** p, size_t bytes);  // hipMalloc that gives the vector pool's freed blocks back on OOM
+// last resort of an allocation that failed twice: the PREFIX tables of every key (Bases::extra) go, the calls they served take the
+// plain path from then on.  False when nothing was freed or an MSM may be reading them (any open GM_MSM_LOCK scope).
+bool release_spare_tables(Context* C);
 
 Bases* find_bases(uint64_t h);
 FrVec* find_vec(uint64_t h);
@@ -310,7 +315,15 @@ uint64_t put_vec(std::unique_ptr<FrVec> v);
 uint64_t put_prover(std::unique_ptr<Sumcheck> p);
 
 #define GM_FR_LOCK(C) std::lock_guard<std::recursive_mutex> gm_fr_lock_((C)->fr_mu)
-#define GM_MSM_LOCK(C) std::lock_guard<std::recursive_mutex> gm_msm_lock_((C)->msm_mu)
+// (the guard also counts the MSM scopes that are open: release_spare_tables must not free a table an MSM in flight reads)
+struct MsmBusyGuard {
+  std::atomic<int>& n;
+  explicit MsmBusyGuard(std::atomic<int>& c) : n(c) { n.fetch_add(1); }
+  ~MsmBusyGuard() { n.fetch_sub(1); }
+};
+#define GM_MSM_LOCK(C)                                                \
+  std::lock_guard<std::recursive_mutex> gm_msm_lock_((C)->msm_mu); \
+  ::gm::MsmBusyGuard gm_msm_busy_((C)->msm_busy)
 
 #define GM_CTX()                                            \
   ::gm::Context* C = ::gm::context();                       \

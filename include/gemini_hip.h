@@ -104,6 +104,10 @@ int gm_g1_bases_table_info(uint64_t handle, int* c, size_t* bytes);
 /* Give the freed blocks of the device-vector pool (up to 55 % of the device memory) back to the driver -- for a host
  * process that shares the GPU with another allocator (torch, a second rank). */
 int gm_pool_trim(void);
+/* Frees the PREFIX tables of every key (the c = 22 / 20 / 16 tables over the first 2^25 / 2^22 / 2^17 points; up to 44 GB for a key of
+ * 2^26+ points): the calls they served take the plain path from then on, with the same results.  The library does this by itself
+ * when a device allocation fails twice (after the vector pool has given its freed blocks back); never while an MSM is running. */
+int gm_g1_release_spare_tables(void);
 
 /* MSM against registered bases.  Pair i uses base[offset + i] (reversed = 0) or base[offset - i]
  * (reversed = 1).  reversed/offset express CommitterKey::commit's prefix slice

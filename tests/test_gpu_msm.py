@@ -243,6 +243,12 @@ def test_prefix_tables_serve_the_short_calls_of_a_big_key(gm, oracle):
         for sc, (m, o, r), g in zip(scs, cases, got):
             assert (reg.msm_bigint(sc, offset=o, reversed_=r) == g).all(), (m, o, r)
         assert (reg.msm_vec_batch(levels, [len(v) for v in levels]) == got_batch).all()
+        # what the library does when a device allocation fails twice: the prefix tables go, the main table stays, same results
+        gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1 << 17)))
+        gm.capi.check(lib.gm_g1_release_spare_tables())
+        assert reg.table_info() == (22, 12 * n * 96)
+        for sc, (m, o, r), g in list(zip(scs, cases, got))[:4]:
+            assert (reg.msm_bigint(sc, offset=o, reversed_=r) == g).all(), (m, o, r)
         for v in levels:
             v.free()
         # and one of them against the CPU Pippenger
