@@ -37,6 +37,8 @@ inline void check(int rc) {
   if (rc != GM_OK) throw Error(rc, gm_last_error());
 }
 inline void init(int device = 0) { check(gm_init(device)); }
+// give the prefix tables of every committer key back (the library does so by itself when a device allocation fails twice)
+inline void release_spare_tables() { check(gm_g1_release_spare_tables()); }
 
 // One process per GPU: after gm::init(local_rank) pick the transport of the library's all-gathers.  Every native prover
 // (SnarkProof::new_time ..., gm_snark_new_time_sharded) then runs on N GPUs when its key is a cyclic share / a shard key.
