@@ -1921,7 +1921,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   // (a window group of a split call uses the chunk length of the whole call: its two accumulations run back to back)
   const uint64_t Nacc_all = nparts > 1 ? Nall : Nacc;
   const uint64_t lanes0 = Nacc_all >= ((uint64_t)1 << 24) ? 262144 : 131072;
-  uint32_t L = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(4, (Nacc_all + lanes0 - 1) / lanes0));
+  static const uint64_t L_cap = getenv("GM_MSM_LCAP") ? (uint64_t)atoi(getenv("GM_MSM_LCAP")) : 256;  // tuning override
+  uint32_t L = (uint32_t)std::min<uint64_t>(L_cap, std::max<uint64_t>(4, (Nacc_all + lanes0 - 1) / lanes0));
   if (L_env > 0) L = (uint32_t)L_env;
   L = (L + 1u) & ~1u;  // even: every lane's chunk starts 16-byte aligned (k_acc0 reads its entries in 16-byte words)
   const uint64_t T0 = (Nacc + L - 1) / L;
