@@ -259,6 +259,48 @@ def test_prefix_tables_serve_the_short_calls_of_a_big_key(gm, oracle):
         reg.free()
 
 
+def test_table_sets_randomised_differential(gm, oracle):
+    """Random (pairs, offset, direction) calls against a key with every kind of table set (main c = 22, prefix c = 20, small c = 16)
+    and against the same key with no tables at all: 60 calls, sizes log-uniform in 2^9 .. 2^22.3, ranges that hug, touch and cross the
+    prefix ends, bit-identical results; scalars uniform, sparse or all equal (the reference's own benchmark instance has equal ones)."""
+    import bench
+
+    lib = gm.capi.load()
+    n = (1 << 23) + 11
+    rng = np.random.default_rng(777)
+    reg = gm.G1Bases.fixed_base(oracle.g1_generator(), bench.uniform_fr(rng, n))
+    pool = bench.uniform_fr(rng, 1 << 23)
+    try:
+        assert reg.table_info()[0] == 22
+        edges = [0, 1 << 17, 1 << 22, n]
+        cases = []
+        for it in range(60):
+            m = int(2 ** rng.uniform(9, 22.3))
+            e = edges[int(rng.integers(0, 4))]
+            rev = bool(rng.integers(0, 2))
+            slack = int(rng.integers(-3, 4)) if it % 2 else int(rng.integers(0, 1 << 16))
+            if rev:  # indices o, o - 1, ..., o - m + 1
+                o = min(max(e - 1 + slack, m - 1), n - 1) if it % 3 else int(rng.integers(m - 1, n))
+            else:  # indices o .. o + m - 1
+                o = min(max(e - m + slack, 0), n - m) if it % 3 else int(rng.integers(0, n - m + 1))
+            cases.append((m, o, rev, it % 4))
+        def scalars(m, kind, it):
+            sc = pool[it * 4099 % (1 << 20):][:m].copy()
+            if kind == 1:
+                sc[::3] = 0
+                sc[1::3, 1:] = 0
+            elif kind == 2:
+                sc[:] = sc[0]
+            return sc
+        got = [reg.msm_bigint(scalars(m, k, i), offset=o, reversed_=r) for i, (m, o, r, k) in enumerate(cases)]
+        gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1 << 62)))
+        for i, ((m, o, r, k), g) in enumerate(zip(cases, got)):
+            assert (reg.msm_bigint(scalars(m, k, i), offset=o, reversed_=r) == g).all(), (m, o, r, k)
+    finally:
+        gm.capi.check(lib.gm_set_msm_table_min(C.c_size_t(1 << 17)))
+        reg.free()
+
+
 def test_prefix_tables_of_a_key_too_long_for_tables_of_its_own(gm, oracle):
     """2^26 points and more cannot have whole-key tables (26-bit pair index in a table entry), but the folding levels of a proof --
     half of its pairs -- walk the first powers: such a key gets c = 22 over its first 2^25 points, c = 20 over the first 2^22 and
