@@ -118,11 +118,12 @@ def test_cyclic_key_native_psnark_same_proof(extra):
 def test_block_sharded_native_prover_same_proof(tail_log):
     """gm_snark_new_time_sharded, block-diagonal instance (local columns): 1 / 2 / 4 / 8 ranks == gm_snark_new_time"""
     one = _single()
-    for world in ((1, 2, 4, 8) if tail_log == 4 else (2, 4)):
+    for world in ((1, 2, 4, 8) if tail_log == 4 else (4,)):
         many = _run(world, ["--block-sharded", "--tail-log", str(tail_log)])
         assert many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
-    many = _run(2, ["--block-sharded", "--tail-log", str(tail_log)], transport="hook")
-    assert many["proof_sha256"] == one["proof_sha256"]
+    if tail_log == 4:  # the embedder-hook transport once (the soak sweeps transports x worlds x tails: tests/soak_dist_native.py)
+        many = _run(2, ["--block-sharded", "--tail-log", str(tail_log)], transport="hook")
+        assert many["proof_sha256"] == one["proof_sha256"]
 
 
 def test_block_sharded_native_prover_general_matrices():
