@@ -66,6 +66,10 @@ int DevBuf::ensure(size_t bytes) {
     (void)hipGetLastError();
     context()->pool.release_all();
     e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory && release_spare_tables(context())) {  // then the prefix tables of the keys (not inside an MSM scope)
+      (void)hipGetLastError();
+      e = hipMalloc(&p, want);
+    }
   }
   if (e != hipSuccess) p = nullptr;
   GM_HIP(e);
@@ -444,10 +448,10 @@ int gm_set_msm_affine_levels(int levels) {
 // budget (default: 30 % of the device memory) the tables are built at registration, outside every prover span.
 static int maybe_auto_tables(Context* C, Bases* b) {
   if (!C->auto_tables || b->n < C->msm_table_min || b->n < ((size_t)1 << 17)) return GM_OK;
-  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT).  Longer keys -- up to 2^28 + 2^20 points, the keys of `snark -i 26 / 27` --
+  // 2^26: the pair-index field of a table entry (msm.hip: ENTRY_W_SHIFT).  Longer keys -- below 2^28 points: the key of `snark -i 26`; the provers at 2^27 / 2^28 constraints need the memory for their vectors --
   // get tables over their first points only (bases_precompute); under memory pressure they are given back (release_spare_tables)
   const bool prefix_only = b->n >= ((size_t)1 << 26);
-  if (prefix_only && b->n > ((size_t)1 << 28) + ((size_t)1 << 20)) return GM_OK;
+  if (prefix_only && b->n >= ((size_t)1 << 28)) return GM_OK;
   const int c = b->n >= ((size_t)1 << 23) ? 22 : 20;
   const size_t W = (256 + c - 1) / c;
   const size_t bytes = (prefix_only ? (size_t)12 * 96 << 25 : W * b->n * 96) + (std::min<size_t>(b->n, (size_t)1 << 22) * 192) +

@@ -319,9 +319,10 @@ __global__ __launch_bounds__(256) void k_lincomb_acc(LincombArgs A, size_t n, ui
 }
 
 // number of trailing (high-index) zero elements: each block reports the highest non-zero index + 1
-__global__ __launch_bounds__(256) void k_high_nonzero(const uint8_t* __restrict__ v, size_t n, unsigned long long* __restrict__ result) {
+// highest index + 1 of a non-zero element of v[lo, n) (0: none)
+__global__ __launch_bounds__(256) void k_high_nonzero(const uint8_t* __restrict__ v, size_t lo, size_t n, unsigned long long* __restrict__ result) {
   unsigned long long best = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr x = fp_load<FrParams>(v + i * FR_BYTES);
     if (!x.is_zero()) best = i + 1;
   }
@@ -1511,12 +1512,20 @@ int fr_trim(Context* C, FrVec* v) {
   if (v->len == 0) return GM_OK;
   int rc = C->fr_scratch.ensure(1 << 20);
   if (rc) return rc;
-  GM_HIP(hipMemsetAsync(C->fr_scratch.p, 0, 8, C->stream));
-  hipLaunchKernelGGL(k_high_nonzero, dim3(grid_for(v->len)), dim3(256), 0, C->stream, v->d, v->len,
-                     C->fr_scratch.as<unsigned long long>());
-  GM_HIP(hipGetLastError());
-  GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, 8, hipMemcpyDeviceToHost, C->stream));
-  GM_HIP(hipStreamSynchronize(C->stream));
+  // the top 2^16 coefficients first: the leading coefficient of a polynomial a prover builds is almost never zero, and a scan of
+  // the whole vector reads 512 MB at 2^24 coefficients (0.18 ms, three times per `snark -i 24` proof)
+  const size_t top = v->len < ((size_t)1 << 16) ? v->len : ((size_t)1 << 16);
+  size_t lo = v->len - top, hi = v->len;
+  for (;;) {
+    GM_HIP(hipMemsetAsync(C->fr_scratch.p, 0, 8, C->stream));
+    hipLaunchKernelGGL(k_high_nonzero, dim3(grid_for(hi - lo)), dim3(256), 0, C->stream, v->d, lo, hi, C->fr_scratch.as<unsigned long long>());
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipMemcpyAsync(C->host_small, C->fr_scratch.p, 8, hipMemcpyDeviceToHost, C->stream));
+    GM_HIP(hipStreamSynchronize(C->stream));
+    if (C->host_small[0] != 0 || lo == 0) break;
+    hi = lo;  // nothing up there: the rest of the vector
+    lo = 0;
+  }
   v->len = (size_t)C->host_small[0];
   return GM_OK;
 }

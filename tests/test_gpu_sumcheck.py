@@ -139,6 +139,12 @@ def test_many_term_passes_vs_oracle(gm, oracle, pyref):
     polys = [oracle.fr_to_mont(oracle.random_fr(8800 + i, n)) for i, n in enumerate(lens)]
     ch = oracle.fr_to_mont(oracle.random_fr(8799, 70))
     assert (gm.linear_combination(polys, ch).to_host() == oracle.linear_combination(polys, ch)).all()
+    # the trim of the result looks at the top 2^16 coefficients first and at the rest only if those are all zero
+    padded = np.zeros((1000 + 70000, 4), dtype=np.uint64)
+    padded[:1000] = polys[3][:1000]
+    got = gm.linear_combination([padded, polys[40]], ch[:2]).to_host()
+    assert len(got) == 1000 and (got == oracle.linear_combination([padded[:1000], polys[40]], ch[:2])).all()
+    assert len(gm.linear_combination([np.zeros((70000, 4), dtype=np.uint64)], ch[:1])) == 0
     x = oracle.fr_to_mont(oracle.random_fr(8798, 1))[0]
     xi = oracle.limbs_to_ints(oracle.fr_from_mont(x.reshape(1, 4)))[0]
     pts = np.stack([x, oracle.fr_to_mont(oracle.ints_to_limbs([(pyref.R_MOD - xi) % pyref.R_MOD], 4))[0]])
