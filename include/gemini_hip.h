@@ -92,7 +92,9 @@ int gm_g1_bases_download(uint64_t handle, size_t offset, size_t n, void* out96);
  * No reference counterpart: ark-ec recomputes. */
 int gm_g1_bases_precompute(uint64_t handle, int c);
 /* Tables BY DEFAULT (on = 1 at gm_init) for the KEY CONSTRUCTORS: gm_g1_fixed_base_register, gm_g1_srs_register and
- * gm_g1_srs_register_segments (the CommitterKey::new analogues) build the tables above for 2^17 .. 2^26 - 1 points when
+ * gm_g1_srs_register_segments (the CommitterKey::new analogues) build the tables above for 2^17 .. 2^26 - 1 points (a key of
+ * 2^26 .. 2^28 - 1 points gets tables over its first 2^25 / 2^22 / 2^17 points only: 44 GB, spare memory -- see
+ * gm_g1_release_spare_tables) when
  * W x n x 96 bytes fit `max_bytes` (0 = 30 % of the device memory) and the free memory; otherwise, silently, the plain path
  * serves the key.  Cost at registration: ~240 doublings per point and W x n x 96 bytes (1.3 GB at 2^20 points).
  * gm_g1_bases_register (points uploaded from the host) never builds them on its own: gm_g1_bases_precompute(handle, -1).
