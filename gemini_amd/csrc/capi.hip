@@ -20,6 +20,41 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return e == hipErrorOutOfMemory ? GM_ENOMEM : GM_EHIP;
 }
 
+// ---- tracked device allocation ---------------------------------------------------------------
+MemStats& mem_stats() {
+  static MemStats* m = new MemStats;  // never destroyed: frees may arrive from static destructors
+  return *m;
+}
+void MemStats::note_cached(ptrdiff_t delta) {
+  std::lock_guard<std::mutex> lk(mu);
+  cached = (size_t)((ptrdiff_t)cached + delta);
+  if (live - cached > peak_in_use) peak_in_use = live - cached;
+}
+hipError_t raw_malloc_v(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && *p) {
+    MemStats& m = mem_stats();
+    std::lock_guard<std::mutex> lk(m.mu);
+    m.sizes[*p] = bytes;
+    m.live += bytes;
+    if (m.live > m.peak_live) m.peak_live = m.live;
+    if (m.live - m.cached > m.peak_in_use) m.peak_in_use = m.live - m.cached;
+  }
+  return e;
+}
+hipError_t raw_free(void* p) {
+  if (p) {
+    MemStats& m = mem_stats();
+    std::lock_guard<std::mutex> lk(m.mu);
+    auto it = m.sizes.find(p);
+    if (it != m.sizes.end()) {
+      m.live -= it->second;
+      m.sizes.erase(it);
+    }
+  }
+  return hipFree(p);
+}
+
 // hipMalloc for the long-lived allocations outside the vector pool (bases, tables, matrices, index vectors): when the device
 // is out of memory the pool may be holding up to 55 % of it in freed blocks -- give them back and retry once
 bool release_spare_tables(Context* C) {
@@ -33,21 +68,26 @@ bool release_spare_tables(Context* C) {
   (void)hipDeviceSynchronize();
   for (auto& kv : C->bases) {
     for (auto& ts : kv.second->extra)
-      if (ts.t) (void)hipFree(ts.t);
+      if (ts.t) (void)gm::raw_free(ts.t);
     kv.second->extra.clear();
+  }
+  {
+    MemStats& m = mem_stats();
+    std::lock_guard<std::mutex> lkm(m.mu);
+    m.spare_table_releases++;
   }
   return true;
 }
 
 hipError_t dev_malloc(void** p, size_t bytes) {
-  hipError_t e = hipMalloc(p, bytes);
+  hipError_t e = gm::raw_malloc(p, bytes);
   if (e == hipErrorOutOfMemory && context()) {
     (void)hipGetLastError();
     context()->pool.release_all();
-    e = hipMalloc(p, bytes);
+    e = gm::raw_malloc(p, bytes);
     if (e == hipErrorOutOfMemory && release_spare_tables(context())) {
       (void)hipGetLastError();
-      e = hipMalloc(p, bytes);
+      e = gm::raw_malloc(p, bytes);
     }
   }
   return e;
@@ -56,19 +96,19 @@ hipError_t dev_malloc(void** p, size_t bytes) {
 int DevBuf::ensure(size_t bytes) {
   if (bytes <= cap) return GM_OK;
   if (p) {
-    (void)hipFree(p);
+    (void)gm::raw_free(p);
     p = nullptr;
     cap = 0;
   }
   size_t want = bytes + bytes / 8 + 256;
-  hipError_t e = hipMalloc(&p, want);
+  hipError_t e = gm::raw_malloc(&p, want);
   if (e == hipErrorOutOfMemory && context()) {  // the vector pool may be hoarding freed blocks: give them back and retry once
     (void)hipGetLastError();
     context()->pool.release_all();
-    e = hipMalloc(&p, want);
+    e = gm::raw_malloc(&p, want);
     if (e == hipErrorOutOfMemory && release_spare_tables(context())) {  // then the prefix tables of the keys (not inside an MSM scope)
       (void)hipGetLastError();
-      e = hipMalloc(&p, want);
+      e = gm::raw_malloc(&p, want);
     }
   }
   if (e != hipSuccess) p = nullptr;
@@ -77,7 +117,7 @@ int DevBuf::ensure(size_t bytes) {
   return GM_OK;
 }
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) (void)gm::raw_free(p);
   p = nullptr;
   cap = 0;
 }
@@ -96,18 +136,19 @@ int DevPool::alloc(size_t bytes, void** p, size_t* cap) {
       *cap = it->first;
       pooled_bytes -= it->first;
       free_list.erase(it);
+      mem_stats().note_cached(-(ptrdiff_t)*cap);
       return GM_OK;
     }
   }
   size_t want = (bytes + 4095) & ~(size_t)4095;
-  hipError_t e = hipMalloc(p, want);
+  hipError_t e = gm::raw_malloc(p, want);
   if (e == hipErrorOutOfMemory) {  // give cached blocks back and retry once
     (void)hipGetLastError();  // the failed attempt must not surface later as a stale hipGetLastError() of an unrelated launch
     release_all();
-    e = hipMalloc(p, want);
+    e = gm::raw_malloc(p, want);
     if (e == hipErrorOutOfMemory && release_spare_tables(context())) {  // then the prefix tables of the keys
       (void)hipGetLastError();
-      e = hipMalloc(p, want);
+      e = gm::raw_malloc(p, want);
     }
   }
   GM_HIP(e);
@@ -121,16 +162,18 @@ void DevPool::free(void* p, size_t cap) {
     if (pooled_bytes + cap <= max_pooled) {
       free_list.emplace(cap, p);
       pooled_bytes += cap;
+      mem_stats().note_cached((ptrdiff_t)cap);
       return;
     }
   }
-  (void)hipFree(p);
+  (void)gm::raw_free(p);
 }
 void DevPool::release_all() {
   std::lock_guard<std::mutex> lk(mu);
-  for (auto& kv : free_list) (void)hipFree(kv.second);
-  free_list.clear();
+  mem_stats().note_cached(-(ptrdiff_t)pooled_bytes);  // before the frees: live - cached must never go negative
   pooled_bytes = 0;
+  for (auto& kv : free_list) (void)gm::raw_free(kv.second);
+  free_list.clear();
 }
 
 void Profiler::begin(int part, int stage, hipStream_t st) {
@@ -310,11 +353,11 @@ void gm_shutdown(void) {
   (void)hipStreamSynchronize(C->stream);
   for (auto& kv : C->bases) {
     bases_free_tables(kv.second.get());
-    if (kv.second->phi) (void)hipFree(kv.second->phi);
-    if (kv.second->d) (void)hipFree(kv.second->d);
+    if (kv.second->phi) (void)gm::raw_free(kv.second->phi);
+    if (kv.second->d) (void)gm::raw_free(kv.second->d);
   }
   for (auto& kv : C->vecs)
-    if (kv.second->d) (void)hipFree(kv.second->d);
+    if (kv.second->d) (void)gm::raw_free(kv.second->d);
   for (auto& kv : C->msm_streams) msm_stream_destroy(C, kv.second.get());
   C->pool.release_all();
   for (auto& kv : C->provers) sc_destroy(kv.second.get());
@@ -322,11 +365,11 @@ void gm_shutdown(void) {
   for (auto& kv : C->herring_g1) hg1_destroy(C, kv.second.get());
   C->partial_bufs.release_all();
   for (auto& kv : C->indices)
-    if (kv.second->d) (void)hipFree(kv.second->d);
+    if (kv.second->d) (void)gm::raw_free(kv.second->d);
   for (auto& kv : C->matrices) {
-    if (kv.second->rowptr) (void)hipFree(kv.second->rowptr);
-    if (kv.second->cols) (void)hipFree(kv.second->cols);
-    if (kv.second->vals) (void)hipFree(kv.second->vals);
+    if (kv.second->rowptr) (void)gm::raw_free(kv.second->rowptr);
+    if (kv.second->cols) (void)gm::raw_free(kv.second->cols);
+    if (kv.second->vals) (void)gm::raw_free(kv.second->vals);
   }
   auto release_ws = [](MsmWorkspace& w) {
     for (DevBuf* b : {&w.scalars, &w.counts, &w.offsets, &w.cursor, &w.entries, &w.tmp_entries, &w.sortmeta, &w.buckets, &w.pk[0], &w.pk[1], &w.pp[0],
@@ -397,6 +440,46 @@ int gm_set_auto_tables(int on, size_t max_bytes) {
 int gm_pool_trim(void) {
   GM_CTX();
   C->pool.release_all();
+  return GM_OK;
+}
+
+int gm_mem_stats(uint64_t out[10]) {
+  GM_CTX();
+  GM_CHECK(out != nullptr, GM_EINVAL, "gm_mem_stats: null output");
+  size_t free_b = 0, total_b = 0;
+  GM_HIP(hipMemGetInfo(&free_b, &total_b));
+  size_t tables = 0, keys = 0;
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    for (auto& kv : C->bases) {
+      const Bases* b = kv.second.get();
+      if (b->d) keys += b->n * 96;
+      if (b->table) tables += (size_t)b->tab_W * b->n * 96;
+      for (auto& ts : b->extra)
+        if (ts.t) tables += (size_t)ts.W * ts.n * 96;
+    }
+  }
+  MemStats& m = mem_stats();
+  std::lock_guard<std::mutex> lk(m.mu);
+  out[0] = total_b;
+  out[1] = free_b;
+  out[2] = m.live;
+  out[3] = m.peak_live;
+  out[4] = m.cached;
+  out[5] = m.live - m.cached;
+  out[6] = m.peak_in_use;
+  out[7] = tables;
+  out[8] = keys;
+  out[9] = m.spare_table_releases;
+  return GM_OK;
+}
+
+int gm_mem_reset_peak(void) {
+  GM_CTX();
+  MemStats& m = mem_stats();
+  std::lock_guard<std::mutex> lk(m.mu);
+  m.peak_live = m.live;
+  m.peak_in_use = m.live - m.cached;
   return GM_OK;
 }
 
@@ -494,8 +577,8 @@ int gm_g1_bases_free(uint64_t handle) {
     C->bases.erase(it);
   }
   bases_free_tables(b.get());
-  if (b->phi) (void)hipFree(b->phi);
-  if (b->d) GM_HIP(hipFree(b->d));
+  if (b->phi) (void)gm::raw_free(b->phi);
+  if (b->d) GM_HIP(gm::raw_free(b->d));
   return GM_OK;
 }
 
@@ -570,7 +653,7 @@ int gm_g1_msm(const void* bases, size_t base_stride, const uint64_t* scalars, si
   int rc = bases_from_host(C, bases, base_stride, n, b);
   if (rc) return rc;
   rc = msm_host_scalars(C, b.get(), 0, 0, scalars, n, out_jac);
-  if (b->d) (void)hipFree(b->d);
+  if (b->d) (void)gm::raw_free(b->d);
   return rc;
 }
 
@@ -736,7 +819,7 @@ int gm_g1_fixed_base_register(const uint64_t base_affine[12], const uint64_t* sc
   }
   std::unique_ptr<Bases> b;
   int rc = fixed_base_generate(C, base_affine, d_sc, 0, n, b);
-  if (d_sc) (void)hipFree(d_sc);
+  if (d_sc) (void)gm::raw_free(d_sc);
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
   if ((rc = maybe_auto_tables(C, b.get()))) return rc;
@@ -757,7 +840,7 @@ int gm_g1_srs_register(const uint64_t base_affine[12], const uint64_t tau[4], si
   int rc = fr_powers(C, tm, n, v.get());
   std::unique_ptr<Bases> b;
   if (!rc) rc = fixed_base_generate(C, base_affine, v->d, 1, n, b);
-  if (v->d) (void)hipFree(v->d);
+  if (v->d) (void)gm::raw_free(v->d);
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
   if ((rc = maybe_auto_tables(C, b.get()))) return rc;
@@ -789,7 +872,7 @@ int gm_g1_srs_register_segments(const uint64_t base_affine[12], const uint64_t t
   }
   std::unique_ptr<Bases> b;
   if (!rc) rc = fixed_base_generate(C, base_affine, v->d, 1, n, b);
-  if (v->d) (void)hipFree(v->d);
+  if (v->d) (void)gm::raw_free(v->d);
   v->d = nullptr;
   if (rc) return rc;
   if ((rc = bases_build_phi(C, b.get()))) return rc;
@@ -1024,7 +1107,7 @@ int gm_idx_free(uint64_t handle) {
     I = std::move(it->second);
     C->indices.erase(it);
   }
-  if (I->d) (void)hipFree(I->d);
+  if (I->d) (void)gm::raw_free(I->d);
   return GM_OK;
 }
 #define GM_IDX(var, h, who)                                                                             \
@@ -1110,9 +1193,9 @@ int gm_spm_free(uint64_t handle) {
     M = std::move(it->second);
     C->matrices.erase(it);
   }
-  if (M->rowptr) (void)hipFree(M->rowptr);
-  if (M->cols) (void)hipFree(M->cols);
-  if (M->vals) (void)hipFree(M->vals);
+  if (M->rowptr) (void)gm::raw_free(M->rowptr);
+  if (M->cols) (void)gm::raw_free(M->cols);
+  if (M->vals) (void)gm::raw_free(M->vals);
   return GM_OK;
 }
 int gm_spm_shape(uint64_t handle, size_t* nrows, size_t* ncols, size_t* nnz) {

@@ -302,7 +302,26 @@ struct Context {
 };
 
 Context* context();  // nullptr before gm_init
-hipError_t dev_malloc(void** p, size_t bytes);  // hipMalloc that gives the vector pool's freed blocks back on OOM
+// Every device allocation of the library goes through these two (hipMalloc / hipFree + bookkeeping): what the process holds from the
+// driver, its high-water mark, and -- minus the vector pool's cached blocks -- what is IN USE and its peak (gm_mem_stats; the
+// footprint contract of the provers is checked against these figures, tests/test_gpu_footprint.py)
+struct MemStats {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> sizes;
+  size_t live = 0, peak_live = 0;  // bytes obtained from the driver and not given back
+  size_t cached = 0;               // of those: freed blocks the vector pool keeps for reuse
+  size_t peak_in_use = 0;          // high-water mark of live - cached
+  uint64_t spare_table_releases = 0;  // release_spare_tables() calls that freed something (no silent degradation)
+  void note_cached(ptrdiff_t delta);  // the pool took (+) or handed out (-) a cached block
+};
+MemStats& mem_stats();
+hipError_t raw_malloc_v(void** p, size_t bytes);
+template <class T>
+inline hipError_t raw_malloc(T** p, size_t bytes) {
+  return raw_malloc_v(reinterpret_cast<void**>(p), bytes);
+}
+hipError_t raw_free(void* p);
+hipError_t dev_malloc(void** p, size_t bytes);  // raw_malloc that gives the vector pool's freed blocks back on OOM
 // last resort of an allocation that failed twice: the PREFIX tables of every key (Bases::extra) go, the calls they served take the
 // plain path from then on.  False when nothing was freed or an MSM may be reading them (any open GM_MSM_LOCK scope).
 bool release_spare_tables(Context* C);

@@ -129,18 +129,18 @@ int ensure_stage(Dist& d, size_t bytes) {
   const size_t out = bytes * (size_t)d.world;
   if (bytes > d.stage_in) {
     if (d.h_in) (void)hipHostFree(d.h_in);
-    if (d.d_in) (void)hipFree(d.d_in);
+    if (d.d_in) (void)gm::raw_free(d.d_in);
     const size_t cap = bytes < 4096 ? 4096 : bytes * 2;
     GM_HIP(hipHostMalloc(&d.h_in, cap, hipHostMallocDefault));
-    GM_HIP(hipMalloc(&d.d_in, cap));
+    GM_HIP(gm::raw_malloc(&d.d_in, cap));
     d.stage_in = cap;
   }
   if (out > d.stage_out) {
     if (d.h_out) (void)hipHostFree(d.h_out);
-    if (d.d_out) (void)hipFree(d.d_out);
+    if (d.d_out) (void)gm::raw_free(d.d_out);
     const size_t cap = out < 4096 * (size_t)d.world ? 4096 * (size_t)d.world : out * 2;
     GM_HIP(hipHostMalloc(&d.h_out, cap, hipHostMallocDefault));
-    GM_HIP(hipMalloc(&d.d_out, cap));
+    GM_HIP(gm::raw_malloc(&d.d_out, cap));
     d.stage_out = cap;
   }
   return GM_OK;
@@ -218,8 +218,8 @@ void reset(Dist& d) {
   }
   if (d.h_in) (void)hipHostFree(d.h_in);
   if (d.h_out) (void)hipHostFree(d.h_out);
-  if (d.d_in) (void)hipFree(d.d_in);
-  if (d.d_out) (void)hipFree(d.d_out);
+  if (d.d_in) (void)gm::raw_free(d.d_in);
+  if (d.d_out) (void)gm::raw_free(d.d_out);
   d.h_in = d.h_out = d.d_in = d.d_out = nullptr;
   d.stage_in = d.stage_out = 0;
   shm_detach(d);

@@ -746,13 +746,13 @@ void PartialBufs::give(uint8_t* dev, uint64_t* host) {
       return;
     }
   }
-  if (dev) (void)hipFree(dev);
+  if (dev) (void)gm::raw_free(dev);
   if (host) (void)hipHostFree(host);
 }
 void PartialBufs::release_all() {
   std::lock_guard<std::mutex> lk(mu);
   for (auto& p : free_pairs) {
-    (void)hipFree(p.first);
+    (void)gm::raw_free(p.first);
     (void)hipHostFree(p.second);
   }
   free_pairs.clear();
@@ -802,7 +802,7 @@ void sc_destroy(Sumcheck* S) {
   }
   if (C) C->partial_bufs.give(S->partials, S->host_partials);
   else {
-    if (S->partials) (void)hipFree(S->partials);
+    if (S->partials) (void)gm::raw_free(S->partials);
     if (S->host_partials) (void)hipHostFree(S->host_partials);
   }
   S->partials = nullptr;
@@ -1128,13 +1128,13 @@ void sp_destroy(Context* C, SpaceProver* S) {
   }
   if (S->tables) {
     if (C) C->pool.free(S->tables, S->tables_cap);
-    else (void)hipFree(S->tables);
+    else (void)gm::raw_free(S->tables);
   }
   S->tables = nullptr;
   S->tables_cap = 0;
   if (C) C->partial_bufs.give(S->partials, S->host_partials);
   else {
-    if (S->partials) (void)hipFree(S->partials);
+    if (S->partials) (void)gm::raw_free(S->partials);
     if (S->host_partials) (void)hipHostFree(S->host_partials);
   }
   S->partials = nullptr;

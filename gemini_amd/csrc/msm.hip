@@ -2525,7 +2525,7 @@ int bases_from_host(Context* C, const void* bases, size_t stride, size_t n, std:
       GM_HIP(hipMemcpyAsync(stage, bases, n * stride, hipMemcpyHostToDevice, C->stream));
       hipLaunchKernelGGL(k_pack_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, C->stream, stage, stride, n, b->d);
       GM_HIP(hipStreamSynchronize(C->stream));
-      GM_HIP(hipFree(stage));
+      GM_HIP(gm::raw_free(stage));
     }
     GM_HIP(hipStreamSynchronize(C->stream));
   }
@@ -2565,7 +2565,7 @@ int bases_export(Context* C, const Bases* b, size_t offset, size_t n, void* out9
   GM_HIP(hipGetLastError());
   GM_HIP(hipMemcpyAsync(out96, tmp, n * AFF_BYTES, hipMemcpyDeviceToHost, C->stream));
   GM_HIP(hipStreamSynchronize(C->stream));
-  GM_HIP(hipFree(tmp));
+  GM_HIP(gm::raw_free(tmp));
   return GM_OK;
 }
 
@@ -2581,13 +2581,13 @@ static int build_fixed_table(Context* C, const uint64_t base_affine[12], uint8_t
     GM_HIP(hipMemcpyAsync(stage, base_affine, AFF_BYTES, hipMemcpyHostToDevice, C->stream));
     hipLaunchKernelGGL(k_pack_bases, dim3(1), dim3(64), 0, C->stream, stage, (size_t)AFF_BYTES, (size_t)1, d_base);
     GM_HIP(hipStreamSynchronize(C->stream));
-    GM_HIP(hipFree(stage));
+    GM_HIP(gm::raw_free(stage));
   }
   hipLaunchKernelGGL(k_fixed_base_table, dim3(32), dim3(256), 0, C->stream, d_base, t_xyzz);
   hipLaunchKernelGGL(k_xyzz_to_affine, dim3(32), dim3(256), 0, C->stream, t_xyzz, (size_t)32 * 256, *table_aff);
   GM_HIP(hipStreamSynchronize(C->stream));
-  GM_HIP(hipFree(d_base));
-  GM_HIP(hipFree(t_xyzz));
+  GM_HIP(gm::raw_free(d_base));
+  GM_HIP(gm::raw_free(t_xyzz));
   return GM_OK;
 }
 
@@ -2807,7 +2807,7 @@ int hg1_create(Context* C, const void* f_bases, size_t stride, size_t nf, const 
 
 void hg1_destroy(Context* C, HerringG1* H) {
   for (int i = 0; i < 2; i++) {
-    if (H->f[i]) (void)hipFree(H->f[i]);
+    if (H->f[i]) (void)gm::raw_free(H->f[i]);
     if (C) C->pool.free(H->g[i], H->gcap[i]);
   }
   if (C) C->pool.free(H->tmp, H->tmpcap);
@@ -2913,7 +2913,7 @@ static int build_window_table(Context* C, const uint8_t* d, size_t n, int c, uin
   uint8_t* xy = nullptr;
   {
     const hipError_t e = dev_malloc((void**)&xy, slab * XYZZ_BYTES);
-    if (e != hipSuccess) (void)hipFree(t);
+    if (e != hipSuccess) (void)gm::raw_free(t);
     GM_HIP(e);
   }
   for (int w = 0; w + 1 < W; w++)
@@ -2926,18 +2926,18 @@ static int build_window_table(Context* C, const uint8_t* d, size_t n, int c, uin
     }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
-  (void)hipFree(xy);
-  if (e != hipSuccess) (void)hipFree(t);
+  (void)gm::raw_free(xy);
+  if (e != hipSuccess) (void)gm::raw_free(t);
   GM_HIP(e);
   *out = t;
   return GM_OK;
 }
 
 void bases_free_tables(Bases* b) {
-  if (b->table) (void)hipFree(b->table);
+  if (b->table) (void)gm::raw_free(b->table);
   b->table = nullptr;
   for (auto& ts : b->extra)
-    if (ts.t) (void)hipFree(ts.t);
+    if (ts.t) (void)gm::raw_free(ts.t);
   b->extra.clear();
 }
 
@@ -3014,8 +3014,8 @@ int fixed_base_generate(Context* C, const uint64_t base_affine[12], const void* 
     }
     GM_HIP(hipGetLastError());
     GM_HIP(hipStreamSynchronize(C->stream));
-    GM_HIP(hipFree(xy));
-    GM_HIP(hipFree(table));
+    GM_HIP(gm::raw_free(xy));
+    GM_HIP(gm::raw_free(table));
   }
   out = std::move(b);
   return GM_OK;

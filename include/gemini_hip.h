@@ -106,6 +106,15 @@ int gm_g1_bases_table_info(uint64_t handle, int* c, size_t* bytes);
 /* Give the freed blocks of the device-vector pool (up to 55 % of the device memory) back to the driver -- for a host
  * process that shares the GPU with another allocator (torch, a second rank). */
 int gm_pool_trim(void);
+/* Device-memory bookkeeping of the library (every allocation it makes is counted): out[0] = device total, [1] = device free
+ * (hipMemGetInfo), [2] = bytes the library holds from the driver, [3] = high-water mark of [2], [4] = of [2]: freed blocks cached by
+ * the vector pool, [5] = in use = [2] - [4], [6] = high-water mark of [5], [7] = fixed-base tables of all keys, [8] = the keys
+ * themselves, [9] = how many times the prefix tables were released under memory pressure (they are not rebuilt: the calls they
+ * served take the plain path).  gm_mem_reset_peak() restarts both high-water marks from the current values.  The reference's memory
+ * story is its constants (README.md:38-46: SPACE_TIME_THRESHOLD, MAX_MSM_BUFFER_LOG); on the device it is these figures and the
+ * footprint contract below (gm_snark_footprint / gm_psnark_footprint). */
+int gm_mem_stats(uint64_t out[10]);
+int gm_mem_reset_peak(void);
 /* Frees the PREFIX tables of every key (the c = 22 / 20 / 16 tables over the first 2^25 / 2^22 / 2^17 points; up to 44 GB for a key of
  * 2^26+ points): the calls they served take the plain path from then on, with the same results.  The library does this by itself
  * when a device allocation fails twice (after the vector pool has given its freed blocks back); never while an MSM is running. */

@@ -87,6 +87,7 @@ def main():
     stamps = []  # clock readings around every proof, for tools/exposed_time.py --stamps
     clocks = lambda: {"boottime_ns": time.clock_gettime_ns(time.CLOCK_BOOTTIME), "monotonic_ns": time.clock_gettime_ns(time.CLOCK_MONOTONIC),
                       "realtime_ns": time.clock_gettime_ns(time.CLOCK_REALTIME)}
+    gm.capi.mem_reset_peak()  # the high-water marks below are those of the proofs, not of the key / index setup
     for _ in range(args.repeat):
         stamps.append({"t0": clocks()})
         if args.elastic:
@@ -107,6 +108,8 @@ def main():
         stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         out["proof_size_B"] = proof.compressed_size()
+    out["mem_GB"] = {k: round(v / 1e9, 3) for k, v in gm.capi.mem_stats().items() if k != "spare_table_releases"}
+    out["spare_table_releases"] = gm.capi.mem_stats()["spare_table_releases"]
     out["stamps"] = stamps
     key = "ark_gemini::psnark::elastic_prover" if args.elastic else "ark_gemini::psnark::time_prover"
     out["elastic_prover_s" if args.elastic else "time_prover_s"] = min(r[key] for r in out["runs"])

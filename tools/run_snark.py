@@ -154,6 +154,7 @@ def main():
     stamps = []  # per proof: clock readings around it, for tools/exposed_time.py --stamps (rocprofv3 timestamps are one of these clocks)
     clocks = lambda: {"boottime_ns": time.clock_gettime_ns(time.CLOCK_BOOTTIME), "monotonic_ns": time.clock_gettime_ns(time.CLOCK_MONOTONIC),
                       "realtime_ns": time.clock_gettime_ns(time.CLOCK_REALTIME)}
+    gm.capi.mem_reset_peak()  # the high-water marks below are those of the proofs, not of the key / index setup
     for _ in range(args.repeat):
         if lib_dist:
             collective.allgather_host(np.zeros(1, dtype=np.uint64))  # a barrier through the library's own transport
@@ -211,6 +212,8 @@ def main():
         assert len({d for _, d in allt}) == 1, "ranks produced different proofs"
         dist.destroy_process_group()
     out["proof_sha256"] = __import__("hashlib").sha256(proof.serialize_compressed()).hexdigest()
+    out["mem_GB"] = {k: round(v / 1e9, 3) for k, v in gm.capi.mem_stats().items() if k != "spare_table_releases"}
+    out["spare_table_releases"] = gm.capi.mem_stats()["spare_table_releases"]
     out["stamps"] = stamps
     if rank == 0:
         print(json.dumps(out))
