@@ -95,16 +95,36 @@ def stats(reset: bool = False) -> dict:
     return {"collectives": n.value, "bytes_received": b.value, "seconds": round(s.value, 6)}
 
 
+ROUTES = ("copy", "hook", "rccl_host_staged", "rccl_device_vectors", "shm")
+CLASS_FIELD, CLASS_G1 = 0, 1
+
+
+def stats_routes() -> dict:
+    """gm_dist_stats_routes: collectives, bytes received and seconds by the route they took"""
+    n, b, s = (C.c_uint64 * 5)(), (C.c_uint64 * 5)(), (C.c_double * 5)()
+    capi.check(capi.load().gm_dist_stats_routes(n, b, s))
+    return {r: {"collectives": int(n[i]), "bytes_received": int(b[i]), "seconds": round(float(s[i]), 6)} for i, r in enumerate(ROUTES) if n[i]}
+
+
+def bench(nbytes: int, iters: int = 200, payload_class: int = CLASS_FIELD, route: str | None = None) -> float:
+    """gm_dist_bench: microseconds per all-gather of `nbytes` per rank; route None = where the class goes, else "rccl_host_staged" / "shm" """
+    us = C.c_double()
+    capi.check(capi.load().gm_dist_bench(C.c_size_t(nbytes), C.c_int(iters), C.c_int(payload_class), C.c_int(-1 if route is None else ROUTES.index(route)),
+                                         C.byref(us)))
+    return us.value
+
+
 def selftest() -> None:
     capi.check(capi.load().gm_dist_selftest())
 
 
-def allgather_host(local: np.ndarray) -> np.ndarray:
+def allgather_host(local: np.ndarray, payload_class: int = CLASS_FIELD) -> np.ndarray:
     """(world, *local.shape) uint64"""
     loc = np.ascontiguousarray(local, dtype=np.uint64)
     _, world, _ = info()
     out = np.empty((world,) + loc.shape, dtype=np.uint64)
-    capi.check(capi.load().gm_dist_allgather_host(loc.ctypes.data_as(C.c_void_p), C.c_size_t(loc.nbytes), out.ctypes.data_as(C.c_void_p)))
+    capi.check(capi.load().gm_dist_allgather_host_class(loc.ctypes.data_as(C.c_void_p), C.c_size_t(loc.nbytes), out.ctypes.data_as(C.c_void_p),
+                                                        C.c_int(payload_class)))
     return out
 
 

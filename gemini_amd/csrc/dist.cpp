@@ -29,10 +29,30 @@
 #include <chrono>
 #include <cstring>
 #include <thread>
-
-#include <rccl/rccl.h>
+#include <type_traits>
 
 #include "ctx.hpp"
+
+// The RCCL types this file needs.  With the development header present (and no -DGM_NO_RCCL) they are RCCL's own and the function
+// pointer types below are compile-checked against its prototypes; without it -- a ROCm image that ships librccl.so but not
+// <rccl/rccl.h>, or a single-GPU build -- the few ABI facts used here are declared locally (a 128-byte id, an opaque communicator,
+// ncclSuccess = 0, ncclChar = 0: stable since NCCL 2.0) and the library still builds; librccl itself is only ever dlopen'ed.
+#if !defined(GM_NO_RCCL) && defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define GM_HAVE_RCCL_HEADER 1
+#endif
+#endif
+#ifndef GM_HAVE_RCCL_HEADER
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclChar = 0 } ncclDataType_t;
+}
+#endif
 
 namespace {
 
@@ -40,13 +60,26 @@ using Clock = std::chrono::steady_clock;
 
 enum Transport { T_NONE = 0, T_HOOK = 1, T_RCCL = 2, T_SHM = 3 };
 
+using GetUniqueId_t = ncclResult_t (*)(ncclUniqueId*);
+using CommInitRank_t = ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int);
+using AllGather_t = ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+using CommDestroy_t = ncclResult_t (*)(ncclComm_t);
+using GetErrorString_t = const char* (*)(ncclResult_t);
+#ifdef GM_HAVE_RCCL_HEADER
+static_assert(std::is_same<GetUniqueId_t, decltype(&ncclGetUniqueId)>::value, "ncclGetUniqueId prototype");
+static_assert(std::is_same<CommInitRank_t, decltype(&ncclCommInitRank)>::value, "ncclCommInitRank prototype");
+static_assert(std::is_same<AllGather_t, decltype(&ncclAllGather)>::value, "ncclAllGather prototype");
+static_assert(std::is_same<CommDestroy_t, decltype(&ncclCommDestroy)>::value, "ncclCommDestroy prototype");
+static_assert(std::is_same<GetErrorString_t, decltype(&ncclGetErrorString)>::value, "ncclGetErrorString prototype");
+#endif
 struct Rccl {
   void* lib = nullptr;
-  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  GetUniqueId_t GetUniqueId = nullptr;
+  CommInitRank_t CommInitRank = nullptr;
+  AllGather_t AllGather = nullptr;
+  CommDestroy_t CommDestroy = nullptr;
+  CommDestroy_t CommAbort = nullptr;  // optional: a rank that fails inside a collective aborts the communicator so that its peers do not hang
+  GetErrorString_t GetErrorString = nullptr;
 };
 
 // shared segment: header, then two banks (call parity) of world slots of slot_bytes
@@ -55,8 +88,15 @@ struct ShmHeader {
   uint64_t world, slot_bytes;
   std::atomic<uint64_t> attached;
   std::atomic<uint64_t> seq[64];  // seq[r] = number of the last call rank r has published
+  // liveness handshake of the attach: a peer stores a fresh random nonce in hello[r] and trusts the segment only once rank 0 OF
+  // THIS RUN has echoed it in ack[r] -- the rank 0 of a crashed run never will, whatever its counters say
+  std::atomic<uint64_t> hello[64], ack[64];
 };
 constexpr uint64_t SHM_MAGIC = 0x474d44495354ull;  // "GMDIST"
+constexpr uint64_t SHM_DEAD = 0x44454144474dull;   // a newer run has replaced this segment (rank 0 poisons what it unlinks)
+
+// routes a collective can take (gm_dist_stats_routes)
+enum Route { R_COPY = 0, R_HOOK = 1, R_RCCL_HOST = 2, R_RCCL_VEC = 3, R_SHM = 4, R_NROUTES = 5 };
 
 struct Dist {
   std::mutex mu;
@@ -70,14 +110,28 @@ struct Dist {
   ncclComm_t comm = nullptr;
   void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;  // staging of host payloads
   size_t stage_in = 0, stage_out = 0;
-  // shm
+  // shm (the transport of gm_dist_init_shm, and the SIDE CHANNEL of gm_dist_init_rccl_node for small host payloads)
   ShmHeader* shm = nullptr;
   size_t shm_bytes = 0, slot_bytes = 0;
   uint64_t shm_call = 0;
   std::string shm_name;
+  ino_t shm_ino = 0;  // the inode the name resolved to when this rank attached: only that one is ever unlinked
+  dev_t shm_dev = 0;
+  // under RCCL: which payload classes go over the side segment (bit 0: field values, bit 1: partial G1 points)
+  unsigned shm_classes = 0;
   // statistics
   uint64_t calls = 0, bytes = 0;
   double seconds = 0.0;
+  uint64_t rcalls[R_NROUTES] = {}, rbytes[R_NROUTES] = {};
+  double rseconds[R_NROUTES] = {};
+  void note(Route r, size_t b, double sec) {
+    calls++;
+    bytes += b;
+    seconds += sec;
+    rcalls[r]++;
+    rbytes[r] += b;
+    rseconds[r] += sec;
+  }
 };
 
 Dist& D() {
@@ -116,6 +170,7 @@ int load_rccl(Rccl& R) {
   GM_SYM(CommDestroy, "ncclCommDestroy");
   GM_SYM(GetErrorString, "ncclGetErrorString");
 #undef GM_SYM
+  R.CommAbort = reinterpret_cast<CommDestroy_t>(dlsym(R.lib, "ncclCommAbort"));
   return GM_OK;
 }
 
@@ -152,11 +207,22 @@ uint8_t* shm_slot(Dist& d, uint64_t call, int r) {
   return base + ((call & 1) * (size_t)d.world + (size_t)r) * d.slot_bytes;
 }
 
-int shm_wait(std::atomic<uint64_t>& a, uint64_t want, const char* what) {
-  const auto t0 = Clock::now();
+double shm_timeout() {
   static const double limit = getenv("GM_DIST_TIMEOUT_S") ? atof(getenv("GM_DIST_TIMEOUT_S")) : 300.0;
+  return limit;
+}
+
+// Wait until a peer's counter reaches call k.  When this rank reads it the peer can only be AT k or ONE call ahead (it cannot
+// publish k + 2 before this rank has published k + 1): any other value means the segment is not the one of this run -- a stale
+// segment of a crashed run a rank attached to before rank 0 replaced it, or a corrupted counter -- and is an error, never data.
+int shm_wait_seq(ShmHeader* h, int r, uint64_t k) {
+  const auto t0 = Clock::now();
+  std::atomic<uint64_t>& a = h->seq[r];
   for (unsigned spin = 0;; spin++) {
-    if (a.load(std::memory_order_acquire) >= want) return GM_OK;
+    const uint64_t v = a.load(std::memory_order_acquire);
+    if (v == k || v == k + 1) return GM_OK;
+    GM_CHECK(v < k, GM_ESTATE, "gm_dist(shm): rank %d is at call %llu while this rank is at call %llu: a stale or corrupted segment", r,
+             (unsigned long long)v, (unsigned long long)k);
     if (spin < 2000) {
 #if defined(__x86_64__)
       __builtin_ia32_pause();
@@ -165,8 +231,9 @@ int shm_wait(std::atomic<uint64_t>& a, uint64_t want, const char* what) {
       // ranks may outnumber the cores the container may use (8 ranks + their helper threads on a 16-CPU quota)
       std::this_thread::yield();
       if ((spin & 1023) == 0) {
-        GM_CHECK(std::chrono::duration<double>(Clock::now() - t0).count() < limit, GM_ESTATE, "gm_dist(shm): %s: a peer did not arrive within %.0f s",
-                 what, limit);
+        GM_CHECK(h->magic.load(std::memory_order_acquire) == SHM_MAGIC, GM_ESTATE, "gm_dist(shm): the segment was replaced by a newer run");
+        GM_CHECK(std::chrono::duration<double>(Clock::now() - t0).count() < shm_timeout(), GM_ESTATE,
+                 "gm_dist(shm): all-gather: rank %d did not arrive within %.0f s", r, shm_timeout());
       }
     }
   }
@@ -182,7 +249,7 @@ int shm_allgather_once(Dist& d, const void* send, size_t bytes, void* recv) {
   for (int i = 0; i < d.world; i++) {
     const int r = (d.rank + i) % d.world;
     if (r != d.rank) {
-      int rc = shm_wait(d.shm->seq[r], k, "all-gather");
+      int rc = shm_wait_seq(d.shm, r, k);
       if (rc) return rc;
     }
     memcpy(static_cast<uint8_t*>(recv) + (size_t)r * bytes, shm_slot(d, k, r), bytes);
@@ -203,12 +270,24 @@ int shm_allgather(Dist& d, const void* send, size_t bytes, void* recv) {
   return GM_OK;
 }
 
-void shm_detach(Dist& d) {
+// does `name` still resolve to the segment this rank mapped?
+bool shm_name_is(const char* name, dev_t dev, ino_t ino) {
+  const int fd = shm_open(name, O_RDWR, 0600);
+  if (fd < 0) return false;
+  struct stat st;
+  const bool same = fstat(fd, &st) == 0 && st.st_dev == dev && st.st_ino == ino;
+  close(fd);
+  return same;
+}
+
+void shm_detach(Dist& d, bool count = true) {
   if (!d.shm) return;
-  const uint64_t left = d.shm->attached.fetch_sub(1) - 1;
+  const uint64_t left = count ? d.shm->attached.fetch_sub(1) - 1 : 1;
   munmap(d.shm, d.shm_bytes);
-  if (left == 0) shm_unlink(d.shm_name.c_str());
+  // the last one out removes the name -- if it still names THIS segment (a re-init under the same name may have replaced it)
+  if (left == 0 && shm_name_is(d.shm_name.c_str(), d.shm_dev, d.shm_ino)) shm_unlink(d.shm_name.c_str());
   d.shm = nullptr;
+  d.shm_classes = 0;
 }
 
 void reset(Dist& d) {
@@ -231,38 +310,234 @@ void reset(Dist& d) {
   d.shm_call = 0;
 }
 
-int allgather_host_locked(Dist& d, const void* send, size_t bytes, void* recv) {
+// GM_DIST_CLASS_*: what a host payload is.  Under RCCL with the node's side segment open (gm_dist_init_rccl_node) the FIELD values
+// of the path -- 64 bytes per sumcheck round, a few evaluations, the 2^10-element tails -- cross processes as a store and a load
+// (a few us) instead of H2D + ncclAllGather + D2H + a stream wait (profiles/r5_collective_latency.txt); partial G1 points keep
+// ncclAllGather (north_star: "a final RCCL reduce of partial G1 points over xGMI") unless GM_DIST_G1_ROUTE=shm.
+int rccl_host_allgather(Dist& d, const void* send, size_t bytes, void* recv) {
+  gm::Context* C = gm::context();
+  GM_CHECK(C != nullptr, GM_ENOTINIT, "gm_init has not been called");
+  int rc = GM_OK;
+  if ((rc = ensure_stage(d, bytes))) return rc;
+  memcpy(d.h_in, send, bytes);
+  // a rank that fails here leaves its peers inside ncclAllGather: abort the communicator so that they return with an error
+  // instead of hanging (the shm transport has a timeout of its own)
+  auto fail = [&](int code) {
+    if (d.comm && d.R.CommAbort) {
+      (void)d.R.CommAbort(d.comm);
+      d.comm = nullptr;
+      d.tr = T_NONE;
+    }
+    return code;
+  };
+  hipError_t e = hipMemcpyAsync(d.d_in, d.h_in, bytes, hipMemcpyHostToDevice, C->stream);
+  if (e != hipSuccess) return fail(gm::hip_fail(e, "hipMemcpyAsync(H2D staging)", __FILE__, __LINE__));
+  ncclResult_t r = d.R.AllGather(d.d_in, d.d_out, bytes, ncclChar, d.comm, C->stream);
+  if (r != ncclSuccess) {
+    gm::set_error("gm_dist: ncclAllGather failed: %s", d.R.GetErrorString(r));
+    return fail(GM_EHIP);
+  }
+  e = hipMemcpyAsync(d.h_out, d.d_out, bytes * (size_t)d.world, hipMemcpyDeviceToHost, C->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
+  if (e != hipSuccess) return fail(gm::hip_fail(e, "D2H staging / wait", __FILE__, __LINE__));
+  memcpy(recv, d.h_out, bytes * (size_t)d.world);
+  return GM_OK;
+}
+
+int allgather_host_locked(Dist& d, const void* send, size_t bytes, void* recv, int cls = GM_DIST_CLASS_FIELD, int force_route = -1) {
   if (bytes == 0) return GM_OK;
   const auto t0 = Clock::now();
   int rc = GM_OK;
+  Route route = R_COPY;
   switch (d.tr) {
     case T_NONE:
       memcpy(recv, send, bytes);
       break;
     case T_HOOK:
+      route = R_HOOK;
       rc = d.fn(d.fn_ctx, send, bytes, recv);
       if (rc) gm::set_error("gm_dist: the all-gather hook returned %d", rc);
       break;
     case T_SHM:
+      route = R_SHM;
       rc = shm_allgather(d, send, bytes, recv);
       break;
     case T_RCCL: {
-      gm::Context* C = gm::context();
-      GM_CHECK(C != nullptr, GM_ENOTINIT, "gm_init has not been called");
-      if ((rc = ensure_stage(d, bytes))) return rc;
-      memcpy(d.h_in, send, bytes);
-      GM_HIP(hipMemcpyAsync(d.d_in, d.h_in, bytes, hipMemcpyHostToDevice, C->stream));
-      GM_NCCL(d, d.R.AllGather(d.d_in, d.d_out, bytes, ncclChar, d.comm, C->stream));
-      GM_HIP(hipMemcpyAsync(d.h_out, d.d_out, bytes * (size_t)d.world, hipMemcpyDeviceToHost, C->stream));
-      GM_HIP(hipStreamSynchronize(C->stream));
-      memcpy(recv, d.h_out, bytes * (size_t)d.world);
+      bool side = d.shm != nullptr && (d.shm_classes >> (cls == GM_DIST_CLASS_G1 ? 1 : 0) & 1u) != 0;
+      if (force_route == R_SHM) side = d.shm != nullptr;
+      if (force_route == R_RCCL_HOST) side = false;
+      route = side ? R_SHM : R_RCCL_HOST;
+      rc = side ? shm_allgather(d, send, bytes, recv) : rccl_host_allgather(d, send, bytes, recv);
       break;
     }
   }
-  d.calls++;
-  d.bytes += bytes * (size_t)d.world;
-  d.seconds += std::chrono::duration<double>(Clock::now() - t0).count();
+  d.note(route, bytes * (size_t)d.world, std::chrono::duration<double>(Clock::now() - t0).count());
   return rc;
+}
+
+// Attach to (rank > 0) or create (rank 0) the segment `name`; leaves d.tr alone.  Rank 0 POISONS a segment of that name it finds
+// (magic = SHM_DEAD) before unlinking it and creates the new one under O_EXCL; a peer accepts a segment only while its magic is
+// SHM_MAGIC and the name still resolves to the inode it mapped, and re-attaches otherwise -- so a peer that opened the stale
+// segment of a crashed run (bench.py reuses "/gm_bench_<port>") either never trusts it or notices within its first wait.
+int shm_open_segment(Dist& d, int rank, int world, const char* name, size_t slot_bytes) {
+  if (slot_bytes == 0) slot_bytes = (size_t)1 << 20;
+  slot_bytes = (slot_bytes + 63) & ~(size_t)63;
+  const size_t total = ((sizeof(ShmHeader) + 63) & ~(size_t)63) + 2 * (size_t)world * slot_bytes;
+  const auto t0 = Clock::now();
+  auto elapsed = [&] { return std::chrono::duration<double>(Clock::now() - t0).count(); };
+  d.shm_name = name;
+  d.slot_bytes = slot_bytes;
+  d.shm_bytes = total;
+  d.shm_call = 0;
+  if (rank == 0) {
+    int old = shm_open(name, O_RDWR, 0600);
+    if (old >= 0) {  // a stale segment of a crashed run (or of a previous init under this name): poison, then unlink
+      struct stat st;
+      if (fstat(old, &st) == 0 && (size_t)st.st_size >= sizeof(ShmHeader)) {
+        void* q = mmap(nullptr, sizeof(ShmHeader), PROT_READ | PROT_WRITE, MAP_SHARED, old, 0);
+        if (q != MAP_FAILED) {
+          static_cast<ShmHeader*>(q)->magic.store(SHM_DEAD, std::memory_order_release);
+          munmap(q, sizeof(ShmHeader));
+        }
+      }
+      close(old);
+      (void)shm_unlink(name);
+    }
+    int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    GM_CHECK(fd >= 0, GM_ESTATE, "gm_dist_init_shm: shm_open(%s) failed: %s", name, strerror(errno));
+    struct stat st;
+    if (ftruncate(fd, (off_t)total) != 0 || fstat(fd, &st) != 0) {
+      close(fd);
+      (void)shm_unlink(name);
+      GM_CHECK(false, GM_ENOMEM, "gm_dist_init_shm: ftruncate(%zu) failed: %s", total, strerror(errno));
+    }
+    void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    GM_CHECK(p != MAP_FAILED, GM_ENOMEM, "gm_dist_init_shm: mmap failed: %s", strerror(errno));
+    d.shm = static_cast<ShmHeader*>(p);
+    d.shm_ino = st.st_ino;
+    d.shm_dev = st.st_dev;
+    d.shm->world = (uint64_t)world;
+    d.shm->slot_bytes = slot_bytes;
+    for (auto& q : d.shm->seq) q.store(0, std::memory_order_relaxed);
+    for (auto& q : d.shm->hello) q.store(0, std::memory_order_relaxed);
+    for (auto& q : d.shm->ack) q.store(0, std::memory_order_relaxed);
+    d.shm->attached.store(1, std::memory_order_relaxed);
+    d.shm->magic.store(SHM_MAGIC, std::memory_order_release);
+    // echo every peer's nonce (in whatever order they arrive)
+    int waiting = world - 1;
+    std::vector<char> seen((size_t)world, 0);
+    for (unsigned spin = 0; waiting > 0; spin++) {
+      for (int r = 1; r < world; r++) {
+        if (seen[(size_t)r]) continue;
+        const uint64_t v = d.shm->hello[r].load(std::memory_order_acquire);
+        if (v != 0) {
+          d.shm->ack[r].store(v, std::memory_order_release);
+          seen[(size_t)r] = 1;
+          waiting--;
+        }
+      }
+      if (waiting > 0) {
+        if (elapsed() > shm_timeout()) {
+          shm_detach(d);
+          GM_CHECK(false, GM_ESTATE, "gm_dist_init_shm: %d of %d peers never attached to %s", waiting, world - 1, name);
+        }
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+    }
+    return GM_OK;
+  }
+  uint64_t nonce = 0;
+  {
+    const int rfd = open("/dev/urandom", O_RDONLY);
+    if (rfd >= 0) {
+      if (read(rfd, &nonce, sizeof nonce) != (ssize_t)sizeof nonce) nonce = 0;
+      close(rfd);
+    }
+    if (nonce == 0) nonce = (uint64_t)Clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ull ^ ((uint64_t)getpid() << 32) ^ (uint64_t)rank ^ 1;
+    if (nonce == 0) nonce = 1;
+  }
+  for (;;) {
+    GM_CHECK(elapsed() < 120.0, GM_ESTATE, "gm_dist_init_shm: rank 0 never created %s", name);
+    int fd = shm_open(name, O_RDWR, 0600);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < total) {
+      if (fd >= 0) close(fd);
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      continue;
+    }
+    void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    GM_CHECK(p != MAP_FAILED, GM_ENOMEM, "gm_dist_init_shm: mmap failed: %s", strerror(errno));
+    ShmHeader* h = static_cast<ShmHeader*>(p);
+    // wait for rank 0 to finish the header of THIS inode; give up on it as soon as it is poisoned or the name moves on
+    bool good = false;
+    for (unsigned spin = 0; elapsed() < 120.0; spin++) {
+      const uint64_t m = h->magic.load(std::memory_order_acquire);
+      if (m == SHM_MAGIC) {
+        good = true;
+        break;
+      }
+      if (m == SHM_DEAD) break;
+      if ((spin & 255) == 255 && !shm_name_is(name, st.st_dev, st.st_ino)) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    if (good && (h->world != (uint64_t)world || h->slot_bytes != slot_bytes)) {
+      // another world / slot size: a stale segment unless rank 0 of this run really disagrees -- the name decides
+      if (shm_name_is(name, st.st_dev, st.st_ino) && elapsed() > 5.0) {
+        munmap(p, total);
+        GM_CHECK(false, GM_EINVAL, "gm_dist_init_shm: %s was created for another world / slot size", name);
+      }
+      good = false;
+    }
+    if (good && !shm_name_is(name, st.st_dev, st.st_ino)) good = false;  // replaced while this rank was looking at it
+    if (good) {  // is the rank 0 behind this segment alive, i.e. of this run?
+      h->hello[rank].store(nonce, std::memory_order_release);
+      good = false;
+      for (unsigned spin = 0; elapsed() < 120.0; spin++) {
+        if (h->ack[rank].load(std::memory_order_acquire) == nonce) {
+          good = true;
+          break;
+        }
+        if (h->magic.load(std::memory_order_acquire) != SHM_MAGIC) break;
+        if ((spin & 255) == 255 && !shm_name_is(name, st.st_dev, st.st_ino)) break;
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+      }
+    }
+    if (!good) {
+      munmap(p, total);
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      continue;
+    }
+    d.shm = h;
+    d.shm_ino = st.st_ino;
+    d.shm_dev = st.st_dev;
+    d.shm->attached.fetch_add(1);
+    return GM_OK;
+  }
+}
+
+// rendezvous on a fresh segment: everybody attached before anybody may finalize (and unlink).  A peer that attached to a stale
+// segment in the window before rank 0 poisoned it fails this all-gather (poisoned magic, or counters that are not 0 / 1 / 2) and
+// attaches again.
+int shm_rendezvous(Dist& d, int rank, int world, const char* name, size_t slot_bytes) {
+  const auto t0 = Clock::now();
+  for (;;) {
+    int rc = shm_open_segment(d, rank, world, name, slot_bytes);
+    if (rc) return rc;
+    const int save_rank = d.rank, save_world = d.world;
+    d.rank = rank;
+    d.world = world;
+    uint64_t one = 1;
+    std::vector<uint64_t> all((size_t)world);
+    rc = shm_allgather(d, &one, sizeof one, all.data());
+    if (rc == GM_OK) return GM_OK;
+    d.rank = save_rank;
+    d.world = save_world;
+    const bool replaced = rank != 0 && (d.shm->magic.load() != SHM_MAGIC || !shm_name_is(name, d.shm_dev, d.shm_ino));
+    shm_detach(d, /*count=*/!replaced);
+    if (!replaced || std::chrono::duration<double>(Clock::now() - t0).count() > 120.0) return rc;
+  }
 }
 
 }  // namespace
@@ -321,90 +596,72 @@ int gm_dist_init_shm(int rank, int world, const char* name, size_t slot_bytes) {
   GM_CHECK(world >= 1 && world <= 64 && rank >= 0 && rank < world && name && name[0] == '/', GM_EINVAL,
            "gm_dist_init_shm: rank %d of %d (<= 64), name must start with '/'", rank, world);
   reset(d);
-  if (slot_bytes == 0) slot_bytes = (size_t)1 << 20;
-  slot_bytes = (slot_bytes + 63) & ~(size_t)63;
-  const size_t total = ((sizeof(ShmHeader) + 63) & ~(size_t)63) + 2 * (size_t)world * slot_bytes;
-  int fd = -1;
-  if (rank == 0) {
-    (void)shm_unlink(name);  // a stale segment of a crashed run
-    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-    GM_CHECK(fd >= 0, GM_ESTATE, "gm_dist_init_shm: shm_open(%s) failed: %s", name, strerror(errno));
-    if (ftruncate(fd, (off_t)total) != 0) {
-      close(fd);
-      GM_CHECK(false, GM_ENOMEM, "gm_dist_init_shm: ftruncate(%zu) failed: %s", total, strerror(errno));
-    }
-  } else {
-    const auto t0 = Clock::now();
-    for (;;) {
-      fd = shm_open(name, O_RDWR, 0600);
-      struct stat st;
-      if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= total) break;
-      if (fd >= 0) close(fd);
-      fd = -1;
-      GM_CHECK(std::chrono::duration<double>(Clock::now() - t0).count() < 120.0, GM_ESTATE, "gm_dist_init_shm: rank 0 never created %s", name);
-      std::this_thread::sleep_for(std::chrono::milliseconds(2));
-    }
-  }
-  void* p = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  GM_CHECK(p != MAP_FAILED, GM_ENOMEM, "gm_dist_init_shm: mmap failed: %s", strerror(errno));
-  d.shm = static_cast<ShmHeader*>(p);
-  d.shm_bytes = total;
-  d.slot_bytes = slot_bytes;
-  d.shm_name = name;
-  if (rank == 0) {
-    d.shm->world = (uint64_t)world;
-    d.shm->slot_bytes = slot_bytes;
-    for (auto& s : d.shm->seq) s.store(0, std::memory_order_relaxed);
-    d.shm->attached.store(1, std::memory_order_relaxed);
-    d.shm->magic.store(SHM_MAGIC, std::memory_order_release);
-  } else {
-    int rc = shm_wait(d.shm->magic, SHM_MAGIC, "attach");
-    if (rc == GM_OK && (d.shm->magic.load() != SHM_MAGIC || d.shm->world != (uint64_t)world || d.shm->slot_bytes != slot_bytes)) {
-      gm::set_error("gm_dist_init_shm: %s was created for another world / slot size", name);
-      rc = GM_EINVAL;
-    }
-    if (rc) {
-      munmap(p, total);
-      d.shm = nullptr;
-      return rc;
-    }
-    d.shm->attached.fetch_add(1);
-  }
+  int rc = shm_rendezvous(d, rank, world, name, slot_bytes);
+  if (rc) return rc;
   d.rank = rank;
   d.world = world;
   d.tr = T_SHM;
-  // everybody attached before anybody may finalize (and unlink)
-  uint64_t one = 1;
-  std::vector<uint64_t> all((size_t)world);
-  return shm_allgather(d, &one, sizeof one, all.data());
+  return GM_OK;
 }
 
 // RCCL on ONE node with no out-of-band channel of the embedder's: the ranks meet in a shared-memory segment `name` (as for
-// gm_dist_init_shm), rank 0 draws the unique id and the segment carries its 128 bytes to the peers; then the segment is left and the
-// communicator is built.  One call per rank after gm_init(local_rank).
+// gm_dist_init_shm), rank 0 draws the unique id and the segment carries its 128 bytes to the peers; then the communicator is
+// built.  The segment STAYS OPEN as the side channel of the small host payloads (allgather_host_locked).  One call per rank after
+// gm_init(local_rank).
 int gm_dist_init_rccl_node(int rank, int world, const char* name) {
-  int rc = gm_dist_init_shm(rank, world, name, 4096);
+  Dist& d = D();
+  std::lock_guard<std::mutex> lk(d.mu);
+  gm::Context* C = gm::context();
+  GM_CHECK(C != nullptr, GM_ENOTINIT, "gm_init has not been called");  // the communicator binds to the device of gm_init
+  GM_CHECK(world >= 1 && world <= 64 && rank >= 0 && rank < world && name && name[0] == '/', GM_EINVAL,
+           "gm_dist_init_rccl_node: rank %d of %d (<= 64), name must start with '/'", rank, world);
+  int rc = load_rccl(d.R);
   if (rc) return rc;
-  uint8_t mine[128];
-  memset(mine, 0, sizeof mine);
-  if (rank == 0 && (rc = gm_dist_rccl_unique_id(mine))) {
-    (void)gm_dist_finalize();
-    return rc;
+  reset(d);
+  if ((rc = shm_rendezvous(d, rank, world, name, (size_t)128 << 10))) return rc;
+  d.rank = rank;
+  d.world = world;
+  ncclUniqueId id;
+  memset(&id, 0, sizeof id);
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in the ABI of include/gemini_hip.h");
+  if (rank == 0) {
+    ncclResult_t r = d.R.GetUniqueId(&id);
+    if (r != ncclSuccess) {
+      gm::set_error("gm_dist: ncclGetUniqueId failed: %s", d.R.GetErrorString(r));
+      memset(&id, 0xff, sizeof id);  // the peers must not wait for an id that will not come: all-ones = "rank 0 failed"
+      rc = GM_EHIP;
+    }
   }
   std::vector<uint8_t> all((size_t)world * 128);
-  rc = gm_dist_allgather_host(mine, 128, all.data());
+  int rc2 = shm_allgather(d, &id, 128, all.data());
+  if (rc == GM_OK) rc = rc2;
+  if (rc == GM_OK) {
+    bool bad = true;
+    for (int i = 0; i < 128; i++) bad = bad && all[(size_t)i] == 0xff;
+    if (bad) {
+      gm::set_error("gm_dist_init_rccl_node: rank 0 could not draw a unique id");
+      rc = GM_EHIP;
+    }
+  }
   if (rc) {
-    (void)gm_dist_finalize();
+    reset(d);
     return rc;
   }
-  // everybody has read rank 0's slot before anybody leaves the segment (the last one out unlinks it)
-  uint64_t one = 1;
-  std::vector<uint64_t> seen((size_t)world);
-  rc = gm_dist_allgather_host(&one, 8, seen.data());
-  (void)gm_dist_finalize();
-  if (rc) return rc;
-  return gm_dist_init_rccl(rank, world, all.data());
+  memcpy(&id, all.data(), sizeof id);
+  hipError_t e = hipSetDevice(C->device);
+  ncclResult_t r = e == hipSuccess ? d.R.CommInitRank(&d.comm, world, id, rank) : ncclSuccess;
+  if (e != hipSuccess || r != ncclSuccess) {
+    if (e != hipSuccess) (void)gm::hip_fail(e, "hipSetDevice", __FILE__, __LINE__);
+    else gm::set_error("gm_dist: ncclCommInitRank failed: %s", d.R.GetErrorString(r));
+    reset(d);
+    return GM_EHIP;
+  }
+  d.tr = T_RCCL;
+  // field values over the segment; partial G1 points over RCCL unless the embedder asks otherwise
+  d.shm_classes = 1u;
+  if (const char* g = getenv("GM_DIST_G1_ROUTE")) d.shm_classes = strcmp(g, "shm") == 0 ? 3u : 1u;
+  if (const char* f = getenv("GM_DIST_FIELD_ROUTE")) d.shm_classes = (d.shm_classes & 2u) | (strcmp(f, "rccl") == 0 ? 0u : 1u);
+  return GM_OK;
 }
 
 int gm_dist_finalize(void) {
@@ -432,8 +689,51 @@ int gm_dist_stats(uint64_t* calls, uint64_t* bytes, double* seconds, int reset_c
   if (reset_counters) {
     d.calls = d.bytes = 0;
     d.seconds = 0.0;
+    for (int i = 0; i < R_NROUTES; i++) {
+      d.rcalls[i] = d.rbytes[i] = 0;
+      d.rseconds[i] = 0.0;
+    }
   }
   return GM_OK;
+}
+
+// the same, split by the route each collective took: 0 copy (world 1), 1 hook, 2 RCCL with host staging, 3 RCCL device vectors,
+// 4 shared memory (the transport of gm_dist_init_shm or the side segment of gm_dist_init_rccl_node)
+int gm_dist_stats_routes(uint64_t calls[5], uint64_t bytes[5], double seconds[5]) {
+  Dist& d = D();
+  std::lock_guard<std::mutex> lk(d.mu);
+  for (int i = 0; i < R_NROUTES; i++) {
+    if (calls) calls[i] = d.rcalls[i];
+    if (bytes) bytes[i] = d.rbytes[i];
+    if (seconds) seconds[i] = d.rseconds[i];
+  }
+  return GM_OK;
+}
+
+int gm_dist_allgather_host_class(const void* send, size_t bytes, void* recv, int payload_class) {
+  Dist& d = D();
+  std::lock_guard<std::mutex> lk(d.mu);
+  GM_CHECK(bytes == 0 || (send && recv), GM_EINVAL, "gm_dist_allgather_host_class: null pointer");
+  GM_CHECK(payload_class == GM_DIST_CLASS_FIELD || payload_class == GM_DIST_CLASS_G1, GM_EINVAL, "gm_dist_allgather_host_class: class %d", payload_class);
+  return allgather_host_locked(d, send, bytes, recv, payload_class);
+}
+
+// `iters` back-to-back all-gathers of `bytes` per rank over one route (-1: the route the class would take; 2: RCCL with host
+// staging; 4: shared memory) -> microseconds per call, every rank.  What decided the routing (profiles/r5_collective_latency.txt).
+int gm_dist_bench(size_t bytes, int iters, int payload_class, int route, double* usec_per_call) {
+  Dist& d = D();
+  std::lock_guard<std::mutex> lk(d.mu);
+  GM_CHECK(bytes > 0 && iters > 0 && usec_per_call, GM_EINVAL, "gm_dist_bench: bad arguments");
+  GM_CHECK(route == -1 || route == R_RCCL_HOST || route == R_SHM, GM_EINVAL, "gm_dist_bench: route %d (want -1, 2 or 4)", route);
+  GM_CHECK(route == -1 || d.tr == T_RCCL, GM_ESTATE, "gm_dist_bench: forcing a route needs the RCCL transport (gm_dist_init_rccl_node)");
+  GM_CHECK(route != R_SHM || d.shm != nullptr, GM_ESTATE, "gm_dist_bench: no side segment (gm_dist_init_rccl opens none)");
+  std::vector<uint8_t> send(bytes, (uint8_t)(d.rank + 1)), recv(bytes * (size_t)d.world);
+  int rc = GM_OK;
+  for (int i = 0; i < 3 && !rc; i++) rc = allgather_host_locked(d, send.data(), bytes, recv.data(), payload_class, route);
+  const auto t0 = Clock::now();
+  for (int i = 0; i < iters && !rc; i++) rc = allgather_host_locked(d, send.data(), bytes, recv.data(), payload_class, route);
+  *usec_per_call = std::chrono::duration<double>(Clock::now() - t0).count() * 1e6 / iters;
+  return rc;
 }
 
 int gm_dist_allgather_host(const void* send, size_t bytes, void* recv) {
@@ -461,8 +761,19 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
     GM_HIP(hipMemcpyAsync(out->d, in->d, bytes, hipMemcpyDeviceToDevice, C->stream));
     GM_HIP(hipStreamSynchronize(C->stream));
   } else if (d.tr == T_RCCL) {
-    GM_NCCL(d, d.R.AllGather(in->d, out->d, bytes, ncclChar, d.comm, C->stream));
-    GM_HIP(hipStreamSynchronize(C->stream));
+    // (a failing rank aborts the communicator so that its peers return instead of hanging: see rccl_host_allgather)
+    ncclResult_t r = d.R.AllGather(in->d, out->d, bytes, ncclChar, d.comm, C->stream);
+    hipError_t e = r == ncclSuccess ? hipStreamSynchronize(C->stream) : hipSuccess;
+    if (r != ncclSuccess || e != hipSuccess) {
+      if (r != ncclSuccess) gm::set_error("gm_dist: ncclAllGather failed: %s", d.R.GetErrorString(r));
+      const int code = r != ncclSuccess ? GM_EHIP : gm::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+      if (d.comm && d.R.CommAbort) {
+        (void)d.R.CommAbort(d.comm);
+        d.comm = nullptr;
+        d.tr = T_NONE;
+      }
+      return code;
+    }
   } else {
     std::vector<uint8_t> h_in(bytes), h_out(bytes * (size_t)d.world);
     GM_HIP(hipMemcpyAsync(h_in.data(), in->d, bytes, hipMemcpyDeviceToHost, C->stream));
@@ -475,9 +786,8 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
     GM_HIP(hipMemcpyAsync(out->d, h_out.data(), h_out.size(), hipMemcpyHostToDevice, C->stream));
     GM_HIP(hipStreamSynchronize(C->stream));
   }
-  d.calls++;
-  d.bytes += bytes * (size_t)d.world;
-  d.seconds += std::chrono::duration<double>(Clock::now() - t0).count();
+  d.note(d.tr == T_NONE ? R_COPY : d.tr == T_RCCL ? R_RCCL_VEC : d.tr == T_HOOK ? R_HOOK : R_SHM, bytes * (size_t)d.world,
+         std::chrono::duration<double>(Clock::now() - t0).count());
   return GM_OK;
 }
 

@@ -152,7 +152,7 @@ static int ck_msm_many(uint64_t ck, const size_t* offsets, int reversed, const u
     for (size_t t = 0; t < idx.size(); t++) memcpy(parts.data() + 18 * idx[t], local.data() + 18 * t, 144);
   }
   std::vector<uint64_t> all(18 * k * world);
-  RC(gm_dist_allgather_host(parts.data(), 144 * k, all.data()));
+  RC(gm_dist_allgather_host_class(parts.data(), 144 * k, all.data(), GM_DIST_CLASS_G1));
   std::vector<uint64_t> col(18 * world);
   for (size_t j = 0; j < k; j++) {
     for (size_t r = 0; r < world; r++) memcpy(col.data() + 18 * r, all.data() + 18 * (r * k + j), 144);
@@ -408,7 +408,7 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
   };
   auto gather_sum = [&](const uint64_t* parts, size_t k, uint64_t* out) -> int {  // all-gather k partial points, add per column
     std::vector<uint64_t> all(18 * k * g), col(18 * g);
-    RC(gm_dist_allgather_host(parts, 144 * k, all.data()));
+    RC(gm_dist_allgather_host_class(parts, 144 * k, all.data(), GM_DIST_CLASS_G1));
     for (size_t j = 0; j < k; j++) {
       for (size_t rr = 0; rr < g; rr++) memcpy(col.data() + 18 * rr, all.data() + 18 * (rr * k + j), 144);
       RC(gm_g1_sum(col.data(), g, out + 18 * j));

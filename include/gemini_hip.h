@@ -547,9 +547,10 @@ int gm_psnark_index(const gm_psnark_instance* instance, uint64_t ck_bases, uint6
  *                      payloads in rank order and returns 0.
  *   gm_dist_init_shm   ranks of one node over a POSIX shared-memory segment `name` ("/something", the same on every rank;
  *                      slot_bytes = 0: 1 MiB per rank and call, longer payloads are cut): the payloads of this path are
- *                      host results of <= 1 KiB, which cross processes in ~1 us this way.  Use a FRESH name per run (a pid, the
- *                      launcher's port): rank 0 removes a stale segment of that name before creating it, and a peer that had already
- *                      opened the stale one would wait for it until the timeout (GM_DIST_TIMEOUT_S, default 300 s).
+ *                      host results of <= 1 KiB, which cross processes in ~1 us this way.  A name may be reused: rank 0 poisons
+ *                      and removes a stale segment of that name before creating its own, a peer trusts a segment only after the
+ *                      rank 0 OF THIS RUN has echoed the peer's fresh nonce, and every wait accepts a peer's call counter only at
+ *                      the one or two values it can legitimately have (anything else is GM_ESTATE, never stale data).
  * Without any of them (or world = 1) an all-gather is a copy.  Collective calls must be made by every rank in the same order. */
 typedef int (*gm_allgather_fn)(void* ctx, const void* send, size_t bytes, void* recv);
 int gm_dist_init_hook(int rank, int world, gm_allgather_fn fn, void* ctx);
@@ -557,7 +558,9 @@ int gm_dist_rccl_unique_id(uint8_t out[128]);
 int gm_dist_init_rccl(int rank, int world, const uint8_t unique_id[128]);
 int gm_dist_init_shm(int rank, int world, const char* name, size_t slot_bytes);
 /* RCCL on one node without any out-of-band channel: the ranks meet in the shared-memory segment `name`, which carries rank 0's
- * unique id to the peers, then build the communicator (gm_dist_rccl_unique_id + gm_dist_init_rccl in one call per rank). */
+ * unique id to the peers, then build the communicator (gm_dist_rccl_unique_id + gm_dist_init_rccl in one call per rank).  The
+ * segment stays open as the side channel of small host payloads (gm_dist_allgather_host_class).  A rank whose RCCL call FAILS
+ * aborts the communicator (ncclCommAbort), so its peers return with an error instead of waiting inside the collective. */
 int gm_dist_init_rccl_node(int rank, int world, const char* name);
 int gm_dist_finalize(void);
 /* transport: 0 none, 1 hook, 2 RCCL, 3 shm */
@@ -565,11 +568,24 @@ int gm_dist_info(int* rank, int* world, int* transport);
 /* recv = world x bytes, rank order.  Host buffers (an MSM partial is finished by the host Horner; sumcheck messages and
  * evaluations are host values too). */
 int gm_dist_allgather_host(const void* send, size_t bytes, void* recv);
+/* The same with the payload's class.  It matters under gm_dist_init_rccl_node only, whose rendezvous segment stays open as a side
+ * channel: FIELD values (sumcheck messages, evaluations, gathered tails; what gm_dist_allgather_host sends) cross it as a store and a
+ * load, a few microseconds, where host staging around ncclAllGather costs H2D + collective + D2H + a stream wait; partial G1 POINTS
+ * -- the all-gather behind every sharded commitment, north_star's "final RCCL reduce of partial G1 points over xGMI" -- go through
+ * ncclAllGather (GM_DIST_G1_ROUTE=shm / GM_DIST_FIELD_ROUTE=rccl override either).  Measured: profiles/r5_collective_latency.txt. */
+#define GM_DIST_CLASS_FIELD 0
+#define GM_DIST_CLASS_G1 1
+int gm_dist_allgather_host_class(const void* send, size_t bytes, void* recv, int payload_class);
 /* out = the local vectors of ranks 0 .. world - 1 back to back (equal lengths; out needs capacity world x len and is
  * resized): device to device over RCCL, staged through the host on the other transports. */
 int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec);
 /* collectives issued by this rank so far, the bytes they received and the wall time spent inside them */
 int gm_dist_stats(uint64_t* calls, uint64_t* bytes, double* seconds, int reset_counters);
+/* the same split by route: [0] copy (world 1), [1] hook, [2] RCCL with host staging, [3] RCCL device vectors, [4] shared memory */
+int gm_dist_stats_routes(uint64_t calls[5], uint64_t bytes[5], double seconds[5]);
+/* `iters` back-to-back all-gathers of `bytes` per rank -> microseconds per call.  route -1: wherever the class goes; 2 / 4: force RCCL
+ * with host staging / the side segment (RCCL transport only).  Collective: every rank calls it with the same arguments. */
+int gm_dist_bench(size_t bytes, int iters, int payload_class, int route, double* usec_per_call);
 /* Patterns of 8 B .. 64 KiB through the active transport, checked on every rank.  With NO transport initialised it opens
  * a one-rank RCCL communicator for the test, so the binding runs on a single-GPU box too. */
 int gm_dist_selftest(void);

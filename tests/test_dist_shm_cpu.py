@@ -97,3 +97,117 @@ def test_single_rank_and_hook_and_errors():
     assert lib.gm_dist_init_shm(C.c_int(2), C.c_int(2), b"/x", C.c_size_t(0)) == -1
     assert lib.gm_dist_init_hook(C.c_int(0), C.c_int(2), collective.ALLGATHER_FN(), None) == -1
     assert lib.gm_dist_init_rccl(C.c_int(0), C.c_int(1), (C.c_uint8 * 128)()) == -2  # needs gm_init: the communicator binds to its device
+
+
+STALE_WORKER = textwrap.dedent("""
+    import os, sys, time
+    import numpy as np
+    sys.path.insert(0, %r)
+    os.environ["GM_NO_TORCH_PRELOAD"] = "1"
+    from gemini_amd import collective
+    rank, world, name, delay = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], float(sys.argv[4])
+    time.sleep(delay)
+    collective.init_shm(rank, world, name, 256)
+    for it in range(50):
+        got = collective.allgather_host(np.array([rank * 7 + it, it], dtype=np.uint64))
+        assert (got[:, 0] == np.arange(world) * 7 + it).all() and (got[:, 1] == it).all(), (rank, it, got)
+    collective.finalize()
+    print("ok", rank)
+""") % ROOT
+
+
+def _stale_segment(name, world, slot, seq_value):
+    """What a crashed run leaves behind: a segment of the right size with a valid header (dist.cpp: ShmHeader = magic, world,
+    slot_bytes, attached, seq[64], hello[64], ack[64]), counters at `seq_value`, slots full of old payload."""
+    header = 8 * (4 + 3 * 64)
+    total = ((header + 63) & ~63) + 2 * world * slot
+    raw = np.zeros(total // 8, dtype=np.uint64)
+    raw[0] = 0x474D44495354  # SHM_MAGIC
+    raw[1], raw[2], raw[3] = world, slot, world
+    raw[4:4 + 64] = seq_value
+    raw[4 + 64:4 + 128] = 0xDEADBEEF  # old nonces, old echoes
+    raw[4 + 128:4 + 192] = 0xDEADBEEF
+    raw[(header + 63) // 64 * 8:] = 0x5A5A5A5A5A5A5A5A
+    with open("/dev/shm" + name, "wb") as f:
+        f.write(raw.tobytes())
+
+
+@pytest.mark.parametrize("seq_value", [1, 2, 123456])
+def test_a_stale_segment_of_a_crashed_run_is_never_trusted(seq_value):
+    """bench.py reuses its segment name; a peer that opens the name BEFORE rank 0 has replaced the stale
+    segment used to accept it (valid magic, world and slot size) and read old payload bytes as GM_OK while rank 0 waited for
+    300 s.  Now a peer trusts a segment only once the rank 0 of THIS run has echoed the peer's fresh nonce, rank 0 poisons what it
+    unlinks, and a counter that is not at the one or two values it can have is an error.  The peers start 1.5 s before rank 0."""
+    world, slot = 3, 256
+    name = f"/gm_stale_{os.getpid()}_{seq_value}"
+    _stale_segment(name, world, slot, seq_value)
+    try:
+        procs = [subprocess.Popen([sys.executable, "-c", STALE_WORKER, str(r), str(world), name, "1.5" if r == 0 else "0"],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+        outs = [p.communicate(timeout=120) for p in procs]
+        for p, (o, e) in zip(procs, outs):
+            assert p.returncode == 0, e[-3000:]
+        assert not os.path.exists("/dev/shm" + name)
+    finally:
+        if os.path.exists("/dev/shm" + name):
+            os.unlink("/dev/shm" + name)
+
+
+CORRUPT_WORKER = textwrap.dedent("""
+    import os, sys, time, mmap
+    import numpy as np
+    sys.path.insert(0, %r)
+    os.environ["GM_NO_TORCH_PRELOAD"] = "1"
+    os.environ["GM_DIST_TIMEOUT_S"] = "20"
+    from gemini_amd import capi, collective
+    rank, name = int(sys.argv[1]), sys.argv[2]
+    collective.init_shm(rank, 2, name, 256)
+    collective.allgather_host(np.array([rank], dtype=np.uint64))
+    if rank == 1:
+        with open("/dev/shm" + name, "r+b") as f:  # a wild write over this rank's own call counter (seq[1])
+            m = mmap.mmap(f.fileno(), 0)
+            m[8 * 5:8 * 6] = (10**9).to_bytes(8, "little")
+            m.close()
+        time.sleep(1.0)
+        print("ok 1")
+    else:
+        time.sleep(0.3)
+        try:
+            collective.allgather_host(np.array([rank], dtype=np.uint64))
+        except capi.GeminiHipError as e:
+            assert e.code == -6 and "stale or corrupted" in str(e), str(e)
+            print("ok 0")
+        else:
+            raise SystemExit("a corrupted counter was accepted")
+""") % ROOT
+
+
+def test_a_corrupted_call_counter_is_an_error_not_data():
+    name = f"/gm_corrupt_{os.getpid()}"
+    try:
+        procs = [subprocess.Popen([sys.executable, "-c", CORRUPT_WORKER, str(r), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=120) for p in procs]
+        for p, (o, e) in zip(procs, outs):
+            assert p.returncode == 0 and o.startswith("ok"), (o, e[-3000:])
+    finally:
+        if os.path.exists("/dev/shm" + name):
+            os.unlink("/dev/shm" + name)
+
+
+def test_reinit_under_the_same_name_does_not_lose_the_new_segment():
+    """A slow rank of the previous init must not unlink the segment a re-init created under the same name (shm_detach compares
+    the inode the name resolves to with the one it mapped)."""
+    os.environ.setdefault("GM_NO_TORCH_PRELOAD", "1")
+    from gemini_amd import collective
+
+    name = f"/gm_reinit_{os.getpid()}"
+    collective.init_shm(0, 1, name, 64)
+    ino = os.stat("/dev/shm" + name).st_ino
+    # somebody replaces the name (a new run's rank 0) while this process still holds the old mapping
+    os.unlink("/dev/shm" + name)
+    with open("/dev/shm" + name, "wb") as f:
+        f.write(b"\0" * 4096)
+    assert os.stat("/dev/shm" + name).st_ino != ino
+    collective.finalize()
+    assert os.path.exists("/dev/shm" + name)  # not ours: left alone
+    os.unlink("/dev/shm" + name)

@@ -90,8 +90,21 @@ def test_rccl_binding_with_one_rank():
     try:
         assert collective.info() == (0, 1, "rccl")
         collective.selftest()
+        # the rendezvous segment stays open as the side channel: field values cross it, partial G1 points take ncclAllGather
+        collective.stats(reset=True)
+        x = np.arange(8, dtype=np.uint64)
+        assert (collective.allgather_host(x) == x[None]).all()
+        assert (collective.allgather_host(x, collective.CLASS_FIELD) == x[None]).all()
+        pts = np.arange(18 * 3, dtype=np.uint64).reshape(3, 18)
+        assert (collective.allgather_host(pts, collective.CLASS_G1) == pts[None]).all()
+        routes = collective.stats_routes()
+        assert routes["shm"]["collectives"] == 2 and routes["rccl_host_staged"]["collectives"] == 1, routes
+        # both routes carry either class when forced (gm_dist_bench: what profiles/r5_collective_latency.txt was measured with)
+        for route in ("shm", "rccl_host_staged"):
+            assert collective.bench(144, 20, collective.CLASS_G1, route) > 0
     finally:
         collective.finalize()
+    assert not os.path.exists(f"/dev/shm/gm_test_rcclnode_{os.getpid()}")
 
 
 @pytest.mark.parametrize("extra", [[], ["--elastic"]], ids=["time", "elastic"])
