@@ -165,7 +165,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
     if world > 1:
         from gemini_amd import collective
 
-        coll = dict(collective.stats(), transport=collective.info()[2])
+        coll = dict(collective.stats(), transport=collective.info()[2], routes=collective.stats_routes())
         # every rank's own stage breakdown of its median run (the field arithmetic is replicated, the MSMs are sharded: the
         # spread between the ranks and the share of the commitment spans say what N GPUs bought)
         import torch.distributed as dist
@@ -240,12 +240,26 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
                 p2 = Proof.new_time(r2, ck2, native=True)
                 g_runs.append(p2.spans[SPAN])
             host_powers = ck2.powers_of_g.download(0, m + 1)
+            # timed on the build of the restatement for today's CPUs (oracle/Makefile: x86-64-v3 + ADX, the Fq product in mulx /
+            # adcx / adox asm -- what ark-ff's `asm` feature gives the reference, Cargo.toml:77-82); the portable checker build
+            # beside it at the smallest size
+            from oracle import oracle as orc_t
+
             t0 = time.perf_counter()
-            port = snark_c.new_time_dummy(e, m, host_powers)
+            with orc_t.native():
+                build = orc_t._which
+                port = snark_c.new_time_dummy(e, m, host_powers)
             cpu_s = time.perf_counter() - t0
             same = wire_ref.snark_proof(port, True) == p2.serialize_compressed()
             measured[lg] = {"cpu_s": round(port["spans"][SPAN], 3), "cpu_run_incl_setup_s": round(cpu_s, 1), "gpu_same_instance_s": round(sorted(g_runs)[1], 4),
-                            "matches_gpu_proof_bytes": bool(same), "spans_s": {k: round(v, 3) for k, v in port["spans"].items()}}
+                            "matches_gpu_proof_bytes": bool(same), "build": build, "spans_s": {k: round(v, 3) for k, v in port["spans"].items()}}
+            if lg == cpu_logn and build == "native":
+                t0 = time.perf_counter()
+                slow = snark_c.new_time_dummy(e, m, host_powers)
+                cpu_s += time.perf_counter() - t0
+                measured[lg]["cpu_run_incl_setup_s"] = round(cpu_s, 1)
+                measured[lg]["portable_build_cpu_s"] = round(slow["spans"][SPAN], 3)
+                measured[lg]["portable_build_same_bytes"] = bool(wire_ref.snark_proof(slow, True) == p2.serialize_compressed())
             r2.free()
             ck2.powers_of_g.free()
             del host_powers
@@ -255,6 +269,8 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
         steps = (logn - top) / 2.0
         cpu = {"value": measured[top]["cpu_s"], "unit": "s", "logn": top, "cores": host_cpus()["effective"],
                "threads_busy": "<= 17 in the MSMs (one task per window, c = 15 at 2^20), 1 elsewhere", "kind": "port",
+               "build": "oracle/libgemini_oracle_native.so (-march=x86-64-v3 -madx, Fq product in mulx/adcx/adox asm); the portable x86-64-v2 "
+                        "checker build beside it at the smallest size (portable_build_cpu_s)",
                "sample": f"Proof::new_time on dummy_r1cs(2^k), k = {lgs}, one run each "
                          f"({sum(v['cpu_run_incl_setup_s'] for v in measured.values()):.0f} s of CPU incl. setup)",
                "measured": {str(k): v for k, v in measured.items()},
@@ -379,7 +395,9 @@ def main():
         ok = 0
         if want == "rccl":
             try:
-                collective.init_rccl_from_torch()
+                # one node: the ranks meet in a shared-memory segment that carries the RCCL id and then STAYS OPEN as the side channel
+                # of the small field payloads (64 bytes per sumcheck round, evaluations); partial G1 points take ncclAllGather
+                collective.init_rccl_node(rank, world, "/gm_bench_%s" % os.environ.get("MASTER_PORT", "0"))
                 collective.selftest()
                 ok = 1
             except Exception as ex:  # noqa: BLE001
@@ -423,7 +441,7 @@ def main():
         if world == 1:
             return part
         # the final reduce of the partial G1 points: ONE all-gather of 144 bytes inside the library, EC adds on every rank
-        return g1_sum(collective.allgather_host(part))
+        return g1_sum(collective.allgather_host(part, collective.CLASS_G1))
 
     def barrier():
         if world > 1:
@@ -618,8 +636,9 @@ def main():
                 "workload": f"2^{args.logn} G1 MSM per GPU (BASELINE configs[1]: 2^20 G1 MSM on one MI355X)",
                 "pairs_per_gpu": n,
                 "parallelism": f"pairs sharded over {world} GPU(s), all-gather of 144-byte partial points + local EC add",
-                "collective": None if world == 1 else {"transport": collective.info()[2], "inside_library": "gm_dist_allgather_host (gemini_amd/csrc/dist.cpp)",
-                                                       "note": transport_note},
+                "collective": None if world == 1 else {"transport": collective.info()[2], "inside_library": "gm_dist_allgather_host_class (gemini_amd/csrc/dist.cpp)",
+                                                       # which route each class of collective took: partial G1 points (the per-MSM reduce) vs field values / barriers
+                                                       "routes": collective.stats_routes(), "note": transport_note},
             },
             "roofline": {
                 "bound": "hbm",
@@ -666,17 +685,29 @@ def main():
             orc.build()
             hb = hb_for_cpu
             cores = host_cpus()["effective"]
+            # the TIMED leg runs the build of the restatement for today's CPUs (oracle/Makefile: x86-64-v3 + ADX, the Fq product in
+            # mulx / adcx / adox asm, branch-free additions -- the reference runs ark-ff with its `asm` feature, Cargo.toml:77-82);
+            # the portable x86-64-v2 checker build is timed beside it
+            with orc.native():
+                build = orc._which
+                orc.msm_pippenger(hb[: 1 << 12], host_scalars[0][: 1 << 12], threads=0)  # thread pool up
+                t1 = time.perf_counter()
+                exp = orc.msm_pippenger(hb, host_scalars[0], threads=0)
+                cpu_s = time.perf_counter() - t1
             t1 = time.perf_counter()
-            exp = orc.msm_pippenger(hb, host_scalars[0], threads=0)
-            cpu_s = time.perf_counter() - t1
-            same = orc.affine_to_ints(orc.g1_to_affine(exp)) == orc.affine_to_ints(orc.g1_to_affine(results[0]))
+            exp_p = orc.msm_pippenger(hb, host_scalars[0], threads=0)
+            cpu_p = time.perf_counter() - t1
+            want = orc.affine_to_ints(orc.g1_to_affine(results[0]))
+            same = orc.affine_to_ints(orc.g1_to_affine(exp)) == want and orc.affine_to_ints(orc.g1_to_affine(exp_p)) == want
             out["cpu_baseline"] = {
                 "value": round(n / cpu_s / 1e6, 4),
                 "unit": "Mscalar/s",
                 "cores": cores,
                 "threads_busy": "<= 17: one OpenMP task per window (c = 15, 17 windows at 2^20), the reference's parallel grain",
                 "kind": "port",
-                "sample": f"one full 2^{args.logn} MSM of the benchmark inputs ({cpu_s:.2f} s), OpenMP one task per window",
+                "build": f"{build}: -march=x86-64-v3 -madx, Fq product in mulx / adcx / adox asm" if build == "native" else "portable (host without BMI2 / ADX)",
+                "portable_build_value": round(n / cpu_p / 1e6, 4),
+                "sample": f"one full 2^{args.logn} MSM of the benchmark inputs ({cpu_s:.2f} s; portable x86-64-v2 build {cpu_p:.2f} s), OpenMP one task per window",
                 "matches_gpu_result": bool(same),
             }
         if tables:

@@ -69,6 +69,7 @@ bool release_spare_tables(Context* C) {
   for (auto& kv : C->bases) {
     for (auto& ts : kv.second->extra)
       if (ts.t) (void)gm::raw_free(ts.t);
+    kv.second->extras_released = kv.second->extras_released || !kv.second->extra.empty();
     kv.second->extra.clear();
   }
   {
@@ -443,7 +444,7 @@ int gm_pool_trim(void) {
   return GM_OK;
 }
 
-int gm_mem_stats(uint64_t out[10]) {
+int gm_mem_stats(uint64_t out[12]) {
   GM_CTX();
   GM_CHECK(out != nullptr, GM_EINVAL, "gm_mem_stats: null output");
   size_t free_b = 0, total_b = 0;
@@ -459,6 +460,8 @@ int gm_mem_stats(uint64_t out[10]) {
         if (ts.t) tables += (size_t)ts.W * ts.n * 96;
     }
   }
+  size_t workspaces = msm_workspace_held(C->msm) + msm_workspace_held(C->msm_b);
+  for (auto& w : C->msm_small) workspaces += msm_workspace_held(w);
   MemStats& m = mem_stats();
   std::lock_guard<std::mutex> lk(m.mu);
   out[0] = total_b;
@@ -471,6 +474,8 @@ int gm_mem_stats(uint64_t out[10]) {
   out[7] = tables;
   out[8] = keys;
   out[9] = m.spare_table_releases;
+  out[10] = workspaces;
+  out[11] = 0;
   return GM_OK;
 }
 
@@ -481,6 +486,136 @@ int gm_mem_reset_peak(void) {
   m.peak_live = m.live;
   m.peak_in_use = m.live - m.cached;
   return GM_OK;
+}
+
+// ---- the footprint contract ----------------------------------------------------------------------------------------------------
+// What a proof will allocate, BEFORE it starts: the high-water mark of its device vectors and prover buffers -- a walk of the
+// prover's own alloc / release sequence (snark.cpp, psnark.cpp, psnark_elastic.cpp; every V.alloc there has its term here), in
+// elements of 32 bytes -- and what the MSM workspaces still have to grow by for its largest calls.  The reference's memory story is
+// its constants (README.md:38-46); a device prover that keeps everything resident owes its caller the number instead.
+namespace {
+struct Footprint {
+  size_t vectors = 0, workspaces = 0;
+};
+size_t next_pow2(size_t n) {
+  size_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+size_t fp_vectors_bytes(size_t elements) {
+  // pool blocks are rounded to 4 KiB and may be reused up to 1.5 x oversized; measured peaks sit 2-4 % above the walk
+  // (profiles/r5_footprint.txt): 6 % and a constant for the small buffers (partial sums, scratch, transcripts of a batch)
+  const size_t b = elements * 32;
+  return b + b / 16 + ((size_t)192 << 20);
+}
+size_t fp_workspaces(gm::Context* C, const gm::Bases* ck, size_t big0, size_t big1) {
+  // the two largest calls of a batch alternate between the two full-size workspaces; the small lanes serve calls <= 2^17 pairs
+  const size_t world = ck && ck->cyclic_n ? (size_t)ck->cyc_world : 1;  // a cyclic share commits to 1 / world of every polynomial
+  big0 = (big0 + world - 1) / world;
+  big1 = (big1 + world - 1) / world;
+  size_t need = 0;
+  const size_t b0 = gm::msm_workspace_bound(C, ck, big0), h0 = gm::msm_workspace_held(C->msm);
+  const size_t b1 = gm::msm_workspace_bound(C, ck, big1), h1 = gm::msm_workspace_held(C->msm_b);
+  need += b0 > h0 ? b0 - h0 : 0;
+  need += b1 > h1 ? b1 - h1 : 0;
+  const size_t bs = gm::msm_workspace_bound(C, ck, std::min<size_t>(big0, (size_t)1 << 17));
+  for (auto& w : C->msm_small) {
+    const size_t h = gm::msm_workspace_held(w);
+    need += bs > h ? bs - h : 0;
+  }
+  return need;
+}
+// snark::Proof::{new_time, new_elastic}: n = |z|
+Footprint fp_snark(gm::Context* C, const gm::Bases* ck, size_t n, int elastic) {
+  const size_t nt = next_pow2(n);
+  Footprint f;
+  // peak = the abc phase: tensor(rho), powers(alpha), their product (3 nt), the three transposed products (3 n), abc (n); the
+  // sumchecks (two or three vectors + 0.75 of each for the prover's folds) and the tensor check (levels n, the merged polynomial,
+  // its quotient, one reversed copy in the elastic form: <= 5 n) stay below it.  z_a, z_b, z_c are released before it.
+  size_t elems = 3 * nt + 4 * n;
+  if (elastic) elems += n;  // lhs / z in both orders around the second sumcheck of the literal form
+  f.vectors = fp_vectors_bytes(elems);
+  f.workspaces = fp_workspaces(C, ck, n, (n + 1) / 2);
+  return f;
+}
+// psnark::Proof::{new_time, new_elastic}: nz = |z|, nnz = joint support.  elastic: 1 = resident schedule, 2 = literal (space provers)
+Footprint fp_psnark(gm::Context* C, const gm::Bases* ck, size_t nz, size_t nnz, int elastic) {
+  const size_t nt = next_pow2(nz);
+  // the nine lookup vectors (set, subset, sorted for r, alpha, z), each one longer as an accumulated product
+  const size_t sum_l = 2 * ((nt + 2) + (nnz + 1) + (nt + nnz + 2)) + ((nz + 2) + (nnz + 1) + (nz + nnz + 2));
+  const size_t sorted = 2 * (nt + nnz) + (nz + nnz);
+  size_t elems;
+  if (elastic == 2) {
+    // literal: accumulated products and rotations in both orders (4 sum_l), the 8 reversed streams of the last four provers,
+    // the time provers the space provers hand over to (<= 1.5 sum_l when the instance is below the threshold from the start)
+    elems = nz + 4 * nnz + sorted + 4 * sum_l + 8 * nnz + sum_l + sum_l / 2 + 3 * nnz;
+  } else {
+    // the third sumcheck: r*, alpha*, ralpha*, z* (4 nnz), the sorted vectors, accumulated products and rotations (2 sum_l), the
+    // three left-hand sides (3 nnz), and 13 time provers with 0.75 of each of their 26 vectors in fold buffers
+    elems = 4 * nnz + sorted + 2 * sum_l + 3 * nnz + (3 * (2 * sum_l) + 3 * (8 * nnz)) / 4 + 16;
+    if (elastic) elems += nz + (2 * nz + 2);  // w in little-endian order; one reversed copy of the longest committed vector
+  }
+  Footprint f;
+  f.vectors = fp_vectors_bytes(elems);
+  const size_t longest = nt + nnz + 2;
+  f.workspaces = fp_workspaces(C, ck, longest, longest);
+  return f;
+}
+// Is there room?  Freed pool blocks are given back on demand (dev_malloc); if that is not enough the PREFIX tables go now, before
+// the proof starts, instead of by reflex after an allocation has failed half-way; if it still does not fit: GM_ENOMEM with the numbers.
+int fp_fill_and_admit(gm::Context* C, const Footprint& f, uint64_t out[4], bool admit, const char* what) {
+  size_t free_b = 0, total_b = 0;
+  GM_HIP(hipMemGetInfo(&free_b, &total_b));
+  size_t cached = 0, spare = 0;
+  {
+    std::lock_guard<std::mutex> lk(C->pool.mu);
+    cached = C->pool.pooled_bytes;
+  }
+  {
+    std::lock_guard<std::mutex> lk(C->mu);
+    for (auto& kv : C->bases)
+      for (auto& ts : kv.second->extra)
+        if (ts.t) spare += (size_t)ts.W * ts.n * 96;
+  }
+  const size_t need = f.vectors + f.workspaces, reserve = (size_t)1 << 30;  // the runtime's own allocations
+  if (out) {
+    out[0] = f.vectors;
+    out[1] = f.workspaces;
+    out[2] = need;
+    out[3] = free_b + cached + spare > reserve ? free_b + cached + spare - reserve : 0;
+  }
+  if (!admit) return GM_OK;
+  if (need + reserve <= free_b + cached) return GM_OK;
+  if (need + reserve <= free_b + cached + spare && gm::release_spare_tables(C)) return GM_OK;
+  GM_CHECK(false, GM_ENOMEM,
+           "%s: the proof needs %.1f GB of device memory (vectors and prover buffers %.1f GB, MSM workspaces still to grow %.1f GB) and %.1f GB can "
+           "be had (free %.1f, pool cache %.1f, prefix tables %.1f); free vectors, register a key without tables (gm_set_auto_tables) or shard",
+           what, need / 1e9, f.vectors / 1e9, f.workspaces / 1e9, (free_b + cached + spare) / 1e9, free_b / 1e9, cached / 1e9, spare / 1e9);
+  return GM_OK;
+}
+}  // namespace
+
+int gm_snark_footprint(uint64_t ck_bases, size_t num_constraints, int elastic, uint64_t out[4]) {
+  GM_CTX();
+  const Bases* ck = find_bases(ck_bases);
+  GM_CHECK(ck != nullptr && out != nullptr, GM_EHANDLE, "gm_snark_footprint: unknown key handle or null output");
+  return fp_fill_and_admit(C, fp_snark(C, ck, num_constraints, elastic), out, false, "gm_snark_footprint");
+}
+int gm_psnark_footprint(uint64_t ck_bases, size_t num_variables, size_t nnz, int elastic, uint64_t out[4]) {
+  GM_CTX();
+  const Bases* ck = find_bases(ck_bases);
+  GM_CHECK(ck != nullptr && out != nullptr, GM_EHANDLE, "gm_psnark_footprint: unknown key handle or null output");
+  return fp_fill_and_admit(C, fp_psnark(C, ck, num_variables, nnz, elastic), out, false, "gm_psnark_footprint");
+}
+// called by the provers compiled into the library before their first allocation
+int gm_footprint_admit(int psnark, uint64_t ck_bases, size_t n, size_t nnz, int elastic) {
+  GM_CTX();
+  static const bool off = getenv("GM_FOOTPRINT_CHECK") && atoi(getenv("GM_FOOTPRINT_CHECK")) == 0;
+  if (off) return GM_OK;
+  const Bases* ck = find_bases(ck_bases);
+  GM_CHECK(ck != nullptr, GM_EHANDLE, "footprint: unknown key handle");
+  const Footprint f = psnark ? fp_psnark(C, ck, n, nnz, elastic) : fp_snark(C, ck, n, elastic);
+  return fp_fill_and_admit(C, f, nullptr, true, psnark ? "psnark prover" : "snark prover");
 }
 
 int gm_g1_release_spare_tables(void) {
@@ -586,6 +721,7 @@ int gm_g1_bases_precompute(uint64_t handle, int c) {
   GM_CTX();
   Bases* b = find_bases(handle);
   GM_CHECK(b != nullptr, GM_EHANDLE, "bases_precompute: unknown handle %llu", (unsigned long long)handle);
+  if (c == -1 && b->extras_released) return bases_build_prefix_sets(C, b);  // given back under memory pressure: rebuilt on demand
   if (c == -1) return (b->table || !b->extra.empty()) ? GM_OK : maybe_auto_tables(C, b);  // automatic: the rule of the key constructors (size range, budget, free memory)
   return bases_precompute(C, b, c);
 }

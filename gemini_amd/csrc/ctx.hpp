@@ -68,6 +68,7 @@ struct Bases {
     size_t n = 0, min_n = 0, max_n = 0;
   };
   std::vector<TableSet> extra;
+  bool extras_released = false;  // the prefix sets were given back under memory pressure (release_spare_tables); gm_g1_bases_precompute(handle, -1) rebuilds them
   // a CYCLIC SHARE of a committer key (gm_g1_bases_set_cyclic): these n points are the powers i = cyc_rank (mod cyc_world)
   // of a key of cyclic_n powers; gm_ck_* and the provers commit through the all-gather of dist.cpp.  0 = a whole key
   size_t cyclic_n = 0;
@@ -349,6 +350,9 @@ struct MsmBusyGuard {
   GM_CHECK(C != nullptr, GM_ENOTINIT, "gm_init has not been called")
 
 // MSM engine (msm.hip)
+int bases_build_prefix_sets(Context* C, Bases* b);
+size_t msm_workspace_held(const MsmWorkspace& ws);
+size_t msm_workspace_bound(Context* C, const Bases* bases, size_t n);
 int msm_run(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
             bool normalize, uint64_t out_jac[18]);
 int msm_run_batch(Context* C, const Bases* bases, int64_t first, int64_t step, const void* const* d_scalars, int mont, const size_t* ns,

@@ -1471,6 +1471,49 @@ static int choose_window(size_t n) {
   return 4;
 }
 
+// ---- the footprint contract (capi.hip: gm_snark_footprint / gm_psnark_footprint) ------------------------------------------------
+// What a workspace holds: every grow-only buffer of it.
+size_t msm_workspace_held(const MsmWorkspace& ws) {
+  size_t b = 0;
+  for (const DevBuf* d : {&ws.scalars, &ws.counts, &ws.offsets, &ws.cursor, &ws.entries, &ws.tmp_entries, &ws.sortmeta, &ws.buckets, &ws.pk[0], &ws.pk[1],
+                          &ws.pp[0], &ws.pp[1], &ws.rows, &ws.cols, &ws.planes, &ws.misc, &ws.clk})
+    b += d->cap;
+  return b;
+}
+// Upper bound of what a workspace holds after ONE call of n pairs walking a prefix of `bases` (the calls of a prover): the same
+// window / table choice as msm_enqueue, its ensure() sizes, DevBuf's 12.5 % growth.  Entries and their sort double dominate:
+// 2 x 8 bytes x windows x pairs (14 GB at 2^26 pairs).
+size_t msm_workspace_bound(Context* C, const Bases* bases, size_t n) {
+  if (n == 0) return 0;
+  n = std::min<size_t>(n, (size_t)1 << 26);  // msm_run cuts longer calls
+  int c = C->msm_c_override ? C->msm_c_override : choose_window(n);
+  bool table = false;
+  if (bases && !C->msm_c_override && n < ((size_t)1 << ENTRY_W_SHIFT)) {
+    if (bases->table && n >= std::max(C->msm_table_min, bases->tab_min)) {
+      c = bases->tab_c;
+      table = true;
+    } else {
+      for (const Bases::TableSet& ts : bases->extra)
+        if (n >= ts.min_n && n < ts.max_n && n <= ts.n) {
+          c = ts.c;
+          table = true;
+          break;
+        }
+    }
+  }
+  const size_t W = (size_t)(256 + c - 1) / (size_t)c;
+  const size_t N = n * W, nbuckets = (table ? 1 : W) << (c - 1);
+  auto grow = [](size_t b) { return b + b / 8 + 256; };
+  const size_t lanes0 = N >= ((size_t)1 << 24) ? 262144 : 131072;
+  const size_t L = std::min<size_t>(256, std::max<size_t>(4, (N + lanes0 - 1) / lanes0)) + 1;
+  const size_t E1 = 2 * ((N / L + 256 + 255) / 256 * 256), E2 = 2 * ((E1 + 127) / 128);
+  size_t b = 2 * grow(N * 8);                                  // entries, tmp_entries
+  b += grow(nbuckets * XYZZ30_BYTES) + 4 * grow((nbuckets + 8192) * 4);  // buckets; counts, offsets, cursor, misc
+  b += grow(E1 * 4) + grow(E1 * XYZZ30_BYTES) + grow(E2 * 4) + grow(E2 * XYZZ30_BYTES);  // keyed partials of the two merge levels
+  b += (size_t)W * ((size_t)3 << 14) * XYZZ30_BYTES + ((size_t)16 << 20);                // row / column sums of the bucket reduction, planes, small buffers
+  return b;
+}
+
 constexpr size_t MSM_SMALL_N = (size_t)1 << 17;
 constexpr size_t MSM_SPLIT_MIN_N = (size_t)1 << 17;  // smaller calls are launch-latency bound: one chain of launches beats two
 static int msm_run_one(Context* C, const Bases* bases, int64_t first, int64_t step, const void* d_scalars, int mont, size_t n,
@@ -2966,6 +3009,19 @@ int bases_precompute(Context* C, Bases* b, int c) {
     b->tab_min = c >= 22 ? ((size_t)1 << 22) : (c >= 21 ? ((size_t)1 << 21) : 0);
   }
   if (!auto_c) return GM_OK;
+  return bases_build_prefix_sets(C, b);
+}
+
+// the PREFIX table sets of a key in automatic mode (also on their own: gm_g1_bases_precompute(handle, -1) after the sets were
+// released under memory pressure, capi.hip: release_spare_tables)
+int bases_build_prefix_sets(Context* C, Bases* b) {
+  GM_MSM_LOCK(C);
+  const bool prefix_only = b->table == nullptr && b->n >= ((size_t)1 << ENTRY_W_SHIFT);
+  int rc = GM_OK;
+  for (auto& ts : b->extra)
+    if (ts.t) (void)gm::raw_free(ts.t);
+  b->extra.clear();
+  b->extras_released = false;
   static const bool prefix_env = !(getenv("GM_PREFIX_TABLES") && atoi(getenv("GM_PREFIX_TABLES")) == 0);
   auto add_set = [&](int sc, size_t points, size_t min_n, size_t max_n) -> int {
     Bases::TableSet ts;

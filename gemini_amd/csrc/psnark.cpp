@@ -28,6 +28,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   RC(gm_ck_len(ck_bases, &nck));
   const size_t nnz = I->nnz;
   if (nck < nnz || nck < I->ext_fre_row_len || nck < I->ext_fre_col_len) return GM_EINVAL;  // index_by zips need as many powers as indices (:119-127,179-183)
+  RC(gm_footprint_admit(1, ck_bases, nz, nnz, 0));  // room for the whole proof, or GM_ENOMEM with the numbers, before the first allocation
   uint64_t one[4];
   Fr::one().to_limbs(one);
 
@@ -61,6 +62,9 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   std::vector<uint64_t> ch1, ch2;
   RC(sumcheck_new_time(T.h, z_abc[0], z_abc[1], alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));  // :92
   P->spans[1] = since(t0);
+  // Vectors are released at their LAST USE, not at the end of a phase: at 2^26 constraints every vector of n elements is 2 GiB and
+  // the third sumcheck holds ~70 of them (gm_psnark_footprint); round 4 held ~93 there and the proof peaked at 308 GB of a 309 GB device
+  for (int k = 0; k < 3; k++) V.release(z_abc[k]);
 
   t0 = Clock::now();
   const size_t nt = (size_t)1 << P->rounds[0];
@@ -78,6 +82,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   uint64_t ralpha_star, r_star, alpha_star, z_star;  // :114-117
   RC(V.alloc(nnz, &ralpha_star));
   RC(gm_fr_gather(a_ch, I->row_index, ralpha_star));
+  V.release(a_ch);
   RC(V.alloc(nnz, &r_star));
   RC(gm_fr_gather(b_ch, I->row_index, r_star));
   RC(V.alloc(nnz, &alpha_star));
@@ -117,6 +122,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   RC(gm_fr_tensor(ch2.data(), P->rounds[1], second_challenges));
   if (((size_t)1 << P->rounds[1]) < nnz) return GM_EINVAL;
   RC(gm_fr_vec_set_len(second_challenges, nnz));  // &second_challenges[..num_non_zero]
+  V.release(r_star_val);
   P->spans[4] = since(t0);
 
   uint64_t zeta[4];
@@ -137,6 +143,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   RC(gm_fr_gather(ahp[1], I->ext_fre_row, sorted[1]));
   RC(V.alloc(I->ext_fre_col_len, &sorted[2]));
   RC(gm_fr_gather(ahp[2], I->ext_fre_col, sorted[2]));
+  for (int k = 0; k < 3; k++) V.release(ahp[k]);
   RC(batch_commit(ck_bases, nck, {sorted[0], sorted[1], sorted[2]}, &P->sorted_commitments[0][0]));  // :179-183
   P->spans[5] = since(t0);
   RC(gm_transcript_append_g1(T.h, L("sorted_alpha_commitment"), 23, P->sorted_commitments[1], 1, 0));  // :186-188
@@ -151,13 +158,22 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   RC(plookup(V, r_star, b_ch, I->row_index, nnz, I->ext_fre_row, I->ext_fre_row_len, gamma, chi, zeta, lookup_vec));
   RC(plookup(V, alpha_star, c_ch, I->row_index, nnz, I->ext_fre_row, I->ext_fre_row_len, gamma, chi, zeta, lookup_vec + 3));
   RC(plookup(V, z_star, I->z, I->col_index, nnz, I->ext_fre_col, I->ext_fre_col_len, gamma, chi, zeta, lookup_vec + 6));
+  V.release(b_ch);
+  V.release(c_ch);
   uint64_t acc_vec[9];  // accumulated_product(monic(v))   :211-214
+  // the right rotation of every lookup vector (shift_monic) is needed twice -- as the g side of the entry-product sumchecks (:223-239)
+  // and as a body of the tensor check (:323-326) -- and the lookup vectors themselves for nothing else: build it here, once, and let
+  // the 12 n elements of the lookup vectors go
+  std::vector<uint64_t> shift_lookup(9);
   for (int k = 0; k < 9; k++) {
     size_t l = 0;
     RC(vec_len(lookup_vec[k], &l));
     RC(V.alloc(l + 1, &acc_vec[k]));
     RC(gm_fr_acc_product(lookup_vec[k], acc_vec[k]));
     RC(gm_fr_vec_download(acc_vec[k], 0, P->products[k], 1));  // the full product is the first accumulated entry
+    RC(V.alloc(l + 1, &shift_lookup[k]));
+    RC(gm_fr_shift_monic(lookup_vec[k], shift_lookup[k]));
+    V.release(lookup_vec[k]);
   }
   P->spans[6] = since(t0);
   RC(gm_transcript_append_fr(T.h, L("set_r_ep"), 8, P->products[3], 1));  // :216-221 (labels as in the reference)
@@ -178,21 +194,13 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   } prover_guard{provers};
   uint64_t psi[4];
   {
-    uint64_t rrot[9];
-    for (int k = 0; k < 9; k++) {
-      size_t l = 0;
-      RC(vec_len(lookup_vec[k], &l));
-      RC(V.alloc(l + 1, &rrot[k]));
-      RC(gm_fr_shift_monic(lookup_vec[k], rrot[k]));
-    }
     RC(batch_commit(ck_bases, nck, std::vector<uint64_t>(acc_vec, acc_vec + 9), &P->acc_v_commitments[0][0]));
     for (int k = 0; k < 9; k++) RC(gm_transcript_append_g1(T.h, L("acc_v"), 5, P->acc_v_commitments[k], 1, 0));
     RC(gm_transcript_challenge_fr(T.h, L("ep-chal"), 7, psi));
     for (int k = 0; k < 9; k++) {
       uint64_t h = 0;
-      RC(gm_sc_new_borrow(acc_vec[k], rrot[k], psi, &h));  // read in place until the first fold: released after the batch
+      RC(gm_sc_new_borrow(acc_vec[k], shift_lookup[k], psi, &h));  // both read in place until the first fold, never written
       provers.push_back(h);
-      borrowed_tmp.push_back(rrot[k]);
     }
     uint64_t acc_chal[9][4];
     RC(gm_fr_eval_le_batch(acc_vec, 9, psi, 1, &acc_chal[0][0]));
@@ -240,6 +248,7 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
     RC(gm_sc_new_borrow(r_star, alpha_star, psi, &pr));
     provers.push_back(pr);
   }
+  V.release(second_challenges);
   t0 = Clock::now();
   std::vector<uint64_t> ch3(cap_rounds * 4, 0);
   RC(gm_sumcheck_prove_batch(T.h, provers.data(), provers.size(), P->messages[2], ch3.data(), cap_rounds, &P->third_final_foldings[0][0], &P->rounds[2]));  // :293
@@ -247,20 +256,12 @@ extern "C" int gm_psnark_new_time(const gm_psnark_instance* I, uint64_t ck_bases
   provers.clear();
   for (uint64_t v : borrowed_tmp) V.release(v);
   P->spans[9] = since(t0);
-  for (uint64_t v : {second_challenges, r_star_val, a_ch, b_ch, c_ch, ahp[0], ahp[1], ahp[2], z_abc[0], z_abc[1], z_abc[2]}) V.release(v);
 
   // ---- TensorcheckProof::new_time(transcript, ck, 22 base polynomials, 4 bodies)   :296-367, tensorcheck/mod.rs:190-275
   t0 = Clock::now();
   std::vector<uint64_t> base = {I->w, ralpha_star, r_star, alpha_star, z_star, I->row, I->col, I->val_a, I->val_b, I->val_c, sorted[0], sorted[1], sorted[2]};
   base.insert(base.end(), acc_vec, acc_vec + 9);
   const size_t n3 = P->rounds[2], n2 = P->rounds[1];
-  std::vector<uint64_t> shift_lookup(9);  // :323-326
-  for (int k = 0; k < 9; k++) {
-    size_t l = 0;
-    RC(vec_len(lookup_vec[k], &l));
-    RC(V.alloc(l + 1, &shift_lookup[k]));
-    RC(gm_fr_shift_monic(lookup_vec[k], shift_lookup[k]));
-  }
   struct Body {
     std::vector<uint64_t> polys;
     std::vector<uint64_t> challenges;  // 4 limbs each

@@ -40,6 +40,14 @@ struct ElasticSc {
     // no copy: the space prover reads the caller's streams until it is freed (every caller below keeps them that long)
     return gm_sp_new_borrow(f_stream, g_stream, twist, &space);
   }
+  // The RESIDENT schedule: the little-endian vectors behind the streams are in HBM anyway, so the prover is a time prover from
+  // its first round (it reads them in place until its first fold) instead of a space prover that re-derives every message from
+  // the whole streams until SPACE_TIME_THRESHOLD rounds remain.  The messages are the same field elements (sumcheck/tests.rs:42-87:
+  // space == time), and it needs LESS memory than the reversed stream copies a device-side space prover reads (0.75 of them).
+  int init_resident(uint64_t f_le, uint64_t g_le, const uint64_t twist[4]) {
+    allow_switch = true;
+    return gm_sc_new_borrow(f_le, g_le, twist, &time);
+  }
   int rounds(size_t* tot) const { return time ? gm_sc_rounds(time, tot, nullptr) : gm_sp_rounds(space, tot, nullptr); }
   // next_message(vm), first half: fold (switching to the time prover when it is time), launch the round
   int begin(const uint64_t* vm, int* has) {
@@ -231,6 +239,7 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
   size_t nz = 0;
   RC(vec_len(z_stream, &nz));
   const size_t nnz = I->nnz;
+  RC(gm_footprint_admit(1, ck_bases, nz, nnz, min_device_chunk > 1 ? 1 : 2));
   uint64_t one[4];
   Fr::one().to_limbs(one);
   TranscriptGuard T;
@@ -259,9 +268,20 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
   }
   RC(gm_transcript_append_fr(T.h, L("zc(alpha)"), 9, P->zc_alpha, 1));
 
+  // min_device_chunk > 1 (the default, 2^26): the embedder lets the device merge flushes, i.e. treats max_msm_buffer as advisory
+  // because everything is resident -- then the sumchecks take the resident schedule too (ElasticSc::init_resident).  min_device_chunk
+  // = 1 is the LITERAL elastic prover: 2^20-pair flushes, space provers until SPACE_TIME_THRESHOLD rounds remain.
+  const bool resident = min_device_chunk > 1;
   t0 = Clock::now();
   std::vector<uint64_t> ch1, ch2;
-  {
+  if (resident) {
+    uint64_t za_le, zb_le;
+    RC(reversed(V, za_stream, &za_le));
+    RC(reversed(V, zb_stream, &zb_le));
+    RC(sumcheck_new_time(T.h, za_le, zb_le, alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));
+    V.release(za_le);
+    V.release(zb_le);
+  } else {
     ElasticSc S1;
     RC(S1.init(za_stream, zb_stream, alpha, false));  // Sumcheck::new_space :97
     RC(prove_one(T.h, S1, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));
@@ -287,6 +307,7 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
   RC(gm_fr_gather(z_le, I->col_index, z_star));
   RC(V.alloc(nnz, &ralpha_star));
   RC(gm_fr_gather(a_ch, I->row_index, ralpha_star));
+  V.release(a_ch);
   RC(V.alloc(nnz, &r_star));
   RC(gm_fr_gather(b_ch, I->row_index, r_star));
   RC(V.alloc(nnz, &alpha_star));
@@ -321,7 +342,9 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
     for (int k = 0; k < 3; k++) V.release(h[k]);
   }
   t0 = Clock::now();
-  {
+  if (resident) {
+    RC(sumcheck_new_time(T.h, z_star, rhs, one, P->messages[1], ch2, cap_rounds, P->final_foldings[1], &P->rounds[1]));
+  } else {
     uint64_t zs, rs;
     RC(reversed(V, z_star, &zs));
     RC(reversed(V, rhs, &rs));
@@ -376,6 +399,9 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
     RC(gm_fr_shift_monic(pls[k], shifts[k]));
     V.release(pls[k]);
   }
+  V.release(b_ch);
+  V.release(c_ch);
+  V.release(z_le);
   P->spans[6] = since(t0);
   RC(gm_transcript_append_fr(T.h, L("set_r_ep"), 8, P->products[3], 1));  // :245-250 (labels as in the reference)
   RC(gm_transcript_append_fr(T.h, L("subset_r_ep"), 11, P->products[4], 1));
@@ -405,6 +431,10 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
       size_t l = 0;
       RC(vec_len(accs[k], &l));
       (Fr::from_limbs(acc_chal[k]) * ci + Fr::from_limbs(P->products[k]) - fr_pow(ci, l)).to_limbs(P->claimed_sumchecks[k]);
+      if (resident) {
+        RC(provers[k].init_resident(accs[k], shifts[k], psi));
+        continue;
+      }
       uint64_t as, ss;
       RC(reversed(V, accs[k], &as));
       RC(reversed(V, shifts[k], &ss));
@@ -458,6 +488,11 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
     for (int k = 0; k < 10; k++) RC(gm_transcript_append_fr(T.h, L("ralpha_star_acc_mu"), 18, P->ralpha_star_acc_mu_evals[k], 1));
     RC(gm_transcript_append_g1(T.h, L("ralpha_star_mu_proof"), 20, P->ralpha_star_acc_mu_proof, 1, 0));
     for (int k = 0; k < 3; k++) {  // :358-377
+      if (resident) {
+        RC(provers[9 + k].init_resident(lh[k], vals[k], one));
+        batch_streams.push_back(lh[k]);  // read in place until the first fold: released after the batch
+        continue;
+      }
       uint64_t ls, vs;
       RC(reversed(V, lh[k], &ls));
       RC(reversed(V, vals[k], &vs));
@@ -466,20 +501,24 @@ extern "C" int gm_psnark_new_elastic(const gm_psnark_instance* I, uint64_t z_str
       batch_streams.push_back(vs);
       V.release(lh[k]);
     }
-    uint64_t rs, as;
-    RC(reversed(V, r_star, &rs));
-    RC(reversed(V, alpha_star, &as));
-    RC(provers[12].init(rs, as, psi, true));
-    batch_streams.push_back(rs);
-    batch_streams.push_back(as);
+    if (resident) {
+      RC(provers[12].init_resident(r_star, alpha_star, psi));
+    } else {
+      uint64_t rs, as;
+      RC(reversed(V, r_star, &rs));
+      RC(reversed(V, alpha_star, &as));
+      RC(provers[12].init(rs, as, psi, true));
+      batch_streams.push_back(rs);
+      batch_streams.push_back(as);
+    }
   }
+  V.release(ep_r);
   t0 = Clock::now();
   std::vector<uint64_t> ch3(cap_rounds * 4, 0);
   RC(prove_batch(T.h, provers, P->messages[2], ch3.data(), cap_rounds, &P->third_final_foldings[0][0], &P->rounds[2]));  // :380
   provers.clear();
   for (uint64_t v : batch_streams) V.release(v);
   P->spans[9] = since(t0);
-  for (uint64_t v : {ep_r, a_ch, b_ch, c_ch}) V.release(v);
 
   // ---- tensorcheck (:384-600)
   t0 = Clock::now();

@@ -30,6 +30,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
     RC(gm_spm_shape(matrices[k], &rows, &cols, nullptr));
     if ((k < 3 ? cols : rows) != nz) return GM_EINVAL;
   }
+  RC(gm_footprint_admit(0, ck_bases, nz, 0, 0));  // room for the whole proof, or GM_ENOMEM with the numbers, before the first allocation
   uint64_t z_abc[3];
   for (int k = 0; k < 3; k++) {
     size_t rows = 0;
@@ -56,6 +57,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   std::vector<uint64_t> ch1, ch2;
   RC(sumcheck_new_time(T.h, z_abc[0], z_abc[1], alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));  // :52
   P->spans[2] = since(t0);
+  for (int k = 0; k < 3; k++) V.release(z_abc[k]);  // vectors go at their last use: the peak of a proof is 9 vectors of n elements, not 16 (gm_snark_footprint)
 
   t0 = Clock::now();
   if (P->rounds[0] == 0) return GM_EINVAL;  // tensor() of no challenges: the reference asserts (src/misc.rs:134)
@@ -86,6 +88,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
   RC(V.alloc(nz, &abc));
   RC(gm_fr_lincomb(t_abc, coeffs, 3, abc));
   RC(gm_fr_vec_set_len(abc, nz));  // vec![0; z.len()]: no trimming (the trimmed tail is zero on the device)
+  for (uint64_t v : {a_ch, b_ch, c_ch, t_abc[0], t_abc[1], t_abc[2]}) V.release(v);
   P->spans[3] = since(t0);
 
   t0 = Clock::now();
@@ -120,6 +123,8 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
     }
     RC(gm_fr_fold_chain(batched, ch2.data(), foldings.size(), foldings.data()));  // one wait for the whole tree
   }
+  V.release(batched);
+  V.release(abc);
   P->nfold = foldings.size();
   if (P->nfold > cap_rounds) return GM_EINVAL;
   if (P->nfold) {
@@ -165,6 +170,7 @@ extern "C" int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_
     RC(V.alloc(lc ? lc - 1 : 0, &quotient));
     uint64_t rem[12];
     RC(gm_fr_div_vanishing(combined, pts, 3, quotient, rem));
+    V.release(combined);
     size_t lq = 0;
     RC(vec_len(quotient, &lq));
     RC(gm_ck_msm(ck_bases, 0, 0, quotient, 0, lq < nck ? lq : nck, P->evaluation_proof));
@@ -208,6 +214,7 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
     RC(gm_spm_shape(matrices_t[k], &rows, nullptr, nullptr));
     if (rows != nz) return GM_EINVAL;
   }
+  RC(gm_footprint_admit(0, ck_bases, nz, 0, 1));
   const size_t flush = max_msm_buffer > min_device_chunk ? max_msm_buffer : min_device_chunk;
   TranscriptGuard T;
   static const char protocol[] = "GEMINI-v0";
@@ -227,12 +234,32 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
     RC(V.alloc(nzc, &zc_le));
     RC(gm_fr_reverse(zc_stream, zc_le));
     RC(gm_fr_eval_le(zc_le, alpha, 1, P->zc_alpha));  // evaluate_be(z_c, alpha) :216
+    V.release(zc_le);
   }
   RC(gm_transcript_append_fr(T.h, L("zc(alpha)"), 9, P->zc_alpha, 1));
 
   t0 = Clock::now();
   std::vector<uint64_t> ch1, ch2;
-  RC(sumcheck_new_elastic(T.h, za_stream, zb_stream, alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));  // :222
+  // min_device_chunk > 1 (the default): everything is resident and max_msm_buffer advisory -- then the sumchecks take the RESIDENT
+  // schedule as well: time provers on the little-endian vectors from the first round instead of space provers that re-derive
+  // every message from the whole streams until SPACE_TIME_THRESHOLD rounds remain (the same field elements: sumcheck/tests.rs:42-87).
+  // min_device_chunk = 1 is the literal elastic prover.
+  const bool resident = min_device_chunk > 1;
+  if (resident) {
+    uint64_t za_le, zb_le;
+    size_t na = 0, nb = 0;
+    RC(vec_len(za_stream, &na));
+    RC(vec_len(zb_stream, &nb));
+    RC(V.alloc(na, &za_le));
+    RC(gm_fr_reverse(za_stream, za_le));
+    RC(V.alloc(nb, &zb_le));
+    RC(gm_fr_reverse(zb_stream, zb_le));
+    RC(sumcheck_new_time(T.h, za_le, zb_le, alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));
+    V.release(za_le);
+    V.release(zb_le);
+  } else {
+    RC(sumcheck_new_elastic(T.h, za_stream, zb_stream, alpha, P->messages[0], ch1, cap_rounds, P->final_foldings[0], &P->rounds[0]));  // :222
+  }
   P->spans[2] = since(t0);
 
   t0 = Clock::now();
@@ -256,27 +283,35 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
     RC(V.alloc(nz, &t_abc[k]));
     RC(gm_spm_mul(matrices_t[k], rand_vecs[k], t_abc[k]));
   }
-  uint64_t lhs_le, lhs;
+  uint64_t lhs_le, lhs = 0, z_le;
   RC(V.alloc(nz, &lhs_le));
   RC(gm_fr_lincomb(t_abc, coeffs, 3, lhs_le));
   RC(gm_fr_vec_set_len(lhs_le, nz));
-  RC(V.alloc(nz, &lhs));
-  RC(gm_fr_reverse(lhs_le, lhs));
+  for (uint64_t v : {a_ch, b_ch, c_ch, t_abc[0], t_abc[1], t_abc[2]}) V.release(v);
+  RC(V.alloc(nz, &z_le));
+  RC(gm_fr_reverse(z_stream, z_le));
+  if (!resident) {
+    RC(V.alloc(nz, &lhs));
+    RC(gm_fr_reverse(lhs_le, lhs));
+  }
   P->spans[3] = since(t0);
 
   t0 = Clock::now();
   uint64_t one[4];
   Fr::one().to_limbs(one);
-  RC(sumcheck_new_elastic(T.h, lhs, z_stream, one, P->messages[1], ch2, cap_rounds, P->final_foldings[1], &P->rounds[1]));  // :241
+  if (resident) {
+    RC(sumcheck_new_time(T.h, lhs_le, z_le, one, P->messages[1], ch2, cap_rounds, P->final_foldings[1], &P->rounds[1]));
+  } else {
+    RC(sumcheck_new_elastic(T.h, lhs, z_stream, one, P->messages[1], ch2, cap_rounds, P->final_foldings[1], &P->rounds[1]));  // :241
+    V.release(lhs);
+  }
   P->spans[4] = since(t0);
 
   // ---- tensorcheck (:105-168) over the folded polynomial tree of body = lhs + batch_challenge * z
   t0 = Clock::now();
   uint64_t batch_challenge[4];
   RC(gm_transcript_challenge_fr(T.h, L("batch_challenge"), 15, batch_challenge));
-  uint64_t z_le, body_le;
-  RC(V.alloc(nz, &z_le));
-  RC(gm_fr_reverse(z_stream, z_le));
+  uint64_t body_le;
   uint64_t lc_coeffs[8];
   Fr::one().to_limbs(lc_coeffs);
   memcpy(lc_coeffs + 4, batch_challenge, 32);
@@ -297,6 +332,7 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
     }
     RC(gm_fr_fold_chain(body_le, ch2.data(), levels.size(), levels.data()));
   }
+  for (uint64_t v : {body_le, lhs_le, z_le}) V.release(v);
   P->nfold = levels.size();
   if (P->nfold > cap_rounds) return GM_EINVAL;
   if (P->nfold) {  // commit_folding (space.rs:192-223): one ChunkedPippenger of max_msm_buffer / depth per level
@@ -312,6 +348,7 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
         RC(V.alloc(level_len[k], &s));
         RC(gm_fr_reverse(levels[k], s));
         RC(stream_msm(ck_bases, s, level_len[k], level_len[k] - 1, lvl_flush, P->fold_commitments + 18 * k));
+        V.release(s);
       }
     }
   }
@@ -362,10 +399,12 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
       RC(vec_len(combined, &lc));
       RC(V.alloc(lc ? lc - 1 : 0, &q));
       RC(gm_fr_div_vanishing(combined, pts, 3, q, rem));
+      V.release(combined);
       RC(vec_len(q, &lb));
       if (lb) {
         RC(V.alloc(lb, &bs));
         RC(gm_fr_reverse(q, bs));
+        V.release(q);
         RC(stream_msm(ck_bases, bs, lb, lb - 1, flush, P->evaluation_proof));
       }
     }

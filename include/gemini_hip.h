@@ -110,11 +110,27 @@ int gm_pool_trim(void);
  * (hipMemGetInfo), [2] = bytes the library holds from the driver, [3] = high-water mark of [2], [4] = of [2]: freed blocks cached by
  * the vector pool, [5] = in use = [2] - [4], [6] = high-water mark of [5], [7] = fixed-base tables of all keys, [8] = the keys
  * themselves, [9] = how many times the prefix tables were released under memory pressure (they are not rebuilt: the calls they
- * served take the plain path).  gm_mem_reset_peak() restarts both high-water marks from the current values.  The reference's memory
+ * served take the plain path), [10] = what the MSM workspaces hold (grow-only), [11] = 0.  gm_mem_reset_peak() restarts both
+ * high-water marks from the current values.  The reference's memory
  * story is its constants (README.md:38-46: SPACE_TIME_THRESHOLD, MAX_MSM_BUFFER_LOG); on the device it is these figures and the
  * footprint contract below (gm_snark_footprint / gm_psnark_footprint). */
-int gm_mem_stats(uint64_t out[10]);
+int gm_mem_stats(uint64_t out[12]);
 int gm_mem_reset_peak(void);
+/* THE FOOTPRINT CONTRACT.  What a proof will allocate beyond what is resident when it is called (the key and its tables, the
+ * instance, the caller's vectors): out[0] = high-water mark of its device vectors and prover buffers, out[1] = what the MSM
+ * workspaces still have to grow by for its largest calls (0 once a proof of that size has run), out[2] = out[0] + out[1], out[3] =
+ * what can be had right now (device free + the vector pool's cached blocks + the prefix tables, which are spare memory).  Upper
+ * bounds, within ~25 % of the measured peaks (tests/test_gpu_footprint.py, profiles/r5_footprint.txt).  Every prover compiled into
+ * the library checks the same figures before its first allocation: if the proof only fits without the prefix tables they are
+ * released THEN (not by reflex after an allocation has failed half-way), and if it does not fit at all the prover returns
+ * GM_ENOMEM with the numbers in gm_last_error() (GM_FOOTPRINT_CHECK=0 switches the admission off).
+ *   gm_snark_footprint   snark::Proof::new_time / new_elastic on num_constraints = |z|; elastic != 0: gm_snark_new_elastic
+ *   gm_psnark_footprint  psnark::Proof::new_time (elastic 0), new_elastic in the resident schedule (1, min_device_chunk > 1) or
+ *                        the literal one (2: space provers over reversed streams, min_device_chunk = 1)
+ * ck_bases: the key the proof will commit under (its tables decide the window widths, a cyclic share divides the MSM sizes). */
+int gm_snark_footprint(uint64_t ck_bases, size_t num_constraints, int elastic, uint64_t out[4]);
+int gm_psnark_footprint(uint64_t ck_bases, size_t num_variables, size_t nnz, int elastic, uint64_t out[4]);
+int gm_footprint_admit(int psnark, uint64_t ck_bases, size_t n, size_t nnz, int elastic);
 /* Frees the PREFIX tables of every key (the c = 22 / 20 / 16 tables over the first 2^25 / 2^22 / 2^17 points; up to 44 GB for a key of
  * 2^26+ points): the calls they served take the plain path from then on, with the same results.  The library does this by itself
  * when a device allocation fails twice (after the vector pool has given its freed blocks back); never while an MSM is running. */

@@ -144,10 +144,81 @@ INL void mont_mul(u64* r, const u64* a, const u64* b, const u64* p, u64 inv, int
 
 /* ---- Fq ---- */
 typedef struct { u64 l[NQ]; } fq;
+#if defined(GO_ADX) && defined(__x86_64__) && defined(__ADX__) && defined(__BMI2__)
+#define GO_NATIVE_FQ 1
+#include <immintrin.h>
+/* timed build: carry-flag chains and branch-free selection (a data-dependent `if (borrow)` mispredicts every other time) */
+INL fq fq_add(fq a, fq b) {
+  fq t, d, r;
+  unsigned long long *tl = (unsigned long long*)t.l, *dl = (unsigned long long*)d.l;
+  unsigned char c = 0, bw = 0;
+  for (int i = 0; i < NQ; i++) c = _addcarry_u64(c, a.l[i], b.l[i], &tl[i]); /* q < 2^381: no carry out */
+  for (int i = 0; i < NQ; i++) bw = _subborrow_u64(bw, t.l[i], Q_MOD[i], &dl[i]);
+  const u64 keep = (u64)0 - (u64)bw; /* borrow: t < q, keep t */
+  for (int i = 0; i < NQ; i++) r.l[i] = (t.l[i] & keep) | (d.l[i] & ~keep);
+  return r;
+}
+INL fq fq_sub(fq a, fq b) {
+  fq d, r;
+  unsigned long long *dl = (unsigned long long*)d.l, *rl = (unsigned long long*)r.l;
+  unsigned char bw = 0, c = 0;
+  for (int i = 0; i < NQ; i++) bw = _subborrow_u64(bw, a.l[i], b.l[i], &dl[i]);
+  const u64 m = (u64)0 - (u64)bw;
+  for (int i = 0; i < NQ; i++) c = _addcarry_u64(c, d.l[i], Q_MOD[i] & m, &rl[i]);
+  return r;
+}
+#else
 INL fq fq_add(fq a, fq b) { fq r; mod_add(r.l, a.l, b.l, Q_MOD, NQ); return r; }
 INL fq fq_sub(fq a, fq b) { fq r; mod_sub(r.l, a.l, b.l, Q_MOD, NQ); return r; }
+#endif
 INL fq fq_neg(fq a) { fq r; mod_neg(r.l, a.l, Q_MOD, NQ); return r; }
+#if defined(GO_ADX) && defined(__x86_64__) && defined(__ADX__) && defined(__BMI2__)
+/* The TIMED build only (libgemini_oracle_native.so, bench.py's cpu_baseline): the reference runs ark-ff with its `asm` feature
+ * (Cargo.toml:77-82: mulx + two carry chains), which the portable __int128 loop above under-represents by 2-3 x.  Same CIOS
+ * recurrence, one round per limb of b: t += a b_i on the adox chain with the high halves on the adcx chain, then m = t0 inv and
+ * t = (t + m q) / 2^64 the same way; q < 2^381 leaves room for both chains without a seventh word.  The portable library stays
+ * the checker; tests/test_oracle_native_cpu.py holds the two equal. */
+#define GO_R(OFF)                                                                       \
+  "xorl %%eax, %%eax\n\t"                                                               \
+  "movq " #OFF "(%[b]), %%rdx\n\t"                                                      \
+  "mulxq 0(%[a]), %%rax, %%r14\n\t adoxq %%rax, %%r8\n\t adcxq %%r14, %%r9\n\t"         \
+  "mulxq 8(%[a]), %%rax, %%r14\n\t adoxq %%rax, %%r9\n\t adcxq %%r14, %%r10\n\t"        \
+  "mulxq 16(%[a]), %%rax, %%r14\n\t adoxq %%rax, %%r10\n\t adcxq %%r14, %%r11\n\t"      \
+  "mulxq 24(%[a]), %%rax, %%r14\n\t adoxq %%rax, %%r11\n\t adcxq %%r14, %%r12\n\t"      \
+  "mulxq 32(%[a]), %%rax, %%r14\n\t adoxq %%rax, %%r12\n\t adcxq %%r14, %%r13\n\t"      \
+  "mulxq 40(%[a]), %%rax, %%r14\n\t adoxq %%rax, %%r13\n\t"                             \
+  "movl $0, %%eax\n\t adcxq %%rax, %%r14\n\t adoxq %%rax, %%r14\n\t"                    \
+  "movq %[inv], %%rdx\n\t imulq %%r8, %%rdx\n\t xorl %%eax, %%eax\n\t"                  \
+  "mulxq 0(%[q]), %%rax, %%rbx\n\t adcxq %%r8, %%rax\n\t movq %%rbx, %%r8\n\t adcxq %%r9, %%r8\n\t" \
+  "mulxq 8(%[q]), %%rax, %%r9\n\t adoxq %%rax, %%r8\n\t adcxq %%r10, %%r9\n\t"          \
+  "mulxq 16(%[q]), %%rax, %%r10\n\t adoxq %%rax, %%r9\n\t adcxq %%r11, %%r10\n\t"       \
+  "mulxq 24(%[q]), %%rax, %%r11\n\t adoxq %%rax, %%r10\n\t adcxq %%r12, %%r11\n\t"      \
+  "mulxq 32(%[q]), %%rax, %%r12\n\t adoxq %%rax, %%r11\n\t adcxq %%r13, %%r12\n\t"      \
+  "mulxq 40(%[q]), %%rax, %%r13\n\t adoxq %%rax, %%r12\n\t"                             \
+  "movl $0, %%eax\n\t adcxq %%rax, %%r13\n\t adoxq %%r14, %%r13\n\t"
+INL fq fq_mul(fq a, fq b) {
+  fq t, r;
+  u64 inv = Q_INV;
+  __asm__ volatile(
+      "xorl %%r8d, %%r8d\n\t xorl %%r9d, %%r9d\n\t xorl %%r10d, %%r10d\n\t xorl %%r11d, %%r11d\n\t xorl %%r12d, %%r12d\n\t xorl %%r13d, %%r13d\n\t"
+      GO_R(0) GO_R(8) GO_R(16) GO_R(24) GO_R(32) GO_R(40)
+      "movq %%r8, 0(%[t])\n\t movq %%r9, 8(%[t])\n\t movq %%r10, 16(%[t])\n\t movq %%r11, 24(%[t])\n\t movq %%r12, 32(%[t])\n\t movq %%r13, 40(%[t])\n\t"
+      : "=m"(t)
+      : [a] "r"(a.l), [b] "r"(b.l), [q] "r"(Q_MOD), [inv] "m"(inv), [t] "r"(t.l), "m"(a), "m"(b)
+      : "rax", "rbx", "rdx", "r8", "r9", "r10", "r11", "r12", "r13", "r14", "cc", "memory");
+  { /* t < 2q: one conditional subtraction, branch-free */
+    unsigned long long* rl = (unsigned long long*)r.l;
+    unsigned char bw = 0;
+    for (int i = 0; i < NQ; i++) bw = _subborrow_u64(bw, t.l[i], Q_MOD[i], &rl[i]);
+    const u64 keep = (u64)0 - (u64)bw;
+    for (int i = 0; i < NQ; i++) r.l[i] = (t.l[i] & keep) | (r.l[i] & ~keep);
+  }
+  return r;
+}
+#undef GO_R
+#else
 INL fq fq_mul(fq a, fq b) { fq r; mont_mul(r.l, a.l, b.l, Q_MOD, Q_INV, NQ); return r; }
+#endif
 INL fq fq_sqr(fq a) { return fq_mul(a, a); }
 INL fq fq_dbl(fq a) { return fq_add(a, a); }
 INL int fq_is_zero(fq a) { return limbs_is_zero(a.l, NQ); }

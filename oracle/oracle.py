@@ -24,24 +24,58 @@ def build(force: bool = False) -> str:
     return _SO
 
 
-_lib = None
+_SO_NATIVE = os.path.join(_HERE, "libgemini_oracle_native.so")
+_libs = {}
+_which = "portable"
+
+
+def _open(path):
+    l = C.CDLL(path)
+    l.go_msm_window.restype = C.c_size_t
+    l.go_msm_window.argtypes = [C.c_size_t]
+    l.go_fold_polynomial.restype = C.c_size_t
+    l.go_linear_combination.restype = C.c_size_t
+    l.go_sumcheck_rounds.restype = C.c_size_t
+    l.go_sumcheck_rounds.argtypes = [C.c_size_t, C.c_size_t]
+    l.go_g1_is_on_curve.restype = C.c_int
+    l.go_g1_jac_eq.restype = C.c_int
+    return l
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_SO):
-            build()
-        _lib = C.CDLL(_SO)
-        _lib.go_msm_window.restype = C.c_size_t
-        _lib.go_msm_window.argtypes = [C.c_size_t]
-        _lib.go_fold_polynomial.restype = C.c_size_t
-        _lib.go_linear_combination.restype = C.c_size_t
-        _lib.go_sumcheck_rounds.restype = C.c_size_t
-        _lib.go_sumcheck_rounds.argtypes = [C.c_size_t, C.c_size_t]
-        _lib.go_g1_is_on_curve.restype = C.c_int
-        _lib.go_g1_jac_eq.restype = C.c_int
-    return _lib
+    """the C restatement every binding below calls: the portable build (the checker) unless a `native()` block is open"""
+    if _which not in _libs:
+        path = _SO if _which == "portable" else _SO_NATIVE
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(path)])
+        _libs[_which] = _open(path)
+    return _libs[_which]
+
+
+def native_available() -> bool:
+    """libgemini_oracle_native.so needs BMI2 + ADX on the host (every x86-64 server since 2015; checked, not assumed)"""
+    try:
+        flags = open("/proc/cpuinfo").read().split("flags", 1)[1].split("\n", 1)[0].split()
+    except Exception:  # noqa: BLE001
+        return False
+    return {"bmi2", "adx", "avx2"} <= set(flags)
+
+
+class native:
+    """`with oracle.native():` -- the same source built for today's CPUs (oracle/Makefile: x86-64-v3 + ADX, the Fq product in
+    mulx / adcx / adox asm), for the TIMED cpu_baseline legs of bench.py only.  The checker stays the portable build."""
+
+    def __enter__(self):
+        global _which
+        self._prev = _which
+        if native_available():
+            _which = "native"
+        return self
+
+    def __exit__(self, *exc):
+        global _which
+        _which = self._prev
+        return False
 
 
 def _p(a: np.ndarray):

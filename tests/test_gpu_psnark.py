@@ -307,7 +307,7 @@ def test_evaluate_index_poly(gm, oracle, pyref, n):
     vec.free()
 
 
-@pytest.mark.parametrize("logn", [18, 20, 22])
+@pytest.mark.parametrize("logn", [18, 20, 22, 26])
 def test_psnark_config5_shape_time_equals_elastic(gm, oracle, pyref, logn):
     """BASELINE configs[4] (`examples/psnark -i 26`) in its own shape at a suite-sized instance: dummy_r1cs(2^logn) and
     the recipe of examples/psnark.rs:70-81 (key of num_constraints + num_variables powers, index from the key).  The
@@ -315,7 +315,12 @@ def test_psnark_config5_shape_time_equals_elastic(gm, oracle, pyref, logn):
     proof (`assert!(elastic_proof == time_proof)`, src/psnark/tests.rs:124), and what the dummy instance fixes in
     closed form must hold on the device proof: z_a = z_b = z_c = [1; n] (src/circuit.rs:349-365), so
     zc(alpha) = (alpha^n - 1) / (alpha - 1) with alpha re-derived by the oracle's transcript from the proof's own
-    witness commitment and the key's G2 powers."""
+    witness commitment and the key's G2 powers.
+
+    logn = 26 is BASELINE configs[4] AT ITS OWN SIZE, as the example runs it without --time-prover: Proof::new_elastic on
+    dummy_r1cs_stream(2^26) over the 3 * 2^26 + 1-point stream key, max_msm_buffer 2^20 (examples/psnark.rs:54-68) -- through
+    gm_psnark_new_elastic, and the compiled gm_psnark_new_time beside it (both ~5 s, ~250-270 GB of device memory in use at the
+    peak: profiles/r5_prover_sweep.txt); the two proofs must be the same bytes."""
     from gemini_amd.circuit import R1csStream, dummy_r1cs
     from gemini_amd.kzg import CommitterKey, CommitterKeyStream
     from gemini_amd.psnark import Proof
@@ -330,14 +335,24 @@ def test_psnark_config5_shape_time_equals_elastic(gm, oracle, pyref, logn):
     ck = CommitterKey.new(3 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
     r1cs = dummy_r1cs(e, n)
     index = Proof.index(ck, r1cs)
-    time_proof = Proof.new_time(ck, r1cs, index)
+    # (2^26: the step-by-step Python driver keeps its temporaries alive longer than the compiled prover -- ~150 GB more)
+    time_proof = Proof.new_time(ck, r1cs, index, native=logn >= 24)
     stream = R1csStream(r1cs)
+    if logn >= 24:  # what the library promised (gm_psnark_footprint) against what the proof then used
+        before = gm.capi.mem_stats()
+        promised = gm.capi.psnark_footprint(ck.powers_of_g.handle, n, n, 1)
+        gm.capi.mem_reset_peak()
     # 2^18: the Python-driven elastic prover beside the compiled one; above: the compiled one (gm_psnark_new_elastic) alone
     if logn == 18:
         stepwise = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20)
         assert stepwise == time_proof and stepwise.serialize_compressed() == time_proof.serialize_compressed()
     elastic_proof = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20, native=True)
     assert elastic_proof == time_proof and elastic_proof.serialize_compressed() == time_proof.serialize_compressed()
+    if logn >= 24:
+        after = gm.capi.mem_stats()
+        used = after["in_use_peak"] - before["in_use"]
+        assert used <= promised["needed"], (used, promised)
+        assert after["spare_table_releases"] == before["spare_table_releases"]  # it fitted as promised: nothing was dropped on the way
     if logn == 22:  # the flushes cut literally: 2^20-pair stream MSMs (and 2^20 / depth in commit_folding), sumchecks that start as space provers
         literal = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck, min_device_chunk=1), stream, index, 1 << 20, native=True)
         assert literal.serialize_compressed() == time_proof.serialize_compressed()
@@ -426,15 +441,15 @@ def test_full_size_device_proof_is_accepted_by_the_reference_verifier(gm, oracle
 
     n = 1 << logn
     e, tau = 0x1D2C3B4A59687766554433221100FFEE % pyref.R_MOD, 0x0123456789ABCDEF0FEDCBA987654321 % pyref.R_MOD
-    if logn >= 26:  # ~150 GB of vectors: start from an empty vector pool whatever ran before in this process
-        gm.capi.check(gm.capi.load().gm_pool_trim())
     r1cs = dummy_r1cs(e, n)
     # examples/psnark.rs:76 asks for max_degree 2n (2n + 1 powers); the accumulated products of the sorted vectors have
     # 2n + 2 coefficients, the commitment would silently drop the top one (src/kzg/time.rs:82) and the proof would not
     # verify -- in the reference as here (oracle: test_reference_example_key_is_one_power_short).  One more power:
     ck = CommitterKey.new(2 * n + 1, 5, oracle.ints_to_limbs([tau], 4)[0])
     index = Proof.index(ck, r1cs)
-    proof = Proof.new_time(ck, r1cs, index)
+    # 2^24 and 2^26 through the prover compiled into the library (gm_psnark_new_time); no gm_pool_trim() beforehand any more: the
+    # prover asks for its footprint up front and the pool gives cached blocks back on demand
+    proof = Proof.new_time(ck, r1cs, index, native=logn >= 24)
     vk = V.VerifierKey.from_trapdoor(tau, 5)
     stub = {"x": [e], "z": range(n)}  # the verifier reads the public input and the number of variables only
     V.psnark_verify(psnark_proof_to_ints(gm, oracle, proof), stub, vk, [jac_to_affine_ints(oracle, c) for c in index], n)

@@ -581,7 +581,6 @@ def _elastic_closed_forms(gm, oracle, pyref, logn, native):
     stream.free()
     r1cs.free()
     ck.powers_of_g.free()
-    gm.capi.load().gm_pool_trim()
     return size
 
 
