@@ -118,7 +118,7 @@ int gm_mem_stats(uint64_t out[12]);
 int gm_mem_reset_peak(void);
 /* THE FOOTPRINT CONTRACT.  What a proof will allocate beyond what is resident when it is called (the key and its tables, the
  * instance, the caller's vectors): out[0] = high-water mark of its device vectors and prover buffers, out[1] = what the MSM
- * workspaces still have to grow by for its largest calls (0 once a proof of that size has run), out[2] = out[0] + out[1], out[3] =
+ * workspaces may still have to grow by for its largest calls (an upper bound; it shrinks as they grow), out[2] = out[0] + out[1], out[3] =
  * what can be had right now (device free + the vector pool's cached blocks + the prefix tables, which are spare memory).  Upper
  * bounds, within ~25 % of the measured peaks (tests/test_gpu_footprint.py, profiles/r5_footprint.txt).  Every prover compiled into
  * the library checks the same figures before its first allocation: if the proof only fits without the prefix tables they are

@@ -56,9 +56,9 @@ def test_snark_promised_vs_used(gm, oracle, logn, elastic):
     assert ws_grown <= promised["workspaces_to_grow"]
     vectors_used = used - ws_grown
     assert promised["vectors"] <= 1.35 * vectors_used + 0.4 * GB, (promised["vectors"] / GB, vectors_used / GB)
-    # a second proof of the same size: the workspaces have grown, nothing more is promised for them
+    # a second proof of the same size: the workspaces have grown, less (an upper bound: not necessarily nothing) is promised for them
     again = gm.capi.snark_footprint(ck.powers_of_g.handle, n, elastic)
-    assert again["workspaces_to_grow"] == 0 and again["vectors"] == promised["vectors"]
+    assert again["workspaces_to_grow"] <= promised["workspaces_to_grow"] - ws_grown and again["vectors"] == promised["vectors"]
     if stream is not None:
         stream.free()
     r1cs.free()
