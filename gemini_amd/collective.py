@@ -137,3 +137,15 @@ def allgather_vec(local, out=None):
         out = FrVec.alloc(len(local) * world)
     capi.check(capi.load().gm_dist_allgather_vec(C.c_uint64(local.handle), C.c_uint64(out.handle)))
     return out
+
+
+def reblock_vecs(local_vecs, new_block: int):
+    """gm_dist_reblock_vecs: every vector is block-distributed with equal blocks; returns this rank's block [rank B, (rank + 1) B) of each"""
+    from .fr import FrVec
+
+    k = len(local_vecs)
+    outs = [FrVec.alloc(max(new_block, 1)) for _ in range(k)]
+    a = (C.c_uint64 * k)(*[v.handle for v in local_vecs])
+    b = (C.c_uint64 * k)(*[v.handle for v in outs])
+    capi.check(capi.load().gm_dist_reblock_vecs(a, C.c_size_t(k), C.c_size_t(new_block), b))
+    return outs

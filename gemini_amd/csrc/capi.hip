@@ -341,6 +341,28 @@ int gm_init(int device) {
   GM_HIP(hipStreamCreateWithPriority(&C->stream, hipStreamNonBlocking, prio ? prio_lo : 0));
   for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithPriority(&C->small_stream[k], hipStreamNonBlocking, prio ? prio_hi : 0));
   GM_HIP(hipStreamCreateWithPriority(&C->stream_b, hipStreamNonBlocking, prio ? prio_hi : 0));
+  if (const char* e = getenv("GM_CU_SPLIT")) {
+    const int T = atoi(e), ncu = C->cu_count;
+    if (T > 0 && T < ncu) {
+      // bit i of the mask = compute unit i of the device (the runtime spreads consecutive bits over the XCDs): the tail partition
+      // takes every (ncu / T)-th CU so that it has a share of every XCD and of its L2, the accumulation partition the rest
+      const int words = (ncu + 31) / 32, stride = ncu / T;
+      std::vector<uint32_t> m_tail((size_t)words, 0u), m_acc((size_t)words, 0u);
+      int taken = 0;
+      for (int i = 0; i < ncu; i++) {
+        const bool tail = taken < T && i % stride == 0;
+        (tail ? m_tail : m_acc)[(size_t)i >> 5] |= 1u << (i & 31);
+        taken += tail ? 1 : 0;
+      }
+      bool ok = true;
+      for (int k = 0; k < 2 + MSM_SMALL_LANES && ok; k++) {
+        ok = hipExtStreamCreateWithCUMask(&C->part_acc[k], (uint32_t)words, m_acc.data()) == hipSuccess &&
+             hipExtStreamCreateWithCUMask(&C->part_tail[k], (uint32_t)words, m_tail.data()) == hipSuccess;
+      }
+      if (ok) C->cu_split = T;
+      else (void)hipGetLastError();
+    }
+  }
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
   if (const char* e = getenv("GM_ZERO_COPY")) C->zero_copy = atoi(e);
   g_ctx = C;

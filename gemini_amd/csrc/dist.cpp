@@ -65,12 +65,16 @@ using CommInitRank_t = ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int);
 using AllGather_t = ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
 using CommDestroy_t = ncclResult_t (*)(ncclComm_t);
 using GetErrorString_t = const char* (*)(ncclResult_t);
+using SendRecv_t = ncclResult_t (*)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);  // ncclSend takes const void*: cast at the call
+using Group_t = ncclResult_t (*)();
 #ifdef GM_HAVE_RCCL_HEADER
 static_assert(std::is_same<GetUniqueId_t, decltype(&ncclGetUniqueId)>::value, "ncclGetUniqueId prototype");
 static_assert(std::is_same<CommInitRank_t, decltype(&ncclCommInitRank)>::value, "ncclCommInitRank prototype");
 static_assert(std::is_same<AllGather_t, decltype(&ncclAllGather)>::value, "ncclAllGather prototype");
 static_assert(std::is_same<CommDestroy_t, decltype(&ncclCommDestroy)>::value, "ncclCommDestroy prototype");
 static_assert(std::is_same<GetErrorString_t, decltype(&ncclGetErrorString)>::value, "ncclGetErrorString prototype");
+static_assert(std::is_same<SendRecv_t, decltype(&ncclRecv)>::value, "ncclRecv prototype (ncclSend: the same with a const buffer)");
+static_assert(std::is_same<Group_t, decltype(&ncclGroupStart)>::value, "ncclGroupStart prototype");
 #endif
 struct Rccl {
   void* lib = nullptr;
@@ -79,6 +83,8 @@ struct Rccl {
   AllGather_t AllGather = nullptr;
   CommDestroy_t CommDestroy = nullptr;
   CommDestroy_t CommAbort = nullptr;  // optional: a rank that fails inside a collective aborts the communicator so that its peers do not hang
+  SendRecv_t Send = nullptr, Recv = nullptr;  // optional (gm_dist_reblock_vecs falls back to all-gathers without them)
+  Group_t GroupStart = nullptr, GroupEnd = nullptr;
   GetErrorString_t GetErrorString = nullptr;
 };
 
@@ -171,6 +177,10 @@ int load_rccl(Rccl& R) {
   GM_SYM(GetErrorString, "ncclGetErrorString");
 #undef GM_SYM
   R.CommAbort = reinterpret_cast<CommDestroy_t>(dlsym(R.lib, "ncclCommAbort"));
+  R.Send = reinterpret_cast<SendRecv_t>(dlsym(R.lib, "ncclSend"));
+  R.Recv = reinterpret_cast<SendRecv_t>(dlsym(R.lib, "ncclRecv"));
+  R.GroupStart = reinterpret_cast<Group_t>(dlsym(R.lib, "ncclGroupStart"));
+  R.GroupEnd = reinterpret_cast<Group_t>(dlsym(R.lib, "ncclGroupEnd"));
   return GM_OK;
 }
 
@@ -788,6 +798,117 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
   }
   d.note(d.tr == T_NONE ? R_COPY : d.tr == T_RCCL ? R_RCCL_VEC : d.tr == T_HOOK ? R_HOOK : R_SHM, bytes * (size_t)d.world,
          std::chrono::duration<double>(Clock::now() - t0).count());
+  return GM_OK;
+}
+
+// RE-BLOCKING.  k device vectors, each block-distributed with equal blocks (rank p holds elements [p b, (p + 1) b) of a global
+// vector of world x b elements, b = the local length); out j = the elements [rank B, (rank + 1) B) of global vector j that exist
+// (length 0 when the range is past its end).  What the n / g opening of the block-sharded prover needs: level i of the folding
+// tree is sharded in blocks of m / 2^i, the opened polynomial in blocks of m.  Over RCCL: ONE group of ncclSend / ncclRecv, every
+// element crosses one xGMI link once (all-gathers of whole vectors when librccl lacks the point-to-point calls); over the host
+// transports (shm, hook: the shared-GPU tests) the blocks are staged through host memory and all-gathered.
+int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block, const uint64_t* out_vecs) {
+  Dist& d = D();
+  std::lock_guard<std::mutex> lk(d.mu);
+  GM_CTX();
+  GM_FR_LOCK(C);
+  GM_CHECK((local_vecs && out_vecs) || k == 0, GM_EINVAL, "gm_dist_reblock_vecs: null pointer");
+  GM_CHECK(new_block > 0, GM_EINVAL, "gm_dist_reblock_vecs: empty blocks");
+  const size_t g = (size_t)d.world, r = (size_t)d.rank, B = new_block;
+  std::vector<gm::FrVec*> in(k), out(k);
+  for (size_t j = 0; j < k; j++) {
+    in[j] = gm::find_vec(local_vecs[j]);
+    out[j] = gm::find_vec(out_vecs[j]);
+    GM_CHECK(in[j] && out[j] && in[j] != out[j], GM_EHANDLE, "gm_dist_reblock_vecs: unknown or aliased vector handle (%zu)", j);
+    const size_t total = g * in[j]->len, lo = r * B, len = lo < total ? std::min(B, total - lo) : 0;
+    GM_CHECK(out[j]->cap >= len, GM_EINVAL, "gm_dist_reblock_vecs: output %zu holds %zu elements, the block has %zu", j, out[j]->cap, len);
+    out[j]->len = len;
+  }
+  if (k == 0) return GM_OK;
+  const auto t0 = Clock::now();
+  size_t moved = 0;
+  const bool p2p = d.tr == T_RCCL && d.R.Send && d.R.Recv && d.R.GroupStart && d.R.GroupEnd;
+  Route route = R_COPY;
+  if (d.tr == T_NONE || p2p) {
+    route = p2p ? R_RCCL_VEC : R_COPY;
+    bool grouped = false;
+    auto fail = [&](ncclResult_t res) {
+      gm::set_error("gm_dist_reblock_vecs: RCCL point-to-point failed: %s", d.R.GetErrorString(res));
+      if (d.comm && d.R.CommAbort) {
+        (void)d.R.CommAbort(d.comm);
+        d.comm = nullptr;
+        d.tr = T_NONE;
+      }
+      return GM_EHIP;
+    };
+    if (p2p && g > 1) {
+      ncclResult_t res = d.R.GroupStart();
+      if (res != ncclSuccess) return fail(res);
+      grouped = true;
+    }
+    for (size_t j = 0; j < k; j++) {
+      const size_t b = in[j]->len, total = g * b;
+      for (size_t p = 0; p < g; p++) {
+        // what rank p wants of my block
+        size_t lo = std::max(p * B, r * b), hi = std::min(std::min((p + 1) * B, (r + 1) * b), total);
+        if (lo < hi) {
+          uint8_t* src = in[j]->d + (lo - r * b) * 32;
+          if (p == r) {
+            GM_HIP(hipMemcpyAsync(out[j]->d + (lo - r * B) * 32, src, (hi - lo) * 32, hipMemcpyDeviceToDevice, C->stream));
+          } else {
+            ncclResult_t res = d.R.Send(src, (hi - lo) * 32, ncclChar, (int)p, d.comm, C->stream);
+            if (res != ncclSuccess) return fail(res);
+          }
+        }
+        if (p == r) continue;
+        // what I want of rank p's block
+        lo = std::max(r * B, p * b);
+        hi = std::min(std::min((r + 1) * B, (p + 1) * b), total);
+        if (lo < hi) {
+          ncclResult_t res = d.R.Recv(out[j]->d + (lo - r * B) * 32, (hi - lo) * 32, ncclChar, (int)p, d.comm, C->stream);
+          if (res != ncclSuccess) return fail(res);
+          moved += (hi - lo) * 32;
+        }
+      }
+    }
+    if (grouped) {
+      ncclResult_t res = d.R.GroupEnd();
+      if (res != ncclSuccess) return fail(res);
+    }
+    GM_HIP(hipStreamSynchronize(C->stream));
+  } else {
+    // whole vectors: ncclAllGather into a temporary (RCCL without send / recv) or the host transports
+    route = d.tr == T_RCCL ? R_RCCL_VEC : d.tr == T_HOOK ? R_HOOK : R_SHM;
+    for (size_t j = 0; j < k; j++) {
+      const size_t b = in[j]->len, bytes = b * 32, len = out[j]->len;
+      if (b == 0) continue;
+      if (d.tr == T_RCCL) {
+        void* tmp = nullptr;
+        GM_HIP(gm::dev_malloc(&tmp, bytes * g));
+        ncclResult_t res = d.R.AllGather(in[j]->d, tmp, bytes, ncclChar, d.comm, C->stream);
+        hipError_t e = res == ncclSuccess && len ? hipMemcpyAsync(out[j]->d, static_cast<uint8_t*>(tmp) + r * B * 32, len * 32, hipMemcpyDeviceToDevice, C->stream) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
+        (void)gm::raw_free(tmp);
+        GM_CHECK(res == ncclSuccess, GM_EHIP, "gm_dist_reblock_vecs: ncclAllGather failed: %s", d.R.GetErrorString(res));
+        GM_HIP(e);
+      } else {
+        std::vector<uint8_t> h_in(bytes), h_all(bytes * g);
+        GM_HIP(hipMemcpyAsync(h_in.data(), in[j]->d, bytes, hipMemcpyDeviceToHost, C->stream));
+        GM_HIP(hipStreamSynchronize(C->stream));
+        int rc = d.tr == T_HOOK ? d.fn(d.fn_ctx, h_in.data(), bytes, h_all.data()) : shm_allgather(d, h_in.data(), bytes, h_all.data());
+        if (rc) {
+          if (d.tr == T_HOOK) gm::set_error("gm_dist: the all-gather hook returned %d", rc);
+          return rc;
+        }
+        if (len) {
+          GM_HIP(hipMemcpyAsync(out[j]->d, h_all.data() + r * B * 32, len * 32, hipMemcpyHostToDevice, C->stream));
+          GM_HIP(hipStreamSynchronize(C->stream));
+        }
+      }
+      moved += bytes * g;
+    }
+  }
+  d.note(route, moved, std::chrono::duration<double>(Clock::now() - t0).count());
   return GM_OK;
 }
 

@@ -1671,6 +1671,10 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     for (int s = 0; s < MSM_SMALL_LANES; s++)
       if (C->small_stream[s]) (void)hipStreamSynchronize(C->small_stream[s]);
     if (C->stream_b) (void)hipStreamSynchronize(C->stream_b);
+    for (int s = 0; s < 2 + MSM_SMALL_LANES && C->cu_split; s++) {
+      (void)hipStreamSynchronize(C->part_acc[s]);
+      (void)hipStreamSynchronize(C->part_tail[s]);
+    }
     return rc;
   };
   auto busy = [&](int lane, int hslot) {
@@ -1825,6 +1829,22 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     e.lane = lane;
     MsmWorkspace& ws = lane > 0 ? C->msm_small[lane - 1] : (lane < 0 ? C->msm_b : C->msm);
     hipStream_t st = lane > 0 ? C->small_stream[lane - 1] : (lane < 0 ? C->stream_b : C->stream);
+    MsmStreams sts{st, st, st};
+    if (C->cu_split) {  // the CU partition of a batch (ctx.hpp): sorts where GM_CU_SPLIT_SORT says, accumulation and tail on their own CUs
+      static const bool sort_on_tail = getenv("GM_CU_SPLIT_SORT") && !strcmp(getenv("GM_CU_SPLIT_SORT"), "tail");
+      static const bool small_whole = getenv("GM_CU_SPLIT_SMALL") && !strcmp(getenv("GM_CU_SPLIT_SMALL"), "tail");
+      const int li = lane > 0 ? 1 + lane : (lane < 0 ? 1 : 0);
+      if (lane > 0 && small_whole) sts = MsmStreams{C->part_tail[li], C->part_tail[li], C->part_tail[li]};  // a small call entirely on the tail CUs
+      else sts = MsmStreams{sort_on_tail ? C->part_tail[li] : C->part_acc[li], C->part_acc[li], C->part_tail[li]};
+      st = sts.sort;
+      // the calls of a lane share its workspace: on ONE stream the order kept them apart, over three streams the next call's sort
+      // must wait for the previous call's tail (it clears the counters the bucket reduction reads)
+      if (ws.have_done_ev)
+        for (int e2 = 0; e2 < MSM_SLOTS; e2++) GM_HIP(hipStreamWaitEvent(sts.sort, ws.done_ev[e2], 0));
+      GM_HIP(hipStreamWaitEvent(sts.sort, C->start_ev, 0));
+      if (sts.tail != sts.sort) GM_HIP(hipStreamWaitEvent(sts.tail, C->start_ev, 0));
+      if (sts.acc != sts.sort) GM_HIP(hipStreamWaitEvent(sts.acc, C->start_ev, 0));
+    } else
     if (st != C->stream) GM_HIP(hipStreamWaitEvent(st, C->start_ev, 0));  // scalars produced on the main stream
     const auto tq0 = std::chrono::steady_clock::now();
     auto start_of = [&](size_t jj) { return pair_offsets ? (int64_t)pair_offsets[jj] : (firsts ? firsts[jj] : first); };
@@ -1840,9 +1860,9 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       }
       e.fused = grp;
       group_done[(size_t)group_of[j]] = 1;
-      rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, 0, step, nullptr, mont, 0, hslot, &e.P, 0, 1, &M);
+      rc = msm_enqueue(C, ws, sts, bases, 0, step, nullptr, mont, 0, hslot, &e.P, 0, 1, &M);
     } else
-      rc = msm_enqueue(C, ws, MsmStreams{st, st, st}, bases, start_of(j), step, d_scalars[j], mont,
+      rc = msm_enqueue(C, ws, sts, bases, start_of(j), step, d_scalars[j], mont,
                          ns[j], hslot, &e.P);
     enqueue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
     if (rc) return fail(rc);

@@ -588,121 +588,126 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
   RC(gm_transcript_challenge_fr(T.h, L("open-chal"), 9, open_chal));
   const Fr oc = Fr::from_limbs(open_chal);
   TR.mark("evaluations + transcript");
-  // the opening (batch_open_multi_points, src/kzg/time.rs:149-159): commit((sum_i eta_i p_i) / Z) = sum_i eta_i commit(p_i div Z).
-  // The quotient of block r of p_i needs the carry from the blocks above: the polynomial c_i of degree < 3 that agrees with
-  // S_r(x) = sum_{r' > r} x^((r' - r - 1) L) P_r'(x) at the three roots of Z -- values that were all-gathered above -- and leaves
-  // a remainder rem_i, the polynomial of degree < 3 that agrees with G_i = eta_i [P_i, c_i] at the roots (host values again:
-  // G_i(x) = eta_i (P_i(x) + x^L c_i(x))).  Level i's quotient q_i = (G_i - rem_i) / Z pairs with the level's key slice, and the
-  // slices sit back to back in ONE registered key at offsets off_i.  So the blocks are laid out in ONE vector at the slices'
-  // offsets, F = sum_i x^(off_i) (G_i - rem_i): eta_i P_i by one scaling pass per level, the 3 + 3 seam coefficients c_i and
-  // -rem_i by one sparse update.  F is exactly divisible, F / Z = sum_i x^(off_i) q_i: ONE division and ONE MSM of ~2 m pairs for
-  // the whole opening (instead of a latency-bound division and MSM per level).  The replicated small levels ride in the prefix
-  // segment on rank 0 only.
+  // The opening (batch_open_multi_points, src/kzg/time.rs:149-159): commit(F div Z), F = sum_i eta_i p_i over w and every level.
+  // Round 4 opened level by level against the per-level key slices -- sum_i |block_i| = 2 n / g pairs per rank.  F itself is ONE
+  // polynomial of n coefficients: rank r takes ITS coefficient range [r m, (r + 1) m) of F and commits the quotient of that block
+  // against the level-0 key slice it already holds -- n / g pairs.  Level i's coefficients of that range live on other ranks (level i
+  // is sharded in blocks of m / 2^i: its range [r m, (r + 1) m) is spread over ranks r 2^i .. (r + 1) 2^i - 1), so the levels are
+  // RE-BLOCKED first (gm_dist_reblock_vecs: one grouped send / recv over xGMI; rank 0 receives the most, (log2 g + 1) m elements,
+  // ~75 MB at -i 24 on 8 GPUs: ~1 ms of one link against the ~5 ms of accumulation the m pairs cost -- and it can run under the
+  // fold commitments).  The quotient of block r needs the carry from the blocks above: the polynomial c of degree < 3 that agrees
+  // with S_r(x) = sum_{r' > r} x^((r' - r - 1) m) F_r'(x) at the three roots of Z (one all-gather of three evaluations per rank),
+  // and leaves a remainder rem that agrees with G = F_r + x^m c at the roots: q_r = (G - rem) / Z exactly, and F div Z =
+  // sum_r x^(r m) q_r.  One linear combination, one division, one MSM of m pairs.
   {
-    const size_t nb = blocks.size();
-    const size_t span = S->key_offsets[PREFIX] + S->key_counts[PREFIX];
-    uint64_t laid;
-    RC(V.alloc(span + 3, &laid));
+    const size_t nb = blocks.size();  // w and the block-sharded levels 1 .. jmax
+    std::vector<uint64_t> pieces, piece_eta;
+    auto add_piece = [&](uint64_t v, const Fr& eta) {
+      pieces.push_back(v);
+      piece_eta.resize(piece_eta.size() + 4);
+      eta.to_limbs(piece_eta.data() + piece_eta.size() - 4);
+    };
+    std::vector<Fr> etas(nb + small.size());
+    {
+      Fr acc = Fr::one();
+      for (auto& e : etas) {
+        e = acc;
+        acc = acc * oc;
+      }
+    }
+    if (nw) add_piece(w_blk, etas[0]);
+    if (g == 1) {
+      for (size_t i = 1; i < nb; i++) add_piece(blocks[i], etas[i]);
+    } else if (nb > 1) {
+      std::vector<uint64_t> outs(nb - 1);
+      for (size_t i = 1; i < nb; i++) RC(V.alloc(m, &outs[i - 1]));
+      RC(gm_dist_reblock_vecs(blocks.data() + 1, nb - 1, m, outs.data()));
+      for (size_t i = 1; i < nb; i++) {
+        size_t len = 0;
+        RC(vec_len(outs[i - 1], &len));
+        if (len) add_piece(outs[i - 1], etas[i]);
+      }
+    }
+    if (r == 0)
+      for (size_t i = 0; i < small.size(); i++) add_piece(small[i], etas[nb + i]);
+    TR.mark("re-block");
+    uint64_t F;
+    RC(V.alloc(m + 3, &F));
     {
       uint64_t zero[4] = {0, 0, 0, 0};
-      RC(gm_fr_vec_fill(laid, zero));
+      RC(gm_fr_vec_fill(F, zero));
     }
-    std::vector<std::pair<size_t, Fr>> seams;  // (position, value to add)
-    auto seam = [&](size_t pos, const Fr& v) {
-      for (auto& s : seams)
-        if (s.first == pos) {
-          s.second = s.second + v;
-          return;
-        }
-      seams.emplace_back(pos, v);
+    size_t lf = 0;
+    if (!pieces.empty()) {
+      RC(gm_fr_lincomb(pieces.data(), piece_eta.data(), pieces.size(), F));
+      RC(vec_len(F, &lf));
+    }
+    GM_CHECK(lf <= m, GM_ESTATE, "snark_new_time_sharded: the block of the opened polynomial has %zu coefficients, more than a block (%zu)", lf, m);
+    const bool carry_in = r + 1 < g;
+    const size_t len_f = carry_in ? m + 3 : std::max<size_t>(lf, 3);
+    RC(gm_fr_vec_set_len(F, len_f));  // (the tail beyond the combination is the zero fill)
+    // F_r at the three roots, all ranks
+    uint64_t mine_ev[12];
+    std::vector<uint64_t> all_ev(12 * g);
+    RC(gm_fr_eval_le(F, pts, 3, mine_ev));
+    RC(gm_dist_allgather_host(mine_ev, 96, all_ev.data()));
+    Fr c[3] = {Fr::zero(), Fr::zero(), Fr::zero()}, gv[3], rem[3];
+    std::vector<size_t> pos;
+    std::vector<uint64_t> val;
+    auto seam = [&](size_t at, const Fr& v) {
+      pos.push_back(at);
+      val.resize(val.size() + 4);
+      v.to_limbs(val.data() + val.size() - 4);
     };
-    std::vector<uint64_t> scaled_in, scaled_c;  // eta_i P_i into the slice of level i: one call for all levels
-    std::vector<size_t> scaled_off;
-    Fr eta_i = Fr::one();
-    for (size_t i = 0; i < nb; i++, eta_i = eta_i * oc) {
-      const size_t Lb = m >> i, off = S->key_offsets[i];
-      size_t len = 0;
-      RC(vec_len(blocks[i], &len));
-      GM_CHECK(len <= Lb && (r + 1 == g || len == Lb), GM_ESTATE, "snark_new_time_sharded: block of %zu elements at level %zu (blocks hold %zu)", len, i, Lb);
-      scaled_in.push_back(blocks[i]);
-      scaled_off.push_back(off);
-      scaled_c.resize(scaled_c.size() + 4);
-      eta_i.to_limbs(scaled_c.data() + scaled_c.size() - 4);
-      Fr gv[3], c[3] = {Fr::zero(), Fr::zero(), Fr::zero()}, rem[3];
-      if (r + 1 < g) {
-        Fr ys[3];
-        for (int q = 0; q < 3; q++) {
-          const Fr step = fr_pow_u64(xs[q], Lb);
-          Fr acc = Fr::zero(), xp = Fr::one();
-          for (size_t rr = r + 1; rr < g; rr++) {
-            acc = acc + xp * Fr::from_limbs(allr.data() + 4 * ((rr * nb + i) * 3 + q));
-            xp = xp * step;
-          }
-          ys[q] = acc;
-        }
-        interp3(xs, ys, c);
-        for (int q = 0; q < 3; q++) seam(off + Lb + q, eta_i * c[q]);
-      }
+    if (carry_in) {
+      Fr ys[3];
       for (int q = 0; q < 3; q++) {
-        const Fr cx = c[0] + xs[q] * (c[1] + xs[q] * c[2]);
-        gv[q] = eta_i * (Fr::from_limbs(allr.data() + 4 * ((r * nb + i) * 3 + q)) + fr_pow_u64(xs[q], Lb) * cx);
+        const Fr step = fr_pow_u64(xs[q], m);
+        Fr acc = Fr::zero(), xp = Fr::one();
+        for (size_t rr = r + 1; rr < g; rr++) {
+          acc = acc + xp * Fr::from_limbs(all_ev.data() + 4 * (rr * 3 + q));
+          xp = xp * step;
+        }
+        ys[q] = acc;
       }
-      interp3(xs, gv, rem);
-      for (int q = 0; q < 3; q++) seam(off + q, rem[q].neg());
+      interp3(xs, ys, c);
+      for (int q = 0; q < 3; q++) seam(m + q, c[q]);
     }
-    RC(gm_fr_scale_into_many(scaled_in.data(), scaled_c.data(), scaled_in.size(), laid, scaled_off.data()));
-    if (!small.empty() && r == 0) {
-      std::vector<uint64_t> etas(4 * small.size());
-      Fr acc = eta_i;  // open_chal^nb
-      size_t longest = 0;
-      for (size_t i = 0; i < small.size(); i++) {
-        acc.to_limbs(etas.data() + 4 * i);
-        acc = acc * oc;
-        size_t l = 0;
-        RC(vec_len(small[i], &l));
-        longest = std::max(longest, l);
-      }
-      uint64_t comb;
-      RC(V.alloc(longest, &comb));
-      RC(gm_fr_lincomb(small.data(), etas.data(), small.size(), comb));
-      size_t lc = 0;
-      RC(vec_len(comb, &lc));
-      GM_CHECK(lc <= S->key_counts[PREFIX] + 3, GM_ESTATE, "snark_new_time_sharded: the small levels hold %zu coefficients, the prefix %zu powers", lc,
-               S->key_counts[PREFIX]);
-      if (lc) {
-        uint64_t one_l[4], cv[12];
-        Fr::one().to_limbs(one_l);
-        RC(gm_fr_scale_into(comb, one_l, laid, S->key_offsets[PREFIX]));
-        RC(gm_fr_eval_le(comb, pts, 3, cv));
-        Fr gv[3], rem[3];
-        for (int q = 0; q < 3; q++) gv[q] = Fr::from_limbs(cv + 4 * q);
-        interp3(xs, gv, rem);
-        for (int q = 0; q < 3; q++) seam(S->key_offsets[PREFIX] + q, rem[q].neg());
+    for (int q = 0; q < 3; q++) {
+      const Fr cx = c[0] + xs[q] * (c[1] + xs[q] * c[2]);
+      gv[q] = Fr::from_limbs(mine_ev + 4 * q) + fr_pow_u64(xs[q], m) * cx;
+    }
+    interp3(xs, gv, rem);
+    for (int q = 0; q < 3; q++) seam(q, rem[q].neg());
+    if (r == 0) {
+      // the remainder of the whole division is known: the polynomial through the claimed evaluations sum_i eta_i p_i(x_q), which
+      // the transcript has already absorbed -- a wrong re-blocking cannot go unnoticed
+      for (int q = 0; q < 3; q++) {
+        Fr want = etas[0] * vals[q];
+        for (size_t i = 1; i < nb; i++) want = want + etas[i] * vals[3 * i + q];
+        for (size_t i = 0; i < small.size(); i++) {
+          if (q == 0) continue;
+          want = want + etas[nb + i] * Fr::from_limbs(P->fold_evaluations + 8 * (sharded.size() + i) + 4 * (q - 1));
+        }
+        if (q != 0) GM_CHECK(want == gv[q], GM_ESTATE, "snark_new_time_sharded: the opened polynomial does not take the claimed value at root %d", q);
       }
     }
-    {
-      std::vector<size_t> pos(seams.size());
-      std::vector<uint64_t> val(4 * seams.size());
-      for (size_t t = 0; t < seams.size(); t++) {
-        pos[t] = seams[t].first;
-        seams[t].second.to_limbs(val.data() + 4 * t);
-      }
-      RC(gm_fr_add_at(laid, pos.data(), val.data(), pos.size()));
-    }
-    uint64_t quot, remz[12];
-    RC(V.alloc(span + 2, &quot));
-    RC(gm_fr_div_vanishing(laid, pts, 3, quot, remz));
-    for (int l = 0; l < 12; l++) GM_CHECK(remz[l] == 0, GM_ESTATE, "snark_new_time_sharded: the laid-out opening is not divisible by Z (seam %d)", l / 4);
-    TR.mark("carries + division");
-    size_t lq = 0;
-    RC(vec_len(quot, &lq));
+    RC(gm_fr_add_at(F, pos.data(), val.data(), pos.size()));
     uint64_t mine[18];
-    if (lq == 0) {
-      memcpy(mine, identity_point(), 144);
-    } else {
-      const size_t zero_off = 0;
-      lq = std::min(lq, span);
-      RC(gm_g1_msm_v_batch_at(S->key, &zero_off, 0, &quot, &lq, 1, 1, mine));
+    memcpy(mine, identity_point(), 144);
+    if (len_f > 3) {
+      uint64_t quot, remz[12];
+      RC(V.alloc(len_f - 3, &quot));
+      RC(gm_fr_div_vanishing(F, pts, 3, quot, remz));
+      for (int l = 0; l < 12; l++) GM_CHECK(remz[l] == 0, GM_ESTATE, "snark_new_time_sharded: the block of the opening is not divisible by Z (limb %d)", l);
+      TR.mark("carries + division");
+      size_t lq = 0;
+      RC(vec_len(quot, &lq));
+      if (lq) {
+        lq = std::min(lq, S->key_counts[0]);
+        const size_t off0 = S->key_offsets[0];
+        RC(gm_g1_msm_v_batch_at(S->key, &off0, 0, &quot, &lq, 1, 1, mine));
+      }
     }
     TR.mark("opening MSM");
     RC(gather_sum(mine, 1, P->evaluation_proof));

@@ -595,6 +595,11 @@ int gm_dist_allgather_host_class(const void* send, size_t bytes, void* recv, int
 /* out = the local vectors of ranks 0 .. world - 1 back to back (equal lengths; out needs capacity world x len and is
  * resized): device to device over RCCL, staged through the host on the other transports. */
 int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec);
+/* RE-BLOCKING: k device vectors, each block-distributed with equal blocks (rank p holds elements [p b, (p + 1) b), b = its local
+ * length); out j (capacity >= new_block) = the elements [rank new_block, (rank + 1) new_block) of global vector j that exist, its
+ * length set accordingly (0 past the end).  One group of ncclSend / ncclRecv over xGMI (every element crosses one link once); staged
+ * through the host on the shm / hook transports; a copy with one rank.  What the n / g opening of gm_snark_new_time_sharded needs. */
+int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block, const uint64_t* out_vecs);
 /* collectives issued by this rank so far, the bytes they received and the wall time spent inside them */
 int gm_dist_stats(uint64_t* calls, uint64_t* bytes, double* seconds, int reset_counters);
 /* the same split by route: [0] copy (world 1), [1] hook, [2] RCCL with host staging, [3] RCCL device vectors, [4] shared memory */

@@ -102,6 +102,13 @@ def test_rccl_binding_with_one_rank():
         # both routes carry either class when forced (gm_dist_bench: what profiles/r5_collective_latency.txt was measured with)
         for route in ("shm", "rccl_host_staged"):
             assert collective.bench(144, 20, collective.CLASS_G1, route) > 0
+        # re-blocking with one rank goes through the grouped ncclSend / ncclRecv branch (no peers: the self part is a device copy)
+        host = np.random.default_rng(5).integers(0, 2**62, size=(100, 4), dtype=np.uint64)
+        v = FrVec.from_host(host)
+        (o64,), (o128,) = collective.reblock_vecs([v], 64), collective.reblock_vecs([v], 128)
+        assert len(o64) == 64 and (o64.to_host() == host[:64]).all() and len(o128) == 100 and (o128.to_host() == host).all()
+        for x in (v, o64, o128):
+            x.free()
     finally:
         collective.finalize()
     assert not os.path.exists(f"/dev/shm/gm_test_rcclnode_{os.getpid()}")
@@ -151,3 +158,50 @@ def test_block_sharded_native_prover_general_matrices():
     for world in (4,):
         many = _run(world, ["--block-sharded", "--global-columns", "--tail-log", "6"])
         assert many["proof_sha256"] == dummy["proof_sha256"], world
+
+
+REBLOCK_WORKER = """
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import gemini_amd as gm
+from gemini_amd import collective
+from gemini_amd.fr import FrVec
+rank, world, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+gm.capi.init(0)
+collective.init_shm(rank, world, name, 4096)
+m = 64
+glob = lambda j, total: (np.arange(total, dtype=np.uint64)[:, None] * np.uint64(1000003) + np.uint64(7919 * j) + np.arange(4, dtype=np.uint64)[None, :])
+# vector j is sharded in blocks of m >> j (the levels of a folding tree); re-block to blocks of m
+locs, tots = [], []
+for j in range(0, 7):
+    b = m >> j
+    g = glob(j, world * b)
+    locs.append(FrVec.from_host(np.ascontiguousarray(g[rank * b:(rank + 1) * b])))
+    tots.append(world * b)
+outs = collective.reblock_vecs(locs, m)
+for j, (o, total) in enumerate(zip(outs, tots)):
+    lo = rank * m
+    want = glob(j, total)[lo:lo + m] if lo < total else np.zeros((0, 4), dtype=np.uint64)
+    assert len(o) == len(want), (rank, j, len(o), len(want))
+    if len(want):
+        assert (o.to_host() == want).all(), (rank, j)
+st = collective.stats_routes()
+assert "shm" in st
+collective.finalize()
+print("ok", rank)
+""" % ROOT
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_reblocking_between_ranks_on_the_shared_gpu(world):
+    """gm_dist_reblock_vecs over the host transport (N processes share the one GPU): the levels of a folding tree, sharded in
+    blocks of m / 2^j, arrive as the blocks [r m, (r + 1) m) of the same global vectors -- what the n / g opening of the
+    block-sharded prover needs (src/kzg/time.rs:149-159 opens ONE polynomial; rank r commits ITS coefficient range of its quotient)"""
+    name = f"/gm_reblock_{os.getpid()}_{world}"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", REBLOCK_WORKER, str(r), str(world), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]
