@@ -92,7 +92,10 @@ struct ScArgs {
   size_t npairs;        // loop bound: pairs of the message vectors (covers both vectors entirely)
 };
 
-template <bool FOLD, bool MSG>
+// LAZY = the three inner products of the message accumulate UNREDUCED 512-bit products (fp_mac_wide: the product half of a
+// multiplication, 80 multiply-adds instead of 137) and are Montgomery-reduced once per 16 pairs -- r^2 < 2^512 / 19, so sixteen
+// products fit sixteen limbs.  The reference does the same on the CPU (`ip_unsafe`, src/misc.rs:235-266).
+template <bool FOLD, bool MSG, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
   const size_t T = (size_t)1 << A.log_threads;
@@ -107,6 +110,14 @@ __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict_
     step.l[i] = A.tau2.p[A.log_threads][i];
   }
   Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};  // a, b1 = sum fe*go*tw, b2 = sum ge*fo*tw
+  FpWide_FrParams wide[3];
+  int pending = 0;
+  if (LAZY) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) wide[k].l[i] = 0;
+  }
   if (MSG && t < A.npairs) tw = fr_mul(tw, pow_from_table(A.tau2, t));
   // message vectors: FOLD ? folded (length ceil(n_in/2)) : the inputs
   const size_t nf = FOLD ? (A.nf_in + 1) / 2 : A.nf_in;
@@ -134,13 +145,32 @@ __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict_
     }
     if (MSG) {
       Fr u = fr_mul(fe, tw), w = fr_mul(fo, tw);
-      acc[0] = fr_add(acc[0], fr_mul(u, ge));
-      acc[1] = fr_add(acc[1], fr_mul(u, go));
-      acc[2] = fr_add(acc[2], fr_mul(w, ge));
+      if (LAZY) {
+        fp_mac_wide(wide[0], u, ge);
+        fp_mac_wide(wide[1], u, go);
+        fp_mac_wide(wide[2], w, ge);
+        if (++pending == 16) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            acc[k] = fr_add(acc[k], fp_redc_wide(wide[k]));
+#pragma unroll
+            for (int i = 0; i < 16; i++) wide[k].l[i] = 0;
+          }
+          pending = 0;
+        }
+      } else {
+        acc[0] = fr_add(acc[0], fr_mul(u, ge));
+        acc[1] = fr_add(acc[1], fr_mul(u, go));
+        acc[2] = fr_add(acc[2], fr_mul(w, ge));
+      }
       tw = fr_mul(tw, step);
     }
   }
   if (MSG) {
+    if (LAZY) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc[k] = fr_add(acc[k], fp_redc_wide(wide[k]));
+    }
     block_sum<3>(acc, lds);
     if (threadIdx.x == 0) {
       // b = b1 + tau * b2

@@ -37,6 +37,9 @@ def emit_macs(pairs, xs_kind, ys_kind, out):
     lines = []
     for x, y in pairs:
         xi = opnum(x, xs_kind)
+        if y == "one":  # lo += x: the inline constant 1 as the multiplier
+            lines.append(f"v_mad_u64_u32 %0, vcc, %{xi}, 1, %0\\n\\tv_addc_co_u32 %1, vcc, 0, %1, vcc")
+            continue
         yi = opnum(y, ys_kind)
         lines.append(mac_str(xi, yi))
     assert len(ops) + 2 <= 30, "asm operand limit"
@@ -83,10 +86,66 @@ def gen_mul(name, params, n, square=False):
     return out
 
 
+def gen_wide(params, n):
+    """Lazy reduction (src/misc.rs:235-266 `ip_unsafe` does the same on the CPU): acc += a * b as INTEGERS into 2n limbs -- the
+    product half of the multiplication alone, {n*n} multiply-adds -- and ONE Montgomery reduction for the sum of up to 16 products
+    (r^2 < 2^512 / 19).  The inner products of a sumcheck message (time_prover.rs:105-118) are sums of such products."""
+    out = []
+    out.append(f"// ---- {params}: wide accumulate ({n * n + 2 * n} v_mad_u64_u32) and its reduction ({n * n + n}) ----")
+    out.append(f"struct FpWide_{params} {{ uint32_t l[{2 * n}]; }};")
+    out.append(f"GM_DEV void fp_mac_wide(FpWide_{params}& acc, const Fp<{params}>& a, const Fp<{params}>& b) {{")
+    out.append("  uint64_t lo = 0;")
+    out.append("  uint32_t hi = 0;")
+    for k in range(2 * n - 1):
+        i0 = max(0, k - n + 1)
+        i1 = min(k, n - 1)
+        out.append(f"  // column {k}")
+        emit_macs([(f"acc.l[{k}]", "one")] + [(f"a.l[{i}]", f"b.l[{k - i}]") for i in range(i0, i1 + 1)], "v", "v", out)
+        out.append(f"  acc.l[{k}] = (uint32_t)lo;")
+        out.append("  lo = (lo >> 32) | ((uint64_t)hi << 32);")
+        out.append("  hi = 0;")
+    out.append(f"  acc.l[{2 * n - 1}] += (uint32_t)lo;  // no carry out: the caller keeps the sum below 2^{64 * n}")
+    out.append("}")
+    # reduction: T (2n limbs) -> T / R mod p, result < 2^(32n) + p before the conditional subtractions
+    out.append(f"GM_DEV Fp<{params}> fp_redc_wide(const FpWide_{params}& T) {{")
+    out.append(f"  using P = {params};")
+    out.append(f"  uint32_t m[{n}];")
+    out.append(f"  uint32_t t[{n}];")
+    out.append("  uint64_t lo = 0;")
+    out.append("  uint32_t hi = 0;")
+    for k in range(2 * n):
+        out.append(f"  // column {k}")
+        emit_macs([(f"T.l[{k}]", "one")], "v", "v", out)
+        if k < n:
+            red = [(f"m[{i}]", f"P::MOD[{k - i}]") for i in range(0, k)]
+        else:
+            red = [(f"m[{i}]", f"P::MOD[{k - i}]") for i in range(k - n + 1, n)]
+        if red:
+            emit_macs(red, "v", "s", out)
+        if k < n:
+            out.append(f"  m[{k}] = (uint32_t)lo * P::INV;")
+            emit_macs([(f"m[{k}]", "P::MOD[0]")], "v", "s", out)
+        else:
+            out.append(f"  t[{k - n}] = (uint32_t)lo;")
+        out.append("  lo = (lo >> 32) | ((uint64_t)hi << 32);")
+        out.append("  hi = 0;")
+    out.append(f"  Fp<{params}> r;")
+    out.append("#pragma unroll")
+    out.append(f"  for (int i = 0; i < {n}; i++) r.l[i] = t[i];")
+    out.append("  // T < 2^(64 n): the quotient is below 2^(32 n) + p -- the carry word and up to two more multiples of p go")
+    out.append(f"  fp_cond_sub<{params}>(r, (uint32_t)lo);")
+    out.append(f"  fp_cond_sub<{params}>(r, 0u);")
+    out.append(f"  fp_cond_sub<{params}>(r, 0u);")
+    out.append("  return r;")
+    out.append("}")
+    return out
+
+
 def main():
     out = ["// GENERATED by gen_field_mul.py -- do not edit; edit the generator.", "// clang-format off"]
     out += gen_mul("Fq", "FqParams", 12)
     out += gen_mul("Fr", "FrParams", 8)
+    out += gen_wide("FrParams", 8)
     out.append("// clang-format on")
     sys.stdout.write("\n".join(out) + "\n")
 

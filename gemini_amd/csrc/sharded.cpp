@@ -697,7 +697,7 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
     memcpy(mine, identity_point(), 144);
     if (len_f > 3) {
       uint64_t quot, remz[12];
-      RC(V.alloc(len_f - 3, &quot));
+      RC(V.alloc(len_f - 1, &quot));  // (the division peels one linear factor at a time: room for the first quotient)
       RC(gm_fr_div_vanishing(F, pts, 3, quot, remz));
       for (int l = 0; l < 12; l++) GM_CHECK(remz[l] == 0, GM_ESTATE, "snark_new_time_sharded: the block of the opening is not divisible by Z (limb %d)", l);
       TR.mark("carries + division");

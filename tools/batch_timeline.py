@@ -20,7 +20,8 @@ for i, (s, e, n, q) in enumerate(rows[1:], 1):
         gaps.append(i)
     end = max(end, e)
 wins = [rows[a:b] for a, b in zip([0] + gaps, gaps + [len(rows)])]
-batches = [w for w in wins if sum(1 for x in w if x[2] in ("k_acc0", "k_acc0_pf")) == 20]
+# (a batch of 20 levels is 20 accumulations, or 9 with the tiny calls fused into one pass: MsmMulti)
+batches = [w for w in wins if 8 <= sum(1 for x in w if x[2] in ("k_acc0", "k_acc0_pf")) <= 20 and sum(1 for x in w if x[2].startswith("k_sort1")) <= 20]
 w = batches[int(sys.argv[2]) if len(sys.argv) > 2 else -1]
 t0 = w[0][0]
 print("window %.3f ms, %d kernels, queues %s" % ((max(x[1] for x in w) - t0) / 1e6, len(w), sorted({x[3] for x in w})))
