@@ -93,8 +93,9 @@ struct ScArgs {
 };
 
 // LAZY = the three inner products of the message accumulate UNREDUCED 512-bit products (fp_mac_wide: the product half of a
-// multiplication, 80 multiply-adds instead of 137) and are Montgomery-reduced once per 16 pairs -- r^2 < 2^512 / 19, so sixteen
-// products fit sixteen limbs.  The reference does the same on the CPU (`ip_unsafe`, src/misc.rs:235-266).
+// multiplication, 80 multiply-adds instead of 137) in 17-limb accumulators and are Montgomery-reduced ONCE per thread (r^2 =
+// 0.205 x 2^512: the seventeenth limb holds what 512 bits cannot).  The reference does the same on the CPU (`ip_unsafe`,
+// src/misc.rs:235-266).
 template <bool FOLD, bool MSG, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
@@ -110,13 +111,12 @@ __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict_
     step.l[i] = A.tau2.p[A.log_threads][i];
   }
   Fr acc[3] = {Fr::zero(), Fr::zero(), Fr::zero()};  // a, b1 = sum fe*go*tw, b2 = sum ge*fo*tw
-  FpWide_FrParams wide[3];
-  int pending = 0;
+  FpWide_FrParams wide[3];  // 17 limbs each: room for 2^34 products of a thread (it sees 2^11 at most)
   if (LAZY) {
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
-      for (int i = 0; i < 16; i++) wide[k].l[i] = 0;
+      for (int i = 0; i < 17; i++) wide[k].l[i] = 0;
   }
   if (MSG && t < A.npairs) tw = fr_mul(tw, pow_from_table(A.tau2, t));
   // message vectors: FOLD ? folded (length ceil(n_in/2)) : the inputs
@@ -149,15 +149,6 @@ __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict_
         fp_mac_wide(wide[0], u, ge);
         fp_mac_wide(wide[1], u, go);
         fp_mac_wide(wide[2], w, ge);
-        if (++pending == 16) {
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            acc[k] = fr_add(acc[k], fp_redc_wide(wide[k]));
-#pragma unroll
-            for (int i = 0; i < 16; i++) wide[k].l[i] = 0;
-          }
-          pending = 0;
-        }
       } else {
         acc[0] = fr_add(acc[0], fr_mul(u, ge));
         acc[1] = fr_add(acc[1], fr_mul(u, go));
@@ -719,10 +710,16 @@ static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::F
   prof.begin(PROF_SC_ROUND, st);
   const bool zc = (C->zero_copy & 1) != 0;  // the blocks write their partial sums into the pinned buffer themselves
   uint8_t* part_out = zc ? reinterpret_cast<uint8_t*>(S->host_partials) : S->partials;
-  if (fold && msg)
+  // lazy reduction of the message's inner products (GM_SC_LAZY=0: the reduced form)
+  static const bool lazy = !(getenv("GM_SC_LAZY") && atoi(getenv("GM_SC_LAZY")) == 0);
+  if (fold && msg && lazy)
+    hipLaunchKernelGGL((k_sc_round<true, true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
+  else if (fold && msg)
     hipLaunchKernelGGL((k_sc_round<true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
   else if (fold)
     hipLaunchKernelGGL((k_sc_round<true, false>), dim3(blocks), dim3(256), 0, st, A, part_out);
+  else if (lazy)
+    hipLaunchKernelGGL((k_sc_round<false, true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
   else
     hipLaunchKernelGGL((k_sc_round<false, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
   prof.end(PROF_SC_ROUND, st);

@@ -89,10 +89,12 @@ def gen_mul(name, params, n, square=False):
 def gen_wide(params, n):
     """Lazy reduction (src/misc.rs:235-266 `ip_unsafe` does the same on the CPU): acc += a * b as INTEGERS into 2n limbs -- the
     product half of the multiplication alone, {n*n} multiply-adds -- and ONE Montgomery reduction for the sum of up to 16 products
-    (r^2 < 2^512 / 19).  The inner products of a sumcheck message (time_prover.rs:105-118) are sums of such products."""
+    -- r^2 = 0.205 x 2^512, so the accumulator has ONE MORE limb than a product (2n + 1: room for 2^32 / 0.205 products) and the
+    reduction folds that limb back in through one ordinary product.  The inner products of a sumcheck message
+    (time_prover.rs:105-118) are sums of such products."""
     out = []
     out.append(f"// ---- {params}: wide accumulate ({n * n + 2 * n} v_mad_u64_u32) and its reduction ({n * n + n}) ----")
-    out.append(f"struct FpWide_{params} {{ uint32_t l[{2 * n}]; }};")
+    out.append(f"struct FpWide_{params} {{ uint32_t l[{2 * n + 1}]; }};")
     out.append(f"GM_DEV void fp_mac_wide(FpWide_{params}& acc, const Fp<{params}>& a, const Fp<{params}>& b) {{")
     out.append("  uint64_t lo = 0;")
     out.append("  uint32_t hi = 0;")
@@ -104,7 +106,10 @@ def gen_wide(params, n):
         out.append(f"  acc.l[{k}] = (uint32_t)lo;")
         out.append("  lo = (lo >> 32) | ((uint64_t)hi << 32);")
         out.append("  hi = 0;")
-    out.append(f"  acc.l[{2 * n - 1}] += (uint32_t)lo;  // no carry out: the caller keeps the sum below 2^{64 * n}")
+    out.append(f"  // column {2 * n - 1}")
+    emit_macs([(f"acc.l[{2 * n - 1}]", "one")], "v", "v", out)
+    out.append(f"  acc.l[{2 * n - 1}] = (uint32_t)lo;")
+    out.append(f"  acc.l[{2 * n}] += (uint32_t)(lo >> 32);  // the extra limb: no carry out of it below 2^32 / 0.205 products")
     out.append("}")
     # reduction: T (2n limbs) -> T / R mod p, result < 2^(32n) + p before the conditional subtractions
     out.append(f"GM_DEV Fp<{params}> fp_redc_wide(const FpWide_{params}& T) {{")
@@ -132,11 +137,14 @@ def gen_wide(params, n):
     out.append(f"  Fp<{params}> r;")
     out.append("#pragma unroll")
     out.append(f"  for (int i = 0; i < {n}; i++) r.l[i] = t[i];")
-    out.append("  // T < 2^(64 n): the quotient is below 2^(32 n) + p -- the carry word and up to two more multiples of p go")
+    out.append("  // the low 2n limbs are below 2^(64 n): their quotient is below 2^(32 n) + p -- the carry word and up to two more multiples of p go")
     out.append(f"  fp_cond_sub<{params}>(r, (uint32_t)lo);")
     out.append(f"  fp_cond_sub<{params}>(r, 0u);")
     out.append(f"  fp_cond_sub<{params}>(r, 0u);")
-    out.append("  return r;")
+    out.append(f"  // the extra limb h stands for h 2^(64 n): times R^-1 that is h R = h R^2 R^-1, one ordinary product")
+    out.append(f"  Fp<{params}> h = Fp<{params}>::zero();")
+    out.append(f"  h.l[0] = T.l[{2 * n}];")
+    out.append(f"  return fp_add<{params}>(r, fp_mul<{params}>(h, Fp<{params}>::r2()));")
     out.append("}")
     return out
 

@@ -72,6 +72,19 @@ def test_time_prover_2_18(gm, oracle):
     _run_both(gm, oracle, f, g, tw, 10)
 
 
+def test_time_prover_2_21_many_pairs_per_thread(gm, oracle):
+    """2^20 pairs in the first round over 2^17 threads: every thread accumulates 8 (then 4, 2) products per inner product before
+    its one Montgomery reduction (k_sc_round<.., LAZY>: 17-limb unreduced accumulators, src/misc.rs:235-266 `ip_unsafe` is the
+    reference's CPU form of the same thing) -- bit for bit against the CPU restatement, every round"""
+    n = (1 << 21) - 5
+    f = oracle.fr_to_mont(oracle.random_fr(17, n))
+    g = oracle.fr_to_mont(oracle.random_fr(18, n))
+    f[:64] = oracle.fr_to_mont(oracle.ints_to_limbs([0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000000] * 64, 4))  # r - 1: the largest products
+    g[:64] = f[:64]
+    tw = oracle.fr_to_mont(oracle.random_fr(19, 1))[0]
+    _run_both(gm, oracle, f, g, tw, 20)
+
+
 def test_sumcheck_verifier_identity_2_20(gm, oracle, pyref):
     """size-independent property at 2^20: each round's quadratic q(x) = a + b x + (claim - a) x^2
     must satisfy q(rho) = next claim, ending at f0 * g0 (subclaim.rs:91-97)."""

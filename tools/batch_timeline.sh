@@ -9,5 +9,5 @@ for T in ${@:-0 32}; do
   echo "== GM_CU_SPLIT=$T"; tail -3 $O/run.txt
   python $R/tools/batch_timeline.py $(find $O -name "*kernel_trace.csv" | head -1) -1 full > $R/gpurun_out/r5_batch_timeline_split$T.txt 2>&1
   head -60 $R/gpurun_out/r5_batch_timeline_split$T.txt
-  find $O -name "*kernel_trace.csv" -delete
+
 done
