@@ -341,8 +341,12 @@ int gm_init(int device) {
   GM_HIP(hipStreamCreateWithPriority(&C->stream, hipStreamNonBlocking, prio ? prio_lo : 0));
   for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithPriority(&C->small_stream[k], hipStreamNonBlocking, prio ? prio_hi : 0));
   GM_HIP(hipStreamCreateWithPriority(&C->stream_b, hipStreamNonBlocking, prio ? prio_hi : 0));
-  if (const char* e = getenv("GM_CU_SPLIT")) {
-    const int T = atoi(e), ncu = C->cu_count;
+  {
+    // default: 32 of the 256 compute units for the tails of a batch (measured on one box, GM_CU_SPLIT = 0 / 16 / 32 / 64: psnark -i 22
+    // 351 / 485 / 334 / 337 ms, snark -i 24 115.3 / 134.7 / 113.5 / 113.2, snark -i 20 13.3 / 14.0 / 13.2 / 13.2, the sharded share
+    // 27.9 / 40.0 / 27.9 / 27.8: profiles/r5_cu_split_probe.txt); GM_CU_SPLIT=0 switches the partition off
+    const char* e = getenv("GM_CU_SPLIT");
+    const int T = e ? atoi(e) : 32, ncu = C->cu_count;
     if (T > 0 && T < ncu) {
       // bit i of the mask = compute unit i of the device (the runtime spreads consecutive bits over the XCDs): the tail partition
       // takes every (ncu / T)-th CU so that it has a share of every XCD and of its L2, the accumulation partition the rest

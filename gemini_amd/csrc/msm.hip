@@ -201,8 +201,42 @@ struct SortGeom {
 };
 constexpr int ENTRY_W_SHIFT = 26;  // entry idx field: pair index in bits 0..25, window in bits 26..30 (tables only)
 
+// SEVERAL calls as the LEVELS of one block-sorted pass (the folding commitments of a tensor check: 2^20, 2^19, ... pairs against
+// slices of one key).  Element i of the concatenation belongs to level l = the range start[l] <= i < start[l + 1]; its scalar
+// is scal[l][i - start[l]], its base index base0[l] + step (i - start[l]) -- ABSOLUTE in the entry: k_acc0 then runs with first = 0,
+// step = 1 --, its bucket set (l, window) (tables: one set per level, the window rides in the entry as for one call).
+// levels = 0: one call, pair i is scalar i and the entry carries i.
+constexpr int MULTI_MAX_LEVELS = 16;
+struct LevelGeom {
+  int levels, step;
+  uint32_t start[MULTI_MAX_LEVELS + 1];
+  const uint32_t* scal[MULTI_MAX_LEVELS];
+  long long base0[MULTI_MAX_LEVELS];
+};
+struct LevelOf {
+  const uint32_t* sp;
+  uint32_t keyoff, idx;
+};
+// where pair i of a (possibly levelled) pass finds its scalar, which bucket sets it feeds, what its entry carries
+GM_DEV LevelOf level_of(const LevelGeom& lg, const SortGeom& sg, const uint32_t* scalars, uint32_t i, bool active) {
+  LevelOf r;
+  if (lg.levels == 0 || !active) {
+    r.sp = (lg.levels == 0 ? scalars : lg.scal[0]) + 8 * (size_t)(active ? i : 0);
+    r.keyoff = 0;
+    r.idx = i;
+    return r;
+  }
+  int l = 0;
+  while (l + 1 < lg.levels && i >= lg.start[l + 1]) l++;
+  const uint32_t il = i - lg.start[l];
+  r.sp = lg.scal[l] + 8 * (size_t)il;
+  r.keyoff = (uint32_t)l * (sg.shared ? sg.B : (uint32_t)sg.Wg * sg.B);
+  r.idx = (uint32_t)(lg.base0[l] + (long long)lg.step * (long long)il);
+  return r;
+}
+
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg,
+__global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg, LevelGeom lg,
                                                uint32_t* __restrict__ gcount_or_cursor, uint64_t* __restrict__ tmp, uint32_t* __restrict__ err) {
   __shared__ uint32_t cnt[SORT_GMAX];
   __shared__ uint32_t base[SCATTER ? SORT_GMAX : 1];
@@ -212,8 +246,9 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
   for (uint32_t s = threadIdx.x; s < SORT_TS; s += 256) {
     const uint32_t i = first + s;
     const bool active = i < n;
+    const LevelOf lv = level_of(lg, sg, scalars, i, active);
     ScalarDigits sd;
-    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, GM_GLV(sg.glv));
+    sd.load(lv.sp, active, mont, GM_GLV(sg.glv));
     DigitIter& it = sd.it;
     for (int half = 0; half <= GM_GLV(sg.glv); half++) {
       sd.start(half, active, GM_GLV(sg.glv));
@@ -223,7 +258,7 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
         // (wave_atomic_inc: one LDS atomic per wave when all lanes hit the same bin -- the all-equal-scalars
         // instance of the reference's benchmark would otherwise serialise 64 same-address atomics)
         const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        wave_atomic_inc(cnt, (active && d != 0) ? (((sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
+        wave_atomic_inc(cnt, (active && d != 0) ? ((lv.keyoff + (sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u)) >> sg.FB) : KEY_INV);
       }
     }
     if (!SCATTER && sd.bad) atomicOr(err, 1u);  // a scalar >= 2^255 (not an Fr image): the call fails with GM_EINVAL
@@ -243,8 +278,9 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
   for (uint32_t s = threadIdx.x; s < SORT_TS; s += 256) {
     const uint32_t i = first + s;
     const bool active = i < n;
+    const LevelOf lv = level_of(lg, sg, scalars, i, active);
     ScalarDigits sd;
-    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, GM_GLV(sg.glv));
+    sd.load(lv.sp, active, mont, GM_GLV(sg.glv));
     DigitIter& it = sd.it;
     for (int half = 0; half <= GM_GLV(sg.glv); half++) {
       sd.start(half, active, GM_GLV(sg.glv));
@@ -254,11 +290,11 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
         if (w < sg.w_lo) continue;
         const bool live = active && d != 0;
         const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-        const uint32_t key = (sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u);
+        const uint32_t key = lv.keyoff + (sg.shared ? 0u : (uint32_t)(w - sg.w_lo) * sg.B) + (mag - 1u);
         const uint32_t g = key >> sg.FB;
         const uint32_t r = wave_atomic_inc(cnt, live ? g : KEY_INV);
         if (live) {
-          const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : (i | ((uint32_t)half << ENTRY_HALF_SHIFT));
+          const uint32_t idx = sg.shared ? (lv.idx | ((uint32_t)w << ENTRY_W_SHIFT)) : (lv.idx | ((uint32_t)half << ENTRY_HALF_SHIFT));
           tmp[(SCATTER ? base[g] : 0u) + r] = ((uint64_t)key << 32) | ((uint64_t)(((d < 0) != hneg) ? 1u : 0u) << 31) | (uint64_t)idx;
         }
       }
@@ -271,7 +307,7 @@ __global__ __launch_bounds__(256) void k_sort1(const uint32_t* __restrict__ scal
 // image out, so a wave writes runs of neighbouring addresses instead of 64 scattered 8-byte words.
 // Dynamic LDS: SORT_TS * W entries + 3 G counters + the scan array (<= 160 KiB for c >= 16).
 constexpr int SORT1_STAGE_WMAX = 16;
-__global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg,
+__global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restrict__ scalars, uint32_t n, int mont, SortGeom sg, LevelGeom lg,
                                                        uint32_t* __restrict__ gcursor, uint64_t* __restrict__ tmp) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* buf = reinterpret_cast<uint64_t*>(smem);
@@ -286,8 +322,9 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
   const bool active = i < n;
   uint64_t e[SORT1_STAGE_WMAX];
   {
+    const LevelOf lv = level_of(lg, sg, scalars, i, active);
     ScalarDigits sd;
-    sd.load(scalars + 8 * (size_t)(active ? i : 0), active, mont, GM_GLV(sg.glv));
+    sd.load(lv.sp, active, mont, GM_GLV(sg.glv));
     DigitIter& it = sd.it;
     // GLV: the register slots are split between the halves (Wg <= SORT1_STAGE_WMAX / 2 windows each)
     constexpr int HS = SORT1_STAGE_WMAX / 2;
@@ -309,8 +346,8 @@ __global__ __launch_bounds__(1024) void k_sort1_staged(const uint32_t* __restric
           int32_t d = w == sg.W - 1 ? it.last(sg.c) : it.next(sg.c);
           if (active && d != 0) {
             const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            const uint32_t key = (sg.shared ? 0u : (uint32_t)jw * sg.B) + (mag - 1u);
-            const uint32_t idx = sg.shared ? (i | ((uint32_t)w << ENTRY_W_SHIFT)) : (i | ((uint32_t)(GM_GLV(sg.glv) ? half : 0) << ENTRY_HALF_SHIFT));
+            const uint32_t key = lv.keyoff + (sg.shared ? 0u : (uint32_t)jw * sg.B) + (mag - 1u);
+            const uint32_t idx = sg.shared ? (lv.idx | ((uint32_t)w << ENTRY_W_SHIFT)) : (lv.idx | ((uint32_t)(GM_GLV(sg.glv) ? half : 0) << ENTRY_HALF_SHIFT));
             e[j] = ((uint64_t)key << 32) | ((uint64_t)(((d < 0) != hneg) ? 1u : 0u) << 31) | (uint64_t)idx;
           }
         }
@@ -704,7 +741,6 @@ __global__ __launch_bounds__(256) void k_digits_flat(const uint32_t* __restrict_
 // bucket sets are (level, window) pairs.  Element i of the concatenation belongs to level l = the range start[l] <= i < start[l + 1],
 // its scalar is scal[l][i - start[l]], its base index base0[l] + step (i - start[l]) (absolute: k_acc0 runs with first = 0,
 // step = 1), its key (l W + w) B + (|digit| - 1).  Digits as in k_digits_flat.
-constexpr int MULTI_MAX_LEVELS = 16;
 struct MultiGeom {
   int c, W, levels, step;
   uint32_t B;
@@ -1532,12 +1568,16 @@ struct MsmStreams {
 };
 // several small calls as the levels of ONE pass (k_digits_multi): level l pairs scalars[l][i], i < n[l], with base start[l] + step i
 struct MsmMulti {
+  // block = false: tiny calls (<= 2^13 pairs), c = 8, the flat three-launch sort; block = true: mid-size calls (up to 2^20 pairs each)
+  // through the block sort, c = 16 or the key's c <= 20 tables -- one sort / accumulation / merge / reduction chain for all of them
+  bool block = false;
   int levels = 0;
   const void* scalars[MULTI_MAX_LEVELS];
   size_t n[MULTI_MAX_LEVELS];
   int64_t start[MULTI_MAX_LEVELS];
 };
 constexpr size_t MSM_MULTI_MAX_N = (size_t)1 << 13;  // calls this small (c = 8 on their own as well) are fused
+constexpr size_t MSM_MULTI_BLOCK_MAX_N = (size_t)1 << 20;  // and the mid-size ones above them, up to this, as the levels of a block-sorted pass
 static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases* bases, int64_t first, int64_t step, const void* d_scalars,
                        int mont, size_t n, int slot, MsmPending* P, int part = 0, int nparts = 1, const MsmMulti* multi = nullptr);
 static int msm_finish_parts(Context* C, const MsmPending* parts, int nparts, bool normalize, uint64_t out_jac[18], bool use_pool = true,
@@ -1790,13 +1830,42 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
         fused_groups.push_back(std::move(grp));
       }
   }
+  // ... and the MID-SIZE calls (2^13 < n <= 2^20: the middle of a folding tree, seven latency-bound chains whose sorts, merges and bucket
+  // reductions do not hide under each other's accumulations -- profiles/r5_batch_timeline.txt) CAN run as the levels of ONE
+  // block-sorted pass: one sort, one accumulation that fills the GPU, one merge, one reduction over (level, window) bucket sets.
+  // MEASURED NEUTRAL, hence off by default (GM_MSM_FUSE_MID=1 turns it on; read per call so that a test can): the batch 2^20 .. 2
+  // takes 8.25 ms fused against 8.09-8.23 apart -- the fused pass is one serial chain (sort 1.0, accumulation 4.6, reduction of
+  // 7 x 2^19 buckets 1.7, host tail 0.6 ms) where the separate calls at least overlap their tails a little; without tables
+  // (c = 13 .. 16) 9.2-9.4 ms.  What an MSM costs beyond its accumulation is work, not launch count (profiles/r5_fused_mid_probe.txt).
+  const bool fuse_mid_env = getenv("GM_MSM_FUSE_MID") && !strcmp(getenv("GM_MSM_FUSE_MID"), "1");
+  std::vector<char> group_block;
+  group_block.assign(fused_groups.size(), 0);
+  if (fuse_env && fuse_mid_env && C->small_stream[0] != nullptr && C->msm_affine_levels <= 0 && !C->msm_c_override && bases->n <= ((size_t)1 << 30)) {
+    std::vector<size_t> mid;
+    for (size_t j = 0; j < k; j++)
+      if (ns[j] > MSM_MULTI_MAX_N && ns[j] <= MSM_MULTI_BLOCK_MAX_N) mid.push_back(j);
+    size_t at = 0;
+    while (mid.size() - at >= 2) {
+      std::vector<size_t> grp;
+      size_t pairs = 0;
+      while (at < mid.size() && grp.size() < (size_t)MULTI_MAX_LEVELS && pairs + ns[mid[at]] <= ((size_t)1 << 22)) {
+        pairs += ns[mid[at]];
+        grp.push_back(mid[at++]);
+      }
+      if (grp.size() < 2) break;
+      for (size_t j : grp) group_of[j] = (int)fused_groups.size();
+      fused_groups.push_back(std::move(grp));
+      group_block.push_back(1);
+    }
+  }
   std::vector<char> group_done(fused_groups.size(), 0);
   bool gated = false;
   for (size_t jo = 0; jo < k; jo++) {
     const size_t j = order[jo];
     const bool fused_here = group_of[j] >= 0;
     if (fused_here && group_done[(size_t)group_of[j]]) continue;
-    const bool small = fused_here || is_small(j);
+    const bool block_here = fused_here && group_block[(size_t)group_of[j]];
+    const bool small = block_here ? false : (fused_here || is_small(j));
     // big calls alternate between the two full-size lanes (0 and -1), each with two result buffers
     static const bool two_big = !(getenv("GM_MSM_BIG_LANES") && !strcmp(getenv("GM_MSM_BIG_LANES"), "1"));
     int lane, hslot;
@@ -1852,6 +1921,7 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     if (fused_here) {
       const std::vector<size_t>& grp = fused_groups[(size_t)group_of[j]];
       MsmMulti M;
+      M.block = block_here;
       M.levels = (int)grp.size();
       for (size_t l = 0; l < grp.size(); l++) {
         M.scalars[l] = d_scalars[grp[l]];
@@ -1865,6 +1935,10 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       rc = msm_enqueue(C, ws, sts, bases, start_of(j), step, d_scalars[j], mont,
                          ns[j], hslot, &e.P);
     enqueue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
+    if (batch_trace)
+      fprintf(stderr, "[gm msm batch]   enqueue call %zu (n = %zu, lane %d): host %.3f .. %.3f ms\n", j, fused_here ? (size_t)0 : ns[j], lane,
+              std::chrono::duration<double, std::milli>(tq0 - t_batch0).count(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_batch0).count());
     if (rc) return fail(rc);
     q.push_back(e);
     finished.push_back(0);
@@ -1902,9 +1976,11 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   P->multi_levels = 0;
   if (multi) {
     GM_CHECK(multi->levels >= 1 && multi->levels <= MULTI_MAX_LEVELS && nparts == 1, GM_EINVAL, "msm: %d fused calls (1 .. %d)", multi->levels, MULTI_MAX_LEVELS);
+    // the entries of a fused pass carry ABSOLUTE base indices in 30 bits (bit 30: the GLV half, bit 31: the sign)
+    GM_CHECK(nbases <= ((size_t)1 << 30), GM_EINVAL, "msm: a key of %zu points is too long for a fused pass (2^30)", nbases);
     n = 0;
     for (int l = 0; l < multi->levels; l++) {
-      GM_CHECK(multi->n[l] >= 1 && multi->n[l] <= MSM_MULTI_MAX_N, GM_EINVAL, "msm: a fused call of %zu pairs", multi->n[l]);
+      GM_CHECK(multi->n[l] >= 1 && multi->n[l] <= (multi->block ? MSM_MULTI_BLOCK_MAX_N : MSM_MULTI_MAX_N), GM_EINVAL, "msm: a fused call of %zu pairs", multi->n[l]);
       const int64_t lo = multi->start[l], hi = multi->start[l] + step * (int64_t)(multi->n[l] - 1);
       GM_CHECK(lo >= 0 && hi >= 0 && (size_t)lo < nbases && (size_t)hi < nbases, GM_EINVAL, "msm: base range [%lld .. %lld] outside registered bases (len %zu)",
                (long long)lo, (long long)hi, nbases);
@@ -1927,6 +2003,31 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   const uint8_t* tab_ptr = nullptr;  // the table set this call takes: the key's main one, or a prefix set that covers its range
   int tab_c_sel = 0;
   size_t tab_n = 0;
+  static const bool fuse_tables_env = !(getenv("GM_MSM_FUSE_TABLES") && atoi(getenv("GM_MSM_FUSE_TABLES")) == 0);  // A/B knob
+  if (multi && multi->block && !C->msm_c_override && fuse_tables_env) {
+    // a levelled pass takes a table set that covers EVERY level's range and whose window leaves the bucket count sane (one set of
+    // 2^(c-1) buckets per level): the key's own c = 20 tables, or a c <= 20 prefix set
+    auto covers = [&](size_t tn) {
+      for (int l = 0; l < multi->levels; l++) {
+        const int64_t lo = multi->start[l], hi = multi->start[l] + step * (int64_t)(multi->n[l] - 1);
+        if (lo < 0 || hi < 0 || (size_t)lo >= tn || (size_t)hi >= tn) return false;
+      }
+      return tn <= ((size_t)1 << ENTRY_W_SHIFT);
+    };
+    if (bases->table != nullptr && bases->tab_c <= 20 && covers(bases->n)) {
+      tab_ptr = bases->table;
+      tab_c_sel = bases->tab_c;
+      tab_n = bases->n;
+    } else {
+      for (const Bases::TableSet& ts : bases->extra)
+        if (ts.c <= 20 && ts.c >= 18 && covers(ts.n)) {
+          tab_ptr = ts.t;
+          tab_c_sel = ts.c;
+          tab_n = ts.n;
+          break;
+        }
+    }
+  }
   if (!multi && !C->msm_c_override && n < ((size_t)1 << ENTRY_W_SHIFT)) {
     if (bases->table != nullptr && n >= tab_min) {
       tab_ptr = bases->table;
@@ -1944,7 +2045,9 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     }
   }
   const bool use_table = tab_ptr != nullptr;
-  const int c = multi ? 8 : (use_table ? tab_c_sel : (C->msm_c_override ? C->msm_c_override : choose_window(n)));
+  const bool multi_block = multi && multi->block;
+  static const int fuse_c_env = getenv("GM_MSM_FUSE_C") ? atoi(getenv("GM_MSM_FUSE_C")) : 16;  // A/B knob: window of a levelled pass without tables
+  const int c = multi ? (multi_block ? (use_table ? tab_c_sel : fuse_c_env) : 8) : (use_table ? tab_c_sel : (C->msm_c_override ? C->msm_c_override : choose_window(n)));
   GM_CHECK(c >= 2 && c <= 22, GM_EINVAL, "msm: window width %d out of range [2, 22]", c);
   // GLV (glv_split): two 128-bit digit strings per scalar over HALF the windows, the second one on phi(P)
   static const bool sort_atomic_env0 = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
@@ -1957,7 +2060,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   GM_CHECK(nparts == 1 || !use_table, GM_EINVAL, "msm: the fixed-base table path is not split into window groups");
   const int w_lo = part * W / nparts, Wg = (part + 1) * W / nparts - w_lo;  // this call's window group
   const uint32_t B = 1u << (c - 1);
-  const int Wb = multi ? multi->levels * W : (use_table ? 1 : Wg);  // bucket sets (fused calls: one set per (call, window))
+  // bucket sets (fused calls: one set per (call, window); with tables one per call)
+  const int Wb = multi ? multi->levels * (use_table ? 1 : W) : (use_table ? 1 : Wg);
   const size_t nbuckets = (size_t)Wb * B;
   const uint8_t* d_bases = use_table ? tab_ptr : bases->d;
   const long long tab_stride = use_table ? (long long)tab_n : 0;
@@ -2026,11 +2130,24 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   };
   static const bool sort_atomic_env = getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "atomic");
   static const bool sort_flat_env = !(getenv("GM_MSM_SORT") && !strcmp(getenv("GM_MSM_SORT"), "blocks"));
-  const bool sort_atomic = sort_atomic_env && !use_table && nparts == 1;
+  const bool sort_atomic = sort_atomic_env && !use_table && nparts == 1 && !multi_block;
   // (a table call keeps the block sort at every size: one shared bucket set means 16 x the contention on the flat path's global
   // counters -- measured with a flat variant for tables: 0.63 against 0.61 ms at 2^14 pairs, 0.90 against 0.81 at 2^16)
-  const bool sort_flat = sort_flat_env && !sort_atomic && !use_table && nparts == 1 && N <= ((uint64_t)1 << 21) && nbuckets <= ((size_t)1 << 18);
-  if (multi) {
+  const bool sort_flat = sort_flat_env && !sort_atomic && !use_table && nparts == 1 && !multi_block && N <= ((uint64_t)1 << 21) && nbuckets <= ((size_t)1 << 18);
+  LevelGeom lg{};
+  if (multi_block) {
+    lg.levels = multi->levels;
+    lg.step = (int)step;
+    uint32_t at = 0;
+    for (int l = 0; l < multi->levels; l++) {
+      lg.start[l] = at;
+      lg.scal[l] = reinterpret_cast<const uint32_t*>(multi->scalars[l]);
+      lg.base0[l] = (long long)multi->start[l];
+      at += (uint32_t)multi->n[l];
+    }
+    lg.start[multi->levels] = at;
+  }
+  if (multi && !multi_block) {
     MultiGeom mg{};
     mg.c = c;
     mg.W = W;
@@ -2101,6 +2218,8 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     sg.B = B;
     sg.shared = use_table ? 1 : 0;
     sg.FB = std::min<uint32_t>((uint32_t)(c - 1), 10u);
+    // (a levelled pass has levels x as many buckets: 2048 fine bins keep the coarse counters of the LDS-staged scatter inside 160 KB)
+    if (multi_block) sg.FB = std::min<uint32_t>((uint32_t)(c - 1), std::max<uint32_t>(sg.FB, 11u));
     while ((nbuckets >> sg.FB) > SORT_GMAX && (1u << sg.FB) < SORT_FMAX) sg.FB++;
     sg.G = (uint32_t)(nbuckets >> sg.FB);
     GM_CHECK(sg.G <= SORT_GMAX, GM_EINVAL, "msm: %u coarse sort bins exceed %u (window %d too wide for this sort)", sg.G, SORT_GMAX, c);
@@ -2113,7 +2232,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
     const uint32_t b1 = (uint32_t)((n + SORT_TS - 1) / SORT_TS);
     const uint32_t b2 = (uint32_t)(N / SORT_CH + sg.G + 1);
     pf.begin(part, PROF_DIGITS, st);
-    hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcount, (uint64_t*)nullptr, d_err);
+    hipLaunchKernelGGL(k_sort1<false>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, lg, gcount, (uint64_t*)nullptr, d_err);
     hipLaunchKernelGGL(k_sort1_scan, dim3(1), dim3(1024), 0, st, gcount, sg.G, goff, gcursor, blkoff);
     const size_t stage1_lds = (size_t)SORT_TS * sg.Wg * (use_glv ? 2 : 1) * 8 + (size_t)3 * sg.G * 4 + 1024 * 4;
     static const bool sort1_staged_env = !(getenv("GM_MSM_SORT1") && !strcmp(getenv("GM_MSM_SORT1"), "direct"));
@@ -2123,9 +2242,9 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
         GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort1_staged), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
       }
-      hipLaunchKernelGGL(k_sort1_staged, dim3(b1), dim3(1024), stage1_lds, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>());
+      hipLaunchKernelGGL(k_sort1_staged, dim3(b1), dim3(1024), stage1_lds, st, sc, (uint32_t)n, mont, sg, lg, gcursor, ws.tmp_entries.as<uint64_t>());
     } else {
-      hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, gcursor, ws.tmp_entries.as<uint64_t>(), d_err);
+      hipLaunchKernelGGL(k_sort1<true>, dim3(b1), dim3(256), 0, st, sc, (uint32_t)n, mont, sg, lg, gcursor, ws.tmp_entries.as<uint64_t>(), d_err);
     }
     pf.end(part, PROF_DIGITS, st);
     pf.begin(part, PROF_SCATTER, st);
@@ -2335,7 +2454,7 @@ static int msm_enqueue(Context* C, MsmWorkspace& ws, MsmStreams sts, const Bases
   GM_HIP(hipEventRecord(ws.done_ev[slot], st));
   P->Wb = Wb;
   P->multi_levels = multi ? multi->levels : 0;
-  P->multi_W = multi ? W : 0;
+  P->multi_W = multi ? (use_table ? 1 : W) : 0;
   P->plane_count = plane_count;
   P->c = c;
   P->m = m;

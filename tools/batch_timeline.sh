@@ -1,13 +1,12 @@
 #!/bin/bash
-# GPU box: kernel timeline of the folding-commitment batch (tools/batch_probe.py) under rocprofv3, for each GM_CU_SPLIT value given
+# GPU box: kernel trace of the folding-commitment batch (tools/batch_probe.py) under rocprofv3 for settings "T[:small]" of the CU
+# partition (GM_CU_SPLIT=T, GM_CU_SPLIT_SMALL=tail with ":small"); the traces stay in gpurun_out/ for tools/batch_timeline.py
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for T in ${@:-0 32}; do
-  O=$R/gpurun_out/batch_tl_$T
+for spec in ${@:-0 32}; do
+  T=${spec%%:*}; SM=""; [[ $spec == *:small ]] && SM=tail
+  O=$R/gpurun_out/batch_tl_${spec/:/_}
   rm -rf $O; mkdir -p $O
-  GM_CU_SPLIT=$T PROBE_BATCH_ONLY=1 rocprofv3 --kernel-trace --output-format csv -d $O -o k -- python $R/tools/batch_probe.py 20 tables > $O/run.txt 2> $O/err.txt
-  echo "== GM_CU_SPLIT=$T"; tail -3 $O/run.txt
-  python $R/tools/batch_timeline.py $(find $O -name "*kernel_trace.csv" | head -1) -1 full > $R/gpurun_out/r5_batch_timeline_split$T.txt 2>&1
-  head -60 $R/gpurun_out/r5_batch_timeline_split$T.txt
-
+  GM_CU_SPLIT=$T GM_CU_SPLIT_SMALL=$SM PROBE_BATCH_ONLY=1 rocprofv3 --kernel-trace --output-format csv -d $O -o k -- python $R/tools/batch_probe.py 20 tables > $O/run.txt 2> $O/err.txt
+  echo "== GM_CU_SPLIT=$T small=$SM: $(tail -1 $O/run.txt)"
 done
