@@ -182,6 +182,27 @@ int gm_sumcheck_prove_sharded(uint64_t transcript, uint64_t f_block, uint64_t g_
   GM_CHECK(lo % 2 == 0, GM_EINVAL, "sumcheck_prove_sharded: the block must start at an even index (pairs fold together)");
   int rank = 0, world = 1;
   RC(dist_rank_world(&rank, &world));
+  {
+    // the blocks must tile [0, n_global) in rank order with equal lengths: anything else sends the ranks down different branches of
+    // the round loop -- a deadlocked all-gather or, worse, messages that silently differ from the single-GPU prover's
+    size_t nf0 = 0, ng0 = 0;
+    RC(vec_len(f_block, &nf0));
+    RC(vec_len(g_block, &ng0));
+    GM_CHECK(nf0 == ng0, GM_EINVAL, "sumcheck_prove_sharded: the blocks of f and g hold %zu and %zu elements", nf0, ng0);
+    GM_CHECK(world == 1 || (nf0 * (size_t)world == n_global && lo == (size_t)rank * nf0), GM_EINVAL,
+             "sumcheck_prove_sharded: rank %d of %d holds [%zu, %zu) of %zu elements; equal blocks in rank order are required", rank, world, lo, lo + nf0,
+             n_global);
+    GM_CHECK(world > 1 || (lo == 0 && nf0 == n_global), GM_EINVAL, "sumcheck_prove_sharded: one rank holds the whole vectors (%zu of %zu from %zu)", nf0, n_global, lo);
+    if (world > 1) {  // and every rank must see the same thing
+      uint64_t mine[2] = {(uint64_t)nf0, (uint64_t)n_global};
+      std::vector<uint64_t> all(2 * (size_t)world);
+      RC(gm_dist_allgather_host(mine, sizeof mine, all.data()));
+      for (int r2 = 0; r2 < world; r2++)
+        GM_CHECK(all[2 * (size_t)r2] == mine[0] && all[2 * (size_t)r2 + 1] == mine[1], GM_EINVAL,
+                 "sumcheck_prove_sharded: rank %d holds blocks of %llu of %llu elements, this rank %zu of %zu", r2, (unsigned long long)all[2 * (size_t)r2],
+                 (unsigned long long)all[2 * (size_t)r2 + 1], nf0, n_global);
+    }
+  }
   constexpr size_t TAIL = (size_t)1 << 10;
   uint64_t prover = 0;
   RC(gm_sc_new_borrow(f_block, g_block, twist, &prover));
@@ -328,8 +349,9 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
   RC(dist_rank_world(&rank_i, &world_i));
   const size_t r = (size_t)rank_i, g = (size_t)world_i, n = S->n;
   GM_CHECK(n >= 2 && (n & (n - 1)) == 0 && (g & (g - 1)) == 0 && n % g == 0, GM_EINVAL, "snark_new_time_sharded: powers of two needed (n = %zu, %zu ranks)", n, g);
-  const size_t m = n / g, tail = (size_t)1 << S->tail_log;
-  GM_CHECK(S->tail_log >= 3 && m >= tail, GM_EINVAL, "snark_new_time_sharded: blocks of %zu elements are shorter than the tail length", m);
+  const size_t m = n / g, tail = (size_t)1 << (S->tail_log < 40 ? S->tail_log : 39);
+  GM_CHECK(S->tail_log >= 3 && S->tail_log < 40 && m >= tail, GM_EINVAL, "snark_new_time_sharded: blocks of %zu elements are shorter than the tail length 2^%zu (3 .. 39)", m,
+           (size_t)S->tail_log);
   size_t jmax = 0;
   while ((m >> (jmax + 1)) >= tail) jmax++;
   GM_CHECK(S->key_segments == jmax + 2, GM_EINVAL, "snark_new_time_sharded: the key has %zu segments, the layout needs %zu", S->key_segments, jmax + 2);

@@ -205,3 +205,29 @@ def test_reblocking_between_ranks_on_the_shared_gpu(world):
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]
+
+
+def test_sharded_sumcheck_refuses_blocks_that_do_not_tile():
+    """gm_sumcheck_prove_sharded is a public entry point; blocks that are not equal, in rank order and covering n_global used to
+    deadlock an all-gather or produce messages that differ from the single-GPU prover's.  Now GM_EINVAL before anything is launched."""
+    import ctypes as C
+
+    import gemini_amd as gm
+    from gemini_amd.fr import FrVec
+
+    gm.capi.init()
+    lib = gm.capi.load()
+    f, g = FrVec.from_host(np.ones((64, 4), dtype=np.uint64)), FrVec.from_host(np.ones((32, 4), dtype=np.uint64))
+    tr = C.c_uint64()
+    gm.capi.check(lib.gm_transcript_new(b"x", C.c_size_t(1), C.byref(tr)))
+    msgs, chal, fin, rounds = np.zeros(64 * 8, np.uint64), np.zeros(64 * 4, np.uint64), np.zeros(8, np.uint64), C.c_size_t()
+    tw = np.ones(4, dtype=np.uint64)
+    call = lambda fv, gv, lo, n: lib.gm_sumcheck_prove_sharded(tr, C.c_uint64(fv.handle), C.c_uint64(gv.handle), gm.capi.ptr(tw), C.c_size_t(lo), C.c_size_t(n),
+                                                               gm.capi.ptr(msgs), gm.capi.ptr(chal), C.c_size_t(64), gm.capi.ptr(fin), C.byref(rounds))
+    assert call(f, g, 0, 64) == -1 and b"blocks of f and g" in lib.gm_last_error()  # unequal blocks
+    assert call(f, f, 2, 64) == -1  # one rank, but not the whole vector
+    assert call(f, f, 0, 128) == -1
+    assert call(f, f, 0, 64) == 0 and rounds.value == 6
+    gm.capi.check(lib.gm_transcript_free(tr))
+    f.free()
+    g.free()
