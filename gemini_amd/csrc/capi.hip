@@ -342,19 +342,24 @@ int gm_init(int device) {
   for (int k = 0; k < MSM_SMALL_LANES; k++) GM_HIP(hipStreamCreateWithPriority(&C->small_stream[k], hipStreamNonBlocking, prio ? prio_hi : 0));
   GM_HIP(hipStreamCreateWithPriority(&C->stream_b, hipStreamNonBlocking, prio ? prio_hi : 0));
   {
-    // default: 32 of the 256 compute units for the tails of a batch (measured on one box, GM_CU_SPLIT = 0 / 16 / 32 / 64: psnark -i 22
-    // 351 / 485 / 334 / 337 ms, snark -i 24 115.3 / 134.7 / 113.5 / 113.2, snark -i 20 13.3 / 14.0 / 13.2 / 13.2, the sharded share
-    // 27.9 / 40.0 / 27.9 / 27.8: profiles/r5_cu_split_probe.txt); GM_CU_SPLIT=0 switches the partition off
+    // XCD PARTITION of a batch: ONE of the eight XCDs (32 of 256 compute units, with its own L2) for the tails of every call, the
+    // other seven for the accumulations.  Bit i of a CU mask is compute unit i / 8 of XCD i % 8 (consecutive bits rotate over the
+    // XCDs), and a mask must cover WHOLE XCDs: the workgroups of a kernel are dealt round-robin to the XCDs its queue may use, so an
+    // XCD left with a fraction of its CUs still gets its full share of workgroups and becomes the straggler -- measured, tail CUs =
+    // 16 / 32 / 48 / 64 / 96 (stride 16 / 8 / 5 / 4 / 2 through the bits): psnark -i 22 485 / 334 / - / 337 / - ms against 351
+    // without, the folding batch 2^20 .. 2: - / 8.2 / 21.6 / 8.2 / 15.5 ms against 8.1 (profiles/r5_cu_split_probe.txt).
+    // GM_CU_SPLIT = 32 k: k XCDs for the tails (default 32); 0 switches the partition off.
     const char* e = getenv("GM_CU_SPLIT");
-    const int T = e ? atoi(e) : 32, ncu = C->cu_count;
-    if (T > 0 && T < ncu) {
-      // bit i of the mask = compute unit i of the device (the runtime spreads consecutive bits over the XCDs): the tail partition
-      // takes every (ncu / T)-th CU so that it has a share of every XCD and of its L2, the accumulation partition the rest
-      const int words = (ncu + 31) / 32, stride = ncu / T;
+    const int ncu = C->cu_count, per_xcd = ncu / 8;
+    int T = e ? atoi(e) : per_xcd;
+    static const bool raw_env = getenv("GM_CU_SPLIT_RAW") != nullptr;  // experiment: any T, every (ncu / T)-th bit (how the table above was measured)
+    if (!raw_env && per_xcd > 0) T = T / per_xcd * per_xcd;  // whole XCDs only
+    if (ncu % 8 == 0 && T > 0 && T < ncu) {
+      const int words = (ncu + 31) / 32, xcds = T / per_xcd, stride = ncu / T;
       std::vector<uint32_t> m_tail((size_t)words, 0u), m_acc((size_t)words, 0u);
       int taken = 0;
       for (int i = 0; i < ncu; i++) {
-        const bool tail = taken < T && i % stride == 0;
+        const bool tail = raw_env ? (taken < T && i % stride == 0) : (i % 8 < xcds);
         (tail ? m_tail : m_acc)[(size_t)i >> 5] |= 1u << (i & 31);
         taken += tail ? 1 : 0;
       }

@@ -282,11 +282,12 @@ struct Context {
   // sort / merge / reduce of one overlap the (ALU-bound) accumulation of the other
   MsmWorkspace msm_b;
   hipStream_t stream_b = nullptr;
-  // CU PARTITION of a batch (GM_CU_SPLIT=T, 0 = off): T compute units are set aside for the latency-bound tail of every call of a
-  // batch (k_merge, the bucket reduction, the copy-out) on streams created with a CU mask, the accumulations (and sorts) run on
-  // streams masked to the other CUs.  Without it a small kernel does not progress beside an accumulation: the SIMD arbiter serves
-  // the oldest waves first and a k_acc0 grid keeps every SIMD supplied with older ones, so the tails of a
-  // batch end up serialised behind the accumulations they were meant to hide under.  Index 0 / 1 / 2.. = main, second big, small lanes
+  // XCD PARTITION of a batch (GM_CU_SPLIT, default one XCD; capi.hip: gm_init): the latency-bound tail of every call of a batch
+  // (k_merge, the bucket reduction, the copy-out) runs on streams created with a CU mask that covers ONE whole XCD, the
+  // accumulations (and sorts) on streams masked to the other seven.  Without it a small kernel does not progress beside an
+  // accumulation: the SIMD arbiter serves the oldest waves first and a k_acc0 grid keeps every SIMD supplied with older ones
+  // (HISTORY section 4.1), so the tails of a batch end up serialised behind the accumulations they were meant to hide under.
+  // Index 0 / 1 / 2.. = main, second big, small lanes
   int cu_split = 0;
   hipStream_t part_acc[2 + MSM_SMALL_LANES] = {};
   hipStream_t part_tail[2 + MSM_SMALL_LANES] = {};

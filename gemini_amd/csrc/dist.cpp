@@ -915,7 +915,16 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
 // Every rank sends patterns of several sizes and checks what it receives from every peer: run at start-up on a multi-GPU
 // node.  With no transport initialised and a GPU context present it opens a ONE-rank RCCL communicator and pushes a 144-byte
 // point through ncclAllGather (the binding, the staging and the stream ordering are then exercised on a single-GPU box too).
+static int selftest_reblock();
+static int selftest_host_payloads();
 int gm_dist_selftest(void) {
+  int rc = selftest_host_payloads();
+  if (rc) return rc;
+  int world = 1;
+  (void)gm_dist_info(nullptr, &world, nullptr);
+  return world > 1 ? selftest_reblock() : GM_OK;
+}
+static int selftest_host_payloads() {
   Dist& d = D();
   std::lock_guard<std::mutex> lk(d.mu);
   bool temp = false;
@@ -945,6 +954,51 @@ int gm_dist_selftest(void) {
     if (rc) break;
   }
   if (temp) reset(d);
+  return rc;
+}
+
+// the device half of the self-test (called by gm_dist_selftest after the host payloads, outside its lock): every rank holds a block
+// of 8 known elements, re-blocked to blocks of 16 and of 4 -- the grouped ncclSend / ncclRecv of gm_dist_reblock_vecs with real peers
+static int selftest_reblock() {
+  if (gm::context() == nullptr) return GM_OK;
+  int rank = 0, world = 1;
+  int rc = gm_dist_info(&rank, &world, nullptr);
+  if (rc) return rc;
+  const size_t b = 8;
+  auto value = [](size_t global, int limb) { return (uint64_t)global * 0x9e3779b97f4a7c15ull + (uint64_t)limb; };
+  std::vector<uint64_t> host(4 * b);
+  for (size_t i = 0; i < b; i++)
+    for (int l = 0; l < 4; l++) host[4 * i + l] = value((size_t)rank * b + i, l) >> 3;  // below 2^61: any limb pattern is fine for a copy
+  uint64_t in = 0, out = 0;
+  if ((rc = gm_fr_vec_alloc(b, &in))) return rc;
+  if ((rc = gm_fr_vec_alloc(16, &out))) {
+    (void)gm_fr_vec_free(in);
+    return rc;
+  }
+  rc = gm_fr_vec_upload(in, 0, host.data(), b);
+  for (size_t B : {(size_t)16, (size_t)4}) {
+    if (rc) break;
+    if ((rc = gm_dist_reblock_vecs(&in, 1, B, &out))) break;
+    size_t len = 0;
+    if ((rc = gm_fr_vec_len(out, &len))) break;
+    const size_t total = (size_t)world * b, lo = (size_t)rank * B, want = lo < total ? (B < total - lo ? B : total - lo) : 0;
+    if (len != want) {
+      gm::set_error("gm_dist_selftest: re-blocking to %zu gave rank %d %zu elements, expected %zu", B, rank, len, want);
+      rc = GM_ESTATE;
+      break;
+    }
+    std::vector<uint64_t> got(4 * (len ? len : 1));
+    if (len && (rc = gm_fr_vec_download(out, 0, got.data(), len))) break;
+    for (size_t i = 0; i < len && !rc; i++)
+      for (int l = 0; l < 4; l++)
+        if (got[4 * i + l] != value(lo + i, l) >> 3) {
+          gm::set_error("gm_dist_selftest: rank %d received a wrong element %zu after re-blocking to %zu", rank, i, B);
+          rc = GM_ESTATE;
+          break;
+        }
+  }
+  (void)gm_fr_vec_free(in);
+  (void)gm_fr_vec_free(out);
   return rc;
 }
 
