@@ -181,7 +181,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
     sc = None
     if world == 1:
         gm.capi.check(lib.gm_prof_enable(C.c_int(1)))
-        Proof.new_time(r1cs, ck)
+        Proof.new_time(r1cs, ck, native=True)  # the driver the timed runs use (gm_snark_new_time): the same launches, the same count
         ms = (C.c_double * 7)()
         cnt = (C.c_uint64 * 7)()
         gm.capi.check(lib.gm_prof_read(ms, cnt, C.c_int(7)))
@@ -196,8 +196,11 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
                   # 129 v_mad_u64_u32 + 128 v_addc_co_u32 + 8 v_mul_lo_u32 at 4.3 cycles + ~40 plain instructions per product
                   "fr_mul_issue_bound": 1.25e11,
                   "alu_frac": round(2 * 8 * n / (ms[6] * 1e-3) / 1.25e11, 4),
+                  "driver": "gm_snark_new_time (the prover the metric times), stage timers on",
                   "note": "two sumchecks of length N = 2^logn; 8 N Fr products per sumcheck = 1 per 24 bytes: with a 1260-cycle product the kernel "
-                          "is integer-ALU bound at <= 3 TB/s (37 % of the HBM peak) in the large rounds and launch-latency bound in the last ~15"}
+                          "is integer-ALU bound at <= 3 TB/s (37 % of the HBM peak) in the large rounds and launch-latency bound in the last ~15; "
+                          "since round 5 the three inner products of a message accumulate unreduced (80 instead of 137 multiply-adds each, "
+                          "one reduction per thread): alu_frac still counts them as whole products"}
 
     # The key was registered with the library's default: fixed-base window tables when they fit (gm_set_auto_tables), so the
     # runs above ARE the default configuration.  The same prover on the plain path (no tables) beside it.

@@ -57,6 +57,9 @@ hipError_t raw_free(void* p) {
 
 // hipMalloc for the long-lived allocations outside the vector pool (bases, tables, matrices, index vectors): when the device
 // is out of memory the pool may be holding up to 55 % of it in freed blocks -- give them back and retry once
+// LOCK ORDER: this takes C->msm_mu (try-lock) and then C->mu, and it is reached from every allocation path (dev_malloc,
+// DevBuf::ensure, DevPool::alloc) -- so no caller may hold C->mu across an allocation (none does: the handle tables are touched
+// only around find_* / put_*).  What it frees is counted (gm_mem_stats[9]) and can be rebuilt (gm_g1_bases_precompute(h, -1)).
 bool release_spare_tables(Context* C) {
   if (!C || C->msm_busy.load() != 0) return false;
   std::unique_lock<std::recursive_mutex> lk(C->msm_mu, std::try_to_lock);
@@ -349,9 +352,11 @@ int gm_init(int device) {
     // 16 / 32 / 48 / 64 / 96 (stride 16 / 8 / 5 / 4 / 2 through the bits): psnark -i 22 485 / 334 / - / 337 / - ms against 351
     // without, the folding batch 2^20 .. 2: - / 8.2 / 21.6 / 8.2 / 15.5 ms against 8.1 (profiles/r5_cu_split_probe.txt).
     // GM_CU_SPLIT = 32 k: k XCDs for the tails (default 32); 0 switches the partition off.
+    // Default ON only for the part this was measured on -- 256 CUs = 8 XCDs of 32 in SPX mode; a partitioned device (CPX: one XCD
+    // per device) has no second XCD to set aside, and any other CU count has not been measured: there the partition is opt-in.
     const char* e = getenv("GM_CU_SPLIT");
     const int ncu = C->cu_count, per_xcd = ncu / 8;
-    int T = e ? atoi(e) : per_xcd;
+    int T = e ? atoi(e) : (ncu == 256 ? per_xcd : 0);
     static const bool raw_env = getenv("GM_CU_SPLIT_RAW") != nullptr;  // experiment: any T, every (ncu / T)-th bit (how the table above was measured)
     if (!raw_env && per_xcd > 0) T = T / per_xcd * per_xcd;  // whole XCDs only
     if (ncu % 8 == 0 && T > 0 && T < ncu) {

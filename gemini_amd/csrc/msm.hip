@@ -1859,6 +1859,12 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     }
   }
   std::vector<char> group_done(fused_groups.size(), 0);
+  size_t last_big_pos = (size_t)-1;  // position in `order` of the last call that takes a big lane
+  for (size_t jo = 0; jo < k; jo++) {
+    const size_t j = order[jo];
+    const bool blk = group_of[j] >= 0 && group_block[(size_t)group_of[j]];
+    if (blk || (group_of[j] < 0 && !is_small(j))) last_big_pos = jo;
+  }
   bool gated = false;
   for (size_t jo = 0; jo < k; jo++) {
     const size_t j = order[jo];
@@ -1905,6 +1911,10 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       const int li = lane > 0 ? 1 + lane : (lane < 0 ? 1 : 0);
       if (lane > 0 && small_whole) sts = MsmStreams{C->part_tail[li], C->part_tail[li], C->part_tail[li]};  // a small call entirely on the tail CUs
       else sts = MsmStreams{sort_on_tail ? C->part_tail[li] : C->part_acc[li], C->part_acc[li], C->part_tail[li]};
+      // the LAST big call has no accumulation after it to hide its tail under: its merge and reduction take the seven XCDs of the
+      // accumulations instead of the one of the tails (GM_CU_SPLIT_LAST=0: the tail XCD like every other call)
+      static const bool last_wide = !(getenv("GM_CU_SPLIT_LAST") && atoi(getenv("GM_CU_SPLIT_LAST")) == 0);
+      if (last_wide && !small && jo == last_big_pos) sts.tail = sts.acc;
       st = sts.sort;
       // the calls of a lane share its workspace: on ONE stream the order kept them apart, over three streams the next call's sort
       // must wait for the previous call's tail (it clears the counters the bucket reduction reads)
