@@ -217,6 +217,23 @@ uint8_t* shm_slot(Dist& d, uint64_t call, int r) {
   return base + ((call & 1) * (size_t)d.world + (size_t)r) * d.slot_bytes;
 }
 
+// A collective over RCCL whose peer never arrives would block hipStreamSynchronize for ever (the shm transport has its own
+// timeout): poll the stream instead and give up after GM_DIST_RCCL_TIMEOUT_S (default 120 s) -- the caller then aborts the communicator.
+hipError_t stream_wait_bounded(hipStream_t st, bool* timed_out) {
+  static const double limit = getenv("GM_DIST_RCCL_TIMEOUT_S") ? atof(getenv("GM_DIST_RCCL_TIMEOUT_S")) : 120.0;
+  *timed_out = false;
+  const auto t0 = Clock::now();
+  for (unsigned spin = 0;; spin++) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (spin > 20000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spin & 1023) == 0 && std::chrono::duration<double>(Clock::now() - t0).count() > limit) {
+      *timed_out = true;
+      return hipErrorNotReady;
+    }
+  }
+}
+
 double shm_timeout() {
   static const double limit = getenv("GM_DIST_TIMEOUT_S") ? atof(getenv("GM_DIST_TIMEOUT_S")) : 300.0;
   return limit;
@@ -348,7 +365,12 @@ int rccl_host_allgather(Dist& d, const void* send, size_t bytes, void* recv) {
     return fail(GM_EHIP);
   }
   e = hipMemcpyAsync(d.h_out, d.d_out, bytes * (size_t)d.world, hipMemcpyDeviceToHost, C->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(C->stream);
+  bool late = false;
+  if (e == hipSuccess) e = d.world > 1 ? stream_wait_bounded(C->stream, &late) : hipStreamSynchronize(C->stream);
+  if (late) {
+    gm::set_error("gm_dist: ncclAllGather did not complete in time: a peer never arrived");
+    return fail(GM_ESTATE);
+  }
   if (e != hipSuccess) return fail(gm::hip_fail(e, "D2H staging / wait", __FILE__, __LINE__));
   memcpy(recv, d.h_out, bytes * (size_t)d.world);
   return GM_OK;
@@ -773,10 +795,12 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
   } else if (d.tr == T_RCCL) {
     // (a failing rank aborts the communicator so that its peers return instead of hanging: see rccl_host_allgather)
     ncclResult_t r = d.R.AllGather(in->d, out->d, bytes, ncclChar, d.comm, C->stream);
-    hipError_t e = r == ncclSuccess ? hipStreamSynchronize(C->stream) : hipSuccess;
+    bool late = false;
+    hipError_t e = r == ncclSuccess ? (d.world > 1 ? stream_wait_bounded(C->stream, &late) : hipStreamSynchronize(C->stream)) : hipSuccess;
     if (r != ncclSuccess || e != hipSuccess) {
       if (r != ncclSuccess) gm::set_error("gm_dist: ncclAllGather failed: %s", d.R.GetErrorString(r));
-      const int code = r != ncclSuccess ? GM_EHIP : gm::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+      if (late) gm::set_error("gm_dist: ncclAllGather of a vector did not complete in time: a peer never arrived");
+      const int code = r != ncclSuccess ? GM_EHIP : (late ? GM_ESTATE : gm::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
       if (d.comm && d.R.CommAbort) {
         (void)d.R.CommAbort(d.comm);
         d.comm = nullptr;
@@ -874,8 +898,21 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
     if (grouped) {
       ncclResult_t res = d.R.GroupEnd();
       if (res != ncclSuccess) return fail(res);
+      bool late = false;
+      const hipError_t e = stream_wait_bounded(C->stream, &late);
+      if (late) {
+        gm::set_error("gm_dist_reblock_vecs: the send / recv group did not complete in time: a peer never arrived");
+        if (d.comm && d.R.CommAbort) {
+          (void)d.R.CommAbort(d.comm);
+          d.comm = nullptr;
+          d.tr = T_NONE;
+        }
+        return GM_ESTATE;
+      }
+      GM_HIP(e);
+    } else {
+      GM_HIP(hipStreamSynchronize(C->stream));
     }
-    GM_HIP(hipStreamSynchronize(C->stream));
   } else {
     // whole vectors: ncclAllGather into a temporary (RCCL without send / recv) or the host transports
     route = d.tr == T_RCCL ? R_RCCL_VEC : d.tr == T_HOOK ? R_HOOK : R_SHM;
