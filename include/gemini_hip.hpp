@@ -39,6 +39,30 @@ inline void check(int rc) {
 inline void init(int device = 0) { check(gm_init(device)); }
 // give the prefix tables of every committer key back (the library does so by itself when a device allocation fails twice)
 inline void release_spare_tables() { check(gm_g1_release_spare_tables()); }
+// The library's device-memory bookkeeping (gm_mem_stats) and the footprint contract: what a proof will allocate, before it starts
+// (the reference's memory story is its constants, README.md:38-46; a prover that keeps its vectors resident owes the number)
+struct MemStats {
+  uint64_t device_total, device_free, held, held_peak, pool_cached, in_use, in_use_peak, tables, keys, spare_table_releases, msm_workspaces, reserved;
+};
+inline MemStats mem_stats() {
+  uint64_t v[12];
+  check(gm_mem_stats(v));
+  return MemStats{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11]};
+}
+inline void mem_reset_peak() { check(gm_mem_reset_peak()); }
+struct Footprint {
+  uint64_t vectors, workspaces_to_grow, needed, available;
+};
+inline Footprint snark_footprint(uint64_t ck_handle, size_t num_constraints, bool elastic = false) {
+  uint64_t v[4];
+  check(gm_snark_footprint(ck_handle, num_constraints, elastic ? 1 : 0, v));
+  return Footprint{v[0], v[1], v[2], v[3]};
+}
+inline Footprint psnark_footprint(uint64_t ck_handle, size_t num_variables, size_t nnz, int elastic = 0) {  // 0 time, 1 elastic (resident), 2 literal
+  uint64_t v[4];
+  check(gm_psnark_footprint(ck_handle, num_variables, nnz, elastic, v));
+  return Footprint{v[0], v[1], v[2], v[3]};
+}
 
 // One process per GPU: after gm::init(local_rank) pick the transport of the library's all-gathers.  Every native prover
 // (SnarkProof::new_time ..., gm_snark_new_time_sharded) then runs on N GPUs when its key is a cyclic share / a shard key.

@@ -79,7 +79,17 @@ int main(int argc, char** argv) {
       std::vector<gm::Fr> z(n, ev[0]), w(n - 1, ev[0]);
       gm::R1cs r1cs(diag, diag, diag, z, w);
       gm::CommitterKey key(srs);
+      // the footprint contract from C++: promised before, used after (gm_snark_footprint / gm_mem_stats)
+      const gm::Footprint fp = gm::snark_footprint(key.handle(), n);
+      const gm::MemStats m0 = gm::mem_stats();
+      gm::mem_reset_peak();
       auto proof = gm::SnarkProof::new_time(r1cs, key);
+      const gm::MemStats m1 = gm::mem_stats();
+      if (fp.needed != fp.vectors + fp.workspaces_to_grow || m1.in_use_peak - m0.in_use > fp.needed || fp.available < fp.needed) {
+        fprintf(stderr, "footprint: promised %llu, used %llu, available %llu\n", (unsigned long long)fp.needed, (unsigned long long)(m1.in_use_peak - m0.in_use),
+                (unsigned long long)fp.available);
+        return 3;
+      }
       print("snark_witness", proof.witness_commitment);
       print("snark_zc_alpha", proof.zc_alpha);
       for (auto& m : proof.first_sumcheck_msgs) {
