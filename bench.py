@@ -589,9 +589,9 @@ def main():
 
     # HBM traffic of the dominant kernel: NOT measured in this run -- hardware counters need rocprofv3 --pmc passes
     # of their own (tools/profile_round.sh); the figure of the committed passes of this library is quoted with its
-    # source (profiles/r4_pmc_msm20.json says how it was collected and corrected)
+    # source (profiles/r5_pmc_msm20.json says how it was collected and corrected)
     traffic, traffic_source = None, None
-    for tag in ("r4", "r3", "r2", "r1"):
+    for tag in ("r5", "r4", "r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_msm20.json")) as fh:
                 if args.logn == LOG_N:
@@ -679,6 +679,9 @@ def main():
             # the host side of a one-call MSM (helper threads, window Horner) runs on the CPUs the container may use; a quota
             # exhausted by pollers or by other tenants throttles the whole process for the rest of a 100 ms period
             "host": dict(host_cpus(), cpu_throttled_usec_in_timed_steps=int(throttled_in_loop)),
+            # the XCD partition of a batch (one XCD for the tails of the calls, seven for the accumulations) acts in batch_commit and
+            # in the provers, not in the one-call headline
+            "runtime": gm.capi.runtime_info(),
         }
         if world == 1 and not args.no_cpu_baseline:
             # the CPU restatement of the reference algorithm (arkworks window rule, signed digits,

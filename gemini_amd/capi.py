@@ -21,7 +21,7 @@ ERRORS = {-1: "GM_EINVAL", -2: "GM_ENOTINIT", -3: "GM_EHANDLE", -4: "GM_EHIP", -
 # every symbol include/gemini_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "gm_init", "gm_shutdown", "gm_last_error", "gm_abi_version",
-    "gm_g1_msm", "gm_g1_bases_register", "gm_g1_bases_free", "gm_g1_bases_len", "gm_g1_bases_download", "gm_g1_bases_precompute", "gm_set_auto_tables", "gm_g1_bases_table_info", "gm_pool_trim", "gm_g1_release_spare_tables", "gm_mem_stats", "gm_mem_reset_peak", "gm_snark_footprint", "gm_psnark_footprint", "gm_footprint_admit",
+    "gm_g1_msm", "gm_g1_bases_register", "gm_g1_bases_free", "gm_g1_bases_len", "gm_g1_bases_download", "gm_g1_bases_precompute", "gm_set_auto_tables", "gm_g1_bases_table_info", "gm_pool_trim", "gm_g1_release_spare_tables", "gm_mem_stats", "gm_mem_reset_peak", "gm_runtime_info", "gm_snark_footprint", "gm_psnark_footprint", "gm_footprint_admit",
     "gm_g1_msm_h", "gm_g1_msm_v", "gm_g1_msm_v_batch", "gm_g1_msm_v_batch_partial", "gm_g1_msm_v_batch_at", "gm_g1_msm_d", "gm_g1_msm_d_partial", "gm_g1_sum",
     "gm_g1_msm_stream_new", "gm_g1_msm_stream_new_h", "gm_g1_msm_stream_add", "gm_g1_msm_stream_finalize", "gm_g1_msm_stream_free", "gm_host_alloc", "gm_host_free",
     "gm_g1_fixed_base_register", "gm_g1_srs_register", "gm_g1_srs_register_segments", "gm_set_msm_window", "gm_set_msm_table_min", "gm_set_msm_affine_levels", "gm_set_msm_split", "gm_set_msm_glv", "gm_prof_enable", "gm_prof_read", "gm_prof_read_clock",
@@ -132,6 +132,12 @@ def psnark_footprint(ck_handle: int, num_variables: int, nnz: int, elastic: int 
     out = np.zeros(4, dtype=np.uint64)
     check(load().gm_psnark_footprint(C.c_uint64(ck_handle), C.c_size_t(num_variables), C.c_size_t(nnz), C.c_int(int(elastic)), ptr(out)))
     return {k: int(v) for k, v in zip(FOOTPRINT_FIELDS, out)}
+
+
+def runtime_info() -> dict:
+    out = (C.c_int * 4)()
+    check(load().gm_runtime_info(out))
+    return {"compute_units": out[0], "batch_tail_cus": out[1], "zero_copy": out[2], "small_lanes": out[3]}
 
 
 def mem_reset_peak():

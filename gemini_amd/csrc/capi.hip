@@ -515,6 +515,16 @@ int gm_mem_stats(uint64_t out[12]) {
   return GM_OK;
 }
 
+int gm_runtime_info(int out[4]) {
+  GM_CTX();
+  GM_CHECK(out != nullptr, GM_EINVAL, "gm_runtime_info: null output");
+  out[0] = C->cu_count;
+  out[1] = C->cu_split;  // compute units set aside for the tails of a batch (whole XCDs; 0 = no partition)
+  out[2] = C->zero_copy;
+  out[3] = MSM_SMALL_LANES;
+  return GM_OK;
+}
+
 int gm_mem_reset_peak(void) {
   GM_CTX();
   MemStats& m = mem_stats();

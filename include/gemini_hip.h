@@ -115,6 +115,9 @@ int gm_pool_trim(void);
  * story is its constants (README.md:38-46: SPACE_TIME_THRESHOLD, MAX_MSM_BUFFER_LOG); on the device it is these figures and the
  * footprint contract below (gm_snark_footprint / gm_psnark_footprint). */
 int gm_mem_stats(uint64_t out[12]);
+/* out[0] = compute units of the device, [1] = of those: set aside for the tails of a batch (the XCD partition, GM_CU_SPLIT; 0 = off),
+ * [2] = zero-copy result paths in use (bit 0 field kernels, bit 1 MSM planes), [3] = small-call lanes of a batch */
+int gm_runtime_info(int out[4]);
 int gm_mem_reset_peak(void);
 /* THE FOOTPRINT CONTRACT.  What a proof will allocate beyond what is resident when it is called (the key and its tables, the
  * instance, the caller's vectors): out[0] = high-water mark of its device vectors and prover buffers, out[1] = what the MSM
