@@ -650,8 +650,22 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
         if (len) add_piece(outs[i - 1], etas[i]);
       }
     }
-    if (r == 0)
-      for (size_t i = 0; i < small.size(); i++) add_piece(small[i], etas[nb + i]);
+    // the gathered levels are replicated: every rank takes ITS range of each (rank 0 all of them when they are shorter than a
+    // block; with a long tail -- 2^tail_log > m / g -- the first gathered level spans several blocks)
+    for (size_t i = 0; i < small.size(); i++) {
+      size_t len = 0;
+      RC(vec_len(small[i], &len));
+      if (r * m >= len) continue;
+      if (r == 0 && len <= m) {
+        add_piece(small[i], etas[nb + i]);
+        continue;
+      }
+      const size_t cnt = std::min(m, len - r * m);
+      uint64_t part;
+      RC(V.alloc(cnt, &part));
+      RC(gm_fr_stride(small[i], r * m, 1, cnt, part));
+      add_piece(part, etas[nb + i]);
+    }
     TR.mark("re-block");
     uint64_t F;
     RC(V.alloc(m + 3, &F));

@@ -34,8 +34,7 @@ def _measure(gm, run):
     return out, used, ws_grown
 
 
-@pytest.mark.parametrize("logn", [12, 18, 21])
-@pytest.mark.parametrize("elastic", [False, True], ids=["time", "elastic"])
+@pytest.mark.parametrize("logn,elastic", [(12, False), (12, True), (18, True), (21, False), (21, True)])
 def test_snark_promised_vs_used(gm, oracle, logn, elastic):
     from gemini_amd import snark
     from gemini_amd.circuit import R1csStream, dummy_r1cs
@@ -65,7 +64,7 @@ def test_snark_promised_vs_used(gm, oracle, logn, elastic):
     ck.powers_of_g.free()
 
 
-@pytest.mark.parametrize("logn,mode", [(10, 0), (10, 1), (10, 2), (16, 0), (16, 2), (20, 0), (20, 1), (20, 2)])
+@pytest.mark.parametrize("logn,mode", [(10, 0), (10, 2), (16, 1), (20, 0), (20, 1), (20, 2)])
 def test_psnark_promised_vs_used(gm, oracle, logn, mode):
     """mode 0: gm_psnark_new_time, 1: gm_psnark_new_elastic in the resident schedule, 2: the literal one (min_device_chunk = 1)"""
     from gemini_amd.circuit import R1csStream, dummy_r1cs
