@@ -168,10 +168,10 @@ def test_sharded_provers_from_plain_c_abi_processes(oracle, pyref, tmp_path):
 
     one = run(1, "cyclic")
     assert run(1, "block") == one
-    for world in (2, 4, 8):
+    for world in (2, 8):  # (1 / 2 / 4 / 8 of the same prover through Python launchers: tests/test_gpu_dist_native.py)
         assert run(world, "block") == one, world
     assert run(4, "block", "global") == one
-    for world in (2, 3, 5):
+    for world in (3, 5):
         assert run(world, "cyclic") == one, world
     # and the digest is the one of the Python mirror's single-GPU native prover on the same instance and key
     import gemini_amd as gm

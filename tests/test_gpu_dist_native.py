@@ -118,7 +118,7 @@ def test_rccl_binding_with_one_rank():
 def test_cyclic_key_native_provers_same_proof(extra):
     """gm_snark_new_time / gm_snark_new_elastic handed a CYCLIC SHARE of the key: 2 and 3 ranks == 1 GPU"""
     one = _single(extra)
-    for world, transport in ((2, "shm"), (3, "shm"), (2, "hook")):
+    for world, transport in ((3, "shm"), (2, "hook")):
         many = _run(world, extra, transport=transport)
         assert many["n_gpus"] == world and many["transport"] == transport
         assert many["proof_sha256"] == one["proof_sha256"], (world, transport, extra)
@@ -140,7 +140,7 @@ def test_block_sharded_native_prover_same_proof(tail_log):
     8 ranks (blocks of 512): the first gathered level is TWO blocks long -- every rank takes its range of the replicated levels in
     the n / g opening, not rank 0 all of them (found by tests/soak_dist_native.py, which sweeps transports x worlds x tails)"""
     one = _single()
-    for world in {4: (1, 2, 4, 8), 6: (4,), 8: (8,)}[tail_log]:
+    for world in {4: (1, 2, 8), 6: (4,), 8: (8,)}[tail_log]:
         many = _run(world, ["--block-sharded", "--tail-log", str(tail_log)], transport="hook" if (tail_log, world) == (4, 2) else "shm")
         assert many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
 
@@ -150,7 +150,7 @@ def test_block_sharded_native_prover_general_matrices():
     indices, on 2 and 4 ranks == the single-GPU prover on the same instance; and dummy_r1cs posed as a general matrix"""
     one = _single(["--random-r1cs", "77"], logn=10)
     assert one["proof_sha256"] != _single(logn=10)["proof_sha256"]
-    for world in (2, 4):
+    for world in (4,):  # (2 ranks and more seeds: tests/soak_dist_native.py)
         many = _run(world, ["--random-r1cs", "77", "--block-sharded", "--tail-log", "5"], logn=10)
         assert many["proof_sha256"] == one["proof_sha256"], world
     dummy = _single()
@@ -192,7 +192,7 @@ print("ok", rank)
 """ % ROOT
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 8])
 def test_reblocking_between_ranks_on_the_shared_gpu(world):
     """gm_dist_reblock_vecs over the host transport (N processes share the one GPU): the levels of a folding tree, sharded in
     blocks of m / 2^j, arrive as the blocks [r m, (r + 1) m) of the same global vectors -- what the n / g opening of the
