@@ -373,8 +373,28 @@ int gm_init(int device) {
         ok = hipExtStreamCreateWithCUMask(&C->part_acc[k], (uint32_t)words, m_acc.data()) == hipSuccess &&
              hipExtStreamCreateWithCUMask(&C->part_tail[k], (uint32_t)words, m_tail.data()) == hipSuccess;
       }
-      if (ok) C->cu_split = T;
-      else (void)hipGetLastError();
+      if (ok) {
+        C->cu_split = T;
+        // queues created with a CU mask must be gone before the runtime tears itself down: left alive they crash the process at exit
+        // under rocprofv3 (every profiled run of round 5's first measurement batch ended in a segmentation fault AFTER its output was
+        // written).  Registered after the runtime's own handlers, so it runs before them.
+        static bool registered = false;
+        if (!registered) {
+          registered = true;
+          atexit([] {
+            Context* c = g_ctx;
+            if (!c || !c->cu_split) return;
+            c->cu_split = 0;
+            for (int k = 0; k < 2 + MSM_SMALL_LANES; k++) {
+              if (c->part_acc[k]) (void)hipStreamSynchronize(c->part_acc[k]), (void)hipStreamDestroy(c->part_acc[k]);
+              if (c->part_tail[k]) (void)hipStreamSynchronize(c->part_tail[k]), (void)hipStreamDestroy(c->part_tail[k]);
+              c->part_acc[k] = c->part_tail[k] = nullptr;
+            }
+          });
+        }
+      } else {
+        (void)hipGetLastError();
+      }
     }
   }
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
@@ -426,6 +446,11 @@ void gm_shutdown(void) {
     release_ws(C->msm_small[k]);
     if (C->small_stream[k]) (void)hipStreamDestroy(C->small_stream[k]);
   }
+  for (int k = 0; k < 2 + MSM_SMALL_LANES; k++) {
+    if (C->part_acc[k]) (void)hipStreamDestroy(C->part_acc[k]);
+    if (C->part_tail[k]) (void)hipStreamDestroy(C->part_tail[k]);
+  }
+  C->cu_split = 0;
   if (C->host_small) (void)hipHostFree(C->host_small);
   if (C->host_batch) (void)hipHostFree(C->host_batch);
   (void)hipStreamDestroy(C->stream);
