@@ -476,8 +476,11 @@ int gm_snark_new_time(const uint64_t matrices[6], uint64_t z, uint64_t w, uint64
  * matrices_t: gm_spm handles of A^T, B^T, C^T (the MatrixTensor streams, :233-238); z_stream, w_stream, za/zb/zc_stream:
  * the BIG-ENDIAN streams of R1csStream (`Reverse(..)`, src/snark/tests.rs:38-52) as device vectors; ck_bases: the key in time
  * order (its stream view Reverse(powers_of_g) is the reversed addressing of the MSMs), at least as long as every stream.
- * Sumchecks run on the space prover until fewer than SPACE_TIME_THRESHOLD = 22 rounds remain; every flush of a streaming
- * MSM shorter than `min_device_chunk` pairs is merged (max_msm_buffer bounds host buffering in the reference).
+ * min_device_chunk = 1: the LITERAL elastic prover -- sumchecks on the space prover until fewer than SPACE_TIME_THRESHOLD = 22
+ * rounds remain, flushes of max_msm_buffer pairs.  min_device_chunk > 1 (the mirror's default 2^26): everything is resident and
+ * max_msm_buffer advisory -- every flush of a streaming MSM shorter than `min_device_chunk` pairs is merged, and the sumchecks
+ * take the RESIDENT schedule: time provers on the little-endian vectors from the first round (the same field elements,
+ * sumcheck/tests.rs:42-87; less memory than reversed stream copies; the elastic prover then costs what the time prover costs).
  * Same proof bytes as gm_snark_new_time on the same instance and key (src/snark/tests.rs:56).  spans[0] is 0: the matrix
  * products belong to the construction of the streams. */
 int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_stream, uint64_t w_stream, uint64_t za_stream, uint64_t zb_stream,
@@ -534,8 +537,9 @@ int gm_psnark_new_time(const gm_psnark_instance* instance, uint64_t ck_bases, in
 /* psnark::Proof::new_elastic (src/psnark/elastic_prover.rs:60-634) over device-resident big-endian streams (reversed vectors: z,
  * the witness, A z, B z, C z -- R1csStream, src/circuit.rs), everything else of `instance` as for gm_psnark_new_time (its z / w
  * fields are not read).  Commitments and openings are the chunked stream MSMs of CommitterKeyStream (src/kzg/space.rs:95-285)
- * with the flush rule of gm_snark_new_elastic (max_msm_buffer [/ depth], never below min_device_chunk); the sumchecks run on space
- * provers that become time provers below SPACE_TIME_THRESHOLD rounds (sumcheck/elastic_prover.rs:44-57), the third one as
+ * with the flush rule of gm_snark_new_elastic (max_msm_buffer [/ depth], never below min_device_chunk); with min_device_chunk = 1
+ * the sumchecks run on space provers that become time provers below SPACE_TIME_THRESHOLD rounds (sumcheck/elastic_prover.rs:44-57),
+ * otherwise on time provers from the first round (the resident schedule, as for gm_snark_new_elastic); the third one as
  * prove_batch over 13 of them.  Same bytes as gm_psnark_new_time (src/psnark/tests.rs:56-124); spans as there. */
 int gm_psnark_new_elastic(const gm_psnark_instance* instance, uint64_t z_stream, uint64_t w_stream, uint64_t za_stream, uint64_t zb_stream,
                           uint64_t zc_stream, uint64_t ck_bases, size_t max_msm_buffer, size_t min_device_chunk, int g1_encoding, size_t cap_rounds,
