@@ -304,6 +304,11 @@ int fr_plookup_set(Context* C, FrVec* v, const uint64_t y[4], const uint64_t z[4
 int fr_add_scalar(Context* C, FrVec* v, const uint64_t y[4], FrVec* out);
 int fr_shift_monic(Context* C, FrVec* v, FrVec* out);
 int fr_acc_product(Context* C, FrVec* v, FrVec* out);
+int fr_acc_product_ex(Context* C, FrVec* v, const uint64_t* carry_in, bool write_monic, FrVec* out, uint64_t* total);
+int fr_tensor_range(Context* C, const uint64_t* rhos, size_t k, size_t start, size_t count, FrVec* out);
+int fr_plookup_set_block(Context* C, FrVec* v, size_t v_off, size_t nv, const uint64_t* prev, size_t nout, const uint64_t y[4], const uint64_t z[4],
+                         FrVec* out);
+int fr_shift_block(Context* C, FrVec* v, const uint64_t first[4], size_t nout, FrVec* out);
 
 }  // namespace gm
 
@@ -1365,6 +1370,50 @@ int gm_fr_acc_product(uint64_t v, uint64_t out) {
   return fr_acc_product(C, vv, vo);
 }
 
+// ---- the builders on one block of a block-sharded vector (gm_psnark_new_time_sharded) ----------
+int gm_fr_tensor_range(const uint64_t* rhos_mont, size_t k, size_t start, size_t count, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_tensor_range");
+  GM_CHECK(rhos_mont != nullptr, GM_EINVAL, "fr_tensor_range: null pointer");
+  return fr_tensor_range(C, rhos_mont, k, start, count, vo);
+}
+int gm_fr_powers_range(const uint64_t x_mont[4], size_t start, size_t count, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_powers_range");
+  GM_CHECK(x_mont != nullptr && vo->cap >= count, GM_EINVAL, "fr_powers_range: output capacity %zu < %zu", vo->cap, count);
+  int rc = fr_powers_at(C, x_mont, start, count, vo->d);
+  if (rc) return rc;
+  vo->len = count;
+  return GM_OK;
+}
+int gm_fr_plookup_set_block(uint64_t v, size_t v_offset, size_t v_count, const uint64_t* prev_or_null, size_t out_count, const uint64_t y_mont[4],
+                            const uint64_t z_mont[4], uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_plookup_set_block");
+  GM_VEC(vo, out, "fr_plookup_set_block");
+  GM_CHECK(y_mont && z_mont, GM_EINVAL, "fr_plookup_set_block: null pointer");
+  return fr_plookup_set_block(C, vv, v_offset, v_count, prev_or_null, out_count, y_mont, z_mont, vo);
+}
+int gm_fr_shift_block(uint64_t v, const uint64_t first_mont[4], size_t out_count, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_shift_block");
+  GM_VEC(vo, out, "fr_shift_block");
+  GM_CHECK(first_mont != nullptr, GM_EINVAL, "fr_shift_block: null pointer");
+  return fr_shift_block(C, vv, first_mont, out_count, vo);
+}
+int gm_fr_product(uint64_t v, uint64_t total_mont[4]) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_product");
+  GM_CHECK(total_mont != nullptr, GM_EINVAL, "fr_product: null pointer");
+  return fr_acc_product_ex(C, vv, nullptr, false, nullptr, total_mont);
+}
+int gm_fr_acc_product_block(uint64_t v, const uint64_t* carry_or_null, int write_monic, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_acc_product_block");
+  GM_VEC(vo, out, "fr_acc_product_block");
+  return fr_acc_product_ex(C, vv, carry_or_null, write_monic != 0, vo, nullptr);
+}
+
 // ---- sparse matrices (R1CS) -------------------------------------------------------------------
 int gm_spm_register(const uint64_t* rowptr, const uint32_t* cols, const uint64_t* vals_mont, size_t nrows, size_t ncols,
                     size_t nnz, uint64_t* handle) {
@@ -1541,6 +1590,17 @@ int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset) {
   GM_CTX();
   GM_SC(S, handle, "sc_set_shard");
   S->pair_offset = pair_offset;
+  return GM_OK;
+}
+// the same for a block whose length says nothing about the rounds of the WHOLE vectors (a short or partial block of a
+// block-sharded prover): the round count is the caller's
+int gm_sc_set_shard_rounds(uint64_t handle, uint64_t pair_offset, size_t tot_rounds) {
+  GM_CTX();
+  GM_SC(S, handle, "sc_set_shard_rounds");
+  std::lock_guard<std::mutex> lk(S->mu);
+  GM_CHECK(S->round == 0 && tot_rounds < 64, GM_ESTATE, "sc_set_shard_rounds: before the first round only (%zu rounds)", tot_rounds);
+  S->pair_offset = pair_offset;
+  S->tot_rounds = tot_rounds;
   return GM_OK;
 }
 // ---- herring provers -------------------------------------------------------------------------------

@@ -210,12 +210,14 @@ __global__ __launch_bounds__(256) void k_tensor_table(const uint32_t* __restrict
   fp_store<FrParams>(tab + (size_t)idx * FR_BYTES, acc);
 }
 // out[idx] = lo[idx & mask] * hi[idx >> klo]                                   misc.rs:133-149
+// (start: the first index of a RANGE of the tensor -- a block of a block-sharded prover, gm_fr_tensor_range)
 __global__ __launch_bounds__(256) void k_tensor(const uint8_t* __restrict__ lo, const uint8_t* __restrict__ hi,
-                                                uint32_t klo, size_t n, uint8_t* __restrict__ out) {
+                                                uint32_t klo, size_t start, size_t n, uint8_t* __restrict__ out) {
   const size_t mask = ((size_t)1 << klo) - 1;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    Fr a = fp_load<FrParams>(lo + (i & mask) * FR_BYTES);
-    Fr b = fp_load<FrParams>(hi + (i >> klo) * FR_BYTES);
+    const size_t idx = start + i;
+    Fr a = fp_load<FrParams>(lo + (idx & mask) * FR_BYTES);
+    Fr b = fp_load<FrParams>(hi + (idx >> klo) * FR_BYTES);
     fp_store<FrParams>(out + i * FR_BYTES, fr_mul(a, b));
   }
 }
@@ -483,6 +485,29 @@ __global__ __launch_bounds__(256) void k_shift_monic(const uint8_t* __restrict__
     fp_store<FrParams>(out + i * FR_BYTES, i == 0 ? Fr::one() : fp_load<FrParams>(v + (i - 1) * FR_BYTES));
 }
 
+// ---- the same builders on ONE BLOCK of a block-sharded vector (gm_psnark_new_time_sharded) ----------------------------
+// plookup_set restricted to the outputs [lo, lo + nout) of a vector of n_global + 1 of them: v = the elements [lo, lo + nv) of the
+// hashed set that exist, prev = element lo - 1 (the last element of the block below: a 32-byte halo; null at lo = 0):
+//   out[t] = (1 + z) y + (t >= 1 ? v[t - 1] : prev) + (t < nv ? z v[t] : 0)
+__global__ __launch_bounds__(256) void k_plookup_set_block(const uint8_t* __restrict__ v, size_t nv, const uint32_t* __restrict__ prev8, size_t nout,
+                                                           const uint32_t* __restrict__ yz8, uint8_t* __restrict__ out) {
+  Fr y1z = fp_load<FrParams>(yz8), z = fp_load<FrParams>(yz8 + 8);
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nout; t += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = y1z;
+    if (t >= 1) acc = fr_add(acc, fp_load<FrParams>(v + (t - 1) * FR_BYTES));
+    else if (prev8) acc = fr_add(acc, fp_load<FrParams>(prev8));
+    if (t < nv) acc = fr_add(acc, fr_mul(z, fp_load<FrParams>(v + t * FR_BYTES)));
+    fp_store<FrParams>(out + t * FR_BYTES, acc);
+  }
+}
+// right_rotation(monic(v)) on a block: out[0] = first (1 on the lowest block, else the last element of the block below),
+// out[t] = v[t - 1]
+__global__ __launch_bounds__(256) void k_shift_block(const uint8_t* __restrict__ v, const uint32_t* __restrict__ first8, size_t nout,
+                                                     uint8_t* __restrict__ out) {
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nout; t += (size_t)gridDim.x * blockDim.x)
+    fp_store<FrParams>(out + t * FR_BYTES, t == 0 ? fp_load<FrParams>(first8) : fp_load<FrParams>(v + (t - 1) * FR_BYTES));
+}
+
 // accumulated_product(monic(v)) (entryproduct/time_prover.rs:25-45): out[i] = prod_{j >= i} v[j], out[n] = 1.
 // The same three-phase blocked scan as the division above with the monoid (Fr, *):
 //   phase 1: p_c = product of chunk c (ACC_K elements per thread)
@@ -512,7 +537,8 @@ __global__ __launch_bounds__(256) void k_accp_phase2a(uint8_t* __restrict__ prod
   fp_store<FrParams>(seg_prods + s * FR_BYTES, acc);
 }
 __global__ __launch_bounds__(256) void k_accp_phase3(const uint8_t* __restrict__ v, size_t n, const uint8_t* __restrict__ prods,
-                                                     const uint8_t* __restrict__ carry, size_t seg, uint8_t* __restrict__ out) {
+                                                     const uint8_t* __restrict__ carry, size_t seg, const uint8_t* __restrict__ top_carry,
+                                                     int write_monic, uint8_t* __restrict__ out) {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t nch = (n + ACC_K - 1) / ACC_K;
   if (c >= nch) return;
@@ -522,8 +548,10 @@ __global__ __launch_bounds__(256) void k_accp_phase3(const uint8_t* __restrict__
     const size_t c1 = c + 1, s1 = c1 / seg;
     state = fr_mul(fp_load<FrParams>(prods + c1 * FR_BYTES), fp_load<FrParams>(carry + s1 * FR_BYTES));
   } else {
-    state = Fr::one();
-    fp_store<FrParams>(out + n * FR_BYTES, state);  // the monic entry
+    // (a block of a sharded vector: the product of the blocks above comes in as carry[nseg]; the monic entry exists on the
+    // rank that holds position n of the whole vector only)
+    state = top_carry ? fp_load<FrParams>(top_carry) : Fr::one();
+    if (write_monic) fp_store<FrParams>(out + n * FR_BYTES, state);  // the monic entry
   }
   const size_t lo = c * ACC_K, hi = min(lo + (size_t)ACC_K, n);
   for (size_t j = hi; j-- > lo;) {
@@ -1380,11 +1408,13 @@ int fr_powers_at(Context* C, const uint64_t x[4], size_t start, size_t n, uint8_
   return GM_OK;
 }
 
-int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out) {
+// out[i] = tensor(rhos)[start + i], i < count: the whole tensor (start = 0, count = 2^k) or a block of it
+int fr_tensor_range(Context* C, const uint64_t* rhos, size_t k, size_t start, size_t count, FrVec* out) {
   GM_FR_LOCK(C);
   GM_CHECK(k >= 1 && k <= 32, GM_EINVAL, "tensor: need 1 <= k <= 32 elements (got %zu)", k);
   const size_t n = (size_t)1 << k;
-  GM_CHECK(out->cap >= n, GM_EINVAL, "tensor: output capacity %zu < %zu", out->cap, n);
+  GM_CHECK(start <= n && count <= n - start, GM_EINVAL, "tensor: range [%zu, %zu + %zu) outside 2^%zu entries", start, start, count, k);
+  GM_CHECK(out->cap >= count, GM_EINVAL, "tensor: output capacity %zu < %zu", out->cap, count);
   const uint32_t klo = (uint32_t)(k / 2 > 0 ? (k + 1) / 2 : k), khi = (uint32_t)k - klo;
   int rc = C->fr_scratch.ensure((1 << 20) + (((size_t)1 << klo) + ((size_t)1 << khi)) * FR_BYTES);
   if (rc) return rc;
@@ -1395,11 +1425,15 @@ int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out) {
   hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << klo)), dim3(256), 0, C->stream, (const uint32_t*)base, klo, lo);
   hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << khi)), dim3(256), 0, C->stream,
                      (const uint32_t*)(base + (size_t)klo * 32), khi, hi);
-  hipLaunchKernelGGL(k_tensor, dim3(grid_for(n)), dim3(256), 0, C->stream, lo, hi, klo, n, out->d);
+  if (count) hipLaunchKernelGGL(k_tensor, dim3(grid_for(count)), dim3(256), 0, C->stream, lo, hi, klo, start, count, out->d);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
-  out->len = n;
+  out->len = count;
   return GM_OK;
+}
+int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out) {
+  GM_CHECK(k >= 1 && k <= 32, GM_EINVAL, "tensor: need 1 <= k <= 32 elements (got %zu)", k);
+  return fr_tensor_range(C, rhos, k, 0, (size_t)1 << k, out);
 }
 
 int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out) {
@@ -1730,17 +1764,24 @@ int fr_shift_monic(Context* C, FrVec* v, FrVec* out) {
   return GM_OK;
 }
 
-int fr_acc_product(Context* C, FrVec* v, FrVec* out) {
+// One block of a block-sharded vector as well (gm_psnark_new_time_sharded): carry_in = the product of the blocks ABOVE this one
+// (null: one), write_monic = whether position n of the whole vector -- the entry 1 -- falls into this block; total (optional) =
+// the product of this block WITHOUT the carry; out = nullptr: the product only (phases 1 and 2).
+int fr_acc_product_ex(Context* C, FrVec* v, const uint64_t* carry_in, bool write_monic, FrVec* out, uint64_t* total) {
   GM_FR_LOCK(C);
   const size_t n = v->len;
-  GM_CHECK(out->cap >= n + 1, GM_EINVAL, "acc_product: output capacity %zu < %zu", out->cap, n + 1);
-  GM_CHECK(out != v, GM_EINVAL, "acc_product: output must not alias the input");
-  out->len = n + 1;
+  const gmh::Fr cin = carry_in ? gmh::Fr::from_limbs(carry_in) : gmh::Fr::one();
+  if (out) {
+    GM_CHECK(out->cap >= n + (write_monic ? 1 : 0), GM_EINVAL, "acc_product: output capacity %zu < %zu", out->cap, n + (write_monic ? 1 : 0));
+    GM_CHECK(out != v, GM_EINVAL, "acc_product: output must not alias the input");
+    out->len = n + (write_monic ? 1 : 0);
+  }
   if (n == 0) {
-    uint64_t one[4];
-    gmh::Fr::one().to_limbs(one);
-    GM_HIP(hipMemcpyAsync(out->d, one, 32, hipMemcpyHostToDevice, C->stream));
-    GM_HIP(hipStreamSynchronize(C->stream));
+    if (total) gmh::Fr::one().to_limbs(total);
+    if (out && write_monic) {
+      GM_HIP(hipMemcpyAsync(out->d, cin.l, 32, hipMemcpyHostToDevice, C->stream));
+      GM_HIP(hipStreamSynchronize(C->stream));
+    }
     return GM_OK;
   }
   const size_t nch = (n + ACC_K - 1) / ACC_K, seg = 64, nseg = (nch + seg - 1) / seg;
@@ -1748,14 +1789,14 @@ int fr_acc_product(Context* C, FrVec* v, FrVec* out) {
   if (rc) return rc;
   uint8_t* prods = C->fr_scratch.as<uint8_t>() + (1 << 20);
   uint8_t* seg_prods = prods + nch * FR_BYTES;
-  uint8_t* carry = seg_prods + nseg * FR_BYTES;
+  uint8_t* carry = seg_prods + nseg * FR_BYTES;  // nseg segment carries + the carry of the top chunk
   // page-locked staging as in fr_div_linear_factors: [segment products][carries]
-  if (C->host_batch_cap < 2 * nseg * FR_BYTES) {
+  if (C->host_batch_cap < (2 * nseg + 1) * FR_BYTES) {
     if (C->host_batch) (void)hipHostFree(C->host_batch);
     C->host_batch = nullptr;
     C->host_batch_cap = 0;
-    GM_HIP(hipHostMalloc((void**)&C->host_batch, 2 * nseg * FR_BYTES, hipHostMallocDefault));
-    C->host_batch_cap = 2 * nseg * FR_BYTES;
+    GM_HIP(hipHostMalloc((void**)&C->host_batch, (2 * nseg + 1) * FR_BYTES, hipHostMallocDefault));
+    C->host_batch_cap = (2 * nseg + 1) * FR_BYTES;
   }
   uint64_t* hs = C->host_batch;
   uint64_t* hc = hs + nseg * 4;
@@ -1765,17 +1806,65 @@ int fr_acc_product(Context* C, FrVec* v, FrVec* out) {
                      zc ? reinterpret_cast<uint8_t*>(hs) : seg_prods);
   GM_HIP(hipGetLastError());
   {
-    // carry[s] = product of the segments above s: nseg <= n / 4096 sequential host multiplications
+    // carry[s] = product of the segments above s (times the carry of the blocks above): nseg <= n / 4096 sequential host multiplications
     if (!zc) GM_HIP(hipMemcpyAsync(hs, seg_prods, nseg * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
     GM_HIP(hipStreamSynchronize(C->stream));
-    gmh::Fr acc = gmh::Fr::one();
+    gmh::Fr acc = cin, plain = gmh::Fr::one();
+    cin.to_limbs(hc + 4 * nseg);
     for (size_t s = nseg; s-- > 0;) {
       acc.to_limbs(hc + 4 * s);
-      acc = acc * gmh::Fr::from_limbs(hs + 4 * s);
+      const gmh::Fr p = gmh::Fr::from_limbs(hs + 4 * s);
+      acc = acc * p;
+      plain = plain * p;
     }
-    GM_HIP(hipMemcpyAsync(carry, hc, nseg * FR_BYTES, hipMemcpyHostToDevice, C->stream));
+    if (total) plain.to_limbs(total);
+    if (!out) return GM_OK;
+    GM_HIP(hipMemcpyAsync(carry, hc, (nseg + 1) * FR_BYTES, hipMemcpyHostToDevice, C->stream));
   }
-  hipLaunchKernelGGL(k_accp_phase3, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, v->d, n, prods, carry, seg, out->d);
+  hipLaunchKernelGGL(k_accp_phase3, dim3(grid_for(nch, 1u << 22)), dim3(256), 0, C->stream, v->d, n, prods, carry, seg,
+                     carry_in ? carry + nseg * FR_BYTES : (const uint8_t*)nullptr, write_monic ? 1 : 0, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
+int fr_acc_product(Context* C, FrVec* v, FrVec* out) { return fr_acc_product_ex(C, v, nullptr, true, out, nullptr); }
+
+// plookup_set on a block (k_plookup_set_block): v_off / nv = the elements of `v` that are this block's part of the hashed set,
+// prev (host, 4 limbs) = the element just below the block or null
+int fr_plookup_set_block(Context* C, FrVec* v, size_t v_off, size_t nv, const uint64_t* prev, size_t nout, const uint64_t y[4], const uint64_t z[4],
+                         FrVec* out) {
+  GM_FR_LOCK(C);
+  GM_CHECK(out != v, GM_EINVAL, "plookup_set_block: output must not alias the input");
+  GM_CHECK(v_off <= v->len && nv <= v->len - v_off, GM_EINVAL, "plookup_set_block: elements [%zu, %zu + %zu) outside a vector of %zu", v_off, v_off, nv, v->len);
+  GM_CHECK(out->cap >= nout && nout <= nv + 1, GM_EINVAL, "plookup_set_block: %zu outputs (capacity %zu) from %zu elements", nout, out->cap, nv);
+  out->len = nout;
+  if (nout == 0) return GM_OK;
+  gmh::Fr zz = gmh::Fr::from_limbs(z);
+  gmh::Fr y1z = (gmh::Fr::one() + zz) * gmh::Fr::from_limbs(y);
+  uint64_t small[12];
+  memcpy(small, y1z.l, 32);
+  memcpy(small + 4, zz.l, 32);
+  if (prev) memcpy(small + 8, prev, 32);
+  uint8_t* d;
+  int rc = upload_small(C, small, 96, &d);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_plookup_set_block, dim3(grid_for(nout)), dim3(256), 0, C->stream, v->d + v_off * FR_BYTES, nv,
+                     prev ? (const uint32_t*)(d + 64) : (const uint32_t*)nullptr, nout, (const uint32_t*)d, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  return GM_OK;
+}
+// out[0] = first, out[t] = v[t - 1], t < nout <= |v| + 1
+int fr_shift_block(Context* C, FrVec* v, const uint64_t first[4], size_t nout, FrVec* out) {
+  GM_FR_LOCK(C);
+  GM_CHECK(out != v, GM_EINVAL, "shift_block: output must not alias the input");
+  GM_CHECK(out->cap >= nout && nout <= v->len + 1, GM_EINVAL, "shift_block: %zu outputs (capacity %zu) from %zu elements", nout, out->cap, v->len);
+  out->len = nout;
+  if (nout == 0) return GM_OK;
+  uint8_t* d;
+  int rc = upload_small(C, first, 32, &d);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_shift_block, dim3(grid_for(nout)), dim3(256), 0, C->stream, v->d, (const uint32_t*)d, nout, out->d);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;

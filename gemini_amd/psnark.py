@@ -742,6 +742,52 @@ def _psnark_ctypes():
     return Instance, ProofRec
 
 
+def _proof_buffers(num_variables: int, nnz: int):
+    """a gm_psnark_proof record with its caller-owned arrays: (record, cap_rounds, (messages, fold commitments, fold evaluations))"""
+    import ctypes as C
+
+    _, ProofRec = _psnark_ctypes()
+    U = C.POINTER(C.c_uint64)
+    cap = max(2 * max(num_variables, nnz) + 4, 4).bit_length() + 3
+    m = [np.zeros((cap, 8), dtype=np.uint64) for _ in range(3)]
+    cap_folds = 4 * cap
+    fc = np.zeros((cap_folds, 18), dtype=np.uint64)
+    fe = np.zeros((cap_folds, 8), dtype=np.uint64)
+    P = ProofRec()
+    for k in range(3):
+        P.messages[k] = m[k].ctypes.data_as(U)
+    P.cap_folds = cap_folds
+    P.fold_commitments = fc.ctypes.data_as(U)
+    P.fold_evaluations = fe.ctypes.data_as(U)
+    return P, cap, (m, fc, fe)
+
+
+def _unpack_proof(P, bufs) -> "Proof":
+    m, fc, fe = bufs
+    A = lambda a: np.array(a, dtype=np.uint64)  # noqa: E731
+    msgs = lambda k: [(m[k][i, :4].copy(), m[k][i, 4:].copy()) for i in range(P.rounds[k])]  # noqa: E731
+    ff = lambda rec: [(A(rec)[:4].copy(), A(rec)[4:].copy())]  # noqa: E731
+    prods = [A(P.products[k]) for k in range(9)]
+    nf = P.nfold
+    tc = TensorcheckProof([fc[i].copy() for i in range(nf)], [fe[i].reshape(2, 4).copy() for i in range(nf)], A(P.evaluation_proof),
+                          [A(P.base_evaluations[k]).reshape(3, 4) for k in range(22)])
+    ep = EntryProductMsgs([A(P.acc_v_commitments[k]) for k in range(9)], [A(P.claimed_sumchecks[k]) for k in range(9)])
+    third_ff = []
+    for j in range(13):
+        r = A(P.third_final_foldings[j])
+        third_ff.append((r[:4].copy(), r[4:].copy()))
+    sc = [A(P.sorted_commitments[k]) for k in range(3)]
+    proof = Proof(
+        witness_commitment=A(P.witness_commitment), zc_alpha=A(P.zc_alpha), first_sumcheck_msgs=(msgs(0), ff(P.final_foldings[0])),
+        r_star_commitments=[A(P.r_star_commitments[k]) for k in range(3)], z_star_commitment=A(P.z_star_commitment),
+        second_sumcheck_msgs=(msgs(1), ff(P.final_foldings[1])),
+        set_r_ep=prods[0], subset_r_ep=prods[1], sorted_r_commitment=sc[0], set_alpha_ep=prods[3], subset_alpha_ep=prods[4],
+        sorted_alpha_commitment=sc[1], set_z_ep=prods[6], subset_z_ep=prods[7], sorted_z_commitment=sc[2], ep_msgs=ep,
+        ralpha_star_acc_mu_evals=[A(P.ralpha_star_acc_mu_evals[k]) for k in range(10)], ralpha_star_acc_mu_proof=A(P.ralpha_star_acc_mu_proof),
+        rstars_vals=[A(P.rstars_vals[0]), A(P.rstars_vals[1])], third_sumcheck_msgs=(msgs(2), third_ff), tensorcheck_proof=tc)
+    return proof
+
+
 def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_library: bool = False, elastic=None) -> "Proof":
     """gm_psnark_new_time; elastic = (ck_stream, r1cs_stream, max_msm_buffer): gm_psnark_new_elastic over the same instance record"""
     import ctypes as C
@@ -769,17 +815,7 @@ def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_li
                      len(jd.row_index), jd.row.handle, jd.col.handle, jd.val_a.handle, jd.val_b.handle, jd.val_c.handle, ext[0].handle, ext[1].handle,
                      len(ext[0]), len(ext[1]), idx.ctypes.data_as(U), C.cast(g2buf, C.POINTER(C.c_uint8)), len(g2))
         nnz = len(jd.row_index)
-    cap = max(2 * max(len(r1cs.z), nnz) + 4, 4).bit_length() + 3
-    m = [np.zeros((cap, 8), dtype=np.uint64) for _ in range(3)]
-    cap_folds = 4 * cap
-    fc = np.zeros((cap_folds, 18), dtype=np.uint64)
-    fe = np.zeros((cap_folds, 8), dtype=np.uint64)
-    P = ProofRec()
-    for k in range(3):
-        P.messages[k] = m[k].ctypes.data_as(U)
-    P.cap_folds = cap_folds
-    P.fold_commitments = fc.ctypes.data_as(U)
-    P.fold_evaluations = fe.ctypes.data_as(U)
+    P, cap, bufs = _proof_buffers(len(r1cs.z), nnz)
     if elastic is None:
         capi.check(capi.load().gm_psnark_new_time(C.byref(I), C.c_uint64(ck.powers_of_g.handle), C.c_int(int(default_group_encoding())), C.c_size_t(cap),
                                                   C.byref(P)))
@@ -789,27 +825,7 @@ def _new_time_native(ck: CommitterKey, r1cs: R1cs, index: list, preprocess_in_li
         capi.check(capi.load().gm_psnark_new_elastic(C.byref(I), h(st.z), h(st.witness), h(st.z_a), h(st.z_b), h(st.z_c), C.c_uint64(cks.powers_of_g.handle),
                                                      C.c_size_t(max_msm_buffer), C.c_size_t(cks.min_device_chunk), C.c_int(int(default_group_encoding())),
                                                      C.c_size_t(cap), C.byref(P)))
-    A = lambda a: np.array(a, dtype=np.uint64)  # noqa: E731
-    msgs = lambda k: [(m[k][i, :4].copy(), m[k][i, 4:].copy()) for i in range(P.rounds[k])]  # noqa: E731
-    ff = lambda rec: [(A(rec)[:4].copy(), A(rec)[4:].copy())]  # noqa: E731
-    prods = [A(P.products[k]) for k in range(9)]
-    nf = P.nfold
-    tc = TensorcheckProof([fc[i].copy() for i in range(nf)], [fe[i].reshape(2, 4).copy() for i in range(nf)], A(P.evaluation_proof),
-                          [A(P.base_evaluations[k]).reshape(3, 4) for k in range(22)])
-    ep = EntryProductMsgs([A(P.acc_v_commitments[k]) for k in range(9)], [A(P.claimed_sumchecks[k]) for k in range(9)])
-    third_ff = []
-    for j in range(13):
-        r = A(P.third_final_foldings[j])
-        third_ff.append((r[:4].copy(), r[4:].copy()))
-    sc = [A(P.sorted_commitments[k]) for k in range(3)]
-    proof = Proof(
-        witness_commitment=A(P.witness_commitment), zc_alpha=A(P.zc_alpha), first_sumcheck_msgs=(msgs(0), ff(P.final_foldings[0])),
-        r_star_commitments=[A(P.r_star_commitments[k]) for k in range(3)], z_star_commitment=A(P.z_star_commitment),
-        second_sumcheck_msgs=(msgs(1), ff(P.final_foldings[1])),
-        set_r_ep=prods[0], subset_r_ep=prods[1], sorted_r_commitment=sc[0], set_alpha_ep=prods[3], subset_alpha_ep=prods[4],
-        sorted_alpha_commitment=sc[1], set_z_ep=prods[6], subset_z_ep=prods[7], sorted_z_commitment=sc[2], ep_msgs=ep,
-        ralpha_star_acc_mu_evals=[A(P.ralpha_star_acc_mu_evals[k]) for k in range(10)], ralpha_star_acc_mu_proof=A(P.ralpha_star_acc_mu_proof),
-        rstars_vals=[A(P.rstars_vals[0]), A(P.rstars_vals[1])], third_sumcheck_msgs=(msgs(2), third_ff), tensorcheck_proof=tc)
+    proof = _unpack_proof(P, bufs)
     proof.spans = {name: P.spans[i] for i, name in enumerate(_PSNARK_SPANS)}
     if elastic is not None:
         proof.spans["ark_gemini::psnark::elastic_prover"] = proof.spans.pop("ark_gemini::psnark::time_prover")

@@ -144,3 +144,148 @@ def new_time_sharded(shard: R1csShard, key: ShardKey):
     S.key_segments, S.n, S.tail_log = key.segments, shard.n, key.tail_log
     capi.check(capi.load().gm_snark_new_time_sharded(C.byref(S), C.c_int(int(default_group_encoding())), C.c_size_t(cap), C.byref(P)))
     return _unpack_native(P, m, fc, fe, _SPAN_NAMES)
+
+
+# ---- psnark::Proof::new_time with every vector block-sharded (gemini_amd/csrc/psnark_sharded.cpp) ---------------------------------
+class _GmPsnarkShard(C.Structure):
+    _fields_ = [("a", C.c_uint64), ("b", C.c_uint64), ("c", C.c_uint64), ("z", C.c_uint64), ("w_block", C.c_uint64), ("w_len", C.c_size_t),
+                ("row_index", C.c_uint64), ("col_index", C.c_uint64), ("row", C.c_uint64), ("col", C.c_uint64), ("val_a", C.c_uint64),
+                ("val_b", C.c_uint64), ("val_c", C.c_uint64), ("ext_fre_row", C.c_uint64), ("ext_fre_col", C.c_uint64),
+                ("ext_fre_row_len", C.c_size_t), ("ext_fre_col_len", C.c_size_t), ("num_constraints", C.c_size_t), ("num_variables", C.c_size_t),
+                ("nnz", C.c_size_t), ("block", C.c_size_t), ("tail_log", C.c_size_t), ("key", C.c_uint64), ("key_offsets", C.POINTER(C.c_size_t)),
+                ("key_counts", C.POINTER(C.c_size_t)), ("key_segments", C.c_size_t), ("key_len", C.c_size_t),
+                ("index_commitments", C.POINTER(C.c_uint64)), ("ck_g2_bytes", C.POINTER(C.c_uint8)), ("ck_g2_len", C.c_size_t)]
+
+
+def psnark_shard_block(longest: int, world: int) -> int:
+    lib = capi.load()
+    lib.gm_psnark_shard_block.restype = C.c_size_t
+    return int(lib.gm_psnark_shard_block(C.c_size_t(longest), C.c_int(world)))
+
+
+class PsnarkShardKey:
+    """gm_psnark_shard_key_new: this rank's slices of a key of max_degree + 1 powers for block size `block` (levels of M >> j while they stay
+    sharded, then the replicated prefix), one handle; plus the G2 half every rank holds whole (the transcript absorbs it)"""
+
+    def __init__(self, max_degree: int, block: int, tail_log: int, tau_canonical, max_eval_points: int = 5, g_affine=None):
+        from . import g2 as G2
+
+        n_key = max_degree + 1  # CommitterKey::new(max_degree, ..) holds max_degree + 1 powers (src/kzg/time.rs:49-72)
+        from .kzg import g1_generator_mont
+        from .msm import G1Bases
+
+        capi.ensure_init()
+        g = g1_generator_mont() if g_affine is None else g_affine
+        tau = np.ascontiguousarray(tau_canonical, dtype=np.uint64).reshape(4)
+        self.offsets = (C.c_size_t * 64)()
+        self.counts = (C.c_size_t * 64)()
+        h, nseg = C.c_uint64(), C.c_size_t()
+        capi.check(capi.load().gm_psnark_shard_key_new(capi.ptr(capi.u64(g).reshape(12)), capi.ptr(tau), C.c_size_t(n_key), C.c_size_t(block), C.c_size_t(tail_log),
+                                                       C.byref(h), self.offsets, self.counts, C.byref(nseg)))
+        self.n_key, self.block, self.tail_log, self.segments = n_key, block, tail_log, nseg.value
+        self.bases = G1Bases(h.value, 0)
+        t = sum(int(v) << (64 * i) for i, v in enumerate(tau))
+        self.g2_bytes = G2.serialize_vec_uncompressed([G2.mul(G2.generator(), pow(t, i, R_MOD)) for i in range(max_eval_points + 1)])
+
+    def free(self):
+        self.bases.free()
+
+
+class PsnarkShard:
+    """this rank's blocks of a psnark instance: rows [r B, (r + 1) B) of A, B, C (global columns), z whole, the blocks of w and of the
+    joint-matrix vectors (src/misc.rs:269-366) and extended frequencies (plookup/time_prover.rs:66-79).  Built from a whole `R1cs`
+    (every rank walks the same host arrays and keeps its slice)."""
+
+    def __init__(self, r1cs, tail_log: int = 10, block: int = None):
+        from .circuit import SparseMatrix
+        from .fr import IdxVec
+        from .psnark import _field_of_index, _joint, compute_frequency, extend_frequency
+
+        rank, world, _ = collective.info()
+        row_index, col_index, val_a, val_b, val_c = _joint(r1cs)
+        nrows, nz, nnz = r1cs.a.nrows, len(r1cs.z), len(row_index)
+        nt = 1 << max(nrows - 1, 0).bit_length()
+        ext_row = extend_frequency(compute_frequency(nt, row_index))
+        ext_col = extend_frequency(compute_frequency(nz, col_index))
+        self.longest = max(len(ext_row) + 2, len(ext_col) + 2, nz + 2, nrows + 2, nnz + 1)
+        self.block = block or psnark_shard_block(self.longest, world)
+        self.tail_log = tail_log
+        lo, hi = rank * self.block, (rank + 1) * self.block
+        self.num_constraints, self.num_variables, self.nnz = nrows, nz, nnz
+        self.ext_row_len, self.ext_col_len, self.w_len = len(ext_row), len(ext_col), len(r1cs.w)
+        self.z = r1cs.z
+        self._own = []
+
+        def keep(x):
+            self._own.append(x)
+            return x
+
+        built = {}
+        self.mats = []
+        for m in (r1cs.a, r1cs.b, r1cs.c):
+            if id(m) not in built:
+                rowptr, cols, vals = m.csr
+                a, b = min(lo, m.nrows), min(hi, m.nrows)
+                if b > a:
+                    e0, e1 = int(rowptr[a]), int(rowptr[b])
+                    built[id(m)] = keep(SparseMatrix.from_csr(rowptr[a:b + 1] - rowptr[a], cols[e0:e1], vals[e0:e1], b - a, nz))
+                else:
+                    built[id(m)] = None
+            self.mats.append(built[id(m)])
+        idx = lambda arr: keep(IdxVec.from_host(arr[lo:hi])) if len(arr[lo:hi]) else None  # noqa: E731
+        vec = lambda arr: keep(FrVec.from_host(np.ascontiguousarray(arr[lo:hi]))) if len(arr[lo:hi]) else None  # noqa: E731
+        self.row_index, self.col_index = idx(row_index), idx(col_index)
+        self.row = keep(_field_of_index(self.row_index)) if self.row_index else None
+        self.col = keep(_field_of_index(self.col_index)) if self.col_index else None
+        self.val_a, self.val_b, self.val_c = vec(val_a), vec(val_b), vec(val_c)
+        self.ext_fre_row, self.ext_fre_col = idx(ext_row), idx(ext_col)
+        w_cnt = max(min(hi, self.w_len) - lo, 0)
+        self.w_block = None
+        if w_cnt:
+            self.w_block = keep(FrVec.alloc(w_cnt))
+            capi.check(capi.load().gm_fr_stride(C.c_uint64(r1cs.w.handle), C.c_size_t(lo), C.c_size_t(1), C.c_size_t(w_cnt), C.c_uint64(self.w_block.handle)))
+
+    def record(self, key: PsnarkShardKey, index=None) -> _GmPsnarkShard:
+        h = lambda x: x.handle if x is not None else 0  # noqa: E731
+        S = _GmPsnarkShard()
+        S.a, S.b, S.c = (h(m) for m in self.mats)
+        S.z, S.w_block, S.w_len = self.z.handle, h(self.w_block), self.w_len
+        S.row_index, S.col_index, S.row, S.col = h(self.row_index), h(self.col_index), h(self.row), h(self.col)
+        S.val_a, S.val_b, S.val_c = h(self.val_a), h(self.val_b), h(self.val_c)
+        S.ext_fre_row, S.ext_fre_col, S.ext_fre_row_len, S.ext_fre_col_len = h(self.ext_fre_row), h(self.ext_fre_col), self.ext_row_len, self.ext_col_len
+        S.num_constraints, S.num_variables, S.nnz = self.num_constraints, self.num_variables, self.nnz
+        S.block, S.tail_log = self.block, self.tail_log
+        S.key, S.key_segments, S.key_len = key.bases.handle, key.segments, key.n_key
+        S.key_offsets = C.cast(key.offsets, C.POINTER(C.c_size_t))
+        S.key_counts = C.cast(key.counts, C.POINTER(C.c_size_t))
+        self._g2buf = (C.c_uint8 * len(key.g2_bytes)).from_buffer_copy(key.g2_bytes)
+        S.ck_g2_bytes, S.ck_g2_len = C.cast(self._g2buf, C.POINTER(C.c_uint8)), len(key.g2_bytes)
+        if index is not None:
+            self._idx = np.ascontiguousarray(np.stack(index), dtype=np.uint64)
+            S.index_commitments = self._idx.ctypes.data_as(C.POINTER(C.c_uint64))
+        return S
+
+    def index(self, key: PsnarkShardKey) -> list:
+        """psnark::Proof::index (src/psnark/time_prover.rs:49-64) over the blocks: gm_psnark_index_sharded"""
+        out = np.zeros((5, 18), dtype=np.uint64)
+        S = self.record(key)
+        capi.check(capi.load().gm_psnark_index_sharded(C.byref(S), capi.ptr(out)))
+        return [out[k].copy() for k in range(5)]
+
+    def free(self):
+        for x in self._own:
+            x.free()
+        self._own = []
+
+
+def psnark_new_time_sharded(shard: PsnarkShard, key: PsnarkShardKey, index: list):
+    """gm_psnark_new_time_sharded; the same `psnark.Proof` on every rank"""
+    from .psnark import _PSNARK_SPANS, _proof_buffers, _unpack_proof
+    from .transcript import default_group_encoding
+
+    P, cap, bufs = _proof_buffers(shard.num_variables, shard.nnz)
+    S = shard.record(key, index)
+    capi.check(capi.load().gm_psnark_new_time_sharded(C.byref(S), C.c_int(int(default_group_encoding())), C.c_size_t(cap), C.byref(P)))
+    proof = _unpack_proof(P, bufs)
+    proof.spans = {name: P.spans[i] for i, name in enumerate(_PSNARK_SPANS)}
+    return proof

@@ -324,6 +324,22 @@ int gm_fr_shift_monic(uint64_t v, uint64_t out);
 /* accumulated_product(monic(v)): out[i] = prod_{j>=i} v[j], out[len] = 1 (reverse prefix-product scan)
  *                                                              src/subprotocols/entryproduct/time_prover.rs:25-45 */
 int gm_fr_acc_product(uint64_t v, uint64_t out);
+/* The same builders on ONE BLOCK of a block-sharded vector (gm_psnark_new_time_sharded; a block = the elements [lo, lo + M) that exist):
+ *   gm_fr_tensor_range / gm_fr_powers_range   out[i] = tensor(rhos)[start + i] / x^(start + i), i < count
+ *   gm_fr_plookup_set_block   plookup_set (plookup/time_prover.rs:23-35) for the outputs [lo, lo + out_count): v[v_offset .. + v_count) = the
+ *                             elements lo .. of the hashed set that exist, prev = element lo - 1 (null at lo = 0)
+ *   gm_fr_shift_block         right_rotation(monic(v)) (entryproduct/time_prover.rs:14-51): out[0] = first (1 on the lowest block, else the
+ *                             last element of the block below), out[t] = v[t - 1]
+ *   gm_fr_product             the product of the elements of v (the carry a higher block hands down)
+ *   gm_fr_acc_product_block   accumulated_product(monic(v)) of a block: the suffix scan started from `carry` (the product of the blocks
+ *                             above; null: one); write_monic: position |whole v| -- the entry 1 -- falls into this block */
+int gm_fr_tensor_range(const uint64_t* rhos_mont, size_t k, size_t start, size_t count, uint64_t out);
+int gm_fr_powers_range(const uint64_t x_mont[4], size_t start, size_t count, uint64_t out);
+int gm_fr_plookup_set_block(uint64_t v, size_t v_offset, size_t v_count, const uint64_t* prev_or_null, size_t out_count, const uint64_t y_mont[4],
+                            const uint64_t z_mont[4], uint64_t out);
+int gm_fr_shift_block(uint64_t v, const uint64_t first_mont[4], size_t out_count, uint64_t out);
+int gm_fr_product(uint64_t v, uint64_t total_mont[4]);
+int gm_fr_acc_product_block(uint64_t v, const uint64_t* carry_or_null, int write_monic, uint64_t out);
 
 /* ---- sparse R1CS matrices ------------------------------------------------------------------------ */
 /* `Matrix<F> = Vec<Vec<(F, usize)>>` (src/circuit.rs:43) as CSR, copied to HBM once.  gm_spm_mul is
@@ -370,6 +386,9 @@ int gm_sc_free(uint64_t handle);
 /* partial-message form for sharded sumchecks: the shard holds pairs
  * [pair_offset, pair_offset + len/2) of the global vectors; twist powers start at tau^(2*pair_offset) */
 int gm_sc_set_shard(uint64_t handle, uint64_t pair_offset);
+/* the same for a block whose length says nothing about the rounds of the WHOLE vectors (a partial block of a block-sharded
+ * prover): the prover keeps producing messages for tot_rounds rounds */
+int gm_sc_set_shard_rounds(uint64_t handle, uint64_t pair_offset, size_t tot_rounds);
 /* current state of the prover (TimeProver's pub fields f, g, twist: time_prover.rs:42-52): lengths and
  * twist, then the vectors themselves -- used when sharded provers hand their tails to one rank */
 int gm_sc_lens(uint64_t handle, size_t* nf, size_t* ng, uint64_t twist_mont[4]);
@@ -671,6 +690,50 @@ typedef struct gm_snark_shard {
 int gm_snark_shard_key_new(const uint64_t base_affine[12], const uint64_t tau[4], size_t n, size_t tail_log, uint64_t* key, size_t offsets[64],
                            size_t counts[64], size_t* segments);
 int gm_snark_new_time_sharded(const gm_snark_shard* shard, int g1_encoding, size_t cap_rounds, gm_snark_proof* proof);
+
+/* psnark::Proof::new_time (src/psnark/time_prover.rs:69-384; the resident schedule of new_elastic, elastic_prover.rs:60-634, is the same
+ * entry) with the FIELD ARITHMETIC block-sharded as well -- BASELINE configs[4] on N GPUs.  ONE block size for the whole proof
+ * (gm_psnark_shard_block(longest vector, world); any world, no power-of-two requirement): rank r of g holds the elements [r B, (r + 1) B)
+ * THAT EXIST of every vector (a block may be partial or empty: handle 0 or a vector of length 0).
+ *   a, b, c        the row blocks of A, B, C with GLOBAL column indices (gm_spm handles; 0 when no row falls into the block)
+ *   z              the WHOLE z on every rank (the lookups of z* and the matrix products read arbitrary entries)
+ *   w_block        this rank's block of w, w_len its whole length
+ *   row_index .. ext_fre_col   this rank's blocks of the joint-matrix index vectors, field vectors and extended frequencies
+ *                  (gm_psnark_instance, whole lengths nnz / ext_fre_*_len)
+ *   key            gm_psnark_shard_key_new: this rank's slices of the key, key_len = powers of the whole key
+ *   index_commitments   gm_psnark_index_sharded (Proof::index over the same blocks)
+ * What crosses ranks: partial G1 points (144 B per commitment), 64 B per prover and sumcheck round (the 13 provers of the third
+ * sumcheck in ONE all-gather per round), the products of the blocks of the nine lookup vectors (the carries of the suffix scans of
+ * accumulated_product, entryproduct/time_prover.rs:34-45) and 32-byte halos (right_rotation, plookup_set read element i - 1),
+ * evaluations, short gathered tails, the re-blocked level sums of the opening.  `lookup(v, index)` (plookup/time_prover.rs:5-8)
+ * needs no exchange: tensor(rho) and powers(alpha) are functions of the index, computed whole on every rank at HBM speed.
+ * The proof is byte-identical to gm_psnark_new_time's on every rank (tests/test_gpu_dist_native.py: 1 / 2 / 3 / 4 / 8 ranks). */
+typedef struct gm_psnark_shard {
+  uint64_t a, b, c;
+  uint64_t z;
+  uint64_t w_block;
+  size_t w_len;
+  uint64_t row_index, col_index;
+  uint64_t row, col, val_a, val_b, val_c;
+  uint64_t ext_fre_row, ext_fre_col;
+  size_t ext_fre_row_len, ext_fre_col_len;
+  size_t num_constraints, num_variables, nnz;
+  size_t block;
+  size_t tail_log;
+  uint64_t key;
+  const size_t* key_offsets;
+  const size_t* key_counts;
+  size_t key_segments;
+  size_t key_len;
+  const uint64_t* index_commitments; /* 5 x 18 limbs */
+  const uint8_t* ck_g2_bytes;
+  size_t ck_g2_len;
+} gm_psnark_shard;
+size_t gm_psnark_shard_block(size_t longest, int world);
+int gm_psnark_shard_key_new(const uint64_t base_affine[12], const uint64_t tau[4], size_t n_key, size_t block, size_t tail_log, uint64_t* key,
+                            size_t offsets[64], size_t counts[64], size_t* segments);
+int gm_psnark_index_sharded(const gm_psnark_shard* shard, uint64_t* out_jac);
+int gm_psnark_new_time_sharded(const gm_psnark_shard* shard, int g1_encoding, size_t cap_rounds, gm_psnark_proof* proof);
 
 #ifdef __cplusplus
 }

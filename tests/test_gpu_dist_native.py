@@ -230,3 +230,35 @@ def test_sharded_sumcheck_refuses_blocks_that_do_not_tile():
     gm.capi.check(lib.gm_transcript_free(tr))
     f.free()
     g.free()
+
+
+# ---- psnark with the FIELD side block-sharded (gm_psnark_new_time_sharded, gemini_amd/csrc/psnark_sharded.cpp) ---------------------
+@pytest.mark.parametrize("world,tail_log,transport", [(1, 4, "shm"), (2, 4, "shm"), (3, 5, "hook"), (4, 3, "shm"), (8, 4, "shm")])
+def test_block_sharded_psnark_same_proof(world, tail_log, transport):
+    """BASELINE configs[4]: psnark::Proof::new_time (src/psnark/time_prover.rs:69-384) with every vector in blocks over 1 / 2 / 3 / 4 / 8 ranks
+    sharing the test GPU == gm_psnark_new_time byte for byte (dummy_r1cs, src/psnark/tests.rs:14-55): lookups from replicated sources, the suffix
+    products with a carry between ranks, the 13-prover batch sumcheck with one all-gather per round, the n / g openings"""
+    one = _single(tool="run_psnark.py", logn=10)
+    many = _run(world, ["--block-sharded", "--tail-log", str(tail_log)], tool="run_psnark.py", logn=10, transport=transport)
+    assert many["n_gpus"] == world and many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
+
+
+@pytest.mark.parametrize("world,tail_log", [(2, 3), (4, 5), (8, 4)])
+def test_block_sharded_psnark_general_matrices(world, tail_log):
+    """the same on a random satisfied R1CS (entries of A and B in arbitrary columns, src/psnark/tests.rs:57-125 random circuits): the joint support is
+    irregular, the extended frequencies repeat indices, the row blocks read z everywhere"""
+    one = _single(["--random-r1cs", "91"], tool="run_psnark.py", logn=9)
+    assert one["proof_sha256"] != _single(tool="run_psnark.py", logn=9)["proof_sha256"]
+    many = _run(world, ["--random-r1cs", "91", "--block-sharded", "--tail-log", str(tail_log)], tool="run_psnark.py", logn=9)
+    assert many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
+
+
+def test_block_sharded_psnark_elastic_and_verifiable_key():
+    """the elastic prover's resident schedule (src/psnark/elastic_prover.rs:60-634: time provers on the same vectors) is the same sharded entry -- against
+    the single-GPU ELASTIC prover on its 3 n key; and the time prover on a key one power longer than the example's (nothing truncated)"""
+    one = _single(["--elastic"], tool="run_psnark.py", logn=10)
+    many = _run(4, ["--elastic", "--block-sharded", "--tail-log", "5"], tool="run_psnark.py", logn=10)
+    assert many["proof_sha256"] == one["proof_sha256"]
+    one = _single(["--verifiable-key"], tool="run_psnark.py", logn=10)
+    many = _run(2, ["--verifiable-key", "--block-sharded", "--tail-log", "6"], tool="run_psnark.py", logn=10)
+    assert many["proof_sha256"] == one["proof_sha256"]

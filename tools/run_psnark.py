@@ -11,6 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -22,6 +23,11 @@ def main():
                     "(examples/psnark.rs elastic_snark_main) instead of --time-prover")
     ap.add_argument("--transport", choices=["shm", "hook", "rccl"], default=None, help="N ranks through the collective layer inside the library "
                     "(gemini_amd/csrc/dist.cpp): the key is an element-cyclic share and the provers compiled into the library commit through gm_ck_*")
+    ap.add_argument("--block-sharded", action="store_true", help="--transport: the FIELD side block-sharded as well (gm_psnark_new_time_sharded): every vector "
+                    "of the prover in blocks of one size over the ranks, the key in per-level slices; any world size")
+    ap.add_argument("--tail-log", type=int, default=10, help="--block-sharded: blocks shorter than 2^k elements are gathered")
+    ap.add_argument("--random-r1cs", type=int, default=None, metavar="SEED", help="a satisfied random GENERAL R1CS (1-3 entries per row of A and B in random "
+                    "columns, C diagonal: tools/run_snark.py random_rows) instead of dummy_r1cs")
     ap.add_argument("--verifiable-key", action="store_true", help="one more power than examples/psnark.rs:76 asks for: the reference's "
                     "time-prover key (2n + 1 powers) is one short of the longest committed polynomial (2n + 2 coefficients), so the proof "
                     "of the example's configuration does not verify (tests/test_oracle_verifier.py::test_reference_example_key_is_one_power_short)")
@@ -65,11 +71,27 @@ def main():
     n = 1 << args.instance_logsize
     rng = np.random.default_rng(2022420)
     rnd = lambda: int.from_bytes(rng.bytes(40), "little") % gm.fr.R_MOD
-    r1cs = dummy_r1cs(rnd(), n)
+    e_inst = rnd()
+    if args.random_r1cs is not None:
+        from gemini_amd.circuit import R1cs, SparseMatrix
+        from gemini_amd.fr import FrVec
+        from run_snark import random_rows
+
+        ra, rb, rc, zh = random_rows(n, args.random_r1cs)
+        mats = [SparseMatrix.from_rows(rows, n) for rows in (ra, rb, rc)] + [SparseMatrix.from_rows(rows, n, transpose=True) for rows in (ra, rb, rc)]
+        r1cs = R1cs(*mats, FrVec.from_host(zh), FrVec.from_host(zh[1:]), FrVec.from_host(zh[:1]))
+    else:
+        r1cs = dummy_r1cs(e_inst, n)
     t0 = time.perf_counter()
     tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
     # examples/psnark.rs: time main num_constraints + num_variables powers (:76), elastic main 3 * instance_size + 1 (:62)
-    if lib_dist:
+    shard = None
+    if lib_dist and args.block_sharded:
+        from gemini_amd.sharded import PsnarkShard, PsnarkShardKey, psnark_new_time_sharded
+
+        shard = PsnarkShard(r1cs, tail_log=args.tail_log)
+        ck = PsnarkShardKey(3 * n if args.elastic else 2 * n + int(args.verifiable_key), shard.block, args.tail_log, tau)
+    elif lib_dist:
         from gemini_amd.sharded import cyclic_committer_key
 
         ck = cyclic_committer_key(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
@@ -81,7 +103,7 @@ def main():
         ck = CommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
-    index = Proof.index(ck, r1cs, native=True) if lib_dist else Proof.index(ck, r1cs)
+    index = shard.index(ck) if shard else Proof.index(ck, r1cs, native=True) if lib_dist else Proof.index(ck, r1cs)
     t_index = time.perf_counter() - t0
     out = {"logn": args.instance_logsize, "srs_s": round(t_srs, 3), "index_s": round(t_index, 3), "runs": []}
     stamps = []  # clock readings around every proof, for tools/exposed_time.py --stamps
@@ -90,7 +112,11 @@ def main():
     gm.capi.mem_reset_peak()  # the high-water marks below are those of the proofs, not of the key / index setup
     for _ in range(args.repeat):
         stamps.append({"t0": clocks()})
-        if args.elastic:
+        if shard:  # (the elastic prover's resident schedule is the same entry: time provers on the little-endian vectors)
+            proof = psnark_new_time_sharded(shard, ck, index)
+            if args.elastic:
+                proof.spans["ark_gemini::psnark::elastic_prover"] = proof.spans.pop("ark_gemini::psnark::time_prover")
+        elif args.elastic:
             from gemini_amd.circuit import R1csStream
             from gemini_amd.kzg import CommitterKeyStream
 
