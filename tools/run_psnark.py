@@ -85,22 +85,25 @@ def main():
     t0 = time.perf_counter()
     tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
     # examples/psnark.rs: time main num_constraints + num_variables powers (:76), elastic main 3 * instance_size + 1 (:62)
+    # examples/psnark.rs: time main num_constraints + num_variables powers (:76), elastic main 3 * instance_size + 1 (:62); a random
+    # general instance has up to 7 n joint non-zero entries and lookup vectors of nnz + n + 2 elements
+    max_degree = 10 * n if args.random_r1cs is not None else 3 * n if args.elastic else 2 * n + int(args.verifiable_key)
     shard = None
     if lib_dist and args.block_sharded:
         from gemini_amd.sharded import PsnarkShard, PsnarkShardKey, psnark_new_time_sharded
 
         shard = PsnarkShard(r1cs, tail_log=args.tail_log)
-        ck = PsnarkShardKey(3 * n if args.elastic else 2 * n + int(args.verifiable_key), shard.block, args.tail_log, tau)
+        ck = PsnarkShardKey(max_degree, shard.block, args.tail_log, tau)
     elif lib_dist:
         from gemini_amd.sharded import cyclic_committer_key
 
-        ck = cyclic_committer_key(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
+        ck = cyclic_committer_key(max_degree, 5, tau)
     elif world > 1:
         from gemini_amd.dist import ShardedCommitterKey
 
-        ck = ShardedCommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau, rank, world)
+        ck = ShardedCommitterKey.new(max_degree, 5, tau, rank, world)
     else:
-        ck = CommitterKey.new(3 * n if args.elastic else 2 * n + int(args.verifiable_key), 5, tau)
+        ck = CommitterKey.new(max_degree, 5, tau)
     t_srs = time.perf_counter() - t0
     t0 = time.perf_counter()
     index = shard.index(ck) if shard else Proof.index(ck, r1cs, native=True) if lib_dist else Proof.index(ck, r1cs)
