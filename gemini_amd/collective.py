@@ -11,7 +11,7 @@ import numpy as np
 
 from . import capi
 
-TRANSPORTS = {0: "none", 1: "hook", 2: "rccl", 3: "shm"}
+TRANSPORTS = {0: "none", 1: "hook", 2: "rccl", 3: "shm", 4: "failed"}
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 _keep = []  # callbacks handed to the library must outlive it
 

@@ -58,7 +58,9 @@ namespace {
 
 using Clock = std::chrono::steady_clock;
 
-enum Transport { T_NONE = 0, T_HOOK = 1, T_RCCL = 2, T_SHM = 3 };
+// T_FAILED: a collective of this communicator failed or timed out and the communicator was aborted.  rank / world keep their values, so
+// every later collective returns GM_ESTATE (instead of "succeeding" as the copy of a one-rank world) until gm_dist_finalize / a re-init
+enum Transport { T_NONE = 0, T_HOOK = 1, T_RCCL = 2, T_SHM = 3, T_FAILED = 4 };
 
 using GetUniqueId_t = ncclResult_t (*)(ncclUniqueId*);
 using CommInitRank_t = ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int);
@@ -155,6 +157,8 @@ int load_rccl(Rccl& R) {
     Dl_info info;
     if (dladdr(reinterpret_cast<void*>(&hipStreamSynchronize), &info) && info.dli_fname) {
       beside = info.dli_fname;
+      // (for a stand-in loaded through GM_RCCL_LIB that must call into THIS runtime: tests/fake_rccl)
+      setenv("GM_HIP_RUNTIME", info.dli_fname, 1);
       const size_t slash = beside.rfind('/');
       beside = slash == std::string::npos ? std::string() : beside.substr(0, slash) + "/librccl.so.1";
     }
@@ -317,6 +321,19 @@ void shm_detach(Dist& d, bool count = true) {
   d.shm_classes = 0;
 }
 
+// a failed / timed-out RCCL collective: abort the communicator (the peers return instead of hanging) and refuse everything after it
+void poison(Dist& d) {
+  if (d.comm && d.R.CommAbort) (void)d.R.CommAbort(d.comm);
+  else if (d.comm) (void)d.R.CommDestroy(d.comm);
+  d.comm = nullptr;
+  d.tr = T_FAILED;
+}
+#define GM_DIST_ALIVE(d)                                                                                                             \
+  GM_CHECK((d).tr != T_FAILED, GM_ESTATE, "gm_dist: an earlier collective of this communicator failed or timed out (rank %d of %d); " \
+                                          "gm_dist_finalize and initialise the transport again",                                        \
+           (d).rank, (d).world);                                                                                                       \
+  GM_CHECK((d).tr != T_NONE || (d).world == 1, GM_ESTATE, "gm_dist: %d ranks but no transport", (d).world)
+
 void reset(Dist& d) {
   if (d.comm) {
     (void)d.R.CommDestroy(d.comm);
@@ -350,11 +367,7 @@ int rccl_host_allgather(Dist& d, const void* send, size_t bytes, void* recv) {
   // a rank that fails here leaves its peers inside ncclAllGather: abort the communicator so that they return with an error
   // instead of hanging (the shm transport has a timeout of its own)
   auto fail = [&](int code) {
-    if (d.comm && d.R.CommAbort) {
-      (void)d.R.CommAbort(d.comm);
-      d.comm = nullptr;
-      d.tr = T_NONE;
-    }
+    poison(d);
     return code;
   };
   hipError_t e = hipMemcpyAsync(d.d_in, d.h_in, bytes, hipMemcpyHostToDevice, C->stream);
@@ -377,11 +390,13 @@ int rccl_host_allgather(Dist& d, const void* send, size_t bytes, void* recv) {
 }
 
 int allgather_host_locked(Dist& d, const void* send, size_t bytes, void* recv, int cls = GM_DIST_CLASS_FIELD, int force_route = -1) {
+  GM_DIST_ALIVE(d);
   if (bytes == 0) return GM_OK;
   const auto t0 = Clock::now();
   int rc = GM_OK;
   Route route = R_COPY;
   switch (d.tr) {
+    case T_FAILED:  // (refused above)
     case T_NONE:
       memcpy(recv, send, bytes);
       break;
@@ -781,6 +796,7 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
   std::lock_guard<std::mutex> lk(d.mu);
   GM_CTX();
   GM_FR_LOCK(C);
+  GM_DIST_ALIVE(d);
   gm::FrVec* in = gm::find_vec(local_vec);
   gm::FrVec* out = gm::find_vec(out_vec);
   GM_CHECK(in && out && in != out, GM_EHANDLE, "gm_dist_allgather_vec: unknown or aliased vector handle");
@@ -801,11 +817,7 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
       if (r != ncclSuccess) gm::set_error("gm_dist: ncclAllGather failed: %s", d.R.GetErrorString(r));
       if (late) gm::set_error("gm_dist: ncclAllGather of a vector did not complete in time: a peer never arrived");
       const int code = r != ncclSuccess ? GM_EHIP : (late ? GM_ESTATE : gm::hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
-      if (d.comm && d.R.CommAbort) {
-        (void)d.R.CommAbort(d.comm);
-        d.comm = nullptr;
-        d.tr = T_NONE;
-      }
+      poison(d);
       return code;
     }
   } else {
@@ -836,6 +848,7 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
   std::lock_guard<std::mutex> lk(d.mu);
   GM_CTX();
   GM_FR_LOCK(C);
+  GM_DIST_ALIVE(d);
   GM_CHECK((local_vecs && out_vecs) || k == 0, GM_EINVAL, "gm_dist_reblock_vecs: null pointer");
   GM_CHECK(new_block > 0, GM_EINVAL, "gm_dist_reblock_vecs: empty blocks");
   const size_t g = (size_t)d.world, r = (size_t)d.rank, B = new_block;
@@ -849,6 +862,18 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
     out[j]->len = len;
   }
   if (k == 0) return GM_OK;
+  if (g > 1) {
+    // the send / recv sizes below assume rank p's block of vector j has MY length: a shorter block somewhere means mismatched sizes
+    // (a hang or silent corruption).  One small all-gather of the k local lengths first
+    std::vector<uint64_t> mine(k), all(k * g);
+    for (size_t j = 0; j < k; j++) mine[j] = in[j]->len;
+    int rcl = allgather_host_locked(d, mine.data(), 8 * k, all.data());
+    if (rcl) return rcl;
+    for (size_t p = 0; p < g; p++)
+      for (size_t j = 0; j < k; j++)
+        GM_CHECK(all[p * k + j] == mine[j], GM_EINVAL, "gm_dist_reblock_vecs: rank %zu holds %llu elements of vector %zu, this rank %llu (equal blocks are required)", p,
+                 (unsigned long long)all[p * k + j], j, (unsigned long long)mine[j]);
+  }
   const auto t0 = Clock::now();
   size_t moved = 0;
   const bool p2p = d.tr == T_RCCL && d.R.Send && d.R.Recv && d.R.GroupStart && d.R.GroupEnd;
@@ -858,11 +883,7 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
     bool grouped = false;
     auto fail = [&](ncclResult_t res) {
       gm::set_error("gm_dist_reblock_vecs: RCCL point-to-point failed: %s", d.R.GetErrorString(res));
-      if (d.comm && d.R.CommAbort) {
-        (void)d.R.CommAbort(d.comm);
-        d.comm = nullptr;
-        d.tr = T_NONE;
-      }
+      poison(d);
       return GM_EHIP;
     };
     if (p2p && g > 1) {
@@ -878,7 +899,12 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
         if (lo < hi) {
           uint8_t* src = in[j]->d + (lo - r * b) * 32;
           if (p == r) {
-            GM_HIP(hipMemcpyAsync(out[j]->d + (lo - r * B) * 32, src, (hi - lo) * 32, hipMemcpyDeviceToDevice, C->stream));
+            const hipError_t ce = hipMemcpyAsync(out[j]->d + (lo - r * B) * 32, src, (hi - lo) * 32, hipMemcpyDeviceToDevice, C->stream);
+            if (ce != hipSuccess) {  // never leave a group open: the peers would wait out their timeout inside it
+              if (grouped) (void)d.R.GroupEnd();
+              if (g > 1) poison(d);
+              return gm::hip_fail(ce, "hipMemcpyAsync(re-block, own part)", __FILE__, __LINE__);
+            }
           } else {
             ncclResult_t res = d.R.Send(src, (hi - lo) * 32, ncclChar, (int)p, d.comm, C->stream);
             if (res != ncclSuccess) return fail(res);
@@ -902,11 +928,7 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
       const hipError_t e = stream_wait_bounded(C->stream, &late);
       if (late) {
         gm::set_error("gm_dist_reblock_vecs: the send / recv group did not complete in time: a peer never arrived");
-        if (d.comm && d.R.CommAbort) {
-          (void)d.R.CommAbort(d.comm);
-          d.comm = nullptr;
-          d.tr = T_NONE;
-        }
+        poison(d);
         return GM_ESTATE;
       }
       GM_HIP(e);

@@ -28,8 +28,9 @@ def _port():
     return p
 
 
-def _run(world, extra, tool="run_snark.py", logn=12, transport="shm"):
+def _run(world, extra, tool="run_snark.py", logn=12, transport="shm", env_extra=None):
     env = dict(os.environ, GM_BENCH_BACKEND="gloo", GM_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
     script = [os.path.join(ROOT, "tools", tool), "-i", str(logn), "--repeat", "1"] + list(extra)
     if world == 1 and transport is None:
         cmd = [sys.executable] + script
@@ -262,3 +263,77 @@ def test_block_sharded_psnark_elastic_and_verifiable_key():
     one = _single(["--verifiable-key"], tool="run_psnark.py", logn=10)
     many = _run(2, ["--verifiable-key", "--block-sharded", "--tail-log", "6"], tool="run_psnark.py", logn=10)
     assert many["proof_sha256"] == one["proof_sha256"]
+
+
+# ---- the N-rank RCCL branches of dist.cpp, through a TEST-ONLY stand-in for librccl (tests/fake_rccl) --------------------------------
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    """RCCL refuses two ranks on one device and no multi-GPU node is available: tests/fake_rccl/fake_rccl.cpp implements the entry points dist.cpp
+    binds (all-gather, grouped send / recv, abort) over shared memory and host-staged copies for processes sharing ONE GPU; GM_RCCL_LIB selects it"""
+    so = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp"), "-ldl", "-lrt", "-lpthread"])
+    return {"GM_RCCL_LIB": so, "GM_FAKE_RCCL_TIMEOUT_S": "120"}
+
+
+@pytest.mark.parametrize("world,transport", [(2, "rccl"), (8, "rccl-node")])
+def test_rccl_branches_with_n_ranks_snark(fake_rccl, world, transport):
+    """gm_snark_new_time_sharded over the RCCL transport with 2 and 8 ranks: ncclAllGather of host payloads (staged) and of device vectors (the gathered
+    level), the grouped ncclSend / ncclRecv of gm_dist_reblock_vecs; with rccl-node the field payloads take the side segment and the G1 points RCCL"""
+    one = _single()
+    many = _run(world, ["--block-sharded", "--tail-log", "5"], transport=transport, env_extra=fake_rccl)
+    assert many["transport"] == "rccl" and many["proof_sha256"] == one["proof_sha256"], (world, transport)
+
+
+@pytest.mark.parametrize("world,transport", [(2, "rccl-node"), (8, "rccl")])
+def test_rccl_branches_with_n_ranks_psnark(fake_rccl, world, transport):
+    """gm_psnark_new_time_sharded the same way (BASELINE configs[4] over the transport the driver's 8-GPU run will use)"""
+    one = _single(tool="run_psnark.py", logn=10)
+    many = _run(world, ["--block-sharded", "--tail-log", "4"], tool="run_psnark.py", logn=10, transport=transport, env_extra=fake_rccl)
+    assert many["transport"] == "rccl" and many["proof_sha256"] == one["proof_sha256"], (world, transport)
+
+
+RCCL_FAIL_WORKER = """
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import gemini_amd as gm
+from gemini_amd import collective
+from gemini_amd.fr import FrVec
+rank, world, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+gm.capi.init(0)
+collective.init_rccl_node(rank, world, name)
+pts = np.arange(18, dtype=np.uint64) + rank
+ok = collective.allgather_host(pts, collective.CLASS_G1)        # collective 1 of the communicator: fine
+assert (ok[:, 0] == np.arange(world)).all()
+codes = []
+for attempt in range(3):                                        # collective 2: rank 1 fails inside it (GM_FAKE_RCCL_FAIL_AT=1:2) and aborts the communicator
+    try:
+        collective.allgather_host(pts, collective.CLASS_G1)
+        codes.append("ok")
+    except Exception as e:
+        codes.append(str(e))
+assert codes[0] != "ok", codes                                   # every rank returns with an error instead of hanging ...
+assert all("earlier collective" in c for c in codes[1:]), codes  # ... and the transport stays refused (not a one-rank copy) until it is initialised again
+assert collective.info()[1:] == (world, "failed")
+v = FrVec.from_host(np.ones((8, 4), dtype=np.uint64))
+try:
+    collective.allgather_vec(v)
+    raise SystemExit("a device all-gather went through a failed transport")
+except RuntimeError:
+    pass
+collective.finalize()
+assert collective.info() == (0, 1, "none")
+print("ok", rank)
+""" % ROOT
+
+
+def test_rccl_failing_rank_aborts_and_poisons_the_transport(fake_rccl):
+    """after a failed RCCL collective the transport used to fall back to T_NONE with world = N -- later all-gathers "succeeded" as
+    copies of one payload.  Now: the failing rank aborts the communicator, its peer returns with an error, and every later collective is GM_ESTATE"""
+    name = f"/gm_rcclfail_{os.getpid()}"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GM_FAKE_RCCL_FAIL_AT="1:2", **fake_rccl)
+    env["GM_FAKE_RCCL_TIMEOUT_S"] = "20"
+    procs = [subprocess.Popen([sys.executable, "-c", RCCL_FAIL_WORKER, str(r), "2", name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]

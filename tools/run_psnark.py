@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--native", action="store_true", help="gm_psnark_new_time: the prover's orchestration compiled into the library (one call per proof)")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/psnark.rs elastic_snark_main) instead of --time-prover")
-    ap.add_argument("--transport", choices=["shm", "hook", "rccl"], default=None, help="N ranks through the collective layer inside the library "
+    ap.add_argument("--transport", choices=["shm", "hook", "rccl", "rccl-node"], default=None, help="N ranks through the collective layer inside the library "
                     "(gemini_amd/csrc/dist.cpp): the key is an element-cyclic share and the provers compiled into the library commit through gm_ck_*")
     ap.add_argument("--block-sharded", action="store_true", help="--transport: the FIELD side block-sharded as well (gm_psnark_new_time_sharded): every vector "
                     "of the prover in blocks of one size over the ranks, the key in per-level slices; any world size")
@@ -48,7 +48,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if os.environ.get("GM_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     lib_dist = args.transport is not None
-    if world > 1 and not (lib_dist and args.transport == "shm"):
+    if world > 1 and not (lib_dist and args.transport in ("shm", "rccl-node")):
         import torch
         import torch.distributed as dist
 
@@ -64,6 +64,8 @@ def main():
 
         if args.transport == "shm":
             collective.init_shm(rank, world, "/gm_run_psnark_%s" % os.environ.get("MASTER_PORT", "0"))
+        elif args.transport == "rccl-node":  # the library's own communicator, the id through a shm segment that stays open as the side channel (bench.py's path)
+            collective.init_rccl_node(rank, world, "/gm_run_psnark_node_%s" % os.environ.get("MASTER_PORT", "0"))
         elif world > 1:
             collective.init_hook_torch() if args.transport == "hook" else collective.init_rccl_from_torch()
         if world > 1:
@@ -155,7 +157,7 @@ def main():
         out["transport"] = collective.info()[2]
         out["collectives"] = collective.stats()
         collective.finalize()
-        if world > 1 and args.transport != "shm":
+        if world > 1 and args.transport not in ("shm", "rccl-node"):
             dist.destroy_process_group()
     elif world > 1:
         allt = [None] * world

@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--block-sharded", action="store_true", help="N ranks, field arithmetic sharded as well: every vector and the key in blocks "
                     "(gemini_amd/dist_prover.py); the world size must be a power of two")
     ap.add_argument("--tail-log", type=int, default=10, help="--block-sharded: blocks shorter than 2^k elements are gathered")
-    ap.add_argument("--transport", choices=["shm", "hook", "rccl"], default=None, help="N ranks through the collective layer INSIDE the library "
+    ap.add_argument("--transport", choices=["shm", "hook", "rccl", "rccl-node"], default=None, help="N ranks through the collective layer INSIDE the library "
                     "(gemini_amd/csrc/dist.cpp) and the provers compiled into it: shm = shared-memory segment (no torch.distributed at all), "
                     "hook = torch.distributed (gloo / nccl) behind gm_dist_init_hook, rccl = the library's own RCCL communicator.  Default sharding: "
                     "the element-cyclic key with the native prover (MSMs sharded); with --block-sharded: gm_snark_new_time_sharded")
@@ -74,7 +74,7 @@ def main():
     if os.environ.get("GM_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     lib_dist = args.transport is not None
-    if world > 1 and not (lib_dist and args.transport == "shm"):
+    if world > 1 and not (lib_dist and args.transport in ("shm", "rccl-node")):
         import torch
         import torch.distributed as dist
 
@@ -90,6 +90,8 @@ def main():
 
         if args.transport == "shm":
             collective.init_shm(rank, world, "/gm_run_snark_%s" % os.environ.get("MASTER_PORT", "0"))
+        elif args.transport == "rccl-node":  # the library's own communicator, the id through a shm segment that stays open as the side channel (bench.py's path)
+            collective.init_rccl_node(rank, world, "/gm_run_snark_node_%s" % os.environ.get("MASTER_PORT", "0"))
         elif args.transport == "hook":
             collective.init_hook_torch() if world > 1 else None
         else:
@@ -200,7 +202,7 @@ def main():
         out["transport"] = collective.info()[2]
         out["collectives"] = collective.stats()
         collective.finalize()
-        if world > 1 and args.transport != "shm":
+        if world > 1 and args.transport not in ("shm", "rccl-node"):
             dist.destroy_process_group()
     elif world > 1:
         import hashlib
