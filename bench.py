@@ -334,6 +334,72 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
     }
 
 
+def psnark_time_prover(gm, logn: int, world: int = 1, rank: int = 0) -> dict:
+    """BASELINE configs[4] (`examples/psnark --time-prover`, src/psnark/time_prover.rs:69-384) as a STRONG-scaling point: dummy_r1cs(2^logn) whole,
+    one GPU through gm_psnark_new_time, N GPUs through gm_psnark_new_time_sharded -- every vector of the prover and the key in blocks over the
+    ranks (gemini_amd/csrc/psnark_sharded.cpp), all-gathers inside the library.  Key of num_constraints + num_variables + 1 powers
+    (examples/psnark.rs:76).  Instance, index and SRS are built before the timer, as in the reference."""
+    import hashlib
+    import warnings
+
+    from gemini_amd import collective
+    from gemini_amd.circuit import dummy_r1cs
+
+    warnings.filterwarnings("ignore", message="commit: polynomial of", category=RuntimeWarning)  # the reference's key is one power short, knowingly
+    SPAN = "ark_gemini::psnark::time_prover"
+    n = 1 << logn
+    rng = np.random.default_rng(2022420)
+    rnd = lambda: int.from_bytes(rng.bytes(40), "little") % R_MOD  # noqa: E731
+    t0 = time.perf_counter()
+    r1cs = dummy_r1cs(rnd(), n)
+    tau_i = rnd()
+    tau = np.array([(tau_i >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+    shard = None
+    if world > 1:
+        from gemini_amd.sharded import PsnarkShard, PsnarkShardKey, psnark_new_time_sharded
+
+        shard = PsnarkShard(r1cs, tail_log=10)
+        ck = PsnarkShardKey(2 * n, shard.block, 10, tau)
+        index = shard.index(ck)
+        prove = lambda: psnark_new_time_sharded(shard, ck, index)  # noqa: E731
+    else:
+        from gemini_amd.kzg import CommitterKey
+        from gemini_amd.psnark import Proof
+
+        ck = CommitterKey.new(2 * n, 5, tau)
+        index = Proof.index(ck, r1cs)
+        prove = lambda: Proof.new_time(ck, r1cs, index, native=True)  # noqa: E731
+    t_setup = time.perf_counter() - t0
+    gm.capi.mem_reset_peak()
+    spans, proof = [], None
+    for i in range(4):  # one warm-up + 3
+        if world > 1:
+            collective.allgather_host(np.zeros(1, dtype=np.uint64))
+        proof = prove()
+        t = proof.spans[SPAN]
+        if world > 1:
+            t = float(collective.allgather_host(np.array([t], dtype=np.float64).view(np.uint64)).view(np.float64).max())  # the slowest rank
+        if i:
+            spans.append((t, dict(proof.spans)))
+    spans.sort(key=lambda x: x[0])
+    digest = hashlib.sha256(proof.serialize_compressed()).hexdigest()
+    mem = gm.capi.mem_stats()
+    out = {
+        "metric": "psnark time_prover", "unit": "s", "logn": logn, "n_gpus": world, "scaling": "strong", "value": round(spans[1][0], 4),
+        "runs_s": [round(t, 4) for t, _ in spans], "higher_is_better": False, "spans_s": {k: round(v, 4) for k, v in spans[1][1].items()},
+        "setup_s": round(t_setup, 2), "proof_sha256": digest, "peak_in_use_GB_rank0": round(mem["in_use_peak"] / 1e9, 2),
+        "driver": "gm_psnark_new_time (gemini_amd/csrc/psnark.cpp)" if world == 1 else
+                  f"gm_psnark_new_time_sharded (gemini_amd/csrc/psnark_sharded.cpp): blocks of {shard.block} elements over {world} ranks, the same proof bytes as one GPU "
+                  "(tests/test_gpu_dist_native.py)",
+    }
+    if world > 1:
+        out["collectives"] = dict(collective.stats(), routes=collective.stats_routes())
+        shard.free()
+        ck.free()
+    r1cs.free()
+    return out
+
+
 def main():
     # the CPU baselines' OpenMP workers sleep when idle instead of spinning: the container's CPU quota (16 of 256 hardware threads on
     # the pool's boxes) is shared with the host side of the device path that is timed next
@@ -352,12 +418,16 @@ def main():
     ap.add_argument("--cpu-snark-logn", type=int, default=20, help="instance size of the time_prover CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-snark-top", action="store_true", help="do not run the time_prover CPU baseline at --snark-logn itself (about a minute at 2^24), "
                     "only at --cpu-snark-logn and two powers above it")
+    ap.add_argument("--psnark-logn", type=int, default=22, help="also time psnark::Proof::new_time on dummy_r1cs(2^k): one GPU natively, N GPUs block-sharded (0 = skip)")
+    ap.add_argument("--strong-msm-logn", type=int, default=24, help="also time ONE MSM of 2^k pairs in total, split n / g over the ranks (strong scaling; 0 = skip)")
     ap.add_argument("--snark-logn", type=int, default=24, help="also time snark::Proof::new_time on dummy_r1cs(2^k) (N=1 only; 0 = skip)")
     args = ap.parse_args()
     if args.headline_only:
         args.no_cpu_baseline = True
         args.no_tables = True
         args.snark_logn = 0
+        args.psnark_logn = 0
+        args.strong_msm_logn = 0
 
     import torch
     import torch.distributed as dist
@@ -582,7 +652,7 @@ def main():
         big.free()
         del pb, ps, d_big
     stage_names = ["digits_hist", "scan", "scatter", "acc0", "merge", "reduce", "sc_round"]
-    # per CALL: a one-call MSM of >= 2^17 pairs runs as two window groups, so each stage is launched twice per step
+    # per STEP (= one one-call MSM: `launches_per_step` in the output says how many launches of each stage that is)
     steps_of = lambda i: args.steps if i == 3 else min(args.steps, 10)  # noqa: E731 -- k_acc0 live in the timed steps, the rest in the pass after
     stages = {k: (ms[i] / steps_of(i) if cnt[i] else None) for i, k in enumerate(stage_names)}
     launches = {k: (cnt[i] / steps_of(i) if cnt[i] else None) for i, k in enumerate(stage_names)}
@@ -617,6 +687,61 @@ def main():
             import traceback
 
             tp = {"metric": "snark time_prover", "error": repr(exc), "traceback": traceback.format_exc()[-1500:]}
+    second_metric_errors = {}
+    if isinstance(tp, dict) and "error" in tp:
+        second_metric_errors["time_prover"] = tp["error"]
+
+    def guarded(name, fn):
+        """a further metric of the N > 1 run must not take the headline with it -- but its failure is printed loudly and lands at the TOP level
+        of the JSON line ("second_metric_error"), not inside a nested record the driver would read as rc 0"""
+        try:
+            return fn()
+        except Exception as exc:  # noqa: BLE001
+            if world == 1:
+                raise
+            import traceback
+
+            sys.stderr.write(f"[bench rank {rank}] {name} FAILED: {exc!r}\n{traceback.format_exc()}\n")
+            second_metric_errors[name] = repr(exc)
+            return {"metric": name, "error": repr(exc), "traceback": traceback.format_exc()[-1500:]}
+
+    # STRONG scaling of the MSM (benches/msm_bench.rs:17-51 shape at a fixed size): ONE MSM of 2^k pairs in total, ceil(2^k / g) per rank, the
+    # partial points all-gathered (144 B) and added on every rank.  The weak-scaling headline above cannot say what N GPUs buy for one MSM
+    strong = None
+    if args.strong_msm_logn > 0:
+        def strong_msm():
+            total = 1 << args.strong_msm_logn
+            per = -(-total // world)
+            mine = max(min(per, total - rank * per), 0)
+            rng_s = np.random.default_rng(0x5354524F4E47 + rank)
+            sb = gm.G1Bases.fixed_base(g_aff, uniform_fr(rng_s, max(mine, 1)))
+            dsc = torch.from_numpy(uniform_fr(rng_s, max(mine, 1)).view(np.int64)).cuda()
+            torch.cuda.synchronize()
+
+            def one():
+                part = sb.msm_device(dsc.data_ptr(), mine, mont=False, partial=world > 1)
+                return part if world == 1 else g1_sum(collective.allgather_host(part, collective.CLASS_G1))
+
+            ref = one()
+            one()
+            barrier()
+            t1 = time.perf_counter()
+            k = 10
+            for _ in range(k):
+                r2 = one()
+                assert (r2 == ref).all(), "non-deterministic MSM result"
+            barrier()
+            dt = (time.perf_counter() - t1) / k
+            if world > 1:
+                dt = float(collective.allgather_host(np.array([dt], dtype=np.float64).view(np.uint64)).view(np.float64).max())
+            sb.free()
+            return {"metric": "G1 MSM, fixed total size", "scaling": "strong", "pairs_total": total, "pairs_per_gpu": per, "n_gpus": world, "ms_per_msm": round(dt * 1e3, 4),
+                    "Mscalar_per_s": round(total / dt / 1e6, 2), "note": "plain one-call MSM per rank (no tables), all-gather of 144-byte partial points inside the library"}
+
+        strong = guarded("strong_scaling_msm", strong_msm)
+    ptp = None
+    if args.psnark_logn > 0:
+        ptp = guarded("psnark_time_prover", lambda: psnark_time_prover(gm, args.psnark_logn, world=world, rank=rank))
     if rank == 0:
         pairs = world * n * args.steps
         value = pairs / elapsed / 1e6
@@ -716,6 +841,24 @@ def main():
                 "sample": f"one full 2^{args.logn} MSM of the benchmark inputs ({cpu_s:.2f} s; portable x86-64-v2 build {cpu_p:.2f} s), OpenMP one task per window",
                 "matches_gpu_result": bool(same),
             }
+            # BASELINE configs[0]: the shape of benches/msm_bench.rs:21-32 at 2^18 pairs -- the CPU restatement timed there too, and the device
+            # result on the same pairs equal to it
+            m18 = min(1 << 18, n)
+            with orc.native():
+                t1 = time.perf_counter()
+                exp18 = orc.msm_pippenger(hb[:m18], host_scalars[0][:m18], threads=0)
+                cpu18 = time.perf_counter() - t1
+            got18 = gm.VariableBaseMSM.msm_bigint(hb[:m18], host_scalars[0][:m18])
+            t1 = time.perf_counter()
+            for _ in range(5):
+                gm.VariableBaseMSM.msm_bigint(hb[:m18], host_scalars[0][:m18])
+            dev18 = (time.perf_counter() - t1) / 5
+            out["msm_bench_shape_2p18"] = {
+                "config": "BASELINE configs[0]: benches/msm_bench.rs 2^18 BLS12-381 G1 MSM (the reference's own CPU-runnable case)",
+                "cpu_restatement_ms": round(cpu18 * 1e3, 2), "cpu_Mscalar_per_s": round(m18 / cpu18 / 1e6, 4), "cores": cores,
+                "device_ms_host_buffers": round(dev18 * 1e3, 3), "device_note": "gm_g1_msm from HOST bases and scalars (upload included: the msm_bigint call shape)",
+                "matches_gpu_result": bool(orc.affine_to_ints(orc.g1_to_affine(exp18)) == orc.affine_to_ints(orc.g1_to_affine(got18))),
+            }
         if tables:
             out["with_fixed_base_tables"] = tables
         if batch:
@@ -724,6 +867,12 @@ def main():
             out["pcie_inclusive"] = pcie
         if tp is not None:
             out["time_prover"] = tp
+        if strong is not None:
+            out["strong_scaling_msm"] = strong
+        if ptp is not None:
+            out["psnark_time_prover"] = ptp
+        if second_metric_errors:
+            out["second_metric_error"] = second_metric_errors
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
