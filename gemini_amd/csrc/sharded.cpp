@@ -753,4 +753,24 @@ int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t c
   return GM_OK;
 }
 
+// snark::Proof::new_elastic (src/snark/elastic_prover.rs:174-266, examples/snark.rs:54-66: BASELINE configs[3], `snark -i 28` on 8 GPUs) with
+// every vector block-sharded.  On the device the elastic prover takes the RESIDENT schedule whenever min_device_chunk > 1 (gm_snark_new_elastic:
+// time provers on the little-endian vectors from the first round -- the same field elements as the space provers over the reversed streams,
+// sumcheck/tests.rs:42-87 -- and every stream MSM as ONE call: max_msm_buffer is advisory because everything is in HBM): that schedule over
+// blocks IS the block-sharded time prover, on the same blocks, so this entry validates the elastic arguments and runs it.  The LITERAL
+// schedule (min_device_chunk = 1: 2^20-pair flushes, space provers to SPACE_TIME_THRESHOLD) re-derives every message from whole streams
+// and stays single-GPU (gm_snark_new_elastic).  The key of examples/snark.rs:59-63 (DummyStreamer: copies of the generator) in slices is
+// gm_snark_shard_key_new with tau = 1.  Same proof bytes as gm_snark_new_elastic and gm_snark_new_time on the same instance and key
+// (src/snark/tests.rs:56), on every rank.
+int gm_snark_new_elastic_sharded(const gm_snark_shard* S, size_t max_msm_buffer, size_t min_device_chunk, int g1_encoding, size_t cap_rounds, gm_snark_proof* P) {
+  GM_CTX();
+  GM_CHECK(max_msm_buffer >= 1, GM_EINVAL, "snark_new_elastic_sharded: max_msm_buffer = 0");
+  GM_CHECK(min_device_chunk > 1, GM_EINVAL,
+           "snark_new_elastic_sharded: min_device_chunk = 1 selects the LITERAL elastic schedule (space provers over whole streams), which is single-GPU: "
+           "gm_snark_new_elastic; the block-sharded entry runs the resident schedule");
+  const int rc = gm_snark_new_time_sharded(S, g1_encoding, cap_rounds, P);
+  if (!rc) P->spans[0] = 0.0;  // as gm_snark_new_elastic: the matrix products belong to the construction of the streams
+  return rc;
+}
+
 }  // extern "C"

@@ -120,8 +120,9 @@ class R1csShard:
         self.w_block.free()
 
 
-def new_time_sharded(shard: R1csShard, key: ShardKey):
-    """gm_snark_new_time_sharded; the same `snark.Proof` on every rank"""
+def new_time_sharded(shard: R1csShard, key: ShardKey, elastic=None):
+    """gm_snark_new_time_sharded; the same `snark.Proof` on every rank.  elastic = (max_msm_buffer, min_device_chunk): gm_snark_new_elastic_sharded
+    (the resident schedule of the elastic prover over the same blocks)"""
     from .snark import _SPAN_NAMES, _GmSnarkProof, _unpack_native
     from .transcript import default_group_encoding
 
@@ -142,8 +143,14 @@ def new_time_sharded(shard: R1csShard, key: ShardKey):
     S.key_offsets = C.cast(key.offsets, C.POINTER(C.c_size_t))
     S.key_counts = C.cast(key.counts, C.POINTER(C.c_size_t))
     S.key_segments, S.n, S.tail_log = key.segments, shard.n, key.tail_log
-    capi.check(capi.load().gm_snark_new_time_sharded(C.byref(S), C.c_int(int(default_group_encoding())), C.c_size_t(cap), C.byref(P)))
-    return _unpack_native(P, m, fc, fe, _SPAN_NAMES)
+    if elastic is None:
+        capi.check(capi.load().gm_snark_new_time_sharded(C.byref(S), C.c_int(int(default_group_encoding())), C.c_size_t(cap), C.byref(P)))
+        return _unpack_native(P, m, fc, fe, _SPAN_NAMES)
+    capi.check(capi.load().gm_snark_new_elastic_sharded(C.byref(S), C.c_size_t(elastic[0]), C.c_size_t(elastic[1]), C.c_int(int(default_group_encoding())), C.c_size_t(cap),
+                                                        C.byref(P)))
+    proof = _unpack_native(P, m, fc, fe, _SPAN_NAMES)
+    proof.spans["ark_gemini::snark::elastic_prover"] = proof.spans.pop("ark_gemini::snark::time_prover")
+    return proof
 
 
 # ---- psnark::Proof::new_time with every vector block-sharded (gemini_amd/csrc/psnark_sharded.cpp) ---------------------------------

@@ -690,6 +690,12 @@ typedef struct gm_snark_shard {
 int gm_snark_shard_key_new(const uint64_t base_affine[12], const uint64_t tau[4], size_t n, size_t tail_log, uint64_t* key, size_t offsets[64],
                            size_t counts[64], size_t* segments);
 int gm_snark_new_time_sharded(const gm_snark_shard* shard, int g1_encoding, size_t cap_rounds, gm_snark_proof* proof);
+/* snark::Proof::new_elastic (src/snark/elastic_prover.rs:174-266; BASELINE configs[3]: `snark -i 28`, elastic, 8 GPUs) over the same blocks: the
+ * RESIDENT schedule of gm_snark_new_elastic (min_device_chunk > 1: time provers on the little-endian vectors, every stream MSM one call) over
+ * blocks is the block-sharded time prover.  min_device_chunk = 1 (the literal schedule) is refused: it is single-GPU.  The DummyStreamer key of
+ * examples/snark.rs:59-63 in slices: gm_snark_shard_key_new with tau = 1.  Same bytes as gm_snark_new_elastic / gm_snark_new_time. */
+int gm_snark_new_elastic_sharded(const gm_snark_shard* shard, size_t max_msm_buffer, size_t min_device_chunk, int g1_encoding, size_t cap_rounds,
+                                 gm_snark_proof* proof);
 
 /* psnark::Proof::new_time (src/psnark/time_prover.rs:69-384; the resident schedule of new_elastic, elastic_prover.rs:60-634, is the same
  * entry) with the FIELD ARITHMETIC block-sharded as well -- BASELINE configs[4] on N GPUs.  ONE block size for the whole proof

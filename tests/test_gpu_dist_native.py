@@ -337,3 +337,13 @@ def test_rccl_failing_rank_aborts_and_poisons_the_transport(fake_rccl):
     outs = [p.communicate(timeout=300) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_block_sharded_elastic_snark_dummy_srs(world):
+    """BASELINE configs[3] as written (examples/snark.rs:54-66: the ELASTIC prover on the DummyStreamer key, 8 GPUs): gm_snark_new_elastic_sharded --
+    the resident schedule of the elastic prover over blocks, the generator-copies key in slices -- == the single-GPU elastic prover on the same key"""
+    one = _single(["--dummy-srs", "--elastic"])
+    assert one["proof_sha256"] != _single(["--elastic"])["proof_sha256"]
+    many = _run(world, ["--dummy-srs", "--elastic", "--block-sharded", "--tail-log", "5"])
+    assert many["proof_sha256"] == one["proof_sha256"] and "elastic_prover_s" in many, world

@@ -125,7 +125,8 @@ def main():
     t0 = time.perf_counter()
     tau = np.array([(rnd() >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
     if args.block_sharded and lib_dist:
-        ck = ShardKey(n, args.tail_log, tau)
+        # --dummy-srs: the DummyStreamer key of examples/snark.rs:59-63 (copies of the generator) in slices = powers of tau = 1
+        ck = ShardKey(n, args.tail_log, np.array([1, 0, 0, 0], dtype=np.uint64) if args.dummy_srs else tau)
     elif lib_dist:
         from gemini_amd.sharded import cyclic_committer_key
 
@@ -163,7 +164,10 @@ def main():
         elif world > 1:
             dist.barrier()
         stamps.append({"t0": clocks()})
-        if args.elastic:
+        if args.elastic and args.block_sharded and lib_dist:
+            # BASELINE configs[3]: the elastic prover's resident schedule over blocks (gm_snark_new_elastic_sharded)
+            proof = new_time_sharded(r1cs, ck, elastic=(1 << args.max_msm_buffer_log, 1 << (26 if args.min_device_chunk_log is None else args.min_device_chunk_log)))
+        elif args.elastic:
             from gemini_amd.circuit import R1csStream
             from gemini_amd.kzg import CommitterKeyStream
 
