@@ -199,9 +199,9 @@ class PsnarkShardKey:
 
 
 class PsnarkShard:
-    """this rank's blocks of a psnark instance: rows [r B, (r + 1) B) of A, B, C (global columns), z whole, the blocks of w and of the
-    joint-matrix vectors (src/misc.rs:269-366) and extended frequencies (plookup/time_prover.rs:66-79).  Built from a whole `R1cs`
-    (every rank walks the same host arrays and keeps its slice)."""
+    """this rank's blocks of a psnark instance: its row block of A, B, C (global columns), z whole, the blocks of w and of the joint-matrix
+    vectors (src/misc.rs:269-366) and extended frequencies (plookup/time_prover.rs:66-79), each family cut at ITS level (blocks of
+    block >> level: gm_psnark_shard_level).  Built from a whole `R1cs` (every rank walks the same host arrays and keeps its slice)."""
 
     def __init__(self, r1cs, tail_log: int = 10, block: int = None):
         from .circuit import SparseMatrix
@@ -217,7 +217,17 @@ class PsnarkShard:
         self.longest = max(len(ext_row) + 2, len(ext_col) + 2, nz + 2, nrows + 2, nnz + 1)
         self.block = block or psnark_shard_block(self.longest, world)
         self.tail_log = tail_log
-        lo, hi = rank * self.block, (rank + 1) * self.block
+        lib = capi.load()
+        lib.gm_psnark_shard_level.restype = C.c_size_t
+        self.levels = {}  # whole length of a family -> its level
+
+        def cut(length: int):
+            """[lo, hi) of this rank's block of a family whose longest member has `length` elements (gm_psnark_shard_level)"""
+            s = int(lib.gm_psnark_shard_level(C.c_size_t(length), C.c_size_t(self.block), C.c_size_t(tail_log), C.c_int(world)))
+            self.levels[length] = s
+            b = self.block >> s
+            return rank * b, (rank + 1) * b
+
         self.num_constraints, self.num_variables, self.nnz = nrows, nz, nnz
         self.ext_row_len, self.ext_col_len, self.w_len = len(ext_row), len(ext_col), len(r1cs.w)
         self.z = r1cs.z
@@ -229,6 +239,7 @@ class PsnarkShard:
 
         built = {}
         self.mats = []
+        lo, hi = cut(nrows)
         for m in (r1cs.a, r1cs.b, r1cs.c):
             if id(m) not in built:
                 rowptr, cols, vals = m.csr
@@ -239,13 +250,22 @@ class PsnarkShard:
                 else:
                     built[id(m)] = None
             self.mats.append(built[id(m)])
-        idx = lambda arr: keep(IdxVec.from_host(arr[lo:hi])) if len(arr[lo:hi]) else None  # noqa: E731
-        vec = lambda arr: keep(FrVec.from_host(np.ascontiguousarray(arr[lo:hi]))) if len(arr[lo:hi]) else None  # noqa: E731
-        self.row_index, self.col_index = idx(row_index), idx(col_index)
+
+        def idx(arr, rng):
+            part = arr[rng[0]:rng[1]]
+            return keep(IdxVec.from_host(part)) if len(part) else None
+
+        def vec(arr, rng):
+            part = arr[rng[0]:rng[1]]
+            return keep(FrVec.from_host(np.ascontiguousarray(part))) if len(part) else None
+
+        c_n = cut(nnz + 1)
+        self.row_index, self.col_index = idx(row_index, c_n), idx(col_index, c_n)
         self.row = keep(_field_of_index(self.row_index)) if self.row_index else None
         self.col = keep(_field_of_index(self.col_index)) if self.col_index else None
-        self.val_a, self.val_b, self.val_c = vec(val_a), vec(val_b), vec(val_c)
-        self.ext_fre_row, self.ext_fre_col = idx(ext_row), idx(ext_col)
+        self.val_a, self.val_b, self.val_c = vec(val_a, c_n), vec(val_b, c_n), vec(val_c, c_n)
+        self.ext_fre_row, self.ext_fre_col = idx(ext_row, cut(len(ext_row) + 2)), idx(ext_col, cut(len(ext_col) + 2))
+        lo, hi = cut(self.w_len)
         w_cnt = max(min(hi, self.w_len) - lo, 0)
         self.w_block = None
         if w_cnt:

@@ -698,9 +698,10 @@ int gm_snark_new_elastic_sharded(const gm_snark_shard* shard, size_t max_msm_buf
                                  gm_snark_proof* proof);
 
 /* psnark::Proof::new_time (src/psnark/time_prover.rs:69-384; the resident schedule of new_elastic, elastic_prover.rs:60-634, is the same
- * entry) with the FIELD ARITHMETIC block-sharded as well -- BASELINE configs[4] on N GPUs.  ONE block size for the whole proof
- * (gm_psnark_shard_block(longest vector, world); any world, no power-of-two requirement): rank r of g holds the elements [r B, (r + 1) B)
- * THAT EXIST of every vector (a block may be partial or empty: handle 0 or a vector of length 0).
+ * entry) with the FIELD ARITHMETIC block-sharded as well -- BASELINE configs[4] on N GPUs.  One block size B for the proof
+ * (gm_psnark_shard_block(longest vector, world); any world, no power-of-two requirement) and a level per family of vectors
+ * (gm_psnark_shard_level, below): rank r of g holds the elements [r (B >> s), (r + 1) (B >> s)) THAT EXIST of a vector of level s (a block may
+ * be partial or empty: handle 0 or a vector of length 0).
  *   a, b, c        the row blocks of A, B, C with GLOBAL column indices (gm_spm handles; 0 when no row falls into the block)
  *   z              the WHOLE z on every rank (the lookups of z* and the matrix products read arbitrary entries)
  *   w_block        this rank's block of w, w_len its whole length
@@ -736,6 +737,15 @@ typedef struct gm_psnark_shard {
   size_t ck_g2_len;
 } gm_psnark_shard;
 size_t gm_psnark_shard_block(size_t longest, int world);
+/* LEVELS.  The prover's vectors come in several lengths (dummy_r1cs: ~n and ~2 n; a general instance: n, nnz ~ 6 n, n + nnz): with one block size
+ * the short ones would sit on the lower ranks only.  A FAMILY of vectors whose longest member has `len` elements lives in blocks of
+ * block >> level, level = the largest one (up to the number of folding levels that stay sharded) whose `world` blocks still hold it: every rank
+ * holds ~1 / world of every vector.  The caller cuts its inputs accordingly:
+ *   a, b, c          level(num_constraints)        w_block                     level(w_len)
+ *   row_index, col_index, row, col, val_a, val_b, val_c                        level(nnz + 1)
+ *   ext_fre_row      level(ext_fre_row_len + 2)    ext_fre_col                 level(ext_fre_col_len + 2)
+ * (a vector of level s is cut at multiples of block >> s).  Combinations across levels are re-blocked inside the prover. */
+size_t gm_psnark_shard_level(size_t len, size_t block, size_t tail_log, int world);
 int gm_psnark_shard_key_new(const uint64_t base_affine[12], const uint64_t tau[4], size_t n_key, size_t block, size_t tail_log, uint64_t* key,
                             size_t offsets[64], size_t counts[64], size_t* segments);
 int gm_psnark_index_sharded(const gm_psnark_shard* shard, uint64_t* out_jac);

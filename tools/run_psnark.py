@@ -147,6 +147,8 @@ def main():
     import hashlib
 
     out["n_gpus"] = world
+    if shard:
+        out["layout"] = {"block": shard.block, "tail_log": shard.tail_log, "levels_by_family_length": {str(k): v for k, v in sorted(shard.levels.items())}}
     out["proof_sha256"] = hashlib.sha256(proof.serialize_compressed()).hexdigest()
     if lib_dist:
         tkey = "elastic_prover_s" if args.elastic else "time_prover_s"
