@@ -805,7 +805,7 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
   out->len = n * (size_t)d.world;
   if (n == 0) return GM_OK;
   const auto t0 = Clock::now();
-  if (d.tr == T_NONE) {
+  if (d.tr == T_NONE || (d.world == 1 && d.tr != T_RCCL)) {
     GM_HIP(hipMemcpyAsync(out->d, in->d, bytes, hipMemcpyDeviceToDevice, C->stream));
     GM_HIP(hipStreamSynchronize(C->stream));
   } else if (d.tr == T_RCCL) {
@@ -832,7 +832,7 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
     GM_HIP(hipMemcpyAsync(out->d, h_out.data(), h_out.size(), hipMemcpyHostToDevice, C->stream));
     GM_HIP(hipStreamSynchronize(C->stream));
   }
-  d.note(d.tr == T_NONE ? R_COPY : d.tr == T_RCCL ? R_RCCL_VEC : d.tr == T_HOOK ? R_HOOK : R_SHM, bytes * (size_t)d.world,
+  d.note(d.tr == T_NONE || (d.world == 1 && d.tr != T_RCCL) ? R_COPY : d.tr == T_RCCL ? R_RCCL_VEC : d.tr == T_HOOK ? R_HOOK : R_SHM, bytes * (size_t)d.world,
          std::chrono::duration<double>(Clock::now() - t0).count());
   return GM_OK;
 }
@@ -878,7 +878,7 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
   size_t moved = 0;
   const bool p2p = d.tr == T_RCCL && d.R.Send && d.R.Recv && d.R.GroupStart && d.R.GroupEnd;
   Route route = R_COPY;
-  if (d.tr == T_NONE || p2p) {
+  if (d.tr == T_NONE || g == 1 || p2p) {  // (one rank: device copies whatever the transport -- nothing to stage through the host)
     route = p2p ? R_RCCL_VEC : R_COPY;
     bool grouped = false;
     auto fail = [&](ncclResult_t res) {

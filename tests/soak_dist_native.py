@@ -1,6 +1,7 @@
 """Sweep of the N-GPU provers compiled into the library (gemini_amd/csrc/sharded.cpp over dist.cpp): instance sizes, world sizes,
 tail lengths, transports (shm / gloo hook), the block-diagonal and the general-matrix form of the dummy instance, random general
-R1CS instances, and the cyclic-key native provers (snark time / elastic, psnark time / elastic) -- every configuration compared
+R1CS instances, the cyclic-key native provers (snark time / elastic, psnark time / elastic), and the block-sharded psnark (any world
+size 1 .. 9, dummy / random general instances, the three key shapes; SOAK_ONLY=psnark: only those) -- every configuration compared
 with the single-GPU proof of the same instance through its SHA-256.  NOT collected by default (the file name); all ranks share
 the one GPU of the test box:
 
@@ -29,10 +30,26 @@ def test_soak_dist_native():
             single[key] = _run(1, extra, tool, logn, transport=None)["proof_sha256"]
         return single[key]
 
+    only_psnark = os.environ.get("SOAK_ONLY", "") == "psnark"
     while time.time() < t_end:
-        kind = int(rng.integers(0, 10))
+        kind = int(rng.integers(10, 16)) if only_psnark else int(rng.integers(0, 16))
         transport = "hook" if rng.integers(0, 4) == 0 else "shm"
-        if kind < 5:  # block-sharded, dummy instance (local or global columns)
+        if kind >= 10:  # block-sharded psnark (gm_psnark_new_time_sharded): ANY world size, dummy or random general instance, time or elastic key
+            logn = int(rng.integers(3, 13))
+            world = int(rng.integers(1, 10))
+            tail_log = int(rng.integers(2, 9))
+            extra = []
+            if kind >= 13:
+                logn = min(logn, 9)
+                extra += ["--random-r1cs", str(int(rng.integers(1, 1 << 30)))]
+            elif rng.integers(0, 3) == 0:
+                extra += ["--elastic"]
+            elif rng.integers(0, 3) == 0:
+                extra += ["--verifiable-key"]
+            want = one(("psnark", logn, tuple(extra)), extra, "run_psnark.py", logn)
+            cfg = {"kind": "psnark block", "logn": logn, "world": world, "tail_log": tail_log, "extra": extra, "transport": transport}
+            got = _run(world, extra + ["--block-sharded", "--tail-log", str(tail_log)], "run_psnark.py", logn, transport=transport)["proof_sha256"]
+        elif kind < 5:  # block-sharded, dummy instance (local or global columns)
             logn = int(rng.integers(8, 18))
             world = int([1, 2, 4, 8, 16][int(rng.integers(0, 5))])
             m_log = logn - world.bit_length() + 1
