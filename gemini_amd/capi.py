@@ -27,7 +27,7 @@ SYMBOLS = [
     "gm_g1_fixed_base_register", "gm_g1_srs_register", "gm_g1_srs_register_segments", "gm_set_msm_window", "gm_set_msm_table_min", "gm_set_msm_affine_levels", "gm_set_msm_split", "gm_set_msm_glv", "gm_prof_enable", "gm_prof_read", "gm_prof_read_clock",
     "gm_idx_register", "gm_idx_free", "gm_fr_gather", "gm_fr_alg_hash", "gm_fr_plookup_set", "gm_fr_add_scalar", "gm_fr_shift_monic",
     "gm_fr_acc_product", "gm_fr_tensor_range", "gm_fr_powers_range", "gm_fr_plookup_set_block", "gm_fr_shift_block", "gm_fr_product", "gm_fr_acc_product_block",
-    "gm_sc_set_shard_rounds", "gm_psnark_shard_block", "gm_psnark_shard_level", "gm_psnark_shard_key_new", "gm_psnark_index_sharded", "gm_psnark_new_time_sharded", "gm_snark_new_elastic_sharded",
+    "gm_sc_set_shard_rounds", "gm_psnark_shard_block", "gm_psnark_shard_level", "gm_psnark_shard_footprint", "gm_psnark_shard_key_new", "gm_psnark_index_sharded", "gm_psnark_new_time_sharded", "gm_snark_new_elastic_sharded",
     "gm_fr_vec_alloc", "gm_fr_vec_free", "gm_fr_vec_len", "gm_fr_vec_upload", "gm_fr_vec_download",
     "gm_fr_vec_fill", "gm_fr_vec_ptr", "gm_fr_vec_set_len",
     "gm_fr_reverse", "gm_fr_stride", "gm_fr_fold", "gm_fr_fold_chain", "gm_fr_powers", "gm_fr_tensor", "gm_fr_hadamard", "gm_fr_ip", "gm_fr_eval_le", "gm_fr_eval_le_batch",
@@ -132,6 +132,14 @@ def psnark_footprint(ck_handle: int, num_variables: int, nnz: int, elastic: int 
     """elastic: 0 time prover, 1 elastic prover in the resident schedule, 2 literal (min_device_chunk = 1)"""
     out = np.zeros(4, dtype=np.uint64)
     check(load().gm_psnark_footprint(C.c_uint64(ck_handle), C.c_size_t(num_variables), C.c_size_t(nnz), C.c_int(int(elastic)), ptr(out)))
+    return {k: int(v) for k, v in zip(FOOTPRINT_FIELDS, out)}
+
+
+def psnark_shard_footprint(key_handle: int, num_constraints: int, num_variables: int, nnz: int, block: int, world: int) -> dict:
+    """one rank of gm_psnark_new_time_sharded (z and the instance's blocks are the caller's)"""
+    out = np.zeros(4, dtype=np.uint64)
+    check(load().gm_psnark_shard_footprint(C.c_uint64(key_handle), C.c_size_t(num_constraints), C.c_size_t(num_variables), C.c_size_t(nnz), C.c_size_t(block),
+                                           C.c_int(world), C.c_int(0), ptr(out)))
     return {k: int(v) for k, v in zip(FOOTPRINT_FIELDS, out)}
 
 

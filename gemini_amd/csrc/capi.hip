@@ -637,6 +637,23 @@ Footprint fp_psnark(gm::Context* C, const gm::Bases* ck, size_t nz, size_t nnz, 
   f.workspaces = fp_workspaces(C, ck, longest, longest);
   return f;
 }
+// gm_psnark_new_time_sharded on `world` ranks with block size `block`: every vector of the resident schedule above in blocks (a family's block is
+// block >> level >= its length / world, within 1 / 32 of it: the rounding of gm_psnark_shard_block), plus what every rank holds WHOLE --
+// tensor(rho), powers(alpha) (2 nt) and one hashed set at a time (max(nt, nz)); z is the caller's -- plus the temporaries of the cross-level
+// combinations (per-level partial sums and their re-blocked copies: <= 4 coarsest blocks)
+Footprint fp_psnark_shard(gm::Context* C, const gm::Bases* key, size_t nrows, size_t nz, size_t nnz, size_t block, size_t world) {
+  const size_t nt = next_pow2(nrows);
+  const size_t sum_l = 2 * ((nt + 2) + (nnz + 1) + (nt + nnz + 2)) + ((nz + 2) + (nnz + 1) + (nz + nnz + 2));
+  const size_t sorted = 2 * (nt + nnz) + (nz + nnz);
+  const size_t whole = 4 * nnz + sorted + 2 * sum_l + 3 * nnz + (3 * (2 * sum_l) + 3 * (8 * nnz)) / 4 + 5 * nnz + nz + 16;  // (+ the instance's own blocks: 5 nnz + w)
+  const size_t g = world ? world : 1;
+  size_t elems = (whole + g - 1) / g;
+  elems += elems / 32 + 2 * nt + std::max(nt, nz) + 4 * block;
+  Footprint f;
+  f.vectors = fp_vectors_bytes(elems);
+  f.workspaces = fp_workspaces(C, key, block, block);
+  return f;
+}
 // Is there room?  Freed pool blocks are given back on demand (dev_malloc); if that is not enough the PREFIX tables go now, before
 // the proof starts, instead of by reflex after an allocation has failed half-way; if it still does not fit: GM_ENOMEM with the numbers.
 int fp_fill_and_admit(gm::Context* C, const Footprint& f, uint64_t out[4], bool admit, const char* what) {
@@ -682,6 +699,14 @@ int gm_psnark_footprint(uint64_t ck_bases, size_t num_variables, size_t nnz, int
   const Bases* ck = find_bases(ck_bases);
   GM_CHECK(ck != nullptr && out != nullptr, GM_EHANDLE, "gm_psnark_footprint: unknown key handle or null output");
   return fp_fill_and_admit(C, fp_psnark(C, ck, num_variables, nnz, elastic), out, false, "gm_psnark_footprint");
+}
+int gm_psnark_shard_footprint(uint64_t key, size_t num_constraints, size_t num_variables, size_t nnz, size_t block, int world, int admit, uint64_t out[4]) {
+  GM_CTX();
+  const Bases* ck = find_bases(key);
+  GM_CHECK(ck != nullptr && (out != nullptr || admit), GM_EHANDLE, "gm_psnark_shard_footprint: unknown key handle or null output");
+  static const bool off = getenv("GM_FOOTPRINT_CHECK") && atoi(getenv("GM_FOOTPRINT_CHECK")) == 0;
+  return fp_fill_and_admit(C, fp_psnark_shard(C, ck, num_constraints, num_variables, nnz, block, world > 0 ? (size_t)world : 1), out, admit && !off,
+                           "block-sharded psnark prover");
 }
 // called by the provers compiled into the library before their first allocation
 int gm_footprint_admit(int psnark, uint64_t ck_bases, size_t n, size_t nnz, int elastic) {

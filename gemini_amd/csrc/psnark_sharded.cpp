@@ -702,6 +702,8 @@ int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t
     const size_t longest = std::max({S->ext_fre_row_len + 2, S->ext_fre_col_len + 2, nz + 2, nrows + 2, nnz + 1});
     GM_CHECK(longest <= g * M, GM_EINVAL, "psnark_new_time_sharded: %zu blocks of %zu elements do not hold the longest vector (%zu)", g, M, longest);
   }
+  // room for this rank's share of the proof, or GM_ENOMEM with the numbers, before the first allocation
+  RC(gm_psnark_shard_footprint(S->key, nrows, nz, nnz, M, (int)g, 1, nullptr));
   uint64_t one[4];
   Fr::one().to_limbs(one);
   // the blocks the caller hands in tile their vectors at the levels of their families

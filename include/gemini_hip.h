@@ -749,6 +749,10 @@ size_t gm_psnark_shard_level(size_t len, size_t block, size_t tail_log, int worl
 int gm_psnark_shard_key_new(const uint64_t base_affine[12], const uint64_t tau[4], size_t n_key, size_t block, size_t tail_log, uint64_t* key,
                             size_t offsets[64], size_t counts[64], size_t* segments);
 int gm_psnark_index_sharded(const gm_psnark_shard* shard, uint64_t* out_jac);
+/* The footprint contract (gm_psnark_footprint) of ONE RANK of the block-sharded prover: out = {vectors and prover buffers, MSM workspaces still
+ * to grow, needed, what can be had}, bytes.  admit != 0: also make room (prefix tables are given back) or fail with GM_ENOMEM and the numbers --
+ * what gm_psnark_new_time_sharded does before its first allocation.  z (whole on every rank) and the instance's blocks are the caller's. */
+int gm_psnark_shard_footprint(uint64_t key, size_t num_constraints, size_t num_variables, size_t nnz, size_t block, int world, int admit, uint64_t out[4]);
 int gm_psnark_new_time_sharded(const gm_psnark_shard* shard, int g1_encoding, size_t cap_rounds, gm_psnark_proof* proof);
 
 #ifdef __cplusplus

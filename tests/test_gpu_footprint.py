@@ -177,3 +177,32 @@ def test_prefix_tables_go_before_the_proof_not_half_way(gm, oracle):
     assert snark.Proof.new_time(r1cs, ck, native=True).serialize_compressed() == want
     r1cs.free()
     ck.powers_of_g.free()
+
+
+@pytest.mark.parametrize("logn", [12, 17])
+def test_block_sharded_psnark_promised_vs_used(gm, oracle, logn):
+    """one rank of gm_psnark_new_time_sharded (world 1: the rank's share is the whole proof, levels and re-blocking included): promised >= used,
+    and the figure for 8 ranks of 2^26 constraints -- BASELINE configs[4] -- stays under 48 GB with the MSM workspaces"""
+    from gemini_amd import collective
+    from gemini_amd.circuit import dummy_r1cs
+    from gemini_amd.sharded import PsnarkShard, PsnarkShardKey, psnark_new_time_sharded, psnark_shard_block
+
+    n = 1 << logn
+    collective.finalize()
+    r1cs = dummy_r1cs(oracle.limbs_to_ints(oracle.random_fr(9500 + logn, 1))[0], n)
+    shard = PsnarkShard(r1cs, tail_log=8)
+    key = PsnarkShardKey(2 * n, shard.block, 8, _tau(oracle, 9600 + logn))
+    index = shard.index(key)
+    promised = gm.capi.psnark_shard_footprint(key.bases.handle, n, n, n, shard.block, 1)
+    assert promised["needed"] == promised["vectors"] + promised["workspaces_to_grow"] and promised["available"] > promised["needed"]
+    _, used, ws_grown = _measure(gm, lambda: psnark_new_time_sharded(shard, key, index))
+    assert used <= promised["needed"], (used / GB, {k: v / GB for k, v in promised.items()})
+    assert ws_grown <= promised["workspaces_to_grow"]
+    assert promised["vectors"] <= 1.6 * (used - ws_grown) + 0.6 * GB, (promised["vectors"] / GB, (used - ws_grown) / GB)
+    big = 1 << 26
+    blk = psnark_shard_block(2 * big + 2, 8)
+    at8 = gm.capi.psnark_shard_footprint(key.bases.handle, big, big, big, blk, 8)
+    assert at8["vectors"] < 40 * GB, at8
+    shard.free()
+    key.free()
+    r1cs.free()
