@@ -267,6 +267,7 @@ void sc_destroy(Sumcheck* S);
 int sc_round(Context* C, Sumcheck* S, const uint64_t* challenge, uint64_t a[4], uint64_t b[4], int* has_msg);
 int sc_round_begin(Context* C, Sumcheck* S, const uint64_t* challenge, int* has_msg);
 int sc_round_end(Context* C, Sumcheck* S, uint64_t a[4], uint64_t b[4]);
+int sc_round_begin_many(Context* C, Sumcheck** S, size_t k, const uint64_t* challenge, int* has_msg);
 int sc_fold(Context* C, Sumcheck* S, const uint64_t challenge[4]);
 int sc_final(Context* C, Sumcheck* S, uint64_t f0[4], uint64_t g0[4], int* has);
 int sp_create(Context* C, const void* f_stream, size_t nf, const void* g_stream, size_t ng, bool src_is_device,
@@ -1562,6 +1563,16 @@ int gm_sc_round_begin(uint64_t handle, const uint64_t* challenge_or_null, int* h
   GM_CHECK(S != nullptr, GM_EHANDLE, "sc_round_begin: unknown prover handle %llu", (unsigned long long)handle);
   GM_CHECK(has_msg != nullptr, GM_EINVAL, "sc_round_begin: null pointer");
   return sc_round_begin(C, S, challenge_or_null, has_msg);
+}
+int gm_sc_round_begin_many(const uint64_t* handles, size_t k, const uint64_t* challenge_or_null, int* has_msg) {
+  GM_CTX();
+  GM_CHECK((handles && has_msg) || k == 0, GM_EINVAL, "sc_round_begin_many: null pointer");
+  std::vector<Sumcheck*> S(k);
+  for (size_t j = 0; j < k; j++) {
+    S[j] = find_prover(handles[j]);
+    GM_CHECK(S[j] != nullptr, GM_EHANDLE, "sc_round_begin_many: unknown prover handle %llu", (unsigned long long)handles[j]);
+  }
+  return k ? sc_round_begin_many(C, S.data(), k, challenge_or_null, has_msg) : GM_OK;
 }
 int gm_sc_round_end(uint64_t handle, uint64_t a_mont[4], uint64_t b_mont[4]) {
   GM_CTX();

@@ -96,8 +96,8 @@ struct ScArgs {
 // multiplication, 80 multiply-adds instead of 137) in 17-limb accumulators and are Montgomery-reduced ONCE per thread (r^2 =
 // 0.205 x 2^512: the seventeenth limb holds what 512 bits cannot).  The reference does the same on the CPU (`ip_unsafe`,
 // src/misc.rs:235-266).
-template <bool FOLD, bool MSG, bool LAZY = false>
-__global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict__ partials) {
+template <bool FOLD, bool MSG, bool LAZY>
+GM_DEV void sc_round_body(const ScArgs& A, uint8_t* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
   const size_t T = (size_t)1 << A.log_threads;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,6 +170,24 @@ __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict_
       fp_store<FrParams>(partials + ((size_t)blockIdx.x * 2 + 1) * FR_BYTES, b);
     }
   }
+}
+template <bool FOLD, bool MSG, bool LAZY = false>
+__global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict__ partials) {
+  sc_round_body<FOLD, MSG, LAZY>(A, partials);
+}
+// The round of SEVERAL provers in one launch (Sumcheck::prove_batch maps its provers over rayon, proof.rs:85; the third sumcheck of psnark
+// has 13 of them, each a launch of its own until round 5 -- ~240 launches per proof whose tails are launch latency): blockIdx.y = prover,
+// its descriptor (the arguments of k_sc_round, where its partial sums go, how many blocks it wants) in device memory
+struct ScMultiDesc {
+  ScArgs A;
+  uint8_t* partials;
+  uint32_t blocks, pad;
+};
+template <bool FOLD, bool MSG, bool LAZY = false>
+__global__ __launch_bounds__(256) void k_sc_round_multi(const ScMultiDesc* __restrict__ descs) {
+  const ScMultiDesc& D = descs[blockIdx.y];
+  if (blockIdx.x >= D.blocks) return;
+  sc_round_body<FOLD, MSG, LAZY>(D.A, D.partials);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -681,8 +699,8 @@ static unsigned grid_for(size_t n, unsigned max_blocks = 2048) {
 // A round is an enqueue (the kernel and the asynchronous copy of its per-block partial sums) and a collect (after the
 // stream has been waited for: the host adds the partials).  Driven one prover at a time the two run back to back
 // (sc_launch); Sumcheck::prove_batch enqueues the round of EVERY prover before it waits once (sc_round_begin / _end).
-static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho) {
-  ScArgs A;
+// sc_prepare: the arguments of the launch (and the prover's buffers it needs); sc_after: the bookkeeping once it is enqueued
+static int sc_prepare(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho, ScArgs& A, unsigned* blocks_out, uint8_t** part_out_p) {
   memset(&A, 0, sizeof A);
   gmh::Fr tau = gmh::Fr::from_limbs(S->twist);
   gmh::Fr tau_msg = fold ? tau.sqr() : tau;
@@ -730,16 +748,45 @@ static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::F
   uint32_t lt = 8;
   while (lt < 17 && ((size_t)1 << lt) < A.npairs) lt++;
   A.log_threads = lt;
-  const unsigned blocks = (unsigned)(((size_t)1 << lt) / 256);
+  *blocks_out = (unsigned)(((size_t)1 << lt) / 256);
+  const bool zc = (C->zero_copy & 1) != 0;  // the blocks write their partial sums into the pinned buffer themselves
+  *part_out_p = zc ? reinterpret_cast<uint8_t*>(S->host_partials) : S->partials;
+  return GM_OK;
+}
+static int sc_after(Context* C, Sumcheck* S, bool fold, bool msg, unsigned blocks) {
+  const bool zc = (C->zero_copy & 1) != 0;
+  S->pending_blocks = 0;
+  if (msg) {
+    if (!zc) GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, C->stream));
+    S->pending_blocks = blocks;
+  }
+  if (fold) {
+    gmh::Fr t2 = gmh::Fr::from_limbs(S->twist).sqr();  // the real twist, also for herring
+    S->cur ^= 1;
+    S->nf = (S->nf + 1) / 2;
+    S->ng = (S->ng + 1) / 2;
+    t2.to_limbs(S->twist);
+    S->pair_offset = S->pair_offset / 2;
+  }
+  return GM_OK;
+}
+static bool sc_lazy() {
+  // lazy reduction of the message's inner products (GM_SC_LAZY=0: the reduced form)
+  static const bool lazy = !(getenv("GM_SC_LAZY") && atoi(getenv("GM_SC_LAZY")) == 0);
+  return lazy;
+}
+static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho) {
+  ScArgs A;
+  unsigned blocks = 0;
+  uint8_t* part_out = nullptr;
+  int rc = sc_prepare(C, S, fold, msg, rho, A, &blocks, &part_out);
+  if (rc) return rc;
   hipStream_t st = C->stream;
   // stage timer of bench.py's sumcheck roofline: only when profiling is on, and then (one event pair) only
   // with provers driven one at a time
   Profiler& prof = C->prof;
   prof.begin(PROF_SC_ROUND, st);
-  const bool zc = (C->zero_copy & 1) != 0;  // the blocks write their partial sums into the pinned buffer themselves
-  uint8_t* part_out = zc ? reinterpret_cast<uint8_t*>(S->host_partials) : S->partials;
-  // lazy reduction of the message's inner products (GM_SC_LAZY=0: the reduced form)
-  static const bool lazy = !(getenv("GM_SC_LAZY") && atoi(getenv("GM_SC_LAZY")) == 0);
+  const bool lazy = sc_lazy();
   if (fold && msg && lazy)
     hipLaunchKernelGGL((k_sc_round<true, true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
   else if (fold && msg)
@@ -753,18 +800,44 @@ static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::F
   prof.end(PROF_SC_ROUND, st);
   GM_HIP(hipGetLastError());
   if (prof.on && !msg) GM_HIP(hipStreamSynchronize(st));
-  S->pending_blocks = 0;
-  if (msg) {
-    if (!zc) GM_HIP(hipMemcpyAsync(S->host_partials, S->partials, (size_t)blocks * 2 * FR_BYTES, hipMemcpyDeviceToHost, st));
-    S->pending_blocks = blocks;
+  return sc_after(C, S, fold, msg, blocks);
+}
+// the same for SEVERAL provers with the same (fold, msg): their descriptors go to the device in one small copy, ONE launch
+static int sc_enqueue_many(Context* C, Sumcheck** S, size_t k, bool fold, bool msg, const gmh::Fr& rho, size_t scratch_slot) {
+  if (k == 1) return sc_enqueue(C, S[0], fold, msg, rho);
+  GM_FR_LOCK(C);  // (the descriptors travel through the small-upload area of the vector scratch)
+  std::vector<ScMultiDesc> d(k);
+  unsigned max_blocks = 0;
+  for (size_t j = 0; j < k; j++) {
+    memset(&d[j], 0, sizeof d[j]);
+    int rc = sc_prepare(C, S[j], fold, msg, rho, d[j].A, &d[j].blocks, &d[j].partials);
+    if (rc) return rc;
+    max_blocks = std::max(max_blocks, d[j].blocks);
   }
-  if (fold) {
-    S->cur ^= 1;
-    S->nf = (S->nf + 1) / 2;
-    S->ng = (S->ng + 1) / 2;
-    gmh::Fr t2 = tau.sqr();  // the real twist, also for herring
-    t2.to_limbs(S->twist);
-    S->pair_offset = S->pair_offset / 2;
+  const size_t bytes = k * sizeof(ScMultiDesc), slot = (size_t)256 << 10;
+  GM_CHECK(bytes <= slot && scratch_slot < 4, GM_EINVAL, "sumcheck: %zu provers in one launch", k);
+  int rc = C->fr_scratch.ensure(1 << 20);
+  if (rc) return rc;
+  uint8_t* dd = C->fr_scratch.as<uint8_t>() + scratch_slot * slot;
+  GM_HIP(hipMemcpyAsync(dd, d.data(), bytes, hipMemcpyHostToDevice, C->stream));  // (pageable source: staged before the call returns)
+  hipStream_t st = C->stream;
+  const dim3 grid(max_blocks, (unsigned)k);
+  const ScMultiDesc* dp = reinterpret_cast<const ScMultiDesc*>(dd);
+  const bool lazy = sc_lazy();
+  if (fold && msg && lazy)
+    hipLaunchKernelGGL((k_sc_round_multi<true, true, true>), grid, dim3(256), 0, st, dp);
+  else if (fold && msg)
+    hipLaunchKernelGGL((k_sc_round_multi<true, true>), grid, dim3(256), 0, st, dp);
+  else if (fold)
+    hipLaunchKernelGGL((k_sc_round_multi<true, false>), grid, dim3(256), 0, st, dp);
+  else if (lazy)
+    hipLaunchKernelGGL((k_sc_round_multi<false, true, true>), grid, dim3(256), 0, st, dp);
+  else
+    hipLaunchKernelGGL((k_sc_round_multi<false, true>), grid, dim3(256), 0, st, dp);
+  GM_HIP(hipGetLastError());
+  for (size_t j = 0; j < k; j++) {
+    rc = sc_after(C, S[j], fold, msg, d[j].blocks);
+    if (rc) return rc;
   }
   return GM_OK;
 }
@@ -1026,6 +1099,41 @@ int sc_round_end(Context* C, Sumcheck* S, uint64_t a[4], uint64_t b[4]) {
   GM_CHECK(S->pending_blocks != 0, GM_ESTATE, "sc_round_end: no round in flight");
   GM_HIP(hipStreamSynchronize(C->stream));
   sc_collect(C, S, a, b);
+  return GM_OK;
+}
+
+// the split-phase round of k provers with the same challenge (Sumcheck::prove_batch): provers on the device with the same (fold,
+// message) share ONE launch; the tails on the host step there.  Every prover is collected with sc_round_end as before.
+int sc_round_begin_many(Context* C, Sumcheck** S, size_t k, const uint64_t* challenge, int* has_msg) {
+  const bool fold = challenge != nullptr;
+  const gmh::Fr rho = fold ? gmh::Fr::from_limbs(challenge) : gmh::Fr::zero();
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (size_t j = 0; j < k; j++) {
+    for (size_t i = 0; i < j; i++) GM_CHECK(S[i] != S[j], GM_EINVAL, "sc_round_begin_many: a prover appears twice");
+    locks.emplace_back(S[j]->mu);
+  }
+  std::vector<Sumcheck*> dev[2];  // [msg]
+  for (size_t j = 0; j < k; j++) {
+    Sumcheck* P = S[j];
+    GM_CHECK(P->round <= P->tot_rounds, GM_ESTATE, "More rounds than needed.");
+    GM_CHECK(P->pending_blocks == 0 && !P->host_msg_pending, GM_ESTATE, "sc_round_begin_many: the previous round has not been collected");
+    const bool msg = P->round != P->tot_rounds;
+    has_msg[j] = msg ? 1 : 0;
+    if (!(fold || msg)) continue;
+    int rc;
+    if (sc_host_ready(C, P, &rc)) sc_host_step(P, fold, msg, rho);
+    else {
+      if (rc) return rc;
+      dev[msg ? 1 : 0].push_back(P);
+    }
+  }
+  for (int m = 1; m >= 0; m--)
+    if (!dev[m].empty()) {
+      int rc = sc_enqueue_many(C, dev[m].data(), dev[m].size(), fold, m == 1, rho, (size_t)m);
+      if (rc) return rc;
+    }
+  for (size_t j = 0; j < k; j++)
+    if (has_msg[j]) S[j]->round += 1;
   return GM_OK;
 }
 

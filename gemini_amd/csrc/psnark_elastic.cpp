@@ -75,6 +75,13 @@ struct ElasticSc {
     }
     return GM_OK;
   }
+  // a prover that is a time prover already takes part in the ONE launch of its round (gm_sc_round_begin_many)
+  bool is_time() const { return time != 0; }
+  uint64_t time_handle() const { return time; }
+  void begun_as_time(int has) {
+    pending_time = has != 0;
+    have_msg = false;
+  }
   int end(uint64_t out_a[4], uint64_t out_b[4]) {
     if (pending_time) {
       pending_time = false;
@@ -138,11 +145,27 @@ int prove_batch(uint64_t transcript, std::vector<ElasticSc>& provers, uint64_t* 
   const uint64_t* vm = nullptr;
   for (size_t r = 0; r < rounds; r++) {
     Fr ma = Fr::zero(), mb = Fr::zero();
-    for (size_t j = 0; j < k; j++) {
-      if (finished[j]) continue;
-      int h = 0;
-      RC(provers[j].begin(vm, &h));
-      has[j] = (char)h;
+    {
+      // the time provers among the live ones share one launch; a space prover (the literal schedule) steps on its own
+      std::vector<uint64_t> th;
+      std::vector<size_t> at;
+      for (size_t j = 0; j < k; j++) {
+        if (finished[j]) continue;
+        if (provers[j].is_time()) {
+          th.push_back(provers[j].time_handle());
+          at.push_back(j);
+          continue;
+        }
+        int h = 0;
+        RC(provers[j].begin(vm, &h));
+        has[j] = (char)h;
+      }
+      std::vector<int> hs(th.size(), 0);
+      RC(gm_sc_round_begin_many(th.data(), th.size(), vm, hs.data()));
+      for (size_t t = 0; t < th.size(); t++) {
+        provers[at[t]].begun_as_time(hs[t]);
+        has[at[t]] = (char)hs[t];
+      }
     }
     for (size_t j = 0; j < k; j++) {
       Fr fa, fb;

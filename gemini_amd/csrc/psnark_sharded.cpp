@@ -393,11 +393,19 @@ int sumcheck_blocks(const Sh& lay, uint64_t transcript, bool batch, const std::v
     bool any_sharded = false;
     for (size_t j = 0; j < k; j++) any_sharded = any_sharded || !rep[j];
     std::vector<char> has(k, 0);
-    for (size_t j = 0; j < k; j++) {
-      if (!S.h[j] || finished[j]) continue;
-      int h = 0;
-      RC(gm_sc_round_begin(S.h[j], folded[j] ? nullptr : vm, &h));
-      has[j] = (char)h;
+    for (int pass = 0; pass < 2; pass++) {
+      // one launch for the provers that fold with the pending challenge, one for those whose fold went into their gathering
+      std::vector<uint64_t> hs;
+      std::vector<size_t> at;
+      for (size_t j = 0; j < k; j++)
+        if (S.h[j] && !finished[j] && (folded[j] != 0) == (pass == 1)) {
+          hs.push_back(S.h[j]);
+          at.push_back(j);
+        }
+      if (hs.empty()) continue;
+      std::vector<int> flags(hs.size(), 0);
+      RC(gm_sc_round_begin_many(hs.data(), hs.size(), pass == 1 ? nullptr : vm, flags.data()));
+      for (size_t t = 0; t < hs.size(); t++) has[at[t]] = (char)flags[t];
     }
     std::vector<uint64_t> part(8 * k, 0);
     bool any = any_sharded;  // (a sharded prover has a message in this round -- rd < tot -- on some rank)

@@ -332,8 +332,8 @@ int gm_sumcheck_prove(uint64_t transcript, uint64_t prover, uint64_t* messages, 
 // Sumcheck::prove_batch (src/subprotocols/sumcheck/proof.rs:69-122): k provers of possibly different
 // lengths run in lock-step for max(rounds) + 1 rounds; coefficients c_j are drawn first
 // (b"batch-sumcheck"); a prover that has run out contributes (f0 * g0, 0); the round message is
-// sum_j c_j * m_j.  The reference maps provers over rayon (:85); their device kernels are
-// independent launches here.  messages: cap_rounds x 8, challenges: cap_rounds x 4,
+// sum_j c_j * m_j.  The reference maps provers over rayon (:85); here the rounds of all live provers
+// are ONE kernel launch (k_sc_round_multi).  messages: cap_rounds x 8, challenges: cap_rounds x 4,
 // final_foldings: k x 8 (lhs || rhs per prover).
 int gm_sumcheck_prove_batch(uint64_t transcript, const uint64_t* provers, size_t k, uint64_t* messages, uint64_t* challenges,
                             size_t cap_rounds, uint64_t* final_foldings, size_t* rounds_out) {
@@ -361,12 +361,19 @@ int gm_sumcheck_prove_batch(uint64_t transcript, const uint64_t* provers, size_t
   for (size_t r = 0; r < rounds; r++) {
     gmh::Fr ma = gmh::Fr::zero(), mb = gmh::Fr::zero();
     // the round of every live prover is enqueued before the first wait (the reference runs them on rayon threads, :85)
-    for (size_t j = 0; j < k; j++) {
-      if (finished[j]) continue;
-      int h = 0;
-      int rc = gm_sc_round_begin(provers[j], vm, &h);
+    {
+      // ONE launch for the live provers of the round (gm_sc_round_begin_many)
+      std::vector<uint64_t> live;
+      std::vector<size_t> at;
+      for (size_t j = 0; j < k; j++)
+        if (!finished[j]) {
+          live.push_back(provers[j]);
+          at.push_back(j);
+        }
+      std::vector<int> hs(live.size(), 0);
+      int rc = gm_sc_round_begin_many(live.data(), live.size(), vm, hs.data());
       if (rc) return rc;
-      has[j] = (char)h;
+      for (size_t t = 0; t < live.size(); t++) has[at[t]] = (char)hs[t];
     }
     for (size_t j = 0; j < k; j++) {
       gmh::Fr fa, fb;

@@ -360,6 +360,9 @@ int gm_spm_download(uint64_t matrix, uint64_t* rowptr, uint32_t* cols, uint64_t*
  * of rounds (no _end call then); a second _begin before the _end of the same prover is GM_ESTATE. */
 int gm_sc_round_begin(uint64_t handle, const uint64_t* challenge_or_null, int* has_msg);
 int gm_sc_round_end(uint64_t handle, uint64_t a_mont[4], uint64_t b_mont[4]);
+/* gm_sc_round_begin for k provers with the SAME challenge (the provers of Sumcheck::prove_batch, proof.rs:85): those on the device share
+ * ONE kernel launch per (fold, message) combination instead of one each; has_msg: k flags.  Collect each with gm_sc_round_end. */
+int gm_sc_round_begin_many(const uint64_t* handles, size_t k, const uint64_t* challenge_or_null, int* has_msg);
 
 /* ---- sumcheck time prover --------------------------------------------------------------------- */
 /* Replaces TimeProver<F> behind `trait Prover<F>` (src/subprotocols/sumcheck/prover.rs:30-45,
