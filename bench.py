@@ -95,7 +95,7 @@ def snark_time_prover(gm, logn: int, with_tables: bool = True, world: int = 1, r
     """second half of BASELINE.json's metric: wall time of the `Proof::new_time` span
     (src/snark/time_prover.rs:23,109) on dummy_r1cs(2^logn) with an SRS of 2^(logn+1)+1 powers
     (examples/snark.rs:69-79).  Instance and SRS are built before the timer, as in the reference.
-    N > 1: the KZG key is sharded element-cyclically over the ranks (gemini_amd/dist.py), every commitment is a
+    N > 1: the KZG key is sharded element-cyclically over the ranks (gm_ck_*, gemini_amd/csrc/sharded.cpp), every commitment is a
     local MSM + one 144-byte all-gather; the span is the max over ranks."""
     import ctypes as C
     import statistics

@@ -1,7 +1,7 @@
 """ctypes face of the library's collective layer (gemini_amd/csrc/dist.cpp, include/gemini_hip.h "Multi-GPU"): the all-gather
 the sharded provers call INSIDE the library, over RCCL, a shared-memory segment or a hook.  The reference has no multi-device
 code; what is sharded is its loop structure (src/snark/time_prover.rs:19-117, src/subprotocols/sumcheck/proof.rs:36-66,
-src/kzg/time.rs:81-107).  `gemini_amd/dist.py` is the older Python composition over torch.distributed; this module only
+src/kzg/time.rs:81-107).  `tests/stepwise/dist.py` is the older Python composition over torch.distributed; this module only
 selects the transport -- the provers themselves are gm_snark_new_time_sharded & co."""
 from __future__ import annotations
 

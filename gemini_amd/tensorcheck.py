@@ -1,10 +1,8 @@
-"""Host mirror of the tensor-check prover, src/subprotocols/tensorcheck/mod.rs:124-133,190-275."""
+"""TensorcheckProof (src/subprotocols/tensorcheck/mod.rs:39-46) as data, and foldings_polynomial (:124-133).  The prover (:190-275) runs inside the
+native provers (gemini_amd/csrc/{snark,psnark}.cpp); its step-wise statement is tests/stepwise/tensorcheck_steps.py."""
 from __future__ import annotations
 
-import numpy as np
-
-from .fr import FrVec, evaluate_le, evaluate_le_batch, fold_polynomial, fr_from_int, fr_to_int, linear_combination, powers, R_MOD
-from .kzg import CommitterKey
+from .fr import FrVec, fold_polynomial
 
 
 def foldings_polynomial(polynomial: FrVec, challenges_mont) -> list:
@@ -23,43 +21,3 @@ class TensorcheckProof:
         self.folded_polynomials_evaluations = folded_polynomials_evaluations
         self.evaluation_proof = evaluation_proof
         self.base_polynomials_evaluations = base_polynomials_evaluations
-
-    @staticmethod
-    def new_time(transcript, ck: CommitterKey, base_polynomials, body_polynomials) -> "TensorcheckProof":
-        """:190-275.  body_polynomials: [(polynomials, challenges)]"""
-        max_len = max((len(p) for p, _ in body_polynomials), default=0)
-        batch_challenge = transcript.get_challenge(b"batch_challenge")
-        batch_challenges = powers(batch_challenge, max_len)
-        assert max_len != 0 and all(len(p) != 0 for p, _ in body_polynomials)
-        bc_host = batch_challenges.to_host()
-        batch_challenges.free()
-        foldings = []
-        batched_list = []
-        for polys, challenges in body_polynomials:
-            batched = linear_combination(polys, bc_host)
-            batched_list.append(batched)
-            foldings.extend(foldings_polynomial(batched, challenges))
-        commitments = ck.batch_commit(foldings)
-        for c in commitments:
-            transcript.append_g1(b"commitment", c)
-        eval_chal = transcript.get_challenge(b"evaluation-chal")
-        ec = fr_to_int(eval_chal)
-        minus_eval_chal = fr_from_int((-ec) % R_MOD)
-        eval_chal2 = fr_from_int(ec * ec % R_MOD)
-        pts3 = np.stack([eval_chal2, eval_chal, minus_eval_chal])
-        # :228-247, one wait per group instead of one per polynomial (22 base polynomials + ~90 foldings in the preprocessing prover)
-        base_evals = list(evaluate_le_batch(list(base_polynomials), pts3)) if all(isinstance(p, FrVec) for p in base_polynomials) \
-            else [evaluate_le(p, pts3) for p in base_polynomials]
-        fold_evals = list(evaluate_le_batch(foldings, pts3[1:]))
-        for e3 in base_evals:
-            for e in e3:
-                transcript.append_fr(b"eval", e)
-        for e2 in fold_evals:
-            for e in e2:
-                transcript.append_fr(b"eval", e)
-        open_chal = transcript.get_challenge(b"open-chal")
-        all_polys = list(base_polynomials) + foldings
-        evaluation_proof = ck.batch_open_multi_points(all_polys, pts3, open_chal)
-        for v in foldings + batched_list:
-            v.free()
-        return TensorcheckProof(commitments, fold_evals, evaluation_proof, base_evals)

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    # the step-wise Python statements of the provers are TEST infrastructure (tests/stepwise): importing the package registers them with
+    # gemini_amd.snark / gemini_amd.psnark, which is what `native=False` (and the Python-level sharded keys) reach
+    import tests.stepwise  # noqa: F401
 
 
 @pytest.fixture(scope="session")

@@ -60,7 +60,7 @@ def test_soak_provers(gm, oracle, pyref):
         merged = CommitterKeyStream.from_committer_key(ck)
         bad = []
         try:
-            stepwise = Proof.new_time(g, ck)
+            stepwise = Proof.new_time(g, ck, native=False)
             want = stepwise.serialize_compressed()
             if Proof.new_time(g, ck, native=True).serialize_compressed() != want:
                 bad.append("native time != stepwise time")

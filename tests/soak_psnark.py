@@ -59,7 +59,7 @@ def test_soak_psnark(gm, oracle, pyref):
         bad = []
         try:
             index = Proof.index(ck, r1cs)
-            stepwise = Proof.new_time(ck, r1cs, index)
+            stepwise = Proof.new_time(ck, r1cs, index, native=False)
             want = stepwise.serialize_compressed()
             if Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() != want:
                 bad.append("native time != stepwise time")

@@ -1,4 +1,4 @@
-"""Sweep of the block-sharded prover (gemini_amd/dist_prover.py) over instance sizes, world sizes and tail lengths, every
+"""Sweep of the block-sharded prover (tests/stepwise/dist_prover.py) over instance sizes, world sizes and tail lengths, every
 configuration compared with the single-GPU proof of the same instance through its SHA-256 and with the pure work model.  NOT
 collected by default (the file name); all ranks share the one GPU of the test box over gloo:
 
@@ -39,7 +39,7 @@ def _run(world, logn, extra):
 
 
 def test_soak_world():
-    from gemini_amd.dist_prover import fr_work
+    from tests.stepwise.dist_prover import fr_work
 
     budget = float(os.environ.get("SOAK_SECONDS", "60"))
     rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "20241003")))

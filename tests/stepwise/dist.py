@@ -1,4 +1,7 @@
-"""Multi-GPU composition of the hot path: one process per GPU, `torch.distributed` (backend "nccl" =
+"""TEST INFRASTRUCTURE (moved out of the product package in round 6: the N-GPU provers of the product are the ones compiled into the library,
+gemini_amd/csrc/{sharded,psnark_sharded,dist}.cpp; this is the older Python composition over torch.distributed, kept as a cross-check).
+
+Multi-GPU composition of the hot path: one process per GPU, `torch.distributed` (backend "nccl" =
 RCCL over xGMI on a GPU node, "gloo" in the CPU tests).
 
 The path shards by independent units, so there is no bulk collective:
@@ -15,8 +18,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from .fr import R_MOD, _to_int, _to_limbs
-from .msm import g1_sum
+from gemini_amd.fr import R_MOD, _to_int, _to_limbs
+from gemini_amd.msm import g1_sum
 
 
 def _dist():
@@ -197,8 +200,8 @@ class ShardedCommitterKey:
     @classmethod
     def new(cls, max_degree: int, max_eval_points: int, tau_canonical, rank: int, world: int, g_affine=None) -> "ShardedCommitterKey":
         """src/kzg/time.rs:49-72, each rank generating only its share: base tau^rank * g, ratio tau^world"""
-        from .kzg import g1_generator_mont
-        from .msm import G1Bases
+        from gemini_amd.kzg import g1_generator_mont
+        from gemini_amd.msm import G1Bases
 
         n = max_degree + 1
         g = g1_generator_mont() if g_affine is None else g_affine
@@ -206,7 +209,7 @@ class ShardedCommitterKey:
         first = G1Bases.fixed_base(g, np.array([_to_limbs(pow(tau, rank, R_MOD))], dtype=np.uint64))
         base = first.download()[0]
         first.free()
-        from . import g2 as G2
+        from gemini_amd import g2 as G2
 
         powers_of_g2 = [G2.mul(G2.generator(), pow(tau, i, R_MOD)) for i in range(max_eval_points + 1)]
         ratio = np.array(_to_limbs(pow(tau, world, R_MOD)), dtype=np.uint64)
@@ -223,13 +226,13 @@ class ShardedCommitterKey:
         return np.arange(self.rank, self.n_global, self.world)
 
     def powers_of_g2_bytes(self) -> bytes:
-        from .kzg import CommitterKey
+        from gemini_amd.kzg import CommitterKey
 
         return CommitterKey.powers_of_g2_bytes(self)
 
     def _hip_msm(self, polynomial, m: int) -> np.ndarray:
-        from .fr import _as_vec, stride
-        from .msm import g1_zero
+        from gemini_amd.fr import _as_vec, stride
+        from gemini_amd.msm import g1_zero
 
         cnt = cyclic_count(m, self.rank, self.world)
         if cnt == 0:
@@ -258,8 +261,8 @@ class ShardedCommitterKey:
         """this rank's UN-NORMALISED shares of commit(p) for every p: the strided gathers of the rank's scalars, then ONE
         pipelined batch call (gm_g1_msm_v_batch_partial: two big lanes + four small ones, host tails under the next
         call's kernels) -- what CommitterKey.batch_commit does on one GPU.  (k, 18)"""
-        from .fr import _as_vec, stride
-        from .msm import g1_zero
+        from gemini_amd.fr import _as_vec, stride
+        from gemini_amd.msm import g1_zero
 
         if self._local_msm != self._hip_msm:  # injected local compute (CPU tests)
             return np.stack([self.partial(p) for p in polys])
@@ -297,18 +300,18 @@ class ShardedCommitterKey:
     # the openings are commitments to quotients computed (replicated) on every rank: same code as the
     # single-GPU key, with `commit` above
     def open_multi_points(self, polynomial, eval_points_mont):
-        from .kzg import CommitterKey
+        from gemini_amd.kzg import CommitterKey
 
         return CommitterKey.open_multi_points(self, polynomial, eval_points_mont)
 
     def batch_open_multi_points(self, polynomials, eval_points_mont, eval_chal_mont):
-        from .kzg import CommitterKey
+        from gemini_amd.kzg import CommitterKey
 
         return CommitterKey.batch_open_multi_points(self, polynomials, eval_points_mont, eval_chal_mont)
 
 
 def _stream_key_base():
-    from .kzg import CommitterKeyStream
+    from gemini_amd.kzg import CommitterKeyStream
 
     return CommitterKeyStream
 
@@ -332,8 +335,8 @@ class ShardedCommitterKeyStream(_stream_key_base()):
         return self.n_global
 
     def _msm_stream(self, scalars_stream, first_stream_pos: int, chunk: int) -> np.ndarray:
-        from .fr import stride
-        from .msm import g1_zero
+        from gemini_amd.fr import stride
+        from gemini_amd.msm import g1_zero
 
         n, total, w = self.n_global, len(scalars_stream), self.world
         # stream position p pairs with power i = n - 1 - (first_stream_pos + p); this rank holds i = rank (mod w):

@@ -1,4 +1,7 @@
-"""`snark::Proof::new_time` (src/snark/time_prover.rs:19-117) with the FIELD ARITHMETIC sharded over the GPUs as well.
+"""TEST INFRASTRUCTURE (moved out of the product package in round 6: the N-GPU provers of the product are the ones compiled into the library,
+gemini_amd/csrc/{sharded,psnark_sharded,dist}.cpp; this is the older Python composition over torch.distributed, kept as a cross-check).
+
+`snark::Proof::new_time` (src/snark/time_prover.rs:19-117) with the FIELD ARITHMETIC sharded over the GPUs as well.
 
 `gemini_amd/dist.py` shards the MSMs (element-cyclic key) and leaves every O(n) field pass replicated.  Here every vector of
 the prover is BLOCK-sharded -- rank r of g holds elements [r m, (r + 1) m), m = n / g -- and so is the key, in per-level slices:
@@ -28,10 +31,10 @@ import time
 
 import numpy as np
 
-from .dist import ShardedTimeProver, all_gather_u64, fr_sum_allgather
-from .fr import (FrVec, R_MOD, div_vanishing, evaluate_le_batch, fold_polynomial, fr_from_int, fr_to_int, hadamard, linear_combination,
+from tests.stepwise.dist import ShardedTimeProver, all_gather_u64, fr_sum_allgather
+from gemini_amd.fr import (FrVec, R_MOD, div_vanishing, evaluate_le_batch, fold_polynomial, fr_from_int, fr_to_int, hadamard, linear_combination,
                  powers, tensor)
-from .msm import g1_sum, g1_zero
+from gemini_amd.msm import g1_sum, g1_zero
 
 TAIL_LOG = 10
 
@@ -69,8 +72,8 @@ class BlockShardedKey:
 
     @classmethod
     def new(cls, n_poly: int, max_eval_points: int, tau_canonical, rank: int, world: int, tail_log: int = TAIL_LOG, g_affine=None):
-        from .kzg import g1_generator_mont
-        from .msm import G1Bases
+        from gemini_amd.kzg import g1_generator_mont
+        from gemini_amd.msm import G1Bases
 
         L = BlockLayout(n_poly, rank, world, tail_log)
         g = g1_generator_mont() if g_affine is None else g_affine
@@ -101,7 +104,7 @@ class R1csBlock:
     @classmethod
     def dummy(cls, e_canonical: int, layout: BlockLayout) -> "R1csBlock":
         """this rank's block of dummy_r1cs(e, n) (src/circuit.rs:349-365): z = [e; n], w = [e; n - 1], A = B = C = diag(1 / e)"""
-        from .circuit import SparseMatrix
+        from gemini_amd.circuit import SparseMatrix
 
         m = layout.m
         e = e_canonical % R_MOD
@@ -146,7 +149,7 @@ def _alloc_spare(n: int) -> FrVec:
 def _fold_spare(cur: FrVec, chal) -> FrVec:
     import ctypes as C
 
-    from . import capi
+    from gemini_amd import capi
 
     out = _alloc_spare((len(cur) + 1) // 2)
     capi.check(capi.load().gm_fr_fold(C.c_uint64(cur.handle), capi.ptr(capi.u64(chal).reshape(4)), C.c_uint64(out.handle)))
@@ -157,7 +160,7 @@ def _append_carry(blk: FrVec, coeffs):
     """blk (allocated by _alloc_spare) becomes [blk..., c0, c1, c2] in place"""
     import ctypes as C
 
-    from . import capi
+    from gemini_amd import capi
 
     n = len(blk)
     blk.set_len(n + 3)
@@ -226,11 +229,11 @@ class _Acct(dict):
 def new_time_block_sharded(r1cs: R1csBlock, key: BlockShardedKey):
     """Proof::new_time on every rank's block; returns the same `snark.Proof` on all ranks (with `.fr_work`: the field elements
     this rank's device passes read + wrote, by phase; the sumchecks are accounted by `ShardedTimeProver`'s own rounds)"""
-    from .msm import VariableBaseMSM
-    from .snark import Proof
-    from .sumcheck import Sumcheck, TimeProver
-    from .tensorcheck import TensorcheckProof
-    from .transcript import PROTOCOL_NAME, Transcript
+    from gemini_amd.msm import VariableBaseMSM
+    from gemini_amd.snark import Proof
+    from gemini_amd.sumcheck import Sumcheck, TimeProver
+    from gemini_amd.tensorcheck import TensorcheckProof
+    from gemini_amd.transcript import PROTOCOL_NAME, Transcript
 
     L = key.layout
     n, g, r, m = L.n, L.world, L.rank, L.m
@@ -349,7 +352,7 @@ def new_time_block_sharded(r1cs: R1csBlock, key: BlockShardedKey):
     w_blk = _alloc_spare(len(r1cs.w))
     import ctypes as C
 
-    from . import capi
+    from gemini_amd import capi
 
     capi.check(capi.load().gm_fr_stride(C.c_uint64(r1cs.w.handle), C.c_size_t(0), C.c_size_t(1), C.c_size_t(len(r1cs.w)), C.c_uint64(w_blk.handle)))
     blocks = [w_blk] + sharded

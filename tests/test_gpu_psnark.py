@@ -251,7 +251,7 @@ def test_entry_product_consistency(gm, oracle, pyref):
     here, the same sumcheck transcripts) on v = [r; 1000]."""
     from gemini_amd import fr as F
     from gemini_amd.kzg import CommitterKey, CommitterKeyStream
-    from gemini_amd.psnark import EntryProduct
+    from tests.stepwise.psnark_steps import EntryProduct
     from gemini_amd.sumcheck import Sumcheck
     from gemini_amd.transcript import Transcript
 
@@ -344,7 +344,7 @@ def test_psnark_config5_shape_time_equals_elastic(gm, oracle, pyref, logn):
         gm.capi.mem_reset_peak()
     # 2^18: the Python-driven elastic prover beside the compiled one; above: the compiled one (gm_psnark_new_elastic) alone
     if logn == 18:
-        stepwise = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20)
+        stepwise = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20, native=False)
         assert stepwise == time_proof and stepwise.serialize_compressed() == time_proof.serialize_compressed()
     elastic_proof = Proof.new_elastic(CommitterKeyStream.from_committer_key(ck), stream, index, 1 << 20, native=True)
     assert elastic_proof == time_proof and elastic_proof.serialize_compressed() == time_proof.serialize_compressed()
@@ -482,7 +482,7 @@ def test_native_psnark_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
     r1cs = dummy_r1cs(e, n)
     ck = CommitterKey.new(2 * n + 1, 5, oracle.ints_to_limbs([tau], 4)[0])
     index = Proof.index(ck, r1cs)
-    stepwise = Proof.new_time(ck, r1cs, index)
+    stepwise = Proof.new_time(ck, r1cs, index, native=False)
     native = Proof.new_time(ck, r1cs, index, native=True)
     assert native == stepwise
     for compress in (True, False):
@@ -511,7 +511,7 @@ def test_native_psnark_prover_on_general_instances(gm, oracle, pyref, n):
     nnz = len(pr.joint_matrices(jm, inst["a"], inst["b"], inst["c"])[0])
     ck = CommitterKey.new(nnz + 2 * n, 3, oracle.ints_to_limbs([tau], 4)[0])
     index = Proof.index(ck, r1cs)
-    want = Proof.new_time(ck, r1cs, index).serialize_compressed()
+    want = Proof.new_time(ck, r1cs, index, native=False).serialize_compressed()
     assert Proof.new_time(ck, r1cs, index, native=True).serialize_compressed() == want
     # the matrix-only part of the instance built inside the library (gm_psnark_preprocess / gm_psnark_index) instead of by
     # gemini_amd/psnark.py::joint_matrices: the same joint support, value vectors, frequencies -> the same index and proof

@@ -277,7 +277,7 @@ def test_sharded_committer_key_single_process(gm, oracle, pyref):
     import torch.distributed as dist
 
     from gemini_amd.circuit import dummy_r1cs
-    from gemini_amd.dist import ShardedCommitterKey
+    from tests.stepwise.dist import ShardedCommitterKey
     from gemini_amd.kzg import CommitterKey
     from gemini_amd.msm import g1_sum
     from gemini_amd.snark import Proof
@@ -349,7 +349,7 @@ def test_sharded_stream_key_single_process(gm, oracle, pyref):
 
     import torch.distributed as dist
 
-    from gemini_amd import dist as gd
+    from tests.stepwise import dist as gd
     from gemini_amd.circuit import R1csStream, dummy_r1cs
     from gemini_amd.kzg import CommitterKey, CommitterKeyStream
     from gemini_amd.msm import g1_sum
@@ -787,7 +787,7 @@ def test_native_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
     tau = oracle.limbs_to_ints(oracle.random_fr(6200 + logn, 1))[0]
     ck = CommitterKey.new(2 * n, 5, oracle.ints_to_limbs([tau], 4)[0])
     r1cs = dummy_r1cs(e, n)
-    stepwise = Proof.new_time(r1cs, ck)
+    stepwise = Proof.new_time(r1cs, ck, native=False)
     native = Proof.new_time(r1cs, ck, native=True)
     assert native == stepwise
     for compress in (True, False):
@@ -803,7 +803,7 @@ def test_native_prover_equals_the_stepwise_one(gm, oracle, pyref, logn):
         dev = lambda rows: [[(M(v), col) for v, col in row] for row in rows]  # noqa: E731
         mats = [SparseMatrix.from_rows(dev(inst[k]), n) for k in "abc"] + [SparseMatrix.from_rows(dev(inst[k]), n, transpose=True) for k in "abc"]
         g = R1cs(*mats, gm.FrVec.from_host(_M(oracle, inst["z"])), gm.FrVec.from_host(_M(oracle, inst["w"])), gm.FrVec.from_host(_M(oracle, inst["x"])))
-        p1, p2 = Proof.new_time(g, ck), Proof.new_time(g, ck, native=True)
+        p1, p2 = Proof.new_time(g, ck, native=False), Proof.new_time(g, ck, native=True)
         assert p1 == p2 and p2.serialize(True, 0) == W.snark_proof(sr.snark_new_time(inst, sr.srs(tau, 2 * n + 1)), True, "arkworks")
         g.free()
     ck.powers_of_g.free()
@@ -834,7 +834,7 @@ def test_native_elastic_prover_equals_the_stepwise_one_and_the_time_prover(gm, o
     assert native.serialize_compressed() == want
     assert len(native.first_sumcheck_msgs[0]) == logn
     if logn <= 20:
-        stepwise = Proof.new_elastic(stream, merged, 1 << 20)
+        stepwise = Proof.new_elastic(stream, merged, 1 << 20, native=False)
         assert native == stepwise and native.serialize_uncompressed() == stepwise.serialize_uncompressed()
         literal = CommitterKeyStream.from_committer_key(ck, min_device_chunk=1)
         assert Proof.new_elastic(stream, literal, 1 << (10 if logn > 10 else 2), native=True).serialize_compressed() == want
@@ -847,7 +847,7 @@ def test_native_elastic_prover_equals_the_stepwise_one_and_the_time_prover(gm, o
         mats = [SparseMatrix.from_rows(dev(inst[k]), n) for k in "abc"] + [SparseMatrix.from_rows(dev(inst[k]), n, transpose=True) for k in "abc"]
         g = R1cs(*mats, gm.FrVec.from_host(_M(oracle, inst["z"])), gm.FrVec.from_host(_M(oracle, inst["w"])), gm.FrVec.from_host(_M(oracle, inst["x"])))
         gs = R1csStream(g)
-        assert Proof.new_elastic(gs, merged, 1 << 20, native=True).serialize_compressed() == Proof.new_time(g, ck).serialize_compressed()
+        assert Proof.new_elastic(gs, merged, 1 << 20, native=True).serialize_compressed() == Proof.new_time(g, ck, native=False).serialize_compressed()
         gs.free()
         g.free()
     ck.powers_of_g.free()

@@ -1,4 +1,4 @@
-"""Two ranks over gloo sharing the one GPU of the test box (the N > 1 code path of gemini_amd/dist.py with the real
+"""Two ranks over gloo sharing the one GPU of the test box (the N > 1 code path of tests/stepwise/dist.py with the real
 device library on every rank): `snark --time-prover` and the elastic prover over the element-cyclic sharded KZG key
 must produce the proof of the single-GPU run, byte for byte (compared through its SHA-256).  The driver's multi-GPU
 bench launches the same entry points with the nccl backend, one rank per GPU."""
@@ -71,10 +71,10 @@ def test_psnark_two_and_three_ranks_one_gpu_same_proof(extra):
 
 @pytest.mark.parametrize("tail_log", [4, 6])
 def test_block_sharded_prover_same_proof(tail_log):
-    """gemini_amd/dist_prover.py: the field arithmetic sharded as well (block-sharded vectors, per-level key slices, sumchecks
+    """tests/stepwise/dist_prover.py: the field arithmetic sharded as well (block-sharded vectors, per-level key slices, sumchecks
     through ShardedTimeProver, the opening through per-block carries): 1, 2, 4 (and 8) ranks on the one GPU of the test box must
     produce the single-GPU proof byte for byte.  tail_log 4 / 6 at 2^12 constraints: 6 / 4 sharded levels at 4 ranks."""
-    from gemini_amd.dist_prover import fr_work
+    from tests.stepwise.dist_prover import fr_work
 
     one = _single()
     for world in ((2,) if tail_log == 4 else (4,)):  # 8 ranks: blocks of 512 constraints, 5 sharded levels (1 / 2 / 4 / 8 of the compiled prover: test_gpu_dist_native.py)

@@ -1,4 +1,4 @@
-"""CPU coverage of the N > 1 path (gemini_amd/dist.py) with world_size 2 over gloo: shard ->
+"""CPU coverage of the N > 1 path (tests/stepwise/dist.py) with world_size 2 over gloo: shard ->
 partial -> all-gather -> combine.  The per-rank device compute is replaced by the CPU oracle
 (there is no GPU here); the collective pattern, the sharding arithmetic (incl. the sumcheck twist
 origin per shard and the tail hand-off) and the library's host-side combination are the real ones."""
@@ -67,7 +67,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
-    from gemini_amd import dist as gd
+    from tests.stepwise import dist as gd
     from oracle import oracle as orc
     from oracle import pyref as P
 
@@ -149,12 +149,12 @@ def test_world2_gloo_msm_and_sumcheck(oracle):
 
 
 def test_cyclic_key_balance():
-    """Load balance of the element-cyclic key (gemini_amd/dist.py::ShardedCommitterKey) for EVERY MSM of a
+    """Load balance of the element-cyclic key (tests/stepwise/dist.py::ShardedCommitterKey) for EVERY MSM of a
     `snark -i 24` proof -- the witness (n - 1 scalars), the 23 foldings (n/2 ... 2), the batched quotient (n - 3) --
     and of `-i 28` / `psnark -i 26` shapes, at 2, 4 and 8 GPUs: the ranks' pair counts differ by at most one, i.e.
     max / min <= 1.1 wherever a rank holds at least ten pairs.  (The contiguous-block layout of round 1 left half of
     the ranks idle: a 2n + 1-power key against polynomials of <= n coefficients, foldings < n/4 on rank 0 alone.)"""
-    from gemini_amd.dist import cyclic_count
+    from tests.stepwise.dist import cyclic_count
 
     for logn in (24, 26, 28):
         n = 1 << logn
@@ -177,12 +177,12 @@ def test_cyclic_key_balance():
 
 
 def test_block_sharded_prover_field_work_scales_with_the_ranks():
-    """gemini_amd/dist_prover.py shards the FIELD arithmetic of `snark --time-prover` too.  Its device passes account the
+    """tests/stepwise/dist_prover.py shards the FIELD arithmetic of `snark --time-prover` too.  Its device passes account the
     field elements they read + write as they run, and the GPU suite holds that count equal to the pure model fr_work /
     fr_work_sumcheck on 1, 2 and 4 ranks (tests/test_gpu_world2.py); here the model is evaluated where the metric is quoted:
     at 2^24 constraints every rank of 2, 4, 8 does at most 1.1 x (the unsharded total / ranks), phase by phase within 1.25 x
     (the gathered tails are the only replicated work)."""
-    from gemini_amd.dist_prover import BlockLayout, fr_work, fr_work_sumcheck
+    from tests.stepwise.dist_prover import BlockLayout, fr_work, fr_work_sumcheck
 
     n = 1 << 24
     single = fr_work(n, 1)

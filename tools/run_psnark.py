@@ -18,7 +18,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-i", "--instance-logsize", type=int, default=16)
     ap.add_argument("--repeat", type=int, default=2)
-    ap.add_argument("--native", action="store_true", help="gm_psnark_new_time: the prover's orchestration compiled into the library (one call per proof)")
+    ap.add_argument("--stepwise", action="store_true", help="the step-wise Python statement of the prover (tests/stepwise: the cross-check, one FFI call per step) instead of the native one")
+    ap.add_argument("--native", action="store_true", help="the default since round 6 (kept for old command lines): the provers compiled into the library")
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/psnark.rs elastic_snark_main) instead of --time-prover")
     ap.add_argument("--transport", choices=["shm", "hook", "rccl", "rccl-node"], default=None, help="N ranks through the collective layer inside the library "
@@ -32,6 +33,7 @@ def main():
                     "time-prover key (2n + 1 powers) is one short of the longest committed polynomial (2n + 2 coefficients), so the proof "
                     "of the example's configuration does not verify (tests/test_oracle_verifier.py::test_reference_example_key_is_one_power_short)")
     args = ap.parse_args()
+    import tests.stepwise  # noqa: F401 -- registers the step-wise cross-check (what --stepwise and the Python-level sharded keys use)
     import warnings
 
     import gemini_amd as gm
@@ -42,7 +44,7 @@ def main():
     if not args.verifiable_key:
         warnings.filterwarnings("ignore", message="commit: polynomial of", category=RuntimeWarning)  # the reference's shape, knowingly
 
-    # N > 1 (torch.distributed.run): KZG key sharded by powers (gemini_amd.dist.ShardedCommitterKey), the
+    # N > 1 (torch.distributed.run): KZG key sharded by powers (tests.stepwise.dist.ShardedCommitterKey), the
     # field arithmetic replicated; GM_BENCH_BACKEND / GM_BENCH_SINGLE_DEVICE as in bench.py
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +103,7 @@ def main():
 
         ck = cyclic_committer_key(max_degree, 5, tau)
     elif world > 1:
-        from gemini_amd.dist import ShardedCommitterKey
+        from tests.stepwise.dist import ShardedCommitterKey
 
         ck = ShardedCommitterKey.new(max_degree, 5, tau, rank, world)
     else:
@@ -127,15 +129,15 @@ def main():
 
             stream = R1csStream(r1cs)
             if world > 1 and not lib_dist:
-                from gemini_amd.dist import ShardedCommitterKeyStream
+                from tests.stepwise.dist import ShardedCommitterKeyStream
 
                 cks = ShardedCommitterKeyStream.from_sharded_key(ck)
             else:
                 cks = CommitterKeyStream.from_committer_key(ck)
-            proof = Proof.new_elastic(cks, stream, index, 1 << 20, native=args.native or lib_dist)
+            proof = Proof.new_elastic(cks, stream, index, 1 << 20, native=not args.stepwise)
             stream.free()
         else:
-            proof = Proof.new_time(ck, r1cs, index, native=args.native or lib_dist)
+            proof = Proof.new_time(ck, r1cs, index, native=not args.stepwise)
         stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         out["proof_size_B"] = proof.compressed_size()

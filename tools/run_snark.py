@@ -45,9 +45,10 @@ def main():
     ap.add_argument("--max-msm-buffer-log", type=int, default=20, help="max_msm_buffer of the elastic prover (examples/snark.rs:57: 2^20)")
     ap.add_argument("--tables", action="store_true", help="gm_g1_bases_precompute on the committer key before proving (13 x the key in HBM)")
     ap.add_argument("--min-device-chunk-log", type=int, default=None, help="CommitterKeyStream.min_device_chunk = 2^k (default: the class default)")
-    ap.add_argument("--native", action="store_true", help="gm_snark_new_time / gm_snark_new_elastic: the prover's orchestration compiled into the library (one call per proof)")
+    ap.add_argument("--stepwise", action="store_true", help="the step-wise Python statement of the prover (tests/stepwise: the cross-check, one FFI call per step) instead of the native one")
+    ap.add_argument("--native", action="store_true", help="the default since round 6 (kept for old command lines): the provers compiled into the library")
     ap.add_argument("--block-sharded", action="store_true", help="N ranks, field arithmetic sharded as well: every vector and the key in blocks "
-                    "(gemini_amd/dist_prover.py); the world size must be a power of two")
+                    "(tests/stepwise/dist_prover.py); the world size must be a power of two")
     ap.add_argument("--tail-log", type=int, default=10, help="--block-sharded: blocks shorter than 2^k elements are gathered")
     ap.add_argument("--transport", choices=["shm", "hook", "rccl", "rccl-node"], default=None, help="N ranks through the collective layer INSIDE the library "
                     "(gemini_amd/csrc/dist.cpp) and the provers compiled into it: shm = shared-memory segment (no torch.distributed at all), "
@@ -60,13 +61,14 @@ def main():
     ap.add_argument("--elastic", action="store_true", help="Proof::new_elastic over device-resident streams, max_msm_buffer = 2^20 "
                     "(examples/snark.rs elastic_snark_main) instead of --time-prover")
     args = ap.parse_args()
+    import tests.stepwise  # noqa: F401 -- registers the step-wise cross-check (what --stepwise and the Python-level sharded keys use)
     import gemini_amd as gm
     from gemini_amd.circuit import dummy_r1cs
     from gemini_amd.kzg import CommitterKey
     from gemini_amd.snark import Proof
 
     # N > 1 (launched by torch.distributed.run): the KZG key is sharded by powers across the ranks
-    # (gemini_amd.dist.ShardedCommitterKey), everything else is replicated.  GM_BENCH_BACKEND=gloo +
+    # (tests.stepwise.dist.ShardedCommitterKey), everything else is replicated.  GM_BENCH_BACKEND=gloo +
     # GM_BENCH_SINGLE_DEVICE=1 are the same test hooks as bench.py (N ranks on one GPU).
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +114,7 @@ def main():
 
         r1cs = R1csShard.from_rows(ra, rb, rc, zh, 1) if args.random_r1cs is not None else R1csShard.dummy(e_inst, n, global_columns=args.global_columns)
     elif args.block_sharded:
-        from gemini_amd.dist_prover import BlockLayout, BlockShardedKey, R1csBlock
+        from tests.stepwise.dist_prover import BlockLayout, BlockShardedKey, R1csBlock
 
         layout = BlockLayout(n, rank, world, args.tail_log)
         r1cs = R1csBlock.dummy(e_inst, layout)
@@ -134,7 +136,7 @@ def main():
     elif args.block_sharded:
         ck = BlockShardedKey.new(n, 5, tau, rank, world, args.tail_log)
     elif world > 1:
-        from gemini_amd.dist import ShardedCommitterKey
+        from tests.stepwise.dist import ShardedCommitterKey
 
         ck = ShardedCommitterKey.new(2 * n, 5, tau, rank, world)
     else:
@@ -173,25 +175,25 @@ def main():
 
             stream = R1csStream(r1cs)
             if world > 1 and not lib_dist:
-                from gemini_amd.dist import ShardedCommitterKeyStream
+                from tests.stepwise.dist import ShardedCommitterKeyStream
 
                 cks = ShardedCommitterKeyStream.from_sharded_key(ck)
             else:
                 cks = CommitterKeyStream.from_committer_key(ck, min_device_chunk=None if args.min_device_chunk_log is None else 1 << args.min_device_chunk_log)
-            proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log, native=args.native or lib_dist)
+            proof = Proof.new_elastic(stream, cks, 1 << args.max_msm_buffer_log, native=not args.stepwise)
             stream.free()
         elif args.block_sharded and lib_dist:
             proof = new_time_sharded(r1cs, ck)
         elif args.block_sharded:
-            from gemini_amd.dist_prover import new_time_block_sharded
+            from tests.stepwise.dist_prover import new_time_block_sharded
 
             proof = new_time_block_sharded(r1cs, ck)
         else:
-            proof = Proof.new_time(r1cs, ck, native=args.native or lib_dist)
+            proof = Proof.new_time(r1cs, ck, native=not args.stepwise)
         stamps[-1]["t1"] = clocks()
         out["runs"].append({k: round(v, 4) for k, v in proof.spans.items()})
         if getattr(proof, "fr_work", None):
-            out["fr_work"] = proof.fr_work  # field elements this rank's device passes read + wrote (gemini_amd/dist_prover.py)
+            out["fr_work"] = proof.fr_work  # field elements this rank's device passes read + wrote (tests/stepwise/dist_prover.py)
         out["proof_size_B"] = proof.compressed_size()  # examples/snark.rs:96 "proof-size {}B"
     key = "ark_gemini::snark::elastic_prover" if args.elastic else "ark_gemini::snark::time_prover"
     out["elastic_prover_s" if args.elastic else "time_prover_s"] = min(r[key] for r in out["runs"])
