@@ -610,7 +610,10 @@ Footprint fp_snark(gm::Context* C, const gm::Bases* ck, size_t n, int elastic) {
   // sumchecks (two or three vectors + 0.75 of each for the prover's folds) and the tensor check (levels n, the merged polynomial,
   // its quotient, one reversed copy in the elastic form: <= 5 n) stay below it.  z_a, z_b, z_c are released before it.
   size_t elems = 3 * nt + 4 * n;
-  if (elastic) elems += n;  // lhs / z in both orders around the second sumcheck of the literal form
+  if (elastic) elems += n;  // lhs / z in both orders around the second sumcheck
+  // elastic = 2, the LITERAL schedule (min_device_chunk = 1): the reversed copies the space provers and the stream MSMs read -- lhs and
+  // the body in stream order (2 n) and the reversed levels of the folding tree (n / 2 + n / 4 + ... < n)
+  if (elastic == 2) elems += 3 * n;
   f.vectors = fp_vectors_bytes(elems);
   f.workspaces = fp_workspaces(C, ck, n, (n + 1) / 2);
   return f;

@@ -530,10 +530,27 @@ int shm_open_segment(Dist& d, int rank, int world, const char* name, size_t slot
       std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     if (good && (h->world != (uint64_t)world || h->slot_bytes != slot_bytes)) {
-      // another world / slot size: a stale segment unless rank 0 of this run really disagrees -- the name decides
-      if (shm_name_is(name, st.st_dev, st.st_ino) && elapsed() > 5.0) {
-        munmap(p, total);
-        GM_CHECK(false, GM_EINVAL, "gm_dist_init_shm: %s was created for another world / slot size", name);
+      // another world / slot size: the stale segment of a crashed run under a reused name -- unless a LIVE rank 0 really disagrees.  Only
+      // a live one echoes this rank's nonce (the hello / ack slots do not depend on the geometry), so ask: an ack within two seconds is a
+      // genuine mismatch (GM_EINVAL now); silence means stale -- keep re-attaching until the attach deadline, however late this run's rank 0 is
+      // (gm_init skew across 8 GPUs exceeded the former 5 s window)
+      if ((size_t)st.st_size >= sizeof(ShmHeader) && rank < 64) {
+        h->hello[rank].store(nonce, std::memory_order_release);
+        const double t_ask = elapsed();
+        bool live = false;
+        while (elapsed() - t_ask < 2.0 && h->magic.load(std::memory_order_acquire) == SHM_MAGIC) {
+          if (h->ack[rank].load(std::memory_order_acquire) == nonce) {
+            live = true;
+            break;
+          }
+          std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (live) {
+          const unsigned long long w2 = (unsigned long long)h->world, s2 = (unsigned long long)h->slot_bytes;
+          munmap(p, total);
+          GM_CHECK(false, GM_EINVAL, "gm_dist_init_shm: %s belongs to a live run of %llu ranks with %llu-byte slots (this rank: %d ranks, %zu bytes)", name, w2, s2, world,
+                   slot_bytes);
+        }
       }
       good = false;
     }

@@ -1866,6 +1866,8 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
     if (blk || (group_of[j] < 0 && !is_small(j))) last_big_pos = jo;
   }
   bool gated = false;
+  std::vector<hipEvent_t> gate_evs;
+  int gate_left = 0;
   for (size_t jo = 0; jo < k; jo++) {
     const size_t j = order[jo];
     const bool fused_here = group_of[j] >= 0;
@@ -1885,13 +1887,11 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       lane = (two_big && C->stream_b && (big_rr & 1)) ? -1 : 0;
       hslot = (big_rr >> 1) & 1;
       big_rr++;
-      if (smalls_first && !smalls_nogate && !gated) {  // the big lanes start behind the small calls that are still in flight
+      if (smalls_first && !smalls_nogate && !gated) {  // (GM_MSM_BATCH_ORDER=smalls) the big lanes start behind the small calls that are still in flight
         gated = true;
         for (size_t t = 0; t < q.size(); t++)
-          if (!finished[t] && q[t].lane > 0 && !q[t].P.empty) {
-            GM_HIP(hipStreamWaitEvent(C->stream, q[t].P.ws->done_ev[q[t].P.slot], 0));
-            if (C->stream_b) GM_HIP(hipStreamWaitEvent(C->stream_b, q[t].P.ws->done_ev[q[t].P.slot], 0));
-          }
+          if (!finished[t] && q[t].lane > 0 && !q[t].P.empty) gate_evs.push_back(q[t].P.ws->done_ev[q[t].P.slot]);
+        gate_left = C->stream_b ? 2 : 1;  // the first call of each big lane waits (its stream order holds the later ones back)
       }
     }
     // a (workspace, result buffer) pair is free again once its previous call has been finished
@@ -1925,6 +1925,12 @@ static int msm_run_batch_at(Context* C, const Bases* bases, int64_t first, int64
       if (sts.acc != sts.sort) GM_HIP(hipStreamWaitEvent(sts.acc, C->start_ev, 0));
     } else
     if (st != C->stream) GM_HIP(hipStreamWaitEvent(st, C->start_ev, 0));  // scalars produced on the main stream
+    if (!small && gate_left > 0) {
+      // on the stream this call's SORT is enqueued on: with the CU partition that is a partition stream, not C->stream / stream_b
+      // (the gate used to wait on those two and was a silent no-op under cu_split)
+      gate_left--;
+      for (hipEvent_t ev : gate_evs) GM_HIP(hipStreamWaitEvent(st, ev, 0));
+    }
     const auto tq0 = std::chrono::steady_clock::now();
     auto start_of = [&](size_t jj) { return pair_offsets ? (int64_t)pair_offsets[jj] : (firsts ? firsts[jj] : first); };
     int rc;

@@ -214,7 +214,7 @@ extern "C" int gm_snark_new_elastic(const uint64_t matrices_t[3], uint64_t z_str
     RC(gm_spm_shape(matrices_t[k], &rows, nullptr, nullptr));
     if (rows != nz) return GM_EINVAL;
   }
-  RC(gm_footprint_admit(0, ck_bases, nz, 0, 1));
+  RC(gm_footprint_admit(0, ck_bases, nz, 0, min_device_chunk > 1 ? 1 : 2));  // (2: the literal schedule holds the reversed copies as well)
   const size_t flush = max_msm_buffer > min_device_chunk ? max_msm_buffer : min_device_chunk;
   TranscriptGuard T;
   static const char protocol[] = "GEMINI-v0";

@@ -90,8 +90,8 @@ def _evaluate_be(stream: FrVec, xs) -> np.ndarray:
 def elastic_tensorcheck(transcript, ck, base_polynomial: FrVec, body_stream: FrVec, challenges, max_msm_buffer: int) -> TensorcheckProof:
     """src/snark/elastic_prover.rs:105-168 (`tensorcheck`): commit_folding, evaluate_folding at +-beta,
     open_multi_points(w) + open_folding(foldings)"""
-    from .kzg import FoldedPolynomialTree
-    from .msm import g1_sum
+    from gemini_amd.kzg import FoldedPolynomialTree
+    from gemini_amd.msm import g1_sum
 
     tc_challenges = list(challenges)[:-1]  # strip_last
     tree = FoldedPolynomialTree(body_stream, tc_challenges)

@@ -119,7 +119,7 @@ def test_rccl_binding_with_one_rank():
 def test_cyclic_key_native_provers_same_proof(extra):
     """gm_snark_new_time / gm_snark_new_elastic handed a CYCLIC SHARE of the key: 2 and 3 ranks == 1 GPU"""
     one = _single(extra)
-    for world, transport in ((3, "shm"), (2, "hook")):
+    for world, transport in (((3, "shm"),) if not extra else ((2, "hook"),)):  # (more combinations: tests/soak_dist_native.py)
         many = _run(world, extra, transport=transport)
         assert many["n_gpus"] == world and many["transport"] == transport
         assert many["proof_sha256"] == one["proof_sha256"], (world, transport, extra)
@@ -130,7 +130,7 @@ def test_cyclic_key_native_provers_same_proof(extra):
 def test_cyclic_key_native_psnark_same_proof(extra):
     """BASELINE configs[4] (`psnark`, 8 GPUs): gm_psnark_new_time (and the elastic prover) over cyclic shares on 2 and 3 ranks"""
     one = _single(extra, tool="run_psnark.py", logn=10)
-    for world in (2, 3):
+    for world in ((3,) if not extra else (2,)):
         many = _run(world, extra, tool="run_psnark.py", logn=10)
         assert many["n_gpus"] == world and many["proof_sha256"] == one["proof_sha256"], (world, extra)
 
@@ -141,7 +141,7 @@ def test_block_sharded_native_prover_same_proof(tail_log):
     8 ranks (blocks of 512): the first gathered level is TWO blocks long -- every rank takes its range of the replicated levels in
     the n / g opening, not rank 0 all of them (found by tests/soak_dist_native.py, which sweeps transports x worlds x tails)"""
     one = _single()
-    for world in {4: (1, 2, 8), 6: (4,), 8: (8,)}[tail_log]:
+    for world in {4: (1, 2), 6: (4,), 8: (8,)}[tail_log]:
         many = _run(world, ["--block-sharded", "--tail-log", str(tail_log)], transport="hook" if (tail_log, world) == (4, 2) else "shm")
         assert many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
 
@@ -234,7 +234,7 @@ def test_sharded_sumcheck_refuses_blocks_that_do_not_tile():
 
 
 # ---- psnark with the FIELD side block-sharded (gm_psnark_new_time_sharded, gemini_amd/csrc/psnark_sharded.cpp) ---------------------
-@pytest.mark.parametrize("world,tail_log,transport", [(1, 4, "shm"), (2, 4, "shm"), (3, 5, "hook"), (4, 3, "shm"), (8, 4, "shm")])
+@pytest.mark.parametrize("world,tail_log,transport", [(1, 4, "shm"), (3, 5, "hook"), (8, 4, "shm")])  # (2, 4, 5, 6, 7, 9 ranks: tests/soak_dist_native.py)
 def test_block_sharded_psnark_same_proof(world, tail_log, transport):
     """BASELINE configs[4]: psnark::Proof::new_time (src/psnark/time_prover.rs:69-384) with every vector in blocks over 1 / 2 / 3 / 4 / 8 ranks
     sharing the test GPU == gm_psnark_new_time byte for byte (dummy_r1cs, src/psnark/tests.rs:14-55): lookups from replicated sources, the suffix
@@ -244,7 +244,7 @@ def test_block_sharded_psnark_same_proof(world, tail_log, transport):
     assert many["n_gpus"] == world and many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
 
 
-@pytest.mark.parametrize("world,tail_log", [(2, 3), (4, 5), (8, 4)])
+@pytest.mark.parametrize("world,tail_log", [(4, 5), (8, 3)])
 def test_block_sharded_psnark_general_matrices(world, tail_log):
     """the same on a random satisfied R1CS (entries of A and B in arbitrary columns, src/psnark/tests.rs:57-125 random circuits): the joint support is
     irregular, the extended frequencies repeat indices, the row blocks read z everywhere"""
@@ -260,8 +260,8 @@ def test_block_sharded_psnark_elastic_and_verifiable_key():
     one = _single(["--elastic"], tool="run_psnark.py", logn=10)
     many = _run(4, ["--elastic", "--block-sharded", "--tail-log", "5"], tool="run_psnark.py", logn=10)
     assert many["proof_sha256"] == one["proof_sha256"]
-    one = _single(["--verifiable-key"], tool="run_psnark.py", logn=10)
-    many = _run(2, ["--verifiable-key", "--block-sharded", "--tail-log", "6"], tool="run_psnark.py", logn=10)
+    one = _single(["--verifiable-key"], tool="run_psnark.py", logn=8)
+    many = _run(2, ["--verifiable-key", "--block-sharded", "--tail-log", "4"], tool="run_psnark.py", logn=8)
     assert many["proof_sha256"] == one["proof_sha256"]
 
 
@@ -287,8 +287,9 @@ def test_rccl_branches_with_n_ranks_snark(fake_rccl, world, transport):
 @pytest.mark.parametrize("world,transport", [(2, "rccl-node"), (8, "rccl")])
 def test_rccl_branches_with_n_ranks_psnark(fake_rccl, world, transport):
     """gm_psnark_new_time_sharded the same way (BASELINE configs[4] over the transport the driver's 8-GPU run will use)"""
-    one = _single(tool="run_psnark.py", logn=10)
-    many = _run(world, ["--block-sharded", "--tail-log", "4"], tool="run_psnark.py", logn=10, transport=transport, env_extra=fake_rccl)
+    logn = 10 if world == 2 else 8  # (the stand-in stages every payload through the host: 8 ranks of it are slow)
+    one = _single(tool="run_psnark.py", logn=logn)
+    many = _run(world, ["--block-sharded", "--tail-log", "4"], tool="run_psnark.py", logn=logn, transport=transport, env_extra=fake_rccl)
     assert many["transport"] == "rccl" and many["proof_sha256"] == one["proof_sha256"], (world, transport)
 
 
@@ -339,7 +340,7 @@ def test_rccl_failing_rank_aborts_and_poisons_the_transport(fake_rccl):
         assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]
 
 
-@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("world", [2, 8])
 def test_block_sharded_elastic_snark_dummy_srs(world):
     """BASELINE configs[3] as written (examples/snark.rs:54-66: the ELASTIC prover on the DummyStreamer key, 8 GPUs): gm_snark_new_elastic_sharded --
     the resident schedule of the elastic prover over blocks, the generator-copies key in slices -- == the single-GPU elastic prover on the same key"""
