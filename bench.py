@@ -661,7 +661,7 @@ def main():
     # of their own (tools/profile_round.sh); the figure of the committed passes of this library is quoted with its
     # source (profiles/r5_pmc_msm20.json says how it was collected and corrected)
     traffic, traffic_source = None, None
-    for tag in ("r5", "r4", "r3", "r2", "r1"):
+    for tag in ("r6", "r5", "r4", "r3", "r2", "r1"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_msm20.json")) as fh:
                 if args.logn == LOG_N:

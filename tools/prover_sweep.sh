@@ -1,11 +1,11 @@
 #!/bin/bash
 # GPU box, round 5: the prover sweep with the library's memory bookkeeping beside every time (gm_mem_stats: high-water mark of the
 # bytes IN USE during the proofs, tables and keys apart).  One process per line so that a failure at a large size loses nothing else.
-O=${1:-gpurun_out/r5_prover_sweep.txt}
+O=${1:-gpurun_out/${TAG:-r6}_prover_sweep.txt}
 : > $O
 one() {  # label, command...
   local label=$1; shift
-  timeout ${PER_RUN_TIMEOUT:-900} "$@" 2>gpurun_out/r5_err_$label.log | python -c "
+  timeout ${PER_RUN_TIMEOUT:-900} "$@" 2>gpurun_out/${TAG:-r6}_err_$label.log | python -c "
 import sys,json
 L=sys.stdin.readlines()
 try:
@@ -14,7 +14,7 @@ try:
 except Exception as e:
     print('$label', 'FAILED', repr(e))
 " >> $O
-  tail -3 gpurun_out/r5_err_$label.log | grep -i "error\|ENOMEM\|Traceback" >> $O
+  tail -3 gpurun_out/${TAG:-r6}_err_$label.log | grep -i "error\|ENOMEM\|Traceback" >> $O
 }
 for i in ${PSNARK_SIZES:-20 22 24 26}; do
   one "psnark_elastic_$i" python tools/run_psnark.py -i $i --repeat ${REPEAT:-2} --elastic --native

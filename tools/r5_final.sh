@@ -6,7 +6,7 @@ python bench.py --steps 20 --warmup 5 > $O/r5_bench_driver_args.json 2> $O/r5_be
 python bench.py > $O/r5_bench.json 2> $O/r5_bench.err
 bash tools/profile_round.sh r5 > $O/r5_profile_round.log 2>&1
 bash tools/exposed_round.sh r5 > $O/r5_exposed_round.log 2>&1
-bash tools/r5_sweep.sh $O/r5_prover_sweep.txt > /dev/null 2>&1
+TAG=r5 bash tools/prover_sweep.sh $O/r5_prover_sweep.txt > /dev/null 2>&1
 bash tools/shard_shares.sh $O/r5_shard_shares.txt > /dev/null 2>&1
 python tools/footprint_table.py > $O/r5_footprint.txt 2> $O/r5_footprint.err
 python tools/collective_latency.py > $O/r5_collective_latency_world1.json 2>/dev/null
