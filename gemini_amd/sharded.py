@@ -272,6 +272,76 @@ class PsnarkShard:
             self.w_block = keep(FrVec.alloc(w_cnt))
             capi.check(capi.load().gm_fr_stride(C.c_uint64(r1cs.w.handle), C.c_size_t(lo), C.c_size_t(1), C.c_size_t(w_cnt), C.c_uint64(self.w_block.handle)))
 
+    @classmethod
+    def dummy(cls, e_canonical: int, n: int, tail_log: int = 10) -> "PsnarkShard":
+        """this rank's blocks of dummy_r1cs(e, n) (src/circuit.rs:349-365: z = [e; n], w = [e; n - 1], A = B = C = diag(1 / e)) in closed form --
+        nothing of size n is built on the host (the joint support is the diagonal: row = col = 0 .. n - 1, the three value vectors 1 / e, every
+        index looked up twice in the extended frequencies): what lets 8 ranks set up `psnark -i 26 .. 28` without 8 whole host copies"""
+        from .circuit import SparseMatrix
+        from .fr import IdxVec
+        from .psnark import _field_of_index
+
+        self = cls.__new__(cls)
+        rank, world, _ = collective.info()
+        e = e_canonical % R_MOD
+        em, im = fr_from_int(e), fr_from_int(pow(e, -1, R_MOD))
+        nt = 1 << max(n - 1, 0).bit_length()
+        self.num_constraints = self.num_variables = self.nnz = n
+        self.ext_row_len, self.ext_col_len, self.w_len = nt + n, 2 * n, n - 1
+        self.longest = max(self.ext_row_len + 2, self.ext_col_len + 2, n + 2, n + 1)
+        self.block = psnark_shard_block(self.longest, world)
+        self.tail_log = tail_log
+        self.levels = {}
+        self._own = []
+        lib = capi.load()
+        lib.gm_psnark_shard_level.restype = C.c_size_t
+
+        def keep(x):
+            self._own.append(x)
+            return x
+
+        def cut(length: int, whole: int):
+            s_ = int(lib.gm_psnark_shard_level(C.c_size_t(length), C.c_size_t(self.block), C.c_size_t(tail_log), C.c_int(world)))
+            self.levels[length] = s_
+            b = self.block >> s_
+            return min(rank * b, whole), min((rank + 1) * b, whole)
+
+        lo, hi = cut(n, n)  # the row block of the diagonal matrix
+        d = keep(SparseMatrix.from_csr(np.arange(hi - lo + 1, dtype=np.uint64), np.arange(lo, hi, dtype=np.uint32), np.tile(im, (hi - lo, 1)), hi - lo, n)) if hi > lo else None
+        self.mats = [d, d, d]
+        self.z = keep(FrVec.alloc(n))
+        self.z.fill(em)
+        lo, hi = cut(n + 1, n)  # the joint support and everything indexed by it
+        self.row_index = keep(IdxVec.from_host(np.arange(lo, hi, dtype=np.uint32))) if hi > lo else None
+        self.col_index = keep(IdxVec.from_host(np.arange(lo, hi, dtype=np.uint32))) if hi > lo else None
+        self.row = keep(_field_of_index(self.row_index)) if self.row_index else None
+        self.col = keep(_field_of_index(self.col_index)) if self.col_index else None
+
+        def vals():
+            if hi <= lo:
+                return None
+            v = keep(FrVec.alloc(hi - lo))
+            v.fill(im)
+            return v
+
+        self.val_a, self.val_b, self.val_c = vals(), vals(), vals()
+
+        def ext(whole: int):
+            # extend_frequency(compute_frequency(set_len, 0 .. n - 1)): i < n twice, n <= i < set_len once
+            a, b = cut(whole + 2, whole)
+            if b <= a:
+                return None
+            j = np.arange(a, b, dtype=np.int64)
+            return keep(IdxVec.from_host(np.where(j < 2 * n, j // 2, n + (j - 2 * n)).astype(np.uint32)))
+
+        self.ext_fre_row, self.ext_fre_col = ext(self.ext_row_len), ext(self.ext_col_len)
+        lo, hi = cut(self.w_len, self.w_len)
+        self.w_block = None
+        if hi > lo:
+            self.w_block = keep(FrVec.alloc(hi - lo))
+            self.w_block.fill(em)
+        return self
+
     def record(self, key: PsnarkShardKey, index=None) -> _GmPsnarkShard:
         h = lambda x: x.handle if x is not None else 0  # noqa: E731
         S = _GmPsnarkShard()

@@ -84,6 +84,8 @@ def main():
         ra, rb, rc, zh = random_rows(n, args.random_r1cs)
         mats = [SparseMatrix.from_rows(rows, n) for rows in (ra, rb, rc)] + [SparseMatrix.from_rows(rows, n, transpose=True) for rows in (ra, rb, rc)]
         r1cs = R1cs(*mats, FrVec.from_host(zh), FrVec.from_host(zh[1:]), FrVec.from_host(zh[:1]))
+    elif lib_dist and args.block_sharded:
+        r1cs = None  # every rank builds ITS blocks of dummy_r1cs in closed form (PsnarkShard.dummy): nothing whole anywhere
     else:
         r1cs = dummy_r1cs(e_inst, n)
     t0 = time.perf_counter()
@@ -96,7 +98,8 @@ def main():
     if lib_dist and args.block_sharded:
         from gemini_amd.sharded import PsnarkShard, PsnarkShardKey, psnark_new_time_sharded
 
-        shard = PsnarkShard(r1cs, tail_log=args.tail_log)
+        # dummy_r1cs in closed form per rank (nothing of size n on the host); a random instance is cut out of the whole one
+        shard = PsnarkShard(r1cs, tail_log=args.tail_log) if args.random_r1cs is not None else PsnarkShard.dummy(e_inst, n, tail_log=args.tail_log)
         ck = PsnarkShardKey(max_degree, shard.block, args.tail_log, tau)
     elif lib_dist:
         from gemini_amd.sharded import cyclic_committer_key
