@@ -168,11 +168,26 @@ def test_sharded_provers_from_plain_c_abi_processes(oracle, pyref, tmp_path):
 
     one = run(1, "cyclic")
     assert run(1, "block") == one
-    for world in (2, 8):  # (1 / 2 / 4 / 8 of the same prover through Python launchers: tests/test_gpu_dist_native.py)
+    for world in (8,):  # (1 / 2 / 4 / 8 of the same prover through Python launchers: tests/test_gpu_dist_native.py)
         assert run(world, "block") == one, world
     assert run(4, "block", "global") == one
     for world in (3, 5):
         assert run(world, "cyclic") == one, world
+    # psnark with every vector in blocks at the level of its family (gm_psnark_new_time_sharded): blocks of dummy_r1cs built in C from closed forms,
+    # any world size
+    import gemini_amd as gm
+    from gemini_amd import g2 as G2
+
+    g2_file = tmp_path / "g2.bin"
+    g2_file.write_bytes(G2.serialize_vec_uncompressed([G2.mul(G2.generator(), pow(tau_i, i, R)) for i in range(6)]))
+
+    def run_p(world, logn=9):
+        out = subprocess.run([exe, str(world), str(logn), "psnark", "global"] + args + [str(g2_file)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.split()[1]
+
+    p_one = run_p(1)  # (one process through the same entry; that world 1 equals gm_psnark_new_time byte for byte: tests/test_gpu_dist_native.py)
+    assert run_p(5) == p_one
     # and the digest is the one of the Python mirror's single-GPU native prover on the same instance and key
     import gemini_amd as gm
     from gemini_amd.circuit import dummy_r1cs
@@ -206,3 +221,4 @@ def test_sharded_provers_from_plain_c_abi_processes(oracle, pyref, tmp_path):
     assert f"{h:016x}" == one
     r1cs.free()
     ck.powers_of_g.free()
+
