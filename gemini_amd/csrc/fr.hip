@@ -96,7 +96,10 @@ struct ScArgs {
 // multiplication, 80 multiply-adds instead of 137) in 17-limb accumulators and are Montgomery-reduced ONCE per thread (r^2 =
 // 0.205 x 2^512: the seventeenth limb holds what 512 bits cannot).  The reference does the same on the CPU (`ip_unsafe`,
 // src/misc.rs:235-266).
-template <bool FOLD, bool MSG, bool LAZY>
+// TW1 = the message's twist is ONE (Sumcheck::new_time(.., &F::one()): the second sumcheck of both SNARKs, three of the thirteen provers of the
+// third; herring's module provers): the running twist power is 1 for every pair, so the two products with it and its own update -- three of the
+// ~ nine multiplications a fold + message pair costs in this ALU-bound kernel -- are not computed at all
+template <bool FOLD, bool MSG, bool LAZY, bool TW1>
 GM_DEV void sc_round_body(const ScArgs& A, uint8_t* __restrict__ partials) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 3 * FR_BYTES];
   const size_t T = (size_t)1 << A.log_threads;
@@ -118,7 +121,7 @@ GM_DEV void sc_round_body(const ScArgs& A, uint8_t* __restrict__ partials) {
 #pragma unroll
       for (int i = 0; i < 17; i++) wide[k].l[i] = 0;
   }
-  if (MSG && t < A.npairs) tw = fr_mul(tw, pow_from_table(A.tau2, t));
+  if (MSG && !TW1 && t < A.npairs) tw = fr_mul(tw, pow_from_table(A.tau2, t));
   // message vectors: FOLD ? folded (length ceil(n_in/2)) : the inputs
   const size_t nf = FOLD ? (A.nf_in + 1) / 2 : A.nf_in;
   const size_t ng = FOLD ? (A.ng_in + 1) / 2 : A.ng_in;
@@ -144,7 +147,7 @@ GM_DEV void sc_round_body(const ScArgs& A, uint8_t* __restrict__ partials) {
       go = fr_load_or_zero(A.g_in, 2 * j + 1, ng);
     }
     if (MSG) {
-      Fr u = fr_mul(fe, tw), w = fr_mul(fo, tw);
+      Fr u = TW1 ? fe : fr_mul(fe, tw), w = TW1 ? fo : fr_mul(fo, tw);
       if (LAZY) {
         fp_mac_wide(wide[0], u, ge);
         fp_mac_wide(wide[1], u, go);
@@ -154,7 +157,7 @@ GM_DEV void sc_round_body(const ScArgs& A, uint8_t* __restrict__ partials) {
         acc[1] = fr_add(acc[1], fr_mul(u, go));
         acc[2] = fr_add(acc[2], fr_mul(w, ge));
       }
-      tw = fr_mul(tw, step);
+      if (!TW1) tw = fr_mul(tw, step);
     }
   }
   if (MSG) {
@@ -165,15 +168,15 @@ GM_DEV void sc_round_body(const ScArgs& A, uint8_t* __restrict__ partials) {
     block_sum<3>(acc, lds);
     if (threadIdx.x == 0) {
       // b = b1 + tau * b2
-      Fr b = fr_add(acc[1], fr_mul(tau, acc[2]));
+      Fr b = fr_add(acc[1], TW1 ? acc[2] : fr_mul(tau, acc[2]));
       fp_store<FrParams>(partials + ((size_t)blockIdx.x * 2) * FR_BYTES, acc[0]);
       fp_store<FrParams>(partials + ((size_t)blockIdx.x * 2 + 1) * FR_BYTES, b);
     }
   }
 }
-template <bool FOLD, bool MSG, bool LAZY = false>
+template <bool FOLD, bool MSG, bool LAZY = false, bool TW1 = false>
 __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict__ partials) {
-  sc_round_body<FOLD, MSG, LAZY>(A, partials);
+  sc_round_body<FOLD, MSG, LAZY, TW1>(A, partials);
 }
 // The round of SEVERAL provers in one launch (Sumcheck::prove_batch maps its provers over rayon, proof.rs:85; the third sumcheck of psnark
 // has 13 of them, each a launch of its own until round 5 -- ~240 launches per proof whose tails are launch latency): blockIdx.y = prover,
@@ -181,13 +184,14 @@ __global__ __launch_bounds__(256) void k_sc_round(ScArgs A, uint8_t* __restrict_
 struct ScMultiDesc {
   ScArgs A;
   uint8_t* partials;
-  uint32_t blocks, pad;
+  uint32_t blocks, tw1;  // tw1: this prover's message twist is one (block-uniform branch)
 };
 template <bool FOLD, bool MSG, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_sc_round_multi(const ScMultiDesc* __restrict__ descs) {
   const ScMultiDesc& D = descs[blockIdx.y];
   if (blockIdx.x >= D.blocks) return;
-  sc_round_body<FOLD, MSG, LAZY>(D.A, D.partials);
+  if (MSG && D.tw1) sc_round_body<FOLD, MSG, LAZY, true>(D.A, D.partials);
+  else sc_round_body<FOLD, MSG, LAZY, false>(D.A, D.partials);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -700,6 +704,10 @@ static unsigned grid_for(size_t n, unsigned max_blocks = 2048) {
 // stream has been waited for: the host adds the partials).  Driven one prover at a time the two run back to back
 // (sc_launch); Sumcheck::prove_batch enqueues the round of EVERY prover before it waits once (sc_round_begin / _end).
 // sc_prepare: the arguments of the launch (and the prover's buffers it needs); sc_after: the bookkeeping once it is enqueued
+static bool sc_twist_one(const ScArgs& A) {
+  static const bool off = getenv("GM_SC_TW1") && atoi(getenv("GM_SC_TW1")) == 0;  // A/B knob
+  return !off && memcmp(A.tau, gmh::Fr::one().l, 32) == 0;
+}
 static int sc_prepare(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::Fr& rho, ScArgs& A, unsigned* blocks_out, uint8_t** part_out_p) {
   memset(&A, 0, sizeof A);
   gmh::Fr tau = gmh::Fr::from_limbs(S->twist);
@@ -787,7 +795,10 @@ static int sc_enqueue(Context* C, Sumcheck* S, bool fold, bool msg, const gmh::F
   Profiler& prof = C->prof;
   prof.begin(PROF_SC_ROUND, st);
   const bool lazy = sc_lazy();
-  if (fold && msg && lazy)
+  if (msg && lazy && sc_twist_one(A)) {
+    if (fold) hipLaunchKernelGGL((k_sc_round<true, true, true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
+    else hipLaunchKernelGGL((k_sc_round<false, true, true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
+  } else if (fold && msg && lazy)
     hipLaunchKernelGGL((k_sc_round<true, true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
   else if (fold && msg)
     hipLaunchKernelGGL((k_sc_round<true, true>), dim3(blocks), dim3(256), 0, st, A, part_out);
@@ -812,6 +823,7 @@ static int sc_enqueue_many(Context* C, Sumcheck** S, size_t k, bool fold, bool m
     memset(&d[j], 0, sizeof d[j]);
     int rc = sc_prepare(C, S[j], fold, msg, rho, d[j].A, &d[j].blocks, &d[j].partials);
     if (rc) return rc;
+    d[j].tw1 = msg && sc_twist_one(d[j].A) ? 1u : 0u;
     max_blocks = std::max(max_blocks, d[j].blocks);
   }
   const size_t bytes = k * sizeof(ScMultiDesc), slot = (size_t)256 << 10;
