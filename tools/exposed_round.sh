@@ -19,4 +19,5 @@ run elastic24 python $R/tools/run_snark.py -i 24 --repeat 3 --elastic --dummy-sr
 run psnark22 python $R/tools/run_psnark.py -i 22 --repeat 3 --native
 run psnark22_elastic python $R/tools/run_psnark.py -i 22 --repeat 3 --elastic --native
 run shard21 python $R/tools/run_snark.py -i 21 --repeat 3 --block-sharded --transport shm
+run pshard19 python $R/tools/run_psnark.py -i 19 --repeat 3 --block-sharded --transport shm
 cat $O/exposed_$TAG.md
