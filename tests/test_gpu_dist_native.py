@@ -242,6 +242,9 @@ def test_block_sharded_psnark_same_proof(world, tail_log, transport):
     one = _single(tool="run_psnark.py", logn=10)
     many = _run(world, ["--block-sharded", "--tail-log", str(tail_log)], tool="run_psnark.py", logn=10, transport=transport)
     assert many["n_gpus"] == world and many["proof_sha256"] == one["proof_sha256"], (world, tail_log)
+    if world == 8:  # the layout really has LEVELS here: the ~n-long families in blocks half the size of the ~2n-long ones
+        levels = many["layout"]["levels_by_family_length"]
+        assert max(levels.values()) >= 1 and min(levels.values()) == 0, levels
 
 
 @pytest.mark.parametrize("world,tail_log", [(4, 3)])
