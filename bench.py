@@ -700,9 +700,7 @@ def main():
         of the JSON line ("second_metric_error"), not inside a nested record the driver would read as rc 0"""
         try:
             return fn()
-        except Exception as exc:  # noqa: BLE001
-            if world == 1:
-                raise
+        except Exception as exc:  # noqa: BLE001 -- also on one GPU: the headline line (the contract) must not be lost to a later leg
             import traceback
 
             sys.stderr.write(f"[bench rank {rank}] {name} FAILED: {exc!r}\n{traceback.format_exc()}\n")
