@@ -422,8 +422,10 @@ def main():
     ap.add_argument("--cpu-snark-logn", type=int, default=20, help="instance size of the time_prover CPU baseline (0 = skip)")
     ap.add_argument("--no-cpu-snark-top", action="store_true", help="do not run the time_prover CPU baseline at --snark-logn itself (about a minute at 2^24), "
                     "only at --cpu-snark-logn and two powers above it")
-    ap.add_argument("--psnark-logn", type=int, default=22, help="also time psnark::Proof::new_time on dummy_r1cs(2^k): one GPU natively, N GPUs block-sharded (0 = skip)")
-    ap.add_argument("--strong-msm-logn", type=int, default=24, help="also time ONE MSM of 2^k pairs in total, split n / g over the ranks (strong scaling; 0 = skip)")
+    # sizes of the strong-scaling legs: large enough that one rank's share on 8 GPUs is still throughput-bound (a share of psnark -i 22 is 45 % accumulation,
+    # of -i 24 most of it: profiles/r6_exposed_time.md; an MSM of 2^23 pairs runs at 1.5 x the rate of one of 2^21)
+    ap.add_argument("--psnark-logn", type=int, default=24, help="also time psnark::Proof::new_time on dummy_r1cs(2^k): one GPU natively, N GPUs block-sharded (0 = skip)")
+    ap.add_argument("--strong-msm-logn", type=int, default=26, help="also time ONE MSM of 2^k pairs in total, split n / g over the ranks (strong scaling; 0 = skip)")
     ap.add_argument("--snark-logn", type=int, default=24, help="also time snark::Proof::new_time on dummy_r1cs(2^k) (N=1 only; 0 = skip)")
     args = ap.parse_args()
     if args.headline_only:
@@ -728,7 +730,7 @@ def main():
             one()
             barrier()
             t1 = time.perf_counter()
-            k = 10
+            k = 5
             for _ in range(k):
                 r2 = one()
                 assert (r2 == ref).all(), "non-deterministic MSM result"
