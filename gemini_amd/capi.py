@@ -26,7 +26,7 @@ SYMBOLS = [
     "gm_g1_msm_stream_new", "gm_g1_msm_stream_new_h", "gm_g1_msm_stream_add", "gm_g1_msm_stream_finalize", "gm_g1_msm_stream_free", "gm_host_alloc", "gm_host_free",
     "gm_g1_fixed_base_register", "gm_g1_srs_register", "gm_g1_srs_register_segments", "gm_set_msm_window", "gm_set_msm_table_min", "gm_set_msm_affine_levels", "gm_set_msm_split", "gm_set_msm_glv", "gm_prof_enable", "gm_prof_read", "gm_prof_read_clock",
     "gm_idx_register", "gm_idx_free", "gm_fr_gather", "gm_fr_alg_hash", "gm_fr_plookup_set", "gm_fr_add_scalar", "gm_fr_shift_monic",
-    "gm_fr_acc_product", "gm_fr_tensor_range", "gm_fr_powers_range", "gm_fr_plookup_set_block", "gm_fr_shift_block", "gm_fr_product", "gm_fr_acc_product_block",
+    "gm_fr_acc_product", "gm_fr_tensor_range", "gm_fr_tensor_gather", "gm_fr_powers_gather", "gm_fr_alg_hash_from", "gm_fr_powers_range", "gm_fr_plookup_set_block", "gm_fr_shift_block", "gm_fr_product", "gm_fr_acc_product_block",
     "gm_sc_set_shard_rounds", "gm_sc_round_begin_many", "gm_psnark_shard_block", "gm_psnark_shard_level", "gm_psnark_shard_footprint", "gm_psnark_shard_key_new", "gm_psnark_index_sharded", "gm_psnark_new_time_sharded", "gm_snark_new_elastic_sharded",
     "gm_fr_vec_alloc", "gm_fr_vec_free", "gm_fr_vec_len", "gm_fr_vec_upload", "gm_fr_vec_download",
     "gm_fr_vec_fill", "gm_fr_vec_ptr", "gm_fr_vec_set_len",

@@ -300,7 +300,9 @@ int fr_reverse(Context* C, FrVec* in, FrVec* out);
 int spm_mul(Context* C, SparseMatrix* M, FrVec* x, FrVec* y);
 int fr_div_linear_factors(Context* C, FrVec* f, const uint64_t* points, size_t k, FrVec* q, uint64_t* rem_out);
 int fr_gather(Context* C, FrVec* src, const IdxVec* index, FrVec* out);
-int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4], FrVec* out);
+int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4], FrVec* out, uint64_t base = 0);
+int fr_tensor_gather(Context* C, const uint64_t* rhos, size_t k, const IdxVec* index, FrVec* out);
+int fr_powers_gather(Context* C, const uint64_t x[4], size_t k, const IdxVec* index, FrVec* out);
 int fr_plookup_set(Context* C, FrVec* v, const uint64_t y[4], const uint64_t z[4], FrVec* out);
 int fr_add_scalar(Context* C, FrVec* v, const uint64_t y[4], FrVec* out);
 int fr_shift_monic(Context* C, FrVec* v, FrVec* out);
@@ -1414,6 +1416,28 @@ int gm_fr_powers_range(const uint64_t x_mont[4], size_t start, size_t count, uin
   if (rc) return rc;
   vo->len = count;
   return GM_OK;
+}
+// lookups of vectors that are FUNCTIONS of the index, without the vectors (k_gather_prod2)
+int gm_fr_tensor_gather(const uint64_t* rhos_mont, size_t k, uint64_t index, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_tensor_gather");
+  GM_IDX(ix, index, "fr_tensor_gather");
+  GM_CHECK(rhos_mont != nullptr, GM_EINVAL, "fr_tensor_gather: null pointer");
+  return fr_tensor_gather(C, rhos_mont, k, ix, vo);
+}
+int gm_fr_powers_gather(const uint64_t x_mont[4], size_t log_len, uint64_t index, uint64_t out) {
+  GM_CTX();
+  GM_VEC(vo, out, "fr_powers_gather");
+  GM_IDX(ix, index, "fr_powers_gather");
+  GM_CHECK(x_mont != nullptr, GM_EINVAL, "fr_powers_gather: null pointer");
+  return fr_powers_gather(C, x_mont, log_len, ix, vo);
+}
+// alg_hash of a RANGE of a vector: out[i] = v[i] + (first_index + i) zeta
+int gm_fr_alg_hash_from(uint64_t v, size_t first_index, const uint64_t zeta_mont[4], uint64_t out) {
+  GM_CTX();
+  GM_VEC(vv, v, "fr_alg_hash_from");
+  GM_VEC(vo, out, "fr_alg_hash_from");
+  return fr_alg_hash(C, vv, nullptr, zeta_mont, vo, (uint64_t)first_index);
 }
 int gm_fr_plookup_set_block(uint64_t v, size_t v_offset, size_t v_count, const uint64_t* prev_or_null, size_t out_count, const uint64_t y_mont[4],
                             const uint64_t z_mont[4], uint64_t out) {

@@ -244,6 +244,20 @@ __global__ __launch_bounds__(256) void k_tensor(const uint8_t* __restrict__ lo, 
   }
 }
 
+// out[i] = lo[idx & mask] * hi[idx >> klo], idx = index[i]: `lookup(v, index)` (plookup/time_prover.rs:5-8) of a vector that is a FUNCTION of the
+// index -- tensor(rho) (lo / hi: the half tables of k_tensor_table) or powers(x) (lo[j] = x^j, hi[j] = x^(j 2^klo)) -- without the vector: one
+// multiplication per looked-up element from two L2-resident tables instead of an O(n) pass to build the vector and a random gather from it
+__global__ __launch_bounds__(256) void k_gather_prod2(const uint8_t* __restrict__ lo, const uint8_t* __restrict__ hi, uint32_t klo,
+                                                      const uint32_t* __restrict__ index, size_t n, uint8_t* __restrict__ out) {
+  const size_t mask = ((size_t)1 << klo) - 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t idx = index[i];
+    Fr a = fp_load<FrParams>(lo + (idx & mask) * FR_BYTES);
+    Fr b = fp_load<FrParams>(hi + (idx >> klo) * FR_BYTES);
+    fp_store<FrParams>(out + i * FR_BYTES, fr_mul(a, b));
+  }
+}
+
 // out = a . b                                                                   misc.rs:205-208
 __global__ __launch_bounds__(256) void k_hadamard(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
                                                   uint8_t* __restrict__ out) {
@@ -471,11 +485,11 @@ __global__ __launch_bounds__(256) void k_gather(const uint8_t* __restrict__ src,
 }
 // out[i] = v[i] + F::from(index[i]) * zeta (index == nullptr: the range 0..n)   plookup/time_prover.rs:11-21
 // zeta2 = zeta * R^2 so that the Montgomery product with the plain integer is (index * zeta) * R
-__global__ __launch_bounds__(256) void k_alg_hash(const uint8_t* __restrict__ v, const uint32_t* __restrict__ index, size_t n,
+__global__ __launch_bounds__(256) void k_alg_hash(const uint8_t* __restrict__ v, const uint32_t* __restrict__ index, size_t n, uint64_t base,
                                                   const uint32_t* __restrict__ zeta2_8, uint8_t* __restrict__ out) {
   Fr z2 = fp_load<FrParams>(zeta2_8);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const uint64_t k = index ? (uint64_t)index[i] : (uint64_t)i;
+    const uint64_t k = index ? (uint64_t)index[i] : base + (uint64_t)i;  // (base: the first index of a RANGE of the hashed vector)
     Fr kk = Fr::zero();
     kk.l[0] = (uint32_t)k;
     kk.l[1] = (uint32_t)(k >> 32);
@@ -1556,6 +1570,52 @@ int fr_tensor(Context* C, const uint64_t* rhos, size_t k, FrVec* out) {
   return fr_tensor_range(C, rhos, k, 0, (size_t)1 << k, out);
 }
 
+// out[i] = tensor(rhos)[index[i]] (k_gather_prod2 on the half tables of the tensor)
+int fr_tensor_gather(Context* C, const uint64_t* rhos, size_t k, const IdxVec* index, FrVec* out) {
+  GM_FR_LOCK(C);
+  GM_CHECK(k >= 1 && k <= 32, GM_EINVAL, "tensor_gather: need 1 <= k <= 32 elements (got %zu)", k);
+  GM_CHECK(out->cap >= index->n, GM_EINVAL, "tensor_gather: output capacity %zu < %zu", out->cap, index->n);
+  GM_CHECK(index->max_plus_1 <= ((size_t)1 << k), GM_EINVAL, "tensor_gather: index %zu outside 2^%zu entries", index->max_plus_1 - 1, k);
+  const uint32_t klo = (uint32_t)(k / 2 > 0 ? (k + 1) / 2 : k), khi = (uint32_t)k - klo;
+  int rc = C->fr_scratch.ensure((1 << 20) + (((size_t)1 << klo) + ((size_t)1 << khi)) * FR_BYTES);
+  if (rc) return rc;
+  uint8_t* base = C->fr_scratch.as<uint8_t>();
+  GM_HIP(hipMemcpyAsync(base, rhos, k * 32, hipMemcpyHostToDevice, C->stream));
+  uint8_t* lo = base + (1 << 20);
+  uint8_t* hi = lo + ((size_t)1 << klo) * FR_BYTES;
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << klo)), dim3(256), 0, C->stream, (const uint32_t*)base, klo, lo);
+  hipLaunchKernelGGL(k_tensor_table, dim3(grid_for((size_t)1 << khi)), dim3(256), 0, C->stream, (const uint32_t*)(base + (size_t)klo * 32), khi, hi);
+  if (index->n) hipLaunchKernelGGL(k_gather_prod2, dim3(grid_for(index->n)), dim3(256), 0, C->stream, lo, hi, klo, index->d, index->n, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = index->n;
+  return GM_OK;
+}
+// out[i] = x^index[i], index[i] < 2^k: lo[j] = x^j (j < 2^klo), hi[j] = (x^(2^klo))^j
+int fr_powers_gather(Context* C, const uint64_t x[4], size_t k, const IdxVec* index, FrVec* out) {
+  GM_FR_LOCK(C);
+  GM_CHECK(k >= 1 && k <= 32, GM_EINVAL, "powers_gather: need 1 <= k <= 32 (got %zu)", k);
+  GM_CHECK(out->cap >= index->n, GM_EINVAL, "powers_gather: output capacity %zu < %zu", out->cap, index->n);
+  GM_CHECK(index->max_plus_1 <= ((size_t)1 << k), GM_EINVAL, "powers_gather: index %zu outside 2^%zu entries", index->max_plus_1 - 1, k);
+  const uint32_t klo = (uint32_t)(k / 2 > 0 ? (k + 1) / 2 : k), khi = (uint32_t)k - klo;
+  int rc = C->fr_scratch.ensure((1 << 20) + (((size_t)1 << klo) + ((size_t)1 << khi)) * FR_BYTES);
+  if (rc) return rc;
+  uint8_t* lo = C->fr_scratch.as<uint8_t>() + (1 << 20);
+  uint8_t* hi = lo + ((size_t)1 << klo) * FR_BYTES;
+  gmh::Fr xx = gmh::Fr::from_limbs(x), step = xx;
+  for (uint32_t b = 0; b < klo; b++) step = step.sqr();  // x^(2^klo)
+  PowTable t;
+  make_pow_table(xx, t);
+  hipLaunchKernelGGL(k_powers, dim3(grid_for((size_t)1 << klo, 512)), dim3(256), 0, C->stream, t, (size_t)0, (size_t)1 << klo, lo);
+  make_pow_table(step, t);
+  hipLaunchKernelGGL(k_powers, dim3(grid_for((size_t)1 << khi, 512)), dim3(256), 0, C->stream, t, (size_t)0, (size_t)1 << khi, hi);
+  if (index->n) hipLaunchKernelGGL(k_gather_prod2, dim3(grid_for(index->n)), dim3(256), 0, C->stream, lo, hi, klo, index->d, index->n, out->d);
+  GM_HIP(hipGetLastError());
+  GM_HIP(hipStreamSynchronize(C->stream));
+  out->len = index->n;
+  return GM_OK;
+}
+
 int fr_hadamard(Context* C, FrVec* a, FrVec* b, FrVec* out) {
   GM_FR_LOCK(C);
   GM_CHECK(a->len == b->len, GM_EINVAL, "hadamard: lengths differ (%zu vs %zu)", a->len, b->len);
@@ -1821,7 +1881,7 @@ int fr_gather(Context* C, FrVec* src, const IdxVec* index, FrVec* out) {
   return GM_OK;
 }
 
-int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4], FrVec* out) {
+int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4], FrVec* out, uint64_t base) {
   GM_FR_LOCK(C);
   // zip semantics of the reference: the shorter of (v, index) decides the length
   const size_t n = index ? std::min(v->len, index->n) : v->len;
@@ -1830,7 +1890,7 @@ int fr_alg_hash(Context* C, FrVec* v, const IdxVec* index, const uint64_t zeta[4
   uint8_t* dz;
   int rc = upload_small(C, z2.l, 32, &dz);
   if (rc) return rc;
-  if (n) hipLaunchKernelGGL(k_alg_hash, dim3(grid_for(n)), dim3(256), 0, C->stream, v->d, index ? index->d : nullptr, n, (const uint32_t*)dz, out->d);
+  if (n) hipLaunchKernelGGL(k_alg_hash, dim3(grid_for(n)), dim3(256), 0, C->stream, v->d, index ? index->d : nullptr, n, base, (const uint32_t*)dz, out->d);
   GM_HIP(hipGetLastError());
   GM_HIP(hipStreamSynchronize(C->stream));
   out->len = n;

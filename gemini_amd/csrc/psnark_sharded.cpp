@@ -13,9 +13,10 @@
 // one (gm_dist_reblock_vecs: every element crosses one link once).
 // What crosses ranks, all through gm_dist's all-gather:
 //   lookups              `lookup(v, index)` (plookup/time_prover.rs:5-8) gathers from tensor(rho), powers(alpha) and z.  The first two are
-//                        FUNCTIONS of the index -- every rank computes them whole, an O(n) pass at HBM speed, cheaper than n elements over
-//                        xGMI -- and z is the instance's (whole on every rank, as for the general matrices of gm_snark_new_time_sharded):
-//                        the gathers are local, with this rank's block of the index vectors
+//                        FUNCTIONS of the index: NO rank ever builds them -- a looked-up element is one multiplication from two half tables
+//                        that stay in L2 (gm_fr_tensor_gather / gm_fr_powers_gather), a contiguous range comes from gm_fr_tensor_range /
+//                        gm_fr_powers_range -- and z is the instance's (whole on every rank, as for the general matrices of
+//                        gm_snark_new_time_sharded): the lookups are local, with this rank's block of the index vectors
 //   prefix products      accumulated_product (entryproduct/time_prover.rs:34-45) is a suffix scan: each rank scans its block from the
 //                        product of the blocks above -- 9 x 32 bytes all-gathered, once
 //   rotations / plookup  right_rotation and plookup_set read element i - 1: a 32-byte halo per vector from the rank below
@@ -774,13 +775,27 @@ int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t
   // extend_frequency(compute_frequency(set_len, index)) has set_len + |index| entries (plookup/time_prover.rs:66-79)
   GM_CHECK(S->ext_fre_row_len == nt + nnz && S->ext_fre_col_len == nz + nnz, GM_EINVAL, "psnark_new_time_sharded: extended frequencies of %zu / %zu entries, expected %zu / %zu",
            S->ext_fre_row_len, S->ext_fre_col_len, nt + nnz, nz + nnz);
-  // tensor(rho) and powers(alpha) WHOLE on every rank (:95-97): functions of the index, an O(n) pass each; their product is only ever
-  // needed at the looked-up positions
-  uint64_t b_ch, c_ch;
-  RC(V.alloc(nt, &b_ch));
-  RC(gm_fr_tensor(ch1.data(), P->rounds[0], b_ch));
-  RC(V.alloc(nt, &c_ch));
-  RC(gm_fr_powers(alpha, nt, c_ch));
+  // tensor(rho) and powers(alpha) (:95-97) are FUNCTIONS of the index: no rank ever builds them.  A lookup is one multiplication per element from
+  // two half tables that stay in L2 (gm_fr_tensor_gather / gm_fr_powers_gather), a contiguous range comes from gm_fr_tensor_range /
+  // gm_fr_powers_range; their product is only ever needed at the looked-up positions.  kind 0: tensor(rho), 1: powers(alpha), 2: z (the instance's, whole)
+  const size_t k0 = P->rounds[0];
+  auto lookup_fn = [&](int kind, uint64_t index, uint64_t out) -> int {
+    if (kind == 2) return gm_fr_gather(S->z, index, out);
+    if (k0 == 0) {  // one constraint: both vectors are [1]
+      size_t n = 0;
+      RC(vec_len(out, &n));
+      return n ? gm_fr_vec_fill(out, one) : GM_OK;
+    }
+    return kind == 0 ? gm_fr_tensor_gather(ch1.data(), k0, index, out) : gm_fr_powers_gather(alpha, k0, index, out);
+  };
+  auto range_fn = [&](int kind, size_t start, size_t count, uint64_t out) -> int {  // elements [start, start + count) of the set of `kind`
+    if (kind == 2) return count ? gm_fr_stride(S->z, start, 1, count, out) : gm_fr_vec_set_len(out, 0);
+    if (k0 == 0) {
+      RC(gm_fr_vec_set_len(out, count));
+      return count ? gm_fr_vec_fill(out, one) : GM_OK;
+    }
+    return kind == 0 ? gm_fr_tensor_range(ch1.data(), k0, start, count, out) : gm_fr_powers_range(alpha, start, count, out);
+  };
   P->spans[2] = since(t0);
 
   const size_t sn = fam.nnz, nnz_blk = lay.cnt(nnz, sn), lo_n = lay.lo(sn);
@@ -790,8 +805,10 @@ int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t
   RC(alloc_len(V, nnz_blk, &ralpha_star.h));
   RC(alloc_len(V, nnz_blk, &z_star.h));
   if (nnz_blk) {
-    RC(gm_fr_gather(b_ch, S->row_index, r_star.h));
-    RC(gm_fr_gather(c_ch, S->row_index, alpha_star.h));
+    RC(gm_fr_vec_set_len(r_star.h, nnz_blk));
+    RC(gm_fr_vec_set_len(alpha_star.h, nnz_blk));
+    RC(lookup_fn(0, S->row_index, r_star.h));
+    RC(lookup_fn(1, S->row_index, alpha_star.h));
     RC(gm_fr_hadamard(r_star.h, alpha_star.h, ralpha_star.h));
     RC(gm_fr_gather(S->z, S->col_index, z_star.h));
     size_t n1 = 0;
@@ -850,7 +867,7 @@ int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t
   // sorted_k = lookup(alg_hash(set_k), extended frequency) = set_k[e] + zeta e for e in this rank's block of the extended frequency (:160-173)
   const size_t ext_len[3] = {S->ext_fre_row_len, S->ext_fre_row_len, S->ext_fre_col_len}, ext_lv[3] = {fam.ext_row, fam.ext_row, fam.ext_col};
   const uint64_t ext_idx[3] = {S->ext_fre_row, S->ext_fre_row, S->ext_fre_col};
-  const uint64_t set_src[3] = {b_ch, c_ch, S->z};
+  const size_t set_len[3] = {nt, nt, nz};
   BV sorted[3];
   for (int k = 0; k < 3; k++) {
     const size_t n = lay.cnt(ext_len[k], ext_lv[k]);
@@ -859,7 +876,7 @@ int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t
     if (!n) continue;
     uint64_t tmp;
     RC(V.alloc(n, &tmp));
-    RC(gm_fr_gather(set_src[k], ext_idx[k], tmp));
+    RC(lookup_fn(k, ext_idx[k], tmp));
     size_t got = 0;
     RC(vec_len(tmp, &got));
     GM_CHECK(got == n, GM_EINVAL, "psnark_new_time_sharded: the block of extended frequency %d holds %zu entries, the layout says %zu", k, got, n);
@@ -891,23 +908,28 @@ int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t
     }
     RC(gm_dist_allgather_host(last.data(), 96, lasts.data()));
     for (int k = 0; k < 3; k++) {
-      size_t nset = 0;
-      RC(vec_len(set_src[k], &nset));
-      // lookup_set = plookup_set(alg_hash(set)): nset + 1 entries, from the WHOLE hashed set (a replicated O(n) pass, transient)
+      const size_t nset = set_len[k];
+      // lookup_set = plookup_set(alg_hash(set)): nset + 1 entries; this rank needs the hashed set on [lo - 1, lo + in_set) only -- a RANGE of a
+      // function of the index (or of z), hashed with its own first index
       BV& ls = lookup_vec[3 * k];
       ls = BV{0, nset + 1, lay.level(nset + 2)};
       const size_t out_set = lay.cnt(nset + 1, ls.s), in_set = lay.cnt(nset, ls.s), lo_s = lay.lo(ls.s);
       RC(alloc_len(V, out_set, &ls.h));
       if (out_set) {
-        uint64_t set_h = set_src[k];
-        if (hashed) {
-          RC(V.alloc(nset, &set_h));
-          RC(gm_fr_alg_hash(set_src[k], 0, zeta, set_h));
+        const size_t halo = lo_s ? 1 : 0, first = lo_s - halo, cnt = in_set + halo;
+        uint64_t rng, set_h;
+        RC(alloc_len(V, cnt, &rng));
+        RC(range_fn(k, first, cnt, rng));
+        set_h = rng;
+        if (hashed && cnt) {
+          RC(alloc_len(V, cnt, &set_h));
+          RC(gm_fr_alg_hash_from(rng, first, zeta, set_h));
+          V.release(rng);
         }
         uint64_t prev[4];
-        if (lo_s) RC(gm_fr_vec_download(set_h, lo_s - 1, prev, 1));
-        RC(gm_fr_plookup_set_block(set_h, in_set ? lo_s : 0, in_set, lo_s ? prev : nullptr, out_set, gamma, chi, ls.h));
-        if (hashed) V.release(set_h);
+        if (halo) RC(gm_fr_vec_download(set_h, 0, prev, 1));
+        RC(gm_fr_plookup_set_block(set_h, halo, in_set, halo ? prev : nullptr, out_set, gamma, chi, ls.h));
+        V.release(set_h);
       }
       // lookup_subset = alg_hash(subset, index) + y
       BV& lb = lookup_vec[3 * k + 1];
@@ -932,8 +954,6 @@ int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t
       if (out_srt) RC(gm_fr_plookup_set_block(sorted[k].h, 0, in_srt, r ? lasts.data() + 12 * (r - 1) + 4 * k : nullptr, out_srt, gamma, chi, lt.h));
     }
   }
-  V.release(b_ch);
-  V.release(c_ch);
   // accumulated_product(monic(v)) and right_rotation(monic(v)) (entryproduct/time_prover.rs:14-51), l + 1 entries each   :211-214
   BV acc_vec[9], shift_lookup[9];
   {

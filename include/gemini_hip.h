@@ -334,6 +334,12 @@ int gm_fr_acc_product(uint64_t v, uint64_t out);
  *   gm_fr_acc_product_block   accumulated_product(monic(v)) of a block: the suffix scan started from `carry` (the product of the blocks
  *                             above; null: one); write_monic: position |whole v| -- the entry 1 -- falls into this block */
 int gm_fr_tensor_range(const uint64_t* rhos_mont, size_t k, size_t start, size_t count, uint64_t out);
+/* `lookup(v, index)` (plookup/time_prover.rs:5-8) of a vector that is a FUNCTION of the index, without the vector: out[i] = tensor(rhos)[index[i]]
+ * resp. x^index[i] (index[i] < 2^k / 2^log_len) -- one multiplication per element from two half tables that stay in L2.  gm_fr_alg_hash_from: the
+ * algebraic hash of a RANGE of a vector, out[i] = v[i] + (first_index + i) zeta. */
+int gm_fr_tensor_gather(const uint64_t* rhos_mont, size_t k, uint64_t index, uint64_t out);
+int gm_fr_powers_gather(const uint64_t x_mont[4], size_t log_len, uint64_t index, uint64_t out);
+int gm_fr_alg_hash_from(uint64_t v, size_t first_index, const uint64_t zeta_mont[4], uint64_t out);
 int gm_fr_powers_range(const uint64_t x_mont[4], size_t start, size_t count, uint64_t out);
 int gm_fr_plookup_set_block(uint64_t v, size_t v_offset, size_t v_count, const uint64_t* prev_or_null, size_t out_count, const uint64_t y_mont[4],
                             const uint64_t z_mont[4], uint64_t out);
@@ -716,7 +722,7 @@ int gm_snark_new_elastic_sharded(const gm_snark_shard* shard, size_t max_msm_buf
  * sumcheck in ONE all-gather per round), the products of the blocks of the nine lookup vectors (the carries of the suffix scans of
  * accumulated_product, entryproduct/time_prover.rs:34-45) and 32-byte halos (right_rotation, plookup_set read element i - 1),
  * evaluations, short gathered tails, the re-blocked level sums of the opening.  `lookup(v, index)` (plookup/time_prover.rs:5-8)
- * needs no exchange: tensor(rho) and powers(alpha) are functions of the index, computed whole on every rank at HBM speed.
+ * needs no exchange and no whole vector: tensor(rho) and powers(alpha) are functions of the index (gm_fr_tensor_gather / gm_fr_powers_gather).
  * The proof is byte-identical to gm_psnark_new_time's on every rank (tests/test_gpu_dist_native.py: 1 / 2 / 3 / 4 / 8 ranks). */
 typedef struct gm_psnark_shard {
   uint64_t a, b, c;
