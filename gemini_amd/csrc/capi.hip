@@ -644,9 +644,9 @@ Footprint fp_psnark(gm::Context* C, const gm::Bases* ck, size_t nz, size_t nnz, 
   return f;
 }
 // gm_psnark_new_time_sharded on `world` ranks with block size `block`: every vector of the resident schedule above in blocks (a family's block is
-// block >> level >= its length / world, within 1 / 32 of it: the rounding of gm_psnark_shard_block), plus what every rank holds WHOLE --
-// tensor(rho), powers(alpha) (2 nt) and one hashed set at a time (max(nt, nz)); z is the caller's -- plus the temporaries of the cross-level
-// combinations (per-level partial sums and their re-blocked copies: <= 4 coarsest blocks)
+// block >> level >= its length / world, within 1 / 32 of it: the rounding of gm_psnark_shard_block); nothing is held WHOLE but z, the caller's
+// (tensor(rho), powers(alpha) are table lookups) -- plus the temporaries of the cross-level combinations and the ranges of the hashed sets
+// (per-level partial sums and their re-blocked copies: <= 6 coarsest blocks)
 Footprint fp_psnark_shard(gm::Context* C, const gm::Bases* key, size_t nrows, size_t nz, size_t nnz, size_t block, size_t world) {
   const size_t nt = next_pow2(nrows);
   const size_t sum_l = 2 * ((nt + 2) + (nnz + 1) + (nt + nnz + 2)) + ((nz + 2) + (nnz + 1) + (nz + nnz + 2));
@@ -654,7 +654,8 @@ Footprint fp_psnark_shard(gm::Context* C, const gm::Bases* key, size_t nrows, si
   const size_t whole = 4 * nnz + sorted + 2 * sum_l + 3 * nnz + (3 * (2 * sum_l) + 3 * (8 * nnz)) / 4 + 5 * nnz + nz + 16;  // (+ the instance's own blocks: 5 nnz + w)
   const size_t g = world ? world : 1;
   size_t elems = (whole + g - 1) / g;
-  elems += elems / 32 + 2 * nt + std::max(nt, nz) + 4 * block;
+  (void)nt;  // (tensor(rho) / powers(alpha) are never built: table lookups; the ranges of the hashed sets are blocks)
+  elems += elems / 32 + 6 * block;
   Footprint f;
   f.vectors = fp_vectors_bytes(elems);
   f.workspaces = fp_workspaces(C, key, block, block);
