@@ -4,7 +4,7 @@
 O=gpurun_out
 PARTS=${@:-suite bench profile exposed sweep shares misc n2}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
-if has suite; then (time python -m pytest tests -q -m gpu 2>&1 | tail -4) > $O/r6_gpu_suite.txt 2>&1; fi
+if has suite; then (time python -m pytest tests -q -m gpu --durations=30 2>&1 | tail -40) > $O/r6_gpu_suite.txt 2>&1; fi
 if has bench; then
   python bench.py --steps 20 --warmup 5 > $O/r6_bench_driver_args.json 2> $O/r6_bench_driver_args.err
   python bench.py > $O/r6_bench.json 2> $O/r6_bench.err
