@@ -406,6 +406,7 @@ int gm_init(int device) {
     }
   }
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
+  GM_HIP(hipHostMalloc((void**)&C->sc_desc_host, 2 << 16, hipHostMallocDefault));
   if (const char* e = getenv("GM_ZERO_COPY")) C->zero_copy = atoi(e);
   g_ctx = C;
   return GM_OK;
@@ -460,6 +461,7 @@ void gm_shutdown(void) {
   }
   C->cu_split = 0;
   if (C->host_small) (void)hipHostFree(C->host_small);
+  if (C->sc_desc_host) (void)hipHostFree(C->sc_desc_host);
   if (C->host_batch) (void)hipHostFree(C->host_batch);
   (void)hipStreamDestroy(C->stream);
   delete C;

@@ -295,6 +295,9 @@ struct Context {
   bool have_start_ev = false;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
+  // pinned staging of the descriptor arrays of k_sc_round_multi (two slots of 64 KiB: the two launches a batch round can make).  The copy to the
+  // device is asynchronous and the round is split-phase, so the source must outlive the call: a local vector would not
+  uint8_t* sc_desc_host = nullptr;
   uint64_t* host_batch = nullptr;  // pinned, grow-only: partial sums of a batch of evaluations (fr_eval_le_batch)
   size_t host_batch_cap = 0;
   int msm_c_override = 0;
