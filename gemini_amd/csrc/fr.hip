@@ -869,6 +869,8 @@ static int sc_enqueue_many(Context* C, Sumcheck** S, size_t k, bool fold, bool m
     rc = sc_after(C, S[j], fold, msg, d[j].blocks);
     if (rc) return rc;
   }
+  // a fold-only launch has no collect phase that would wait for the stream: wait here, so that its descriptor slot is free for the next launch
+  if (!msg) GM_HIP(hipStreamSynchronize(C->stream));
   return GM_OK;
 }
 
