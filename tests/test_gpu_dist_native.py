@@ -62,6 +62,10 @@ def test_rccl_binding_with_one_rank():
     from gemini_amd import collective
     from gemini_amd.fr import FrVec
 
+    # ONE node, one rank: RCCL needs no network transport here.  Once in ~10 suite runs on the pool this test took 286 s instead of 7-9 s (three
+    # communicator creations stalling in RCCL's own bootstrap on that box); keep its bootstrap on the loopback and its InfiniBand probe off
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
     gm.capi.init()
     collective.finalize()
     collective.selftest()  # no transport: a temporary one-rank RCCL communicator
