@@ -39,7 +39,7 @@ SYMBOLS = [
     "gm_sc_set_herring", "gm_hg1_new", "gm_hg1_round", "gm_hg1_fold", "gm_hg1_rounds", "gm_hg1_final", "gm_hg1_free",
     "gm_transcript_new", "gm_transcript_free", "gm_transcript_append_message", "gm_transcript_challenge_bytes",
     "gm_transcript_append_fr", "gm_transcript_append_g1", "gm_transcript_set_g1_encoding", "gm_transcript_challenge_fr", "gm_sumcheck_prove", "gm_sumcheck_prove_batch",
-    "gm_dist_init_hook", "gm_dist_rccl_unique_id", "gm_dist_init_rccl", "gm_dist_init_shm", "gm_dist_init_rccl_node", "gm_dist_finalize", "gm_dist_info", "gm_dist_allgather_host",
+    "gm_dist_init_hook", "gm_dist_rccl_unique_id", "gm_dist_init_rccl", "gm_dist_init_shm", "gm_dist_init_rccl_node", "gm_dist_finalize", "gm_dist_abort", "gm_dist_info", "gm_dist_allgather_host",
     "gm_dist_allgather_vec", "gm_dist_stats", "gm_dist_selftest", "gm_dist_allgather_host_class", "gm_dist_stats_routes", "gm_dist_bench", "gm_dist_reblock_vecs",
     "gm_g1_bases_set_cyclic", "gm_g1_srs_register_cyclic", "gm_ck_len", "gm_ck_msm", "gm_ck_msm_batch", "gm_sumcheck_prove_sharded",
     "gm_snark_shard_key_new", "gm_snark_new_time_sharded",

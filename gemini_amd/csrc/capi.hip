@@ -406,7 +406,7 @@ int gm_init(int device) {
     }
   }
   GM_HIP(hipHostMalloc((void**)&C->host_small, 1 << 16, hipHostMallocDefault));
-  GM_HIP(hipHostMalloc((void**)&C->sc_desc_host, 2 << 16, hipHostMallocDefault));
+  GM_HIP(hipHostMalloc((void**)&C->sc_desc_host, 8 << 15, hipHostMallocDefault));
   if (const char* e = getenv("GM_ZERO_COPY")) C->zero_copy = atoi(e);
   g_ctx = C;
   return GM_OK;

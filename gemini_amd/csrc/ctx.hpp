@@ -295,9 +295,12 @@ struct Context {
   bool have_start_ev = false;
   DevBuf fr_scratch;
   uint64_t* host_small = nullptr;  // pinned, 64 KiB, for small results
-  // pinned staging of the descriptor arrays of k_sc_round_multi (two slots of 64 KiB: the two launches a batch round can make).  The copy to the
-  // device is asynchronous and the round is split-phase, so the source must outlive the call: a local vector would not
+  // pinned staging of the descriptor arrays of k_sc_round_multi: a RING of 8 slots of 32 KiB, one per launch.  The copy to the device is
+  // asynchronous and the round is split-phase, so the source must outlive the call (a local vector would not) and must not be rewritten by the
+  // next launch of the same round (a sharded batch makes up to four per round); a slot comes round again after 8 launches, i.e. after at least
+  // one collected round (sc_round_end waits for the stream)
   uint8_t* sc_desc_host = nullptr;
+  unsigned sc_desc_next = 0;
   uint64_t* host_batch = nullptr;  // pinned, grow-only: partial sums of a batch of evaluations (fr_eval_le_batch)
   size_t host_batch_cap = 0;
   int msm_c_override = 0;

@@ -99,6 +99,9 @@ struct ShmHeader {
   // liveness handshake of the attach: a peer stores a fresh random nonce in hello[r] and trusts the segment only once rank 0 OF
   // THIS RUN has echoed it in ack[r] -- the rank 0 of a crashed run never will, whatever its counters say
   std::atomic<uint64_t> hello[64], ack[64];
+  // 1 + the rank that called gm_dist_abort (a prover that failed OUTSIDE a collective: its peers would otherwise wait out their timeout in the
+  // next all-gather); every wait on this segment returns GM_ESTATE once it is set
+  std::atomic<uint64_t> abort_by;
 };
 constexpr uint64_t SHM_MAGIC = 0x474d44495354ull;  // "GMDIST"
 constexpr uint64_t SHM_DEAD = 0x44454144474dull;   // a newer run has replaced this segment (rank 0 poisons what it unlinks)
@@ -223,13 +226,17 @@ uint8_t* shm_slot(Dist& d, uint64_t call, int r) {
 
 // A collective over RCCL whose peer never arrives would block hipStreamSynchronize for ever (the shm transport has its own
 // timeout): poll the stream instead and give up after GM_DIST_RCCL_TIMEOUT_S (default 120 s) -- the caller then aborts the communicator.
-hipError_t stream_wait_bounded(hipStream_t st, bool* timed_out) {
+hipError_t stream_wait_bounded(hipStream_t st, bool* timed_out, const std::atomic<uint64_t>* abort_flag = nullptr) {
   static const double limit = getenv("GM_DIST_RCCL_TIMEOUT_S") ? atof(getenv("GM_DIST_RCCL_TIMEOUT_S")) : 120.0;
   *timed_out = false;
   const auto t0 = Clock::now();
   for (unsigned spin = 0;; spin++) {
     const hipError_t e = hipStreamQuery(st);
     if (e != hipErrorNotReady) return e;
+    if (abort_flag && (spin & 63) == 0 && abort_flag->load(std::memory_order_acquire) != 0) {  // a peer called gm_dist_abort: it will never arrive
+      *timed_out = true;
+      return hipErrorNotReady;
+    }
     if (spin > 20000) std::this_thread::sleep_for(std::chrono::microseconds(50));
     if ((spin & 1023) == 0 && std::chrono::duration<double>(Clock::now() - t0).count() > limit) {
       *timed_out = true;
@@ -252,6 +259,11 @@ int shm_wait_seq(ShmHeader* h, int r, uint64_t k) {
   for (unsigned spin = 0;; spin++) {
     const uint64_t v = a.load(std::memory_order_acquire);
     if (v == k || v == k + 1) return GM_OK;
+    {
+      const uint64_t ab = h->abort_by.load(std::memory_order_acquire);
+      GM_CHECK(ab == 0, GM_ESTATE, "gm_dist: rank %llu aborted the run (gm_dist_abort: a prover failed on that rank); this rank stops waiting for rank %d",
+               (unsigned long long)(ab - 1), r);
+    }
     GM_CHECK(v < k, GM_ESTATE, "gm_dist(shm): rank %d is at call %llu while this rank is at call %llu: a stale or corrupted segment", r,
              (unsigned long long)v, (unsigned long long)k);
     if (spin < 2000) {
@@ -379,7 +391,7 @@ int rccl_host_allgather(Dist& d, const void* send, size_t bytes, void* recv) {
   }
   e = hipMemcpyAsync(d.h_out, d.d_out, bytes * (size_t)d.world, hipMemcpyDeviceToHost, C->stream);
   bool late = false;
-  if (e == hipSuccess) e = d.world > 1 ? stream_wait_bounded(C->stream, &late) : hipStreamSynchronize(C->stream);
+  if (e == hipSuccess) e = d.world > 1 ? stream_wait_bounded(C->stream, &late, d.shm ? &d.shm->abort_by : nullptr) : hipStreamSynchronize(C->stream);
   if (late) {
     gm::set_error("gm_dist: ncclAllGather did not complete in time: a peer never arrived");
     return fail(GM_ESTATE);
@@ -469,6 +481,7 @@ int shm_open_segment(Dist& d, int rank, int world, const char* name, size_t slot
     for (auto& q : d.shm->seq) q.store(0, std::memory_order_relaxed);
     for (auto& q : d.shm->hello) q.store(0, std::memory_order_relaxed);
     for (auto& q : d.shm->ack) q.store(0, std::memory_order_relaxed);
+    d.shm->abort_by.store(0, std::memory_order_relaxed);
     d.shm->attached.store(1, std::memory_order_relaxed);
     d.shm->magic.store(SHM_MAGIC, std::memory_order_release);
     // echo every peer's nonce (in whatever order they arrive)
@@ -735,6 +748,20 @@ int gm_dist_finalize(void) {
   return GM_OK;
 }
 
+// A prover that FAILS on this rank outside a collective (an allocation, a bad input, a device error) would leave its peers waiting in their next
+// all-gather until a timeout (300 s on the segment, 120 s under RCCL).  gm_dist_abort tells them: the flag in the node's segment makes every wait on it --
+// and every bounded wait on an RCCL collective of a communicator that keeps the segment as its side channel -- return GM_ESTATE at once; the
+// communicator is aborted and the transport of THIS rank refuses everything until it is initialised again.  The sharded provers call it on every
+// failure; a hook transport has no channel for it (the embedder's collective must have its own failure detection).
+int gm_dist_abort(void) {
+  Dist& d = D();
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (d.world <= 1 || d.tr == T_NONE) return GM_OK;
+  if (d.shm) d.shm->abort_by.store(1 + (uint64_t)d.rank, std::memory_order_release);
+  poison(d);
+  return GM_OK;
+}
+
 int gm_dist_info(int* rank, int* world, int* transport) {
   Dist& d = D();
   std::lock_guard<std::mutex> lk(d.mu);
@@ -829,7 +856,7 @@ int gm_dist_allgather_vec(uint64_t local_vec, uint64_t out_vec) {
     // (a failing rank aborts the communicator so that its peers return instead of hanging: see rccl_host_allgather)
     ncclResult_t r = d.R.AllGather(in->d, out->d, bytes, ncclChar, d.comm, C->stream);
     bool late = false;
-    hipError_t e = r == ncclSuccess ? (d.world > 1 ? stream_wait_bounded(C->stream, &late) : hipStreamSynchronize(C->stream)) : hipSuccess;
+    hipError_t e = r == ncclSuccess ? (d.world > 1 ? stream_wait_bounded(C->stream, &late, d.shm ? &d.shm->abort_by : nullptr) : hipStreamSynchronize(C->stream)) : hipSuccess;
     if (r != ncclSuccess || e != hipSuccess) {
       if (r != ncclSuccess) gm::set_error("gm_dist: ncclAllGather failed: %s", d.R.GetErrorString(r));
       if (late) gm::set_error("gm_dist: ncclAllGather of a vector did not complete in time: a peer never arrived");
@@ -942,7 +969,7 @@ int gm_dist_reblock_vecs(const uint64_t* local_vecs, size_t k, size_t new_block,
       ncclResult_t res = d.R.GroupEnd();
       if (res != ncclSuccess) return fail(res);
       bool late = false;
-      const hipError_t e = stream_wait_bounded(C->stream, &late);
+      const hipError_t e = stream_wait_bounded(C->stream, &late, d.shm ? &d.shm->abort_by : nullptr);
       if (late) {
         gm::set_error("gm_dist_reblock_vecs: the send / recv group did not complete in time: a peer never arrived");
         poison(d);

@@ -840,14 +840,17 @@ static int sc_enqueue_many(Context* C, Sumcheck** S, size_t k, bool fold, bool m
     d[j].tw1 = msg && sc_twist_one(d[j].A) ? 1u : 0u;
     max_blocks = std::max(max_blocks, d[j].blocks);
   }
-  const size_t bytes = k * sizeof(ScMultiDesc), slot = (size_t)64 << 10;
-  GM_CHECK(bytes <= slot && scratch_slot < 2 && C->sc_desc_host, GM_EINVAL, "sumcheck: %zu provers in one launch", k);
+  const size_t bytes = k * sizeof(ScMultiDesc), slot = (size_t)32 << 10;
+  GM_CHECK(bytes <= slot && C->sc_desc_host, GM_EINVAL, "sumcheck: %zu provers in one launch", k);
+  (void)scratch_slot;
   int rc = C->fr_scratch.ensure(1 << 20);
   if (rc) return rc;
-  uint8_t* dd = C->fr_scratch.as<uint8_t>() + scratch_slot * slot;
-  // through PINNED memory of the context: the copy is asynchronous and nothing waits before this call returns (the previous round's copy out of
-  // the same slot has completed: every prover of it was collected with sc_round_end, which waits for the stream)
-  uint8_t* hs = C->sc_desc_host + scratch_slot * slot;
+  // through PINNED memory of the context, one ring slot per launch: the copy is asynchronous and nothing waits before this call returns.  (The
+  // first version used one slot per (fold, message) kind: the two launches of a round in which some provers of a sharded batch leave their
+  // sharded phase shared it, and the first launch read the second one's descriptors -- ranks produced different proofs at 8 ranks.)
+  const unsigned ring = C->sc_desc_next++ & 7u;
+  uint8_t* dd = C->fr_scratch.as<uint8_t>() + ring * slot;
+  uint8_t* hs = C->sc_desc_host + ring * slot;
   memcpy(hs, d.data(), bytes);
   GM_HIP(hipMemcpyAsync(dd, hs, bytes, hipMemcpyHostToDevice, C->stream));
   hipStream_t st = C->stream;

@@ -688,7 +688,14 @@ int gm_psnark_index_sharded(const gm_psnark_shard* S, uint64_t* out_jac) {
   return commit_blocks(lay, K, {{S->row, S->nnz, s}, {S->col, S->nnz, s}, {S->val_a, S->nnz, s}, {S->val_b, S->nnz, s}, {S->val_c, S->nnz, s}}, out_jac);
 }
 
+static int psnark_new_time_sharded_impl(const gm_psnark_shard* S, int g1_encoding, size_t cap_rounds, gm_psnark_proof* P);
+// (a failure on this rank -- outside a collective as well: a bad input, an allocation -- tells the peers instead of leaving them in their next all-gather)
 int gm_psnark_new_time_sharded(const gm_psnark_shard* S, int g1_encoding, size_t cap_rounds, gm_psnark_proof* P) {
+  const int rc = psnark_new_time_sharded_impl(S, g1_encoding, cap_rounds, P);
+  if (rc) (void)gm_dist_abort();
+  return rc;
+}
+static int psnark_new_time_sharded_impl(const gm_psnark_shard* S, int g1_encoding, size_t cap_rounds, gm_psnark_proof* P) {
   GM_CTX();
   GM_CHECK(S && P && S->index_commitments && P->messages[0] && P->messages[1] && P->messages[2] && P->fold_commitments && P->fold_evaluations, GM_EINVAL,
            "psnark_new_time_sharded: null pointer");

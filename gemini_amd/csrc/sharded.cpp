@@ -341,7 +341,14 @@ struct PhaseTrace {
   }
 };
 
+static int snark_new_time_sharded_impl(const gm_snark_shard* S, int g1_encoding, size_t cap_rounds, gm_snark_proof* P);
+// (a failure on this rank -- outside a collective as well: a bad input, an allocation -- tells the peers instead of leaving them in their next all-gather)
 int gm_snark_new_time_sharded(const gm_snark_shard* S, int g1_encoding, size_t cap_rounds, gm_snark_proof* P) {
+  const int rc = snark_new_time_sharded_impl(S, g1_encoding, cap_rounds, P);
+  if (rc) (void)gm_dist_abort();
+  return rc;
+}
+static int snark_new_time_sharded_impl(const gm_snark_shard* S, int g1_encoding, size_t cap_rounds, gm_snark_proof* P) {
   GM_CTX();
   GM_CHECK(S && P && P->messages[0] && P->messages[1] && P->fold_commitments && P->fold_evaluations, GM_EINVAL, "snark_new_time_sharded: null pointer");
   const auto t_all = Clock::now();

@@ -614,6 +614,11 @@ int gm_dist_init_shm(int rank, int world, const char* name, size_t slot_bytes);
  * aborts the communicator (ncclCommAbort), so its peers return with an error instead of waiting inside the collective. */
 int gm_dist_init_rccl_node(int rank, int world, const char* name);
 int gm_dist_finalize(void);
+/* A prover that fails on this rank OUTSIDE a collective would leave its peers waiting in their next all-gather until a timeout.  gm_dist_abort raises a
+ * flag in the node's segment (every wait on it, and every bounded wait on an RCCL collective with the segment as side channel, returns GM_ESTATE at
+ * once), aborts the communicator and poisons this rank's transport (transport 4) until it is initialised again.  The sharded provers call it on every
+ * failure.  No effect with one rank; a hook transport has no channel for it. */
+int gm_dist_abort(void);
 /* transport: 0 none, 1 hook, 2 RCCL, 3 shm */
 int gm_dist_info(int* rank, int* world, int* transport);
 /* recv = world x bytes, rank order.  Host buffers (an MSM partial is finished by the host Horner; sumcheck messages and

@@ -353,3 +353,47 @@ def test_block_sharded_elastic_snark_dummy_srs(world):
     assert one["proof_sha256"] != _single(["--elastic"])["proof_sha256"]
     many = _run(world, ["--dummy-srs", "--elastic", "--block-sharded", "--tail-log", "5"])
     assert many["proof_sha256"] == one["proof_sha256"] and "elastic_prover_s" in many, world
+
+
+ABORT_WORKER = """
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+import gemini_amd as gm
+from gemini_amd import collective
+from gemini_amd.sharded import PsnarkShard, PsnarkShardKey, psnark_new_time_sharded
+rank, world, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+gm.capi.init(0)
+collective.init_shm(rank, world, name)
+n = 1 << 9
+shard = PsnarkShard.dummy(12345, n, tail_log=4)
+key = PsnarkShardKey(2 * n, shard.block, 4, np.array([7, 0, 0, 0], dtype=np.uint64))
+index = shard.index(key)
+good = psnark_new_time_sharded(shard, key, index)           # a proof goes through
+if rank == 1:
+    shard.w_len += 1                                         # this rank's input no longer tiles: GM_EINVAL before its first collective
+t0 = time.time()
+try:
+    psnark_new_time_sharded(shard, key, index)
+    raise SystemExit("the broken proof went through on rank %%d" %% rank)
+except RuntimeError as e:
+    msg = str(e)
+dt = time.time() - t0
+assert dt < 30, dt                                           # the healthy rank does not wait out the 300 s of the segment
+assert ("input block" in msg) if rank == 1 else ("aborted the run" in msg), (rank, msg)
+assert collective.info()[2] == "failed"
+collective.finalize()
+print("ok", rank, round(dt, 2))
+""" % ROOT
+
+
+def test_a_prover_failing_on_one_rank_releases_its_peers():
+    """gm_dist_abort: a sharded prover that fails on one rank OUTSIDE a collective (here: an input block that does not tile, refused before the first
+    all-gather) raises a flag in the node's segment -- its peer, already waiting in the first commitment's all-gather, returns GM_ESTATE within
+    seconds instead of after the segment's 300 s timeout, and both transports refuse further collectives until they are initialised again"""
+    name = f"/gm_abort_{os.getpid()}"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-c", ABORT_WORKER, str(r), "2", name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=400) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]
