@@ -211,3 +211,81 @@ def test_reinit_under_the_same_name_does_not_lose_the_new_segment():
     collective.finalize()
     assert os.path.exists("/dev/shm" + name)  # not ours: left alone
     os.unlink("/dev/shm" + name)
+
+
+ABORT_WORKER = textwrap.dedent("""
+    import os, sys, time
+    import numpy as np
+    sys.path.insert(0, %r)
+    os.environ["GM_NO_TORCH_PRELOAD"] = "1"
+    from gemini_amd import capi, collective
+    rank, world, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    collective.init_shm(rank, world, name, 256)
+    got = collective.allgather_host(np.array([rank], dtype=np.uint64))
+    assert (got[:, 0] == np.arange(world)).all()
+    t0 = time.time()
+    if rank == 1:
+        time.sleep(0.3)                      # the others are already waiting for this rank
+        capi.check(capi.load().gm_dist_abort())
+    else:
+        try:
+            collective.allgather_host(np.array([rank], dtype=np.uint64))
+            raise SystemExit("an all-gather completed without rank 1")
+        except RuntimeError as e:
+            assert "aborted the run" in str(e), str(e)
+        assert time.time() - t0 < 20         # not the 300 s of the segment's timeout
+        capi.check(capi.load().gm_dist_abort())   # (what a failing prover does; idempotent)
+    assert collective.info()[1:] == (world, "failed")
+    try:
+        collective.allgather_host(np.array([rank], dtype=np.uint64))
+        raise SystemExit("a collective went through a failed transport")
+    except RuntimeError as e:
+        assert "earlier collective" in str(e), str(e)
+    collective.finalize()
+    assert collective.info() == (0, 1, "none")
+    print("ok", rank)
+""") % ROOT
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_abort_releases_the_waiting_ranks(world):
+    """gm_dist_abort (round 6): the rank that fails outside a collective raises a flag in the segment; every rank waiting for it returns GM_ESTATE within
+    moments instead of after the 300 s timeout, and the transport of every rank refuses further collectives until it is initialised again"""
+    name = f"/gm_test_abort_{os.getpid()}_{world}"
+    procs = [subprocess.Popen([sys.executable, "-c", ABORT_WORKER, str(r), str(world), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]
+
+
+def test_psnark_shard_layout_functions():
+    """gm_psnark_shard_block / gm_psnark_shard_level (pure functions of the lengths, no device): the block is a multiple of 4 within 1/64 of
+    ceil(longest / world); a family's level is the finest one whose `world` blocks still hold it, the blocks of every level up to it halve exactly"""
+    import ctypes as C
+
+    os.environ.setdefault("GM_NO_TORCH_PRELOAD", "1")
+    from gemini_amd import capi
+
+    lib = capi.load()
+    lib.gm_psnark_shard_block.restype = C.c_size_t
+    lib.gm_psnark_shard_level.restype = C.c_size_t
+    rng = np.random.default_rng(11)
+    for _ in range(400):
+        world = int(rng.integers(1, 17))
+        longest = int(rng.integers(8, 1 << int(rng.integers(4, 30))))
+        tail_log = int(rng.integers(2, 12))
+        block = int(lib.gm_psnark_shard_block(C.c_size_t(longest), C.c_int(world)))
+        per = -(-longest // world)
+        assert block % 4 == 0 and block >= per and block * world >= longest
+        assert block - per <= max(per // 32, 8), (longest, world, block)
+        for length in (longest, longest // 2 + 1, longest // 7 + 1, 1):
+            s = int(lib.gm_psnark_shard_level(C.c_size_t(length), C.c_size_t(block), C.c_size_t(tail_log), C.c_int(world)))
+            assert world * (block >> s) >= length                                  # the family fits its blocks
+            for j in range(s + 1):
+                assert (block >> j) << j == block and (block >> j) % 2 == 0        # every level up to it halves exactly and stays even
+            if s > 0:
+                assert (block >> s) >= (1 << tail_log)                             # sharded levels are never shorter than the tail
+            # maximal: one level finer would not hold the family, or is not a sharded level any more
+            nxt = block >> (s + 1)
+            finer_ok = world * nxt >= length and (block >> s) % 2 == 0 and nxt % 2 == 0 and nxt >= (1 << tail_log)
+            assert not finer_ok, (length, block, s, world, tail_log)
