@@ -83,6 +83,11 @@ def finalize() -> None:
     capi.check(capi.load().gm_dist_finalize())
 
 
+def abort() -> None:
+    """gm_dist_abort: this rank failed outside a collective -- release the peers waiting for it (they get GM_ESTATE), poison this rank's transport"""
+    capi.check(capi.load().gm_dist_abort())
+
+
 def info():
     r, w, t = C.c_int(), C.c_int(), C.c_int()
     capi.check(capi.load().gm_dist_info(C.byref(r), C.byref(w), C.byref(t)))

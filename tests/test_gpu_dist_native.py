@@ -397,3 +397,25 @@ def test_a_prover_failing_on_one_rank_releases_its_peers():
     outs = [p.communicate(timeout=400) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0 and o.strip().startswith("ok"), e[-3000:]
+
+
+def test_elastic_sharded_entry_refuses_the_literal_schedule():
+    """gm_snark_new_elastic_sharded runs the RESIDENT schedule over blocks; min_device_chunk = 1 selects the literal elastic prover (space provers over
+    whole streams, src/snark/elastic_prover.rs:174-266 as written), which is single-GPU: refused with GM_EINVAL and a message, before anything is launched"""
+    import ctypes as C
+
+    import gemini_amd as gm
+    from gemini_amd import collective
+    from gemini_amd.sharded import R1csShard, ShardKey, new_time_sharded
+
+    gm.capi.init()
+    collective.finalize()
+    n = 1 << 8
+    shard = R1csShard.dummy(4242, n)
+    key = ShardKey(n, 4, np.array([1, 0, 0, 0], dtype=np.uint64))  # the DummyStreamer key: copies of the generator = powers of tau = 1
+    resident = new_time_sharded(shard, key, elastic=(1 << 20, 1 << 26))
+    assert resident.serialize_compressed() == new_time_sharded(shard, key).serialize_compressed()  # the same proof as the sharded time prover
+    with pytest.raises(RuntimeError, match="LITERAL"):
+        new_time_sharded(shard, key, elastic=(1 << 20, 1))
+    shard.free()
+    key.free()
