@@ -64,6 +64,15 @@ inline Footprint psnark_footprint(uint64_t ck_handle, size_t num_variables, size
   return Footprint{v[0], v[1], v[2], v[3]};
 }
 
+// one rank of gm_psnark_new_time_sharded (block = psnark_shard_block(longest vector, world)); z and the instance's blocks are the caller's
+inline size_t psnark_shard_block(size_t longest, int world) { return gm_psnark_shard_block(longest, world); }
+inline size_t psnark_shard_level(size_t family_len, size_t block, size_t tail_log, int world) { return gm_psnark_shard_level(family_len, block, tail_log, world); }
+inline Footprint psnark_shard_footprint(uint64_t key_handle, size_t num_constraints, size_t num_variables, size_t nnz, size_t block, int world) {
+  uint64_t v[4];
+  check(gm_psnark_shard_footprint(key_handle, num_constraints, num_variables, nnz, block, world, 0, v));
+  return Footprint{v[0], v[1], v[2], v[3]};
+}
+
 // One process per GPU: after gm::init(local_rank) pick the transport of the library's all-gathers.  Every native prover
 // (SnarkProof::new_time ..., gm_snark_new_time_sharded) then runs on N GPUs when its key is a cyclic share / a shard key.
 namespace dist {
@@ -78,6 +87,8 @@ inline void init_shm(int rank, int world, const std::string& name, size_t slot_b
 inline void init_hook(int rank, int world, gm_allgather_fn fn, void* ctx) { check(gm_dist_init_hook(rank, world, fn, ctx)); }
 inline void selftest() { check(gm_dist_selftest()); }
 inline void finalize() { check(gm_dist_finalize()); }
+// this rank failed OUTSIDE a collective: release the peers waiting for it (they get GM_ESTATE), poison this rank's transport (round 6)
+inline void abort() { check(gm_dist_abort()); }
 inline int rank() {
   int r = 0;
   check(gm_dist_info(&r, nullptr, nullptr));
